@@ -1,0 +1,160 @@
+/*
+ * goat_hip.h — C ABI of libgoat_hip.so: hand-written gfx950 (CDNA4) kernels for GOAT's cross-modal
+ * transformer forward/backward (VLN-GOAT pre-training / fine-tuning hot path).
+ *
+ * The reference (CrystalSixone/VLN-GOAT) is pure PyTorch: it has NO native interface for this path
+ * (SURVEY.md §2.1).  Each entry point below therefore replaces a *PyTorch eager op sequence* of the
+ * reference; the sequence is cited as file:line (P/ = pretrain_src/, M/ = map_nav_src/).  A maintainer
+ * binds these with ctypes; `vln-goat_amd/_lib.py` is that binding.
+ *
+ * Conventions
+ *   - plain C, raw device pointers, explicit sizes/strides (in ELEMENTS), no ownership transfer;
+ *   - `stream` is a hipStream_t; every call is stream-ordered, never synchronises, never allocates
+ *     (hipGraph-capturable);
+ *   - dtype: GOAT_F32 = 0 (exact-f32 MFMA path), GOAT_BF16 = 1 (bf16 storage, f32 accumulate);
+ *   - parameters (bias, LayerNorm gamma/beta) and statistics are always float32;
+ *   - return 0 on success, negative on invalid argument / unsupported shape (GOAT_E_*), or the positive
+ *     hipError_t of a failed launch.  No global state except lazily-set kernel attributes.
+ */
+#ifndef GOAT_HIP_H
+#define GOAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOAT_F32 0
+#define GOAT_BF16 1
+
+#define GOAT_E_ARG (-1)    /* null pointer / bad enum */
+#define GOAT_E_SHAPE (-2)  /* unsupported shape or alignment */
+
+/* epilogues of goat_gemm_nt */
+#define GOAT_EPI_NONE 0       /* C = A·Bᵀ (+bias) */
+#define GOAT_EPI_GELU 1       /* u = A·Bᵀ+bias ; aux<-u (if aux) ; C = erf-gelu(u)   P/model/Bert_backbone.py:41-47,345-357 */
+#define GOAT_EPI_RELU 2       /* same with relu                                   P/model/pretrain_goat.py:32-35 */
+#define GOAT_EPI_MUL_DGELU 3  /* C = (A·Bᵀ) * gelu'(aux)   (backward of the GELU epilogue) */
+#define GOAT_EPI_MUL_DRELU 4  /* C = (A·Bᵀ) * [aux>0] */
+
+/* library/version probe: returns 100*major+minor */
+int goat_version(void);
+
+/* C[M,N] = epilogue(A[M,K] · B[N,K]ᵀ + bias[N]).  Both operands K-contiguous ("NT"), which is
+ * torch.nn.Linear's layout: replaces F.linear / addmm (P/model/Bert_backbone.py:170-172,302,348,362;
+ * nn.MultiheadAttention in_proj/out_proj P/model/transformer.py:137; heads P/model/pretrain_goat.py:18-35).
+ * Also used for dgrad (B = Wᵀ shadow) and wgrad (A = dYᵀ, B = Xᵀ, split_k>1, out f32).
+ *   dtype_in : element type of A, B, aux        dtype_out: element type of C (GOAT_F32 allowed with bf16 in)
+ *   K and lda/ldb must be multiples of 16 bytes worth of elements (8 bf16 / 4 f32); bases 16-B aligned.
+ *   split_k>1 : K is split over gridDim.y and partial tiles are atomically added into C (requires
+ *               dtype_out==GOAT_F32, epilogue NONE, bias NULL; C must hold the value to accumulate onto).
+ */
+int goat_gemm_nt(void* stream, int dtype_in, int dtype_out,
+                 const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                 int M, int N, int K, const float* bias, int epilogue,
+                 void* aux, int64_t ldaux, int split_k);
+
+/* out[c, r] = in[r, c] for r<R, c<C; out columns R..ld_out-1 are zero-filled (so the result can feed
+ * goat_gemm_nt as a K-padded operand).  If colsum!=NULL, colsum[c] += sum_r in[r,c] (float32, atomic):
+ * that is the bias gradient of a Linear (autograd of P/model/Bert_backbone.py:302 et al.). */
+int goat_transpose(void* stream, int dtype, const void* in, int64_t ld_in, void* out, int64_t ld_out,
+                   int R, int C, float* colsum);
+
+/* z = residual + dropout_p(x) ; y = LayerNorm(z)*gamma+beta.   BertSelfOutput/BertOutput
+ * (P/model/Bert_backbone.py:306-310,366-370), RobertaEmbeddings LN (:115-116), pre-LN norms
+ * (P/model/transformer.py:174,178).  residual may be NULL; p may be 0.  z_out may be NULL when
+ * residual==NULL and p==0 (then z==x).  mean/rstd: float32[M] saved for backward.
+ * Dropout keep-mask for flat element index i is hash(seed + *rng_dev, offset+i) (see csrc/common.hpp);
+ * rng_dev (device uint64, may be NULL) lets a captured hipGraph draw fresh masks on every replay. */
+int goat_ln_fwd(void* stream, int dtype, const void* x, const void* residual,
+                const float* gamma, const float* beta, float eps,
+                float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev,
+                void* y, void* z_out, float* mean, float* rstd, int M, int H);
+
+/* backward of goat_ln_fwd.  dz = LN-backward(dy) ; d_res<-dz (if non-NULL) ; dx<-dz*mask/(1-p) (if non-NULL).
+ * dgamma/dbeta: float32[H], OVERWRITTEN.  ws: float32 scratch of goat_ln_bwd_ws_floats(H) elements
+ * (per-block column partials; a second tiny kernel reduces them — no atomics, deterministic). */
+int goat_ln_bwd_ws_floats(int H);
+int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* z,
+                const float* gamma, const float* mean, const float* rstd,
+                float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev,
+                void* dx, void* d_res, float* dgamma, float* dbeta, float* ws, int M, int H);
+
+/* y = residual + dropout_p(x)  (residual may be NULL, y may alias x).  nn.Dropout + pre-LN residual adds
+ * (P/model/transformer.py:177,181; P/model/vilmodel_goat.py:316). n = element count. */
+int goat_dropout_add_fwd(void* stream, int dtype, const void* x, const void* residual, void* y,
+                         int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev);
+/* dx = dy * mask/(1-p) with the same (seed, offset). */
+int goat_dropout_bwd(void* stream, int dtype, const void* dy, void* dx,
+                     int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev);
+
+/* dx = dropmask_p(dy) * act'(u), act = GOAT_EPI_GELU | GOAT_EPI_RELU: backward of h = dropout_p(act(u)),
+ * the inner activation (+dropout) of the panorama encoder FFN (P/model/transformer.py:179) and of the small heads. */
+int goat_act_bwd(void* stream, int dtype, const void* dy, const void* u, void* dx, int64_t n, int act,
+                 float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev);
+
+/* Masked multi-head attention, head_dim fixed at 64.
+ *   O[b,q,h,:] = dropout_p(softmax_k(scale * Q[b,q,h,:]·K[b,k,h,:] + kmask[b,k] + bias[b,q,k])) · V[b,k,h,:]
+ * Replaces BertSelfAttention.forward (P/model/Bert_backbone.py:246-290; additive -10000 masks P/model/ops.py:25-34,
+ * graph_sprels bias :690-691) and F.multi_head_attention_forward with key_padding_mask (-inf)
+ * (P/model/transformer.py:172-176).  Q/K/V/O are [B, L, nh*64] views with explicit row and batch strides
+ * (so q,k,v may be slices of one fused QKV projection).  kmask: float32 [B,Lk] additive or NULL;
+ * bias: float32 [B,Lq,Lk] additive or NULL.  lse: float32 [B,nh,Lq] saved for backward.
+ * Lk <= 256.  Rows whose keys are all -inf produce zeros. */
+int goat_attn_fwd(void* stream, int dtype,
+                  const void* Q, int64_t q_rs, int64_t q_bs,
+                  const void* K, int64_t k_rs, int64_t k_bs,
+                  const void* V, int64_t v_rs, int64_t v_bs,
+                  void* O, int64_t o_rs, int64_t o_bs,
+                  const float* kmask, const float* bias, float* lse,
+                  int B, int nh, int Lq, int Lk, float scale,
+                  float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev);
+
+/* backward of goat_attn_fwd.  dQ/dK/dV share the stride convention; dbias: float32 [B,Lq,Lk] or NULL,
+ * ACCUMULATED (atomic; caller zero-fills) with the sum over heads of dS (the gradient of `bias`; feeds sprel_linear's 1->1 Linear,
+ * P/model/vilmodel_goat.py:496-497). */
+int goat_attn_bwd(void* stream, int dtype,
+                  const void* Q, int64_t q_rs, int64_t q_bs,
+                  const void* K, int64_t k_rs, int64_t k_bs,
+                  const void* V, int64_t v_rs, int64_t v_bs,
+                  const void* O, int64_t o_rs, int64_t o_bs,
+                  const void* dO, int64_t do_rs, int64_t do_bs,
+                  void* dQ, int64_t dq_rs, int64_t dq_bs,
+                  void* dK, int64_t dk_rs, int64_t dk_bs,
+                  void* dV, int64_t dv_rs, int64_t dv_bs,
+                  const float* kmask, const float* bias, const float* lse, float* dbias,
+                  int B, int nh, int Lq, int Lk, float scale,
+                  float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev);
+
+/* Adaptive panorama fusion: w = softmax_v(tanh(x[n,v,:]·a + a0)) over ALL V slots (no mask);
+ * fused[n,:] = sum_v w_v x[n,v,:]    (P/model/vilmodel_goat.py:354-361).  a: float32[H], a0: float32[1].
+ * wsave: float32 [N,V] softmax weights saved for backward. */
+int goat_pano_fusion_fwd(void* stream, int dtype, const void* x, const float* a, const float* a0,
+                         void* fused, float* wsave, int N, int V, int H);
+/* backward: dx (overwritten), da/da0 float32 accumulated atomically. */
+int goat_pano_fusion_bwd(void* stream, int dtype, const void* x, const float* a, const float* a0,
+                         const float* wsave, const void* dfused, void* dx, float* da, float* da0,
+                         int N, int V, int H);
+
+/* Row gather / segment mean:  out[i,:] = scale[i] * sum_{j in [start[i],start[i+1])} src[idx[j],:]
+ * (idx = -1 contributes zero).  One launch replaces the host triple loop of
+ * GlobalMapEncoder._aggregate_gmap_features (P/model/vilmodel_goat.py:438-460), the [stop]-token
+ * concat/pad of vp_input_embedding (:377-391) and pad_tensors_wgrad (P/model/ops.py:46-68).
+ * idx/start are int32 device arrays built once per batch on the host from the string ids. */
+int goat_gather_segmean_fwd(void* stream, int dtype, const void* src, int64_t src_rows,
+                            const int32_t* idx, const int32_t* start, const float* scale,
+                            void* out, int n_out, int H);
+/* backward: dsrc[idx[j],:] += scale[i]*dout[i,:]  (float atomics into float32 dsrc32 [src_rows,H]). */
+int goat_gather_segmean_bwd(void* stream, int dtype, const void* dout,
+                            const int32_t* idx, const int32_t* start, const float* scale,
+                            float* dsrc32, int n_out, int H);
+
+/* Debug/probe helper used by tests: fills out[64*4] with the element indices returned by
+ * ds_read_b64_tr_b16 when lane l points at elements 4l..4l+3 of an LDS array holding 0,1,2,... */
+int goat_probe_tr16(void* stream, uint16_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOAT_HIP_H */

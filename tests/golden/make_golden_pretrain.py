@@ -1,0 +1,128 @@
+"""Generate golden vectors for the pre-training path FROM THE IMPORTED REFERENCE (this container only).
+
+    python tests/golden/make_golden_pretrain.py            # writes tests/golden/pretrain_*.npz
+
+For every case: the product's seeded weights (vln_goat_amd.synth.seeded_state_dict) are loaded into the
+reference `GlocalTextPathCMTPreTraining` (/root/reference/pretrain_src/model/pretrain_goat.py:40), the
+synthetic batch (vln_goat_amd.synth.make_pretrain_batch) is fed to `model(batch, task, compute_loss)`,
+and outputs + gradient fingerprints are stored.  Dropout is disabled (model.eval(), grads enabled).
+Only small tensors are stored; weights and inputs are regenerated from the seeds by the tests.
+The CFP loss is recomputed from the four returned vectors with the formula of pretrain_goat.py:522-534
+(the reference hard-codes `.cuda()` at :520).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_shim  # noqa: E402
+
+CASES = {
+    # name: (config overrides, batch kwargs)
+    'pretrain_small_fixed': (dict(num_l_layers=2, num_top_layer=2, num_pano_layers=2, vocab_size=1000),
+                             dict(B=4, T=5, L=80, seed=1, vocab_size=1000, style='survey')),
+    'pretrain_small_ragged': (dict(num_l_layers=2, num_top_layer=2, num_pano_layers=2, vocab_size=1000),
+                              dict(B=4, T=[1, 3, 5, 2], L=[80, 33, 20, 57], seed=2, vocab_size=1000, style='rich',
+                                   ragged_views=True)),
+    'pretrain_config1': (dict(num_l_layers=2, num_top_layer=2, num_pano_layers=2),
+                         dict(B=4, T=5, L=80, seed=3, style='survey')),
+}
+WEIGHT_SEED = 7
+TASKS = ('mlm', 'sap', 'cfp')
+REF_CFG_JSON = '/root/reference/pretrain_src/config/r2r_GOAT_model_config.json'
+
+
+def grad_fingerprint(model):
+    """name -> [L2 norm, first 8 elements] of .grad (zeros when a parameter received no gradient)."""
+    out = {}
+    for n, p in model.named_parameters():
+        g = p.grad
+        if g is None:
+            out[n] = np.zeros(9, dtype=np.float32)
+        else:
+            flat = g.detach().float().reshape(-1)
+            first = torch.zeros(8)
+            first[:min(8, flat.numel())] = flat[:8]
+            out[n] = np.concatenate([[float(flat.double().norm())], first.numpy()]).astype(np.float32)
+    return out
+
+
+def cfp_loss_from_outputs(go, vo, fo, to, temperature):
+    B = go.shape[0]
+    tgt = torch.arange(B)
+
+    def sym(x):
+        sim = (x @ to.T) / temperature
+        return (F.cross_entropy(sim, tgt, reduction='none') + F.cross_entropy(sim.T, tgt, reduction='none')) / 2.0
+    return sym(go) + sym(vo) + sym(fo)
+
+
+def main(only=None):
+    pg = ref_shim.import_pretrain()
+    from vln_goat_amd import config as gcfg, pretrain_model, synth
+
+    for name, (cfg_over, bkw) in CASES.items():
+        if only and name not in only:
+            continue
+        torch.manual_seed(0)
+        ref_cfg = ref_shim.make_config(REF_CFG_JSON, pretrain_tasks={'mlm', 'sap', 'cfp'}, name='R2R', **cfg_over)
+        ref = pg.GlocalTextPathCMTPreTraining(ref_cfg)
+        ours = pretrain_model.GlocalTextPathCMTPreTraining(gcfg.make_config(**cfg_over))
+        sd = synth.seeded_state_dict(ours, seed=WEIGHT_SEED)
+        # the product's state_dict keys must be exactly the reference's
+        ref_keys, our_keys = set(ref.state_dict().keys()), set(sd.keys())
+        assert ref_keys == our_keys, (sorted(ref_keys - our_keys)[:5], sorted(our_keys - ref_keys)[:5])
+        for k, v in ref.state_dict().items():
+            assert tuple(v.shape) == tuple(sd[k].shape), k
+        ref.load_state_dict(sd)
+        ref.tie_weights()
+        ref.eval()
+        batch = synth.make_pretrain_batch(**bkw)
+        store = {'param_names': np.array([n for n, _ in ref.named_parameters()])}
+        for task in TASKS:
+            ref.zero_grad(set_to_none=True)
+            if task == 'cfp':
+                go, vo, fo, to = ref(batch, task, compute_loss=False)
+                loss_vec = cfp_loss_from_outputs(go, vo, fo, to, ref_cfg.cfp_temperature)
+                for k, v in (('gmap_out', go), ('vp_out', vo), ('fused_out', fo), ('txt_out', to)):
+                    store['cfp_' + k] = v.detach().numpy()
+            else:
+                loss_vec = ref(batch, task, compute_loss=True)
+            loss_vec.mean().backward()
+            store[task + '_loss_vec'] = loss_vec.detach().numpy()
+            fp = grad_fingerprint(ref)
+            store[task + '_grad_fp'] = np.stack([fp[n] for n in store['param_names']])
+            with torch.no_grad():
+                if task == 'sap':
+                    gl, ll, fl, _, _ = ref(batch, task, compute_loss=False)
+                    store['sap_global_logits'], store['sap_local_logits'], store['sap_fused_logits'] = \
+                        gl.numpy(), ll.numpy(), fl.numpy()
+                if task == 'mlm':
+                    sc = ref(batch, task, compute_loss=False)
+                    store['mlm_scores_head'] = sc[:, :64].numpy()
+                    store['mlm_scores_lse'] = torch.logsumexp(sc, 1).numpy()
+        # intermediate activations of the backbone (small slices) for debugging / per-module parity
+        with torch.no_grad():
+            b2 = dict(batch)
+            gm, vp, tx = ref.bert(b2['txt_ids'], b2['txt_lens'], b2['traj_view_img_fts'], None, b2['traj_loc_fts'],
+                                  b2['traj_nav_types'], b2['traj_step_lens'], b2['traj_vp_view_lens'], None,
+                                  b2['traj_vpids'], b2['traj_cand_vpids'], b2['gmap_lens'], b2['gmap_step_ids'],
+                                  b2['gmap_pos_fts'], b2['gmap_pair_dists'], b2['gmap_vpids'], b2['vp_pos_fts'],
+                                  return_txt_embeds=True)
+            store['bert_gmap_embeds'] = gm[:, :, :16].numpy()
+            store['bert_vp_embeds'] = vp[:, :, :16].numpy()
+            store['bert_txt_embeds'] = tx[:, :, :16].numpy()
+        path = os.path.join(HERE, name + '.npz')
+        np.savez_compressed(path, **store)
+        print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:] or None)

@@ -1,0 +1,55 @@
+"""The CPU oracle (oracle/goat_oracle.py) against golden vectors produced by the imported reference
+(tests/golden/make_golden_pretrain.py).  This pins the oracle: <= 1e-5 on losses/logits, gradients of
+every parameter to 1e-4 relative on the L2 norm and the leading elements."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, build_case, fingerprint, load_golden, oracle_run, ROOT
+
+SMALL = ['pretrain_small_fixed', 'pretrain_small_ragged']
+ALL = SMALL + (['pretrain_config1'] if os.path.exists(os.path.join(ROOT, 'tests/golden/pretrain_config1.npz')) else [])
+
+
+@pytest.mark.parametrize('case', ALL)
+@pytest.mark.parametrize('task', ['mlm', 'sap', 'cfp'])
+def test_oracle_matches_reference_golden(case, task):
+    gold = load_golden(case)
+    cfg, model, batch = build_case(case)
+    sd = model.state_dict()
+    loss_vec, grads = oracle_run(cfg, sd, batch, task)
+    np.testing.assert_allclose(loss_vec.numpy(), gold[task + '_loss_vec'], rtol=1e-5, atol=1e-5)
+    names = [str(n) for n in gold['param_names']]
+    fp = gold[task + '_grad_fp']
+    worst = 0.0
+    for i, n in enumerate(names):
+        got = fingerprint(grads.get(n))
+        ref = fp[i]
+        scale = max(abs(ref[0]), 1e-6)
+        err = np.abs(got - ref).max() / scale
+        worst = max(worst, err)
+        assert err < 2e-4, (n, got, ref)
+    assert worst < 2e-4
+
+
+@pytest.mark.parametrize('case', SMALL)
+def test_oracle_logits_and_pooled_vectors(case):
+    from oracle import goat_oracle
+    gold = load_golden(case)
+    cfg, model, batch = build_case(case)
+    sd = model.state_dict()
+    with torch.no_grad():
+        gl, ll, fl = goat_oracle.forward(cfg, sd, batch, 'sap', compute_loss=False)
+        go, vo, fo, to = goat_oracle.forward(cfg, sd, batch, 'cfp', compute_loss=False)
+        sc = goat_oracle.forward(cfg, sd, batch, 'mlm', compute_loss=False)
+    for got, key in ((gl, 'sap_global_logits'), (ll, 'sap_local_logits'), (fl, 'sap_fused_logits')):
+        ref = gold[key]
+        assert np.array_equal(np.isinf(got.numpy()), np.isinf(ref))
+        m = ~np.isinf(ref)
+        np.testing.assert_allclose(got.numpy()[m], ref[m], rtol=1e-5, atol=2e-5)
+    for got, key in ((go, 'cfp_gmap_out'), (vo, 'cfp_vp_out'), (fo, 'cfp_fused_out'), (to, 'cfp_txt_out')):
+        np.testing.assert_allclose(got.numpy(), gold[key], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(sc[:, :64].numpy(), gold['mlm_scores_head'], rtol=1e-5, atol=5e-5)
+    np.testing.assert_allclose(torch.logsumexp(sc, 1).numpy(), gold['mlm_scores_lse'], rtol=1e-5, atol=5e-5)

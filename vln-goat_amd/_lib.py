@@ -1,0 +1,96 @@
+"""ctypes binding of libgoat_hip.so (the C ABI declared in include/goat_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+`torch` is imported first on purpose: libgoat_hip.so needs libamdhip64.so.7, and the dynamic loader then
+re-uses the copy PyTorch already loaded, so HIP streams and device pointers are shared with torch.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libgoat_hip.so')
+SOURCES = ['gemm.hip', 'attention.hip', 'rowops.hip']
+
+GOAT_F32, GOAT_BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU = 0, 1, 2, 3, 4
+
+_lib = None
+
+_vp = ctypes.c_void_p
+_i32 = ctypes.c_int
+_i64 = ctypes.c_int64
+_u64 = ctypes.c_uint64
+_f32 = ctypes.c_float
+
+# name -> argtypes; must list every symbol include/goat_hip.h declares (checked by tests/test_abi.py)
+SIGNATURES = {
+    'goat_version': [],
+    'goat_gemm_nt': [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i32],
+    'goat_transpose': [_vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _vp],
+    'goat_ln_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
+    'goat_ln_bwd_ws_floats': [_i32],
+    'goat_ln_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
+    'goat_dropout_add_fwd': [_vp, _i32, _vp, _vp, _vp, _i64, _f32, _u64, _u64, _vp],
+    'goat_dropout_bwd': [_vp, _i32, _vp, _vp, _i64, _f32, _u64, _u64, _vp],
+    'goat_act_bwd': [_vp, _i32, _vp, _vp, _vp, _i64, _i32, _f32, _u64, _u64, _vp],
+    'goat_attn_fwd': [_vp, _i32] + [_vp, _i64, _i64] * 4 + [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _u64, _vp],
+    'goat_attn_bwd': [_vp, _i32] + [_vp, _i64, _i64] * 8 + [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _u64, _vp],
+    'goat_pano_fusion_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
+    'goat_pano_fusion_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
+    'goat_gather_segmean_fwd': [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32],
+    'goat_gather_segmean_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
+    'goat_probe_tr16': [_vp, _vp],
+}
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into csrc/libgoat_hip.so (in-tree, travels with the repo snapshot)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, 'common.hpp'), os.path.join(_HERE, '..', 'include', 'goat_hip.h')]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    for s in srcs:
+        o = s[:-4] + '.o'
+        objs.append(o)
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), out.decode()))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError('link failed: %s\n%s' % (' '.join(cmd), r.stdout.decode()))
+    return LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises loudly if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libgoat_hip.so not found at %s — the GOAT HIP kernels are required (no CPU/eager fallback). '
+                'Run `python -c "import __graft_entry__ as g; g.build()"` from the repo root.' % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, argt in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = argt
+            fn.restype = ctypes.c_int
+        _lib = h
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError('libgoat_hip: %s failed with status %d' % (what, status))

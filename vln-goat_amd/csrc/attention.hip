@@ -1,0 +1,520 @@
+// goat_attn_fwd / goat_attn_bwd: masked multi-head attention (head_dim 64) on MFMA 32x32 tiles.
+//
+// GOAT's sequences are tiny (36 views, <=80..200 tokens, <=~60 map nodes), so instead of flash-style
+// streaming one workgroup owns a whole (sample, head): forward = one wave per 32-query tile with the full
+// score row-block held in accumulators (S^T = K·Q^T, so a softmax row is lane-local: keys live in the
+// accumulator registers, queries across lanes); V (forward) / K, Q_i, dO_i (backward) are staged row-major
+// in LDS and the "transposed" MFMA operands are gathered from there, exploiting that the k-order inside an
+// MFMA step is free as long as A and B agree.  Dropout on the probabilities uses the stateless counter hash
+// of common.hpp and is regenerated in the backward pass.
+#include "common.hpp"
+
+namespace {
+
+constexpr int HD = 64;  // head dim
+
+struct AttnArgs {
+  const void *Q, *K, *V, *O, *dO;
+  void *Ow, *dQ, *dK, *dV;
+  int64_t q_rs, q_bs, k_rs, k_bs, v_rs, v_bs, o_rs, o_bs, do_rs, do_bs;
+  int64_t dq_rs, dq_bs, dk_rs, dk_bs, dv_rs, dv_bs;
+  const float *kmask, *bias;
+  float* lse;
+  float* dbias;
+  int B, nh, Lq, Lk;
+  float scale, p;
+  uint64_t seed, offset;
+  const uint64_t* rng_dev;
+};
+
+template <typename T> struct AT {
+  typedef typename FragT<T>::type Frag;
+  static constexpr int NE = DT<T>::EPC;                 // elements per 16-B chunk
+  static constexpr int ROWB = HD * (int)sizeof(T);      // bytes per head row
+  static constexpr int KSTEPS = ROWB / 32;              // 32-byte k-steps over d (bf16 4, f32 8)
+  static constexpr int LSTR = HD + NE;                  // LDS row stride (elements) of [row][64] tiles
+  static constexpr int TSTEPS = 32 / (2 * NE);          // k-steps over a 32-wide tile (bf16 2, f32 4)
+  static constexpr int PSTR = 32 + NE;                  // LDS row stride of [32][32] tiles
+};
+
+template <typename T>
+__device__ __forceinline__ typename AT<T>::Frag zero_frag() {
+  typename AT<T>::Frag f;
+#pragma unroll
+  for (int e = 0; e < AT<T>::NE; ++e) f[e] = (T)0.f;
+  return f;
+}
+
+// 16-B chunk (ks, hi) of a 64-wide row in global memory
+template <typename T>
+__device__ __forceinline__ typename AT<T>::Frag gfrag(const T* row_ptr, bool valid, int ks, int hi) {
+  typedef typename AT<T>::Frag Frag;
+  if (!valid) return zero_frag<T>();
+  return *reinterpret_cast<const Frag*>(row_ptr + (ks * 2 + hi) * AT<T>::NE);
+}
+
+// gather an MFMA B fragment "fixed column, accumulator-pattern rows" from a row-major LDS tile
+template <typename T>
+__device__ __forceinline__ typename AT<T>::Frag gather_crow(const T* lds, int stride, int row_base, int step, int col,
+                                                             int lane) {
+  typename AT<T>::Frag f;
+#pragma unroll
+  for (int e = 0; e < AT<T>::NE; ++e) f[e] = lds[(row_base + c_row(step * AT<T>::NE + e, lane)) * stride + col];
+  return f;
+}
+// gather "fixed column, rows (2*step+hi)*NE + e"
+template <typename T>
+__device__ __forceinline__ typename AT<T>::Frag gather_lin(const T* lds, int stride, int step, int hi, int col) {
+  typename AT<T>::Frag f;
+#pragma unroll
+  for (int e = 0; e < AT<T>::NE; ++e) f[e] = lds[((2 * step + hi) * AT<T>::NE + e) * stride + col];
+  return f;
+}
+template <typename T>
+__device__ __forceinline__ typename AT<T>::Frag acc_frag(const f32x16& a, int step) {
+  typename AT<T>::Frag f;
+#pragma unroll
+  for (int e = 0; e < AT<T>::NE; ++e) f[e] = from_f<T>(a[step * AT<T>::NE + e]);
+  return f;
+}
+
+// cooperative copy of `nrows` 64-wide rows (global, strided) into LDS [rows_pad][LSTR]; rows >= nrows zero
+template <typename T>
+__device__ __forceinline__ void stage_rows(T* lds, const T* g, int64_t rs, int row0, int nrows_valid, int rows_pad,
+                                           int tid, int nthreads) {
+  constexpr int CPR = HD / AT<T>::NE;  // chunks per row
+  for (int c = tid; c < rows_pad * CPR; c += nthreads) {
+    int r = c / CPR, cc = c % CPR;
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (row0 + r < nrows_valid) v = *reinterpret_cast<const uint4*>(g + (int64_t)(row0 + r) * rs + cc * AT<T>::NE);
+    *reinterpret_cast<uint4*>(lds + r * AT<T>::LSTR + cc * AT<T>::NE) = v;
+  }
+}
+
+// ======================================================================================== forward
+template <typename T, int NKT>
+__global__ void attn_fwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename AT<T>::Frag Frag;
+  constexpr int KSTEPS = AT<T>::KSTEPS, LSTR = AT<T>::LSTR, TSTEPS = AT<T>::TSTEPS;
+  T* vl = reinterpret_cast<T*>(smem);  // [NKT*32][LSTR]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+  const int q0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 32;
+
+  const T* Qb = reinterpret_cast<const T*>(p.Q) + b * p.q_bs + h * HD;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + b * p.k_bs + h * HD;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + b * p.v_bs + h * HD;
+  T* Ob = reinterpret_cast<T*>(p.Ow) + b * p.o_bs + h * HD;
+
+  stage_rows<T>(vl, Vb, p.v_rs, 0, p.Lk, NKT * 32, tid, blockDim.x);
+
+  const int q = q0 + l31;
+  const bool qv = q < p.Lq;
+  Frag qf[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = gfrag<T>(Qb + (int64_t)q * p.q_rs, qv, ks, hi);
+
+  // S^T tiles: rows = keys (accumulator regs), cols = queries (lanes)
+  f32x16 s[NKT];
+#pragma unroll
+  for (int jt = 0; jt < NKT; ++jt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[jt][r] = 0.f;
+    const int key = jt * 32 + l31;
+    const bool kv = key < p.Lk;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      Frag kf = gfrag<T>(Kb + (int64_t)key * p.k_rs, kv, ks, hi);
+      mma32(s[jt], kf, qf[ks]);
+    }
+  }
+
+  // scale + masks, row max
+  float m = -INFINITY;
+#pragma unroll
+  for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = jt * 32 + c_row(r, lane);
+      float v = -INFINITY;
+      if (key < p.Lk) {
+        v = s[jt][r] * p.scale;
+        if (p.kmask) v += p.kmask[(int64_t)b * p.Lk + key];
+        if (p.bias && qv) v += p.bias[((int64_t)b * p.Lq + q) * p.Lk + key];
+      }
+      s[jt][r] = v;
+      m = fmaxf(m, v);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float l = 0.f;
+  const float msafe = (m == -INFINITY) ? 0.f : m;
+#pragma unroll
+  for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float e = __expf(s[jt][r] - msafe);
+      s[jt][r] = e;
+      l += e;
+    }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  if (qv && hi == 0) p.lse[((int64_t)b * p.nh + h) * p.Lq + q] = (l > 0.f) ? (msafe + __logf(l)) : -INFINITY;
+
+  const bool drop = p.p > 0.f;
+  const uint32_t thr = goat_thr24(p.p);
+  const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
+  const uint64_t ctr0 = p.offset + (((uint64_t)b * p.nh + h) * p.Lq + q) * (uint64_t)p.Lk;
+  const uint64_t seed = p.seed + (p.rng_dev ? *p.rng_dev : 0ull);
+#pragma unroll
+  for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float pv = s[jt][r] * inv;
+      if (drop) {
+        const int key = jt * 32 + c_row(r, lane);
+        pv = goat_keep(seed, ctr0 + key, thr) ? pv * keep_scale : 0.f;
+      }
+      s[jt][r] = pv;
+    }
+
+  __syncthreads();  // V staged
+
+  // O (q x d) = P (q x keys) · V (keys x d)
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+    for (int st = 0; st < TSTEPS; ++st) {
+      Frag pa = acc_frag<T>(s[jt], st);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        Frag vb = gather_crow<T>(vl, LSTR, jt * 32, st, dt * 32 + l31, lane);
+        mma32(o[dt], pa, vb);
+      }
+    }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = q0 + c_row(r, lane);
+      if (qq < p.Lq) Ob[(int64_t)qq * p.o_rs + dt * 32 + l31] = from_f<T>(o[dt][r]);
+    }
+}
+
+// ======================================================================================== backward
+// One workgroup per (b, h); wave w owns key tile w and loops over the query tiles.
+template <typename T, int NKT>
+__global__ void attn_bwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename AT<T>::Frag Frag;
+  constexpr int KSTEPS = AT<T>::KSTEPS, LSTR = AT<T>::LSTR, TSTEPS = AT<T>::TSTEPS, PSTR = AT<T>::PSTR;
+  constexpr int NE = AT<T>::NE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+  const int nthreads = NKT * 64;
+
+  // LDS carve-up
+  T* kl = reinterpret_cast<T*>(smem);                 // [NKT*32][LSTR]   all keys
+  T* ql = kl + NKT * 32 * LSTR;                       // [32][LSTR]       Q_i
+  T* dol = ql + 32 * LSTR;                            // [32][LSTR]       dO_i
+  T* pt = dol + 32 * LSTR + wave * 32 * PSTR;         // per-wave [32 keys][PSTR] tile (P then dS)
+  float* dql = reinterpret_cast<float*>(dol + 32 * LSTR + NKT * 32 * PSTR);  // [32][HD] f32
+  float* rowd = dql + 32 * HD;                        // [32] D_i
+  float* rowl = rowd + 32;                            // [32] lse_i
+
+  const T* Qb = reinterpret_cast<const T*>(p.Q) + b * p.q_bs + h * HD;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + b * p.k_bs + h * HD;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + b * p.v_bs + h * HD;
+  const T* Ob = reinterpret_cast<const T*>(p.O) + b * p.o_bs + h * HD;
+  const T* dOb = reinterpret_cast<const T*>(p.dO) + b * p.do_bs + h * HD;
+  T* dQb = reinterpret_cast<T*>(p.dQ) + b * p.dq_bs + h * HD;
+  T* dKb = reinterpret_cast<T*>(p.dK) + b * p.dk_bs + h * HD;
+  T* dVb = reinterpret_cast<T*>(p.dV) + b * p.dv_bs + h * HD;
+
+  stage_rows<T>(kl, Kb, p.k_rs, 0, p.Lk, NKT * 32, tid, nthreads);
+
+  const int key_l = wave * 32 + l31;  // this lane's key when keys are across lanes (A operand rows)
+  const bool kvl = key_l < p.Lk;
+  Frag kf[KSTEPS], vf[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    kf[ks] = gfrag<T>(Kb + (int64_t)key_l * p.k_rs, kvl, ks, hi);
+    vf[ks] = gfrag<T>(Vb + (int64_t)key_l * p.v_rs, kvl, ks, hi);
+  }
+  float kmv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = wave * 32 + c_row(r, lane);
+    kmv[r] = (key < p.Lk) ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + key] : 0.f) : -INFINITY;
+  }
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+
+  const bool drop = p.p > 0.f;
+  const uint32_t thr = goat_thr24(p.p);
+  const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
+  const uint64_t seed = p.seed + (p.rng_dev ? *p.rng_dev : 0ull);
+
+  const int nqt = (p.Lq + 31) / 32;
+  for (int it = 0; it < nqt; ++it) {
+    const int q0 = it * 32;
+    __syncthreads();  // previous iteration's consumers done
+    stage_rows<T>(ql, Qb, p.q_rs, q0, p.Lq, 32, tid, nthreads);
+    stage_rows<T>(dol, dOb, p.do_rs, q0, p.Lq, 32, tid, nthreads);
+    for (int i = tid; i < 32 * HD; i += nthreads) dql[i] = 0.f;
+    if (wave == 0) {  // D_q = sum_d dO*O ; lse
+      const int qq = q0 + l31;
+      float dsum = 0.f;
+      if (qq < p.Lq) {
+        const T* orow = Ob + (int64_t)qq * p.o_rs + hi * 32;
+        const T* drow = dOb + (int64_t)qq * p.do_rs + hi * 32;
+#pragma unroll
+        for (int c = 0; c < 32 / NE; ++c) {
+          Chunk<T> a, d2;
+          a.load(orow + c * NE);
+          d2.load(drow + c * NE);
+#pragma unroll
+          for (int e = 0; e < NE; ++e) dsum += a.v[e] * d2.v[e];
+        }
+      }
+      dsum += __shfl_xor(dsum, 32, 64);
+      if (hi == 0) {
+        rowd[l31] = dsum;
+        rowl[l31] = (qq < p.Lq) ? p.lse[((int64_t)b * p.nh + h) * p.Lq + qq] : 0.f;
+      }
+    }
+    __syncthreads();
+
+    const int q = q0 + l31;
+    const bool qv = q < p.Lq;
+    // S^T (keys x q) and dPd^T (keys x q)
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      Frag qf = *reinterpret_cast<const Frag*>(ql + l31 * LSTR + (ks * 2 + hi) * NE);
+      Frag df = *reinterpret_cast<const Frag*>(dol + l31 * LSTR + (ks * 2 + hi) * NE);
+      mma32(s, kf[ks], qf);
+      mma32(dp, vf[ks], df);
+    }
+    const float lse_q = rowl[l31];
+    const float d_q = rowd[l31];
+    const bool lse_ok = (lse_q != -INFINITY);
+    const uint64_t ctr0 = p.offset + (((uint64_t)b * p.nh + h) * p.Lq + q) * (uint64_t)p.Lk;
+    f32x16 pd, ds;  // dropped probs ; dS (unscaled)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = wave * 32 + c_row(r, lane);
+      float pr = 0.f;
+      if (qv && key < p.Lk && lse_ok) {
+        float v = s[r] * p.scale + kmv[r];
+        if (p.bias) v += p.bias[((int64_t)b * p.Lq + q) * p.Lk + key];
+        pr = __expf(v - lse_q);
+      }
+      float keep = 1.f;
+      if (drop) keep = goat_keep(seed, ctr0 + key, thr) ? keep_scale : 0.f;
+      pd[r] = pr * keep;
+      ds[r] = pr * (dp[r] * keep - d_q);
+    }
+    if (p.dbias) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = wave * 32 + c_row(r, lane);
+        if (qv && key < p.Lk) atomicAdd(p.dbias + ((int64_t)b * p.Lq + q) * p.Lk + key, ds[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ds[r] *= p.scale;
+
+    // dQ_i partial (q x d) += dS (q x keys_w) · K_w (keys x d)   [A from accumulator regs, B gathered]
+    {
+      f32x16 dq[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < TSTEPS; ++st) {
+        Frag a = acc_frag<T>(ds, st);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          Frag kb = gather_crow<T>(kl, LSTR, wave * 32, st, dt * 32 + l31, lane);
+          mma32(dq[dt], a, kb);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(&dql[c_row(r, lane) * HD + dt * 32 + l31], dq[dt][r]);
+    }
+
+    // dV_w (keys x d) += Pd^T (keys x q) · dO_i (q x d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pt[c_row(r, lane) * PSTR + l31] = from_f<T>(pd[r]);
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < TSTEPS; ++st) {
+      Frag a = *reinterpret_cast<const Frag*>(pt + l31 * PSTR + (2 * st + hi) * NE);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        Frag bb = gather_lin<T>(dol, LSTR, st, hi, dt * 32 + l31);
+        mma32(dv[dt], a, bb);
+      }
+    }
+    __syncthreads();
+    // dK_w (keys x d) += dS^T (keys x q) · Q_i (q x d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pt[c_row(r, lane) * PSTR + l31] = from_f<T>(ds[r]);
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < TSTEPS; ++st) {
+      Frag a = *reinterpret_cast<const Frag*>(pt + l31 * PSTR + (2 * st + hi) * NE);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        Frag bb = gather_lin<T>(ql, LSTR, st, hi, dt * 32 + l31);
+        mma32(dk[dt], a, bb);
+      }
+    }
+    // write dQ_i (all waves' atomics are complete after this barrier)
+    __syncthreads();
+    for (int c = tid; c < 32 * (HD / NE); c += nthreads) {
+      int r = c / (HD / NE), cc = c % (HD / NE);
+      if (q0 + r < p.Lq) {
+        Chunk<T> ch;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) ch.v[e] = dql[r * HD + cc * NE + e];
+        ch.store(dQb + (int64_t)(q0 + r) * p.dq_rs + cc * NE);
+      }
+    }
+  }
+
+  // dK_w, dV_w -> global (C layout: col = d (lanes), rows = keys)
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = wave * 32 + c_row(r, lane);
+      if (key < p.Lk) {
+        dKb[(int64_t)key * p.dk_rs + dt * 32 + l31] = from_f<T>(dk[dt][r]);
+        dVb[(int64_t)key * p.dv_rs + dt * 32 + l31] = from_f<T>(dv[dt][r]);
+      }
+    }
+}
+
+template <typename T>
+size_t fwd_smem(int nkt) { return (size_t)nkt * 32 * AT<T>::LSTR * sizeof(T); }
+template <typename T>
+size_t bwd_smem(int nkt) {
+  return ((size_t)nkt * 32 * AT<T>::LSTR + 2 * 32 * AT<T>::LSTR + (size_t)nkt * 32 * AT<T>::PSTR) * sizeof(T) +
+         (32 * HD + 64) * sizeof(float);
+}
+
+template <typename K>
+int set_smem(K kern, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+template <typename T, int NKT>
+int launch_fwd(hipStream_t st, const AttnArgs& a) {
+  const int nqt = (a.Lq + 31) / 32;
+  const int wpb = nqt < 8 ? nqt : 8;  // waves per block
+  dim3 grid(a.B * a.nh, (nqt + wpb - 1) / wpb);
+  size_t sm = fwd_smem<T>(NKT);
+  int e = set_smem(attn_fwd_kernel<T, NKT>, sm);
+  if (e) return e;
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NKT>), grid, dim3(64 * wpb), sm, st, a);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T, int NKT>
+int launch_bwd(hipStream_t st, const AttnArgs& a) {
+  size_t sm = bwd_smem<T>(NKT);
+  if (sm > 160 * 1024) return GOAT_E_SHAPE;
+  int e = set_smem(attn_bwd_kernel<T, NKT>, sm);
+  if (e) return e;
+  hipLaunchKernelGGL((attn_bwd_kernel<T, NKT>), dim3(a.B * a.nh), dim3(64 * NKT), sm, st, a);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+int dispatch(hipStream_t st, const AttnArgs& a, bool bwd) {
+  const int nkt = (a.Lk + 31) / 32;
+#define GOAT_ATTN_CASE(N) \
+  case N: return bwd ? launch_bwd<T, N>(st, a) : launch_fwd<T, N>(st, a);
+  switch (nkt) {
+    GOAT_ATTN_CASE(1) GOAT_ATTN_CASE(2) GOAT_ATTN_CASE(3) GOAT_ATTN_CASE(4)
+    GOAT_ATTN_CASE(5) GOAT_ATTN_CASE(6) GOAT_ATTN_CASE(7) GOAT_ATTN_CASE(8)
+  }
+#undef GOAT_ATTN_CASE
+  return GOAT_E_SHAPE;
+}
+
+bool strides_ok(int dtype, int64_t rs, int64_t bs, const void* ptr) {
+  const int epc = dtype == GOAT_BF16 ? 8 : 4;
+  return (rs % epc) == 0 && (bs % epc) == 0 && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0;
+}
+
+}  // namespace
+
+extern "C" int goat_attn_fwd(void* stream, int dtype, const void* Q, int64_t q_rs, int64_t q_bs, const void* K,
+                             int64_t k_rs, int64_t k_bs, const void* V, int64_t v_rs, int64_t v_bs, void* O,
+                             int64_t o_rs, int64_t o_bs, const float* kmask, const float* bias, float* lse, int B,
+                             int nh, int Lq, int Lk, float scale, float p, uint64_t seed, uint64_t offset,
+                             const uint64_t* rng_dev) {
+  if (!Q || !K || !V || !O || !lse) return GOAT_E_ARG;
+  if (B <= 0 || nh <= 0 || Lq <= 0 || Lk <= 0 || Lk > 256) return GOAT_E_SHAPE;
+  if (dtype != GOAT_F32 && dtype != GOAT_BF16) return GOAT_E_ARG;
+  if (!strides_ok(dtype, q_rs, q_bs, Q) || !strides_ok(dtype, k_rs, k_bs, K) || !strides_ok(dtype, v_rs, v_bs, V))
+    return GOAT_E_SHAPE;
+  AttnArgs a = {};
+  a.Q = Q; a.K = K; a.V = V; a.Ow = O;
+  a.q_rs = q_rs; a.q_bs = q_bs; a.k_rs = k_rs; a.k_bs = k_bs; a.v_rs = v_rs; a.v_bs = v_bs; a.o_rs = o_rs; a.o_bs = o_bs;
+  a.kmask = kmask; a.bias = bias; a.lse = lse;
+  a.B = B; a.nh = nh; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.p = p; a.seed = seed; a.offset = offset; a.rng_dev = rng_dev;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return dtype == GOAT_BF16 ? dispatch<bf16_t>(st, a, false) : dispatch<float>(st, a, false);
+}
+
+extern "C" int goat_attn_bwd(void* stream, int dtype, const void* Q, int64_t q_rs, int64_t q_bs, const void* K,
+                             int64_t k_rs, int64_t k_bs, const void* V, int64_t v_rs, int64_t v_bs, const void* O,
+                             int64_t o_rs, int64_t o_bs, const void* dO, int64_t do_rs, int64_t do_bs, void* dQ,
+                             int64_t dq_rs, int64_t dq_bs, void* dK, int64_t dk_rs, int64_t dk_bs, void* dV,
+                             int64_t dv_rs, int64_t dv_bs, const float* kmask, const float* bias, const float* lse,
+                             float* dbias, int B, int nh, int Lq, int Lk, float scale, float p, uint64_t seed,
+                             uint64_t offset, const uint64_t* rng_dev) {
+  if (!Q || !K || !V || !O || !dO || !dQ || !dK || !dV || !lse) return GOAT_E_ARG;
+  if (B <= 0 || nh <= 0 || Lq <= 0 || Lk <= 0 || Lk > 256) return GOAT_E_SHAPE;
+  if (dtype != GOAT_F32 && dtype != GOAT_BF16) return GOAT_E_ARG;
+  if (!strides_ok(dtype, q_rs, q_bs, Q) || !strides_ok(dtype, k_rs, k_bs, K) || !strides_ok(dtype, v_rs, v_bs, V) ||
+      !strides_ok(dtype, o_rs, o_bs, O) || !strides_ok(dtype, do_rs, do_bs, dO) || !strides_ok(dtype, dq_rs, dq_bs, dQ))
+    return GOAT_E_SHAPE;
+  AttnArgs a = {};
+  a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV;
+  a.q_rs = q_rs; a.q_bs = q_bs; a.k_rs = k_rs; a.k_bs = k_bs; a.v_rs = v_rs; a.v_bs = v_bs; a.o_rs = o_rs; a.o_bs = o_bs;
+  a.do_rs = do_rs; a.do_bs = do_bs; a.dq_rs = dq_rs; a.dq_bs = dq_bs; a.dk_rs = dk_rs; a.dk_bs = dk_bs;
+  a.dv_rs = dv_rs; a.dv_bs = dv_bs;
+  a.kmask = kmask; a.bias = bias; a.lse = const_cast<float*>(lse); a.dbias = dbias;
+  a.B = B; a.nh = nh; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.p = p; a.seed = seed; a.offset = offset; a.rng_dev = rng_dev;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return dtype == GOAT_BF16 ? dispatch<bf16_t>(st, a, true) : dispatch<float>(st, a, true);
+}

@@ -1,0 +1,127 @@
+// Shared device helpers for the gfx950 kernels of libgoat_hip.so (wave64, MFMA 32x32 fragments).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/goat_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+
+#define GOAT_LAUNCH_CHECK()                          \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) return (int)e__;          \
+  } while (0)
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int id = GOAT_F32;
+  static constexpr int EPC = 4;  // elements per 16-byte chunk
+};
+template <> struct DT<bf16_t> {
+  static constexpr int id = GOAT_BF16;
+  static constexpr int EPC = 8;
+};
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return (bf16_t)v; }
+
+// ---- 16-byte chunk load/store as floats -------------------------------------------------------
+template <typename T> struct Chunk;  // EPC values as float
+template <> struct Chunk<float> {
+  float v[4];
+  __device__ __forceinline__ void load(const float* p) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+template <> struct Chunk<bf16_t> {
+  float v[8];
+  __device__ __forceinline__ void load(const bf16_t* p) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+  }
+  __device__ __forceinline__ void store(bf16_t* p) const {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  }
+};
+
+// ---- counter-based dropout RNG -----------------------------------------------------------------
+// keep(i) for flat element index i under (seed, offset): two rounds of a multiply-xorshift hash of the
+// 64-bit counter; 24-bit uniform compared with p.  Stateless, so the backward pass regenerates the mask.
+__device__ __forceinline__ uint32_t goat_hash(uint64_t seed, uint64_t ctr) {
+  uint64_t x = ctr + seed * 0x9E3779B97F4A7C15ull;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return (uint32_t)x;
+}
+__device__ __forceinline__ bool goat_keep(uint64_t seed, uint64_t ctr, uint32_t thr24) {
+  return (goat_hash(seed, ctr) >> 8) >= thr24;
+}
+__host__ __device__ __forceinline__ uint32_t goat_thr24(float p) {
+  return (uint32_t)(p * 16777216.0f);
+}
+
+// ---- wave64 reductions ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// reduce across the 32 lanes of each half-wave (lanes sharing lane>>5)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- MFMA 32x32 tile step on a pair of 16-byte operand chunks --------------------------------------
+// Lane l holds, for A: row (l&31) of the 32-row tile, the 16-byte k-chunk number (l>>5) of a 32-byte
+// k-step; same for B.  bf16: one v_mfma_f32_32x32x16_bf16.  f32: the chunk is 4 floats and the k-order
+// inside the step is permuted identically for A and B (a dot product is order-free), so four
+// v_mfma_f32_32x32x2_f32 consume it exactly.
+// C/D layout (both): col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5), r in [0,16).
+__device__ __forceinline__ void mma32(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16& acc, const f32x4& a, const f32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+}
+template <typename T> struct FragT;
+template <> struct FragT<float> { typedef f32x4 type; };
+template <> struct FragT<bf16_t> { typedef bf16x8 type; };
+
+__device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}

@@ -1,0 +1,658 @@
+// HBM-bound row kernels: residual+dropout+LayerNorm (fwd/bwd), dropout, transpose(+column sums),
+// adaptive panorama fusion, gather / segment-mean.  One wave64 per 768-wide row, 16-byte vector loads,
+// wavefront shuffles for the reductions, statistics in f32.
+#include "common.hpp"
+
+namespace {
+
+constexpr int MAXC = 8;  // 16-B chunks per lane kept in registers: H <= 64*MAXC*EPC
+
+// ------------------------------------------------------------------------------------ LayerNorm fwd
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, float p, uint64_t seed, uint64_t offset,
+                                                     const uint64_t* __restrict__ rng_dev, T* __restrict__ y, T* __restrict__ zout, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int M, int H) {
+  constexpr int EPC = DT<T>::EPC;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  if (rng_dev) seed += *rng_dev;
+  const int nchunk = H / EPC;
+  const bool drop = p > 0.f;
+  const uint32_t thr = goat_thr24(p);
+  const float ks = drop ? 1.f / (1.f - p) : 1.f;
+  Chunk<T> v[MAXC];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const int64_t base = (int64_t)row * H + c * EPC;
+      v[i].load(x + base);
+      if (drop) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[i].v[e] = goat_keep(seed, offset + base + e, thr) ? v[i].v[e] * ks : 0.f;
+      }
+      if (res) {
+        Chunk<T> r;
+        r.load(res + base);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[i].v[e] += r.v[e];
+      }
+      // round z to the storage type so forward statistics and backward recomputation agree
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[i].v[e] = to_f(from_f<T>(v[i].v[e]));
+      if (zout) v[i].store(zout + base);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) sum += v[i].v[e];
+    }
+  }
+  const float mu = wave_sum(sum) / H;
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { float d = v[i].v[e] - mu; var += d * d; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(var) / H + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      Chunk<T> o;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) o.v[e] = (v[i].v[e] - mu) * rs * gamma[c * EPC + e] + beta[c * EPC + e];
+      o.store(y + (int64_t)row * H + c * EPC);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm bwd
+// grid = NPART blocks of 4 waves; wave w of block b walks rows (b*4+w), +4*NPART, ...
+// partial dgamma/dbeta per block -> ws[block][2][H]; ln_bwd_reduce sums them.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float p, uint64_t seed,
+                                                     uint64_t offset, const uint64_t* __restrict__ rng_dev,
+                                                     T* __restrict__ dx, T* __restrict__ dres,
+                                                     float* __restrict__ ws, int M, int H) {
+  constexpr int EPC = DT<T>::EPC;
+  extern __shared__ float lsum[];  // [4][2][H]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (rng_dev) seed += *rng_dev;
+  const int nchunk = H / EPC;
+  const bool drop = p > 0.f;
+  const uint32_t thr = goat_thr24(p);
+  const float ks = drop ? 1.f / (1.f - p) : 1.f;
+  float dg[MAXC][EPC], db[MAXC][EPC], g[MAXC][EPC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      dg[i][e] = 0.f; db[i][e] = 0.f;
+      const int c = lane + 64 * i;
+      g[i][e] = (c < nchunk) ? gamma[c * EPC + e] : 0.f;
+    }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    Chunk<T> vdy[MAXC], vz[MAXC];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        const int64_t base = (int64_t)row * H + c * EPC;
+        vdy[i].load(dy + base);
+        vz[i].load(z + base);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float xh = (vz[i].v[e] - mu) * rs;
+          const float d = vdy[i].v[e];
+          dg[i][e] += d * xh;
+          db[i][e] += d;
+          const float dxh = d * g[i][e];
+          c1 += dxh;
+          c2 += dxh * xh;
+          vz[i].v[e] = xh;
+          vdy[i].v[e] = dxh;
+        }
+      }
+    }
+    c1 = wave_sum(c1) / H;
+    c2 = wave_sum(c2) / H;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        const int64_t base = (int64_t)row * H + c * EPC;
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.v[e] = (vdy[i].v[e] - c1 - vz[i].v[e] * c2) * rs;
+        if (dres) o.store(dres + base);
+        if (drop) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) o.v[e] = goat_keep(seed, offset + base + e, thr) ? o.v[e] * ks : 0.f;
+        }
+        if (dx) o.store(dx + base);
+      }
+    }
+  }
+  // block reduction of the column partials
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        lsum[(wave * 2 + 0) * H + c * EPC + e] = dg[i][e];
+        lsum[(wave * 2 + 1) * H + c * EPC + e] = db[i][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * H; i += 256) {
+    const int which = i / H, col = i % H;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += lsum[(w * 2 + which) * H + col];
+    ws[(int64_t)blockIdx.x * 2 * H + i] = s;
+  }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     int nparts, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * H) return;
+  float s = 0.f;
+  for (int b = 0; b < nparts; ++b) s += ws[(int64_t)b * 2 * H + i];
+  if (i < H) dgamma[i] = s; else dbeta[i - H] = s;
+}
+
+// ------------------------------------------------------------------------------------ dropout (+add)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                      int64_t n, float p, uint64_t seed, uint64_t offset,
+                                                      const uint64_t* __restrict__ rng_dev) {
+  constexpr int EPC = DT<T>::EPC;
+  if (rng_dev) seed += *rng_dev;
+  const uint32_t thr = goat_thr24(p);
+  const bool drop = p > 0.f;
+  const float ks = drop ? 1.f / (1.f - p) : 1.f;
+  const int64_t nchunk = n / EPC;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * blockDim.x) {
+    Chunk<T> v;
+    v.load(x + c * EPC);
+    if (drop) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v.v[e] = goat_keep(seed, offset + c * EPC + e, thr) ? v.v[e] * ks : 0.f;
+    }
+    if (!BWD && res) {
+      Chunk<T> r;
+      r.load(res + c * EPC);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v.v[e] += r.v[e];
+    }
+    v.store(y + c * EPC);
+  }
+  // tail
+  if (blockIdx.x == 0 && threadIdx.x < (n - nchunk * EPC)) {
+    const int64_t i = nchunk * EPC + threadIdx.x;
+    float v = to_f(x[i]);
+    if (drop) v = goat_keep(seed, offset + i, thr) ? v * ks : 0.f;
+    if (!BWD && res) v += to_f(res[i]);
+    y[i] = from_f<T>(v);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------ activation backward
+// dx = dropmask(dy) * act'(u)   (act: 1 gelu, 2 relu): backward of  h = dropout_p(act(u)).
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ u, T* __restrict__ dx,
+                                                      int64_t n, int act, float p, uint64_t seed, uint64_t offset,
+                                                      const uint64_t* __restrict__ rng_dev) {
+  constexpr int EPC = DT<T>::EPC;
+  if (rng_dev) seed += *rng_dev;
+  const uint32_t thr = goat_thr24(p);
+  const bool drop = p > 0.f;
+  const float ks = drop ? 1.f / (1.f - p) : 1.f;
+  const int64_t nchunk = n / EPC;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * blockDim.x) {
+    Chunk<T> d, uu;
+    d.load(dy + c * EPC);
+    uu.load(u + c * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float g = d.v[e];
+      if (drop) g = goat_keep(seed, offset + c * EPC + e, thr) ? g * ks : 0.f;
+      g *= (act == 1) ? dgelu_f(uu.v[e]) : (uu.v[e] > 0.f ? 1.f : 0.f);
+      d.v[e] = g;
+    }
+    d.store(dx + c * EPC);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - nchunk * EPC)) {
+    const int64_t i = nchunk * EPC + threadIdx.x;
+    float g = to_f(dy[i]);
+    const float uv = to_f(u[i]);
+    if (drop) g = goat_keep(seed, offset + i, thr) ? g * ks : 0.f;
+    g *= (act == 1) ? dgelu_f(uv) : (uv > 0.f ? 1.f : 0.f);
+    dx[i] = from_f<T>(g);
+  }
+}
+
+// ------------------------------------------------------------------------------------ transpose
+// 64x64 tiles through LDS; each block walks RT consecutive row tiles of one column tile so the column
+// sums (bias gradient) cost one atomic per column per block.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, int64_t ld_in, T* __restrict__ out,
+                                                        int64_t ld_out, int R, int C, float* __restrict__ colsum, int RT) {
+  __shared__ T tile[64][66];
+  __shared__ float csum[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty 0..3
+  const int c0 = blockIdx.y * 64;
+  float acc = 0.f;
+  for (int t = 0; t < RT; ++t) {
+    const int r0 = (blockIdx.x * RT + t) * 64;
+    if (r0 >= R && r0 >= (int)ld_out) break;
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+      const int r = r0 + i, c = c0 + tx;
+      T v = (T)0.f;
+      if (r < R && c < C) v = in[(int64_t)r * ld_in + c];
+      tile[i][tx] = v;
+      acc += to_f(v);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+      const int c = c0 + i, r = r0 + tx;
+      if (c < C && r < (int)ld_out) out[(int64_t)c * ld_out + r] = tile[tx][i];
+    }
+    __syncthreads();
+  }
+  if (colsum) {
+    csum[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c0 + tx < C) atomicAdd(colsum + c0 + tx, csum[0][tx] + csum[1][tx] + csum[2][tx] + csum[3][tx]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ pano fusion
+// one block (4 waves) per panorama; V <= 64 slots.  score_v = tanh(x_v·a + a0); w = softmax_v(score)
+template <typename T>
+__global__ __launch_bounds__(256) void pano_fusion_fwd_kernel(const T* __restrict__ x, const float* __restrict__ a,
+                                                              const float* __restrict__ a0, T* __restrict__ fused,
+                                                              float* __restrict__ wsave, int V, int H) {
+  __shared__ float sc[64];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* xb = x + (int64_t)n * V * H;
+  for (int v = wave; v < V; v += 4) {
+    float s = 0.f;
+    for (int i = lane; i < H; i += 64) s += to_f(xb[(int64_t)v * H + i]) * a[i];
+    s = wave_sum(s);
+    if (lane == 0) sc[v] = tanhf(s + a0[0]);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float v = lane < V ? sc[lane] : -INFINITY;
+    float m = wave_max(v);
+    float e = lane < V ? __expf(v - m) : 0.f;
+    float l = wave_sum(e);
+    if (lane < V) { sc[lane] = e / l; wsave[(int64_t)n * V + lane] = e / l; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H; i += 256) {
+    float s = 0.f;
+    for (int v = 0; v < V; ++v) s += sc[v] * to_f(xb[(int64_t)v * H + i]);
+    fused[(int64_t)n * H + i] = from_f<T>(s);
+  }
+}
+
+// backward: df[H] given.  g_v = x_v·df ; d(softmax in)_v = w_v (g_v - sum_u w_u g_u) ;
+// dscore_v = d(softmax in)_v * (1 - tanh^2(x_v·a + a0)) ; dx_v = w_v*df + dscore_v * a
+template <typename T>
+__global__ __launch_bounds__(256) void pano_fusion_bwd_kernel(const T* __restrict__ x, const float* __restrict__ a,
+                                                              const float* __restrict__ a0,
+                                                              const float* __restrict__ wsave, const T* __restrict__ dfused,
+                                                              T* __restrict__ dx, float* __restrict__ da,
+                                                              float* __restrict__ da0, int V, int H) {
+  __shared__ float gl[64], tl[64], dsc[64];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* xb = x + (int64_t)n * V * H;
+  const T* df = dfused + (int64_t)n * H;
+  for (int v = wave; v < V; v += 4) {
+    float g = 0.f, s = 0.f;
+    for (int i = lane; i < H; i += 64) {
+      const float xv = to_f(xb[(int64_t)v * H + i]);
+      g += xv * to_f(df[i]);
+      s += xv * a[i];
+    }
+    g = wave_sum(g);
+    s = wave_sum(s);
+    if (lane == 0) { gl[v] = g; tl[v] = tanhf(s + a0[0]); }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float w = lane < V ? wsave[(int64_t)n * V + lane] : 0.f;
+    const float g = lane < V ? gl[lane] : 0.f;
+    const float wg = wave_sum(w * g);
+    if (lane < V) dsc[lane] = w * (g - wg) * (1.f - tl[lane] * tl[lane]);
+  }
+  __syncthreads();
+  for (int v = wave; v < V; v += 4) {
+    const float w = wsave[(int64_t)n * V + v];
+    const float d = dsc[v];
+    for (int i = lane; i < H; i += 64)
+      dx[((int64_t)n * V + v) * H + i] = from_f<T>(w * to_f(df[i]) + d * a[i]);
+  }
+  for (int i = threadIdx.x; i < H; i += 256) {
+    float s = 0.f;
+    for (int v = 0; v < V; ++v) s += dsc[v] * to_f(xb[(int64_t)v * H + i]);
+    atomicAdd(da + i, s);
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int v = 0; v < V; ++v) s += dsc[v];
+    atomicAdd(da0, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------ gather / segment mean
+template <typename T>
+__global__ __launch_bounds__(256) void gather_fwd_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx,
+                                                         const int32_t* __restrict__ start, const float* __restrict__ scale,
+                                                         T* __restrict__ out, int n_out, int H) {
+  constexpr int EPC = DT<T>::EPC;
+  const int nchunk = H / EPC;
+  const int64_t total = (int64_t)n_out * nchunk;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t / nchunk), c = (int)(t % nchunk);
+    Chunk<T> acc;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc.v[e] = 0.f;
+    for (int j = start[i]; j < start[i + 1]; ++j) {
+      const int s = idx[j];
+      if (s >= 0) {
+        Chunk<T> v;
+        v.load(src + (int64_t)s * H + c * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc.v[e] += v.v[e];
+      }
+    }
+    const float sc = scale ? scale[i] : 1.f;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc.v[e] *= sc;
+    acc.store(out + (int64_t)i * H + c * EPC);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_bwd_kernel(const T* __restrict__ dout, const int32_t* __restrict__ idx,
+                                                         const int32_t* __restrict__ start, const float* __restrict__ scale,
+                                                         float* __restrict__ dsrc, int n_out, int H) {
+  constexpr int EPC = DT<T>::EPC;
+  const int nchunk = H / EPC;
+  const int64_t total = (int64_t)n_out * nchunk;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t / nchunk), c = (int)(t % nchunk);
+    if (start[i] == start[i + 1]) continue;
+    Chunk<T> g;
+    g.load(dout + (int64_t)i * H + c * EPC);
+    const float sc = scale ? scale[i] : 1.f;
+    for (int j = start[i]; j < start[i + 1]; ++j) {
+      const int s = idx[j];
+      if (s >= 0) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) atomicAdd(dsrc + (int64_t)s * H + c * EPC + e, g.v[e] * sc);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ tr16 probe
+__global__ void probe_tr16_kernel(uint16_t* out) {
+  __shared__ __attribute__((aligned(16))) uint16_t sm[64 * 4];
+  const int l = threadIdx.x;
+  for (int j = 0; j < 4; ++j) sm[l * 4 + j] = (uint16_t)(l * 4 + j);
+  __syncthreads();
+  typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+  s16x4 t;
+  const uint32_t addr = (uint32_t)(uintptr_t)(sm + l * 4);
+  asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(addr) : "memory");
+  for (int j = 0; j < 4; ++j) out[l * 4 + j] = (uint16_t)t[j];
+}
+
+template <typename T>
+int ln_check(int H) {
+  const int epc = DT<T>::EPC;
+  if (H % epc) return GOAT_E_SHAPE;
+  if (H > 64 * MAXC * epc) return GOAT_E_SHAPE;
+  return 0;
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int goat_version(void) { return 101; }
+
+extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* residual, const float* gamma,
+                           const float* beta, float eps, float p, uint64_t seed, uint64_t offset,
+                           const uint64_t* rng_dev, void* y, void* z_out, float* mean, float* rstd, int M, int H) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd) return GOAT_E_ARG;
+  if (M <= 0) return GOAT_E_SHAPE;
+  if ((residual || p > 0.f) && !z_out) return GOAT_E_ARG;
+  dim3 grid((M + 3) / 4);
+  if (dtype == GOAT_BF16) {
+    if (int e = ln_check<bf16_t>(H)) return e;
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)x, (const bf16_t*)residual,
+                       gamma, beta, eps, p, seed, offset, rng_dev, (bf16_t*)y, (bf16_t*)z_out, mean, rstd, M, H);
+  } else if (dtype == GOAT_F32) {
+    if (int e = ln_check<float>(H)) return e;
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)x, (const float*)residual,
+                       gamma, beta, eps, p, seed, offset, rng_dev, (float*)y, (float*)z_out, mean, rstd, M, H);
+  } else {
+    return GOAT_E_ARG;
+  }
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+#define GOAT_LN_BWD_PARTS 256
+
+extern "C" int goat_ln_bwd_ws_floats(int H) { return GOAT_LN_BWD_PARTS * 2 * H; }
+
+extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* z, const float* gamma,
+                           const float* mean, const float* rstd, float p, uint64_t seed, uint64_t offset,
+                           const uint64_t* rng_dev, void* dx, void* d_res, float* dgamma, float* dbeta, float* ws,
+                           int M, int H) {
+  if (!dy || !z || !gamma || !mean || !rstd || !dgamma || !dbeta || !ws) return GOAT_E_ARG;
+  if (M <= 0) return GOAT_E_SHAPE;
+  int nparts = (M + 3) / 4;
+  if (nparts > GOAT_LN_BWD_PARTS) nparts = GOAT_LN_BWD_PARTS;
+  const size_t sm = (size_t)8 * H * sizeof(float);
+  if (sm > 64 * 1024) return GOAT_E_SHAPE;
+  if (dtype == GOAT_BF16) {
+    if (int e = ln_check<bf16_t>(H)) return e;
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nparts), dim3(256), sm, ST(stream), (const bf16_t*)dy,
+                       (const bf16_t*)z, gamma, mean, rstd, p, seed, offset, rng_dev, (bf16_t*)dx, (bf16_t*)d_res, ws, M, H);
+  } else if (dtype == GOAT_F32) {
+    if (int e = ln_check<float>(H)) return e;
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nparts), dim3(256), sm, ST(stream), (const float*)dy, (const float*)z,
+                       gamma, mean, rstd, p, seed, offset, rng_dev, (float*)dx, (float*)d_res, ws, M, H);
+  } else {
+    return GOAT_E_ARG;
+  }
+  GOAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, ST(stream), ws, dgamma, dbeta, nparts,
+                     H);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_dropout_add_fwd(void* stream, int dtype, const void* x, const void* residual, void* y, int64_t n,
+                                    float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev) {
+  if (!x || !y) return GOAT_E_ARG;
+  if (n <= 0) return GOAT_E_SHAPE;
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL((dropout_kernel<bf16_t, false>), dim3((int)blocks), dim3(256), 0, ST(stream), (const bf16_t*)x,
+                       (const bf16_t*)residual, (bf16_t*)y, n, p, seed, offset, rng_dev);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL((dropout_kernel<float, false>), dim3((int)blocks), dim3(256), 0, ST(stream), (const float*)x,
+                       (const float*)residual, (float*)y, n, p, seed, offset, rng_dev);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_dropout_bwd(void* stream, int dtype, const void* dy, void* dx, int64_t n, float p, uint64_t seed,
+                                uint64_t offset, const uint64_t* rng_dev) {
+  if (!dy || !dx) return GOAT_E_ARG;
+  if (n <= 0) return GOAT_E_SHAPE;
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL((dropout_kernel<bf16_t, true>), dim3((int)blocks), dim3(256), 0, ST(stream), (const bf16_t*)dy,
+                       (const bf16_t*)nullptr, (bf16_t*)dx, n, p, seed, offset, rng_dev);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL((dropout_kernel<float, true>), dim3((int)blocks), dim3(256), 0, ST(stream), (const float*)dy,
+                       (const float*)nullptr, (float*)dx, n, p, seed, offset, rng_dev);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_act_bwd(void* stream, int dtype, const void* dy, const void* u, void* dx, int64_t n, int act,
+                            float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev) {
+  if (!dy || !u || !dx) return GOAT_E_ARG;
+  if (n <= 0) return GOAT_E_SHAPE;
+  if (act != GOAT_EPI_GELU && act != GOAT_EPI_RELU) return GOAT_E_ARG;
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, ST(stream), (const bf16_t*)dy,
+                       (const bf16_t*)u, (bf16_t*)dx, n, act, p, seed, offset, rng_dev);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(act_bwd_kernel<float>, dim3((int)blocks), dim3(256), 0, ST(stream), (const float*)dy,
+                       (const float*)u, (float*)dx, n, act, p, seed, offset, rng_dev);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_transpose(void* stream, int dtype, const void* in, int64_t ld_in, void* out, int64_t ld_out, int R,
+                              int C, float* colsum) {
+  if (!in || !out) return GOAT_E_ARG;
+  if (R <= 0 || C <= 0 || ld_out < R || ld_in < C) return GOAT_E_SHAPE;
+  const int rtiles = (int)((ld_out + 63) / 64), ctiles = (C + 63) / 64;
+  int RT = 1;
+  while (RT < 16 && (int64_t)((rtiles + 2 * RT - 1) / (2 * RT)) * ctiles >= 1024) RT *= 2;
+  dim3 grid((rtiles + RT - 1) / RT, ctiles);
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)in, ld_in, (bf16_t*)out,
+                       ld_out, R, C, colsum, RT);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)in, ld_in, (float*)out,
+                       ld_out, R, C, colsum, RT);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_pano_fusion_fwd(void* stream, int dtype, const void* x, const float* a, const float* a0, void* fused,
+                                    float* wsave, int N, int V, int H) {
+  if (!x || !a || !a0 || !fused || !wsave) return GOAT_E_ARG;
+  if (N <= 0 || V <= 0 || V > 64 || H <= 0) return GOAT_E_SHAPE;
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(pano_fusion_fwd_kernel<bf16_t>, dim3(N), dim3(256), 0, ST(stream), (const bf16_t*)x, a, a0,
+                       (bf16_t*)fused, wsave, V, H);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(pano_fusion_fwd_kernel<float>, dim3(N), dim3(256), 0, ST(stream), (const float*)x, a, a0,
+                       (float*)fused, wsave, V, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_pano_fusion_bwd(void* stream, int dtype, const void* x, const float* a, const float* a0,
+                                    const float* wsave, const void* dfused, void* dx, float* da, float* da0, int N,
+                                    int V, int H) {
+  if (!x || !a || !a0 || !wsave || !dfused || !dx || !da || !da0) return GOAT_E_ARG;
+  if (N <= 0 || V <= 0 || V > 64 || H <= 0) return GOAT_E_SHAPE;
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(pano_fusion_bwd_kernel<bf16_t>, dim3(N), dim3(256), 0, ST(stream), (const bf16_t*)x, a, a0,
+                       wsave, (const bf16_t*)dfused, (bf16_t*)dx, da, da0, V, H);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(pano_fusion_bwd_kernel<float>, dim3(N), dim3(256), 0, ST(stream), (const float*)x, a, a0, wsave,
+                       (const float*)dfused, (float*)dx, da, da0, V, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_gather_segmean_fwd(void* stream, int dtype, const void* src, int64_t src_rows, const int32_t* idx,
+                                       const int32_t* start, const float* scale, void* out, int n_out, int H) {
+  if (!src || !idx || !start || !out) return GOAT_E_ARG;
+  if (n_out <= 0 || H <= 0 || src_rows <= 0) return GOAT_E_SHAPE;
+  const int epc = dtype == GOAT_BF16 ? 8 : 4;
+  if (H % epc) return GOAT_E_SHAPE;
+  int64_t total = (int64_t)n_out * (H / epc);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(gather_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST(stream), (const bf16_t*)src, idx, start,
+                       scale, (bf16_t*)out, n_out, H);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(gather_fwd_kernel<float>, dim3(blocks), dim3(256), 0, ST(stream), (const float*)src, idx, start,
+                       scale, (float*)out, n_out, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_gather_segmean_bwd(void* stream, int dtype, const void* dout, const int32_t* idx,
+                                       const int32_t* start, const float* scale, float* dsrc32, int n_out, int H) {
+  if (!dout || !idx || !start || !dsrc32) return GOAT_E_ARG;
+  if (n_out <= 0 || H <= 0) return GOAT_E_SHAPE;
+  const int epc = dtype == GOAT_BF16 ? 8 : 4;
+  if (H % epc) return GOAT_E_SHAPE;
+  int64_t total = (int64_t)n_out * (H / epc);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(gather_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST(stream), (const bf16_t*)dout, idx, start,
+                       scale, dsrc32, n_out, H);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(gather_bwd_kernel<float>, dim3(blocks), dim3(256), 0, ST(stream), (const float*)dout, idx, start,
+                       scale, dsrc32, n_out, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_probe_tr16(void* stream, uint16_t* out) {
+  if (!out) return GOAT_E_ARG;
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, ST(stream), out);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,111 @@
+"""Host-side index building for the graph-map token assembly.
+
+The reference assembles global-map tokens, local [stop]-prefixed tokens and the SAP logit fusion with
+Python loops over viewpoint-id *strings* that launch thousands of tiny index/stack kernels
+(GlobalMapEncoder._aggregate_gmap_features P/model/vilmodel_goat.py:430-468, vp_input_embedding :377-391,
+forward_sap fusion loop P/model/pretrain_goat.py:329-345).  Here the strings are resolved ONCE per batch
+on the host into small int32 index tensors; the device work is then one gather/segment-mean kernel
+(goat_gather_segmean_*) and one tiny matmul.
+"""
+import numpy as np
+import torch
+
+
+def _to_list(x):
+    if torch.is_tensor(x):
+        return x.detach().cpu().tolist()
+    return list(x)
+
+
+def build_gmap_index(traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids, gmap_vpids, n_gmap, V, fused):
+    """CSR description of gmap token sources.
+
+    Source rows: [0, N*V) = panorama token (pano n, view j) at n*V+j ; [N*V, N*V+N) = fused panorama row n.
+    Output token (b, g) -> segment b*n_gmap+g.  Semantics follow _aggregate_gmap_features exactly: a visited
+    node takes the fused embedding of its (last) visit step (or the masked mean over views when fusion is
+    off); an unvisited node the mean of every candidate-view embedding that saw it, where "visited" is
+    evaluated progressively step by step as in the reference loop; g = 0 is the zero [stop] token.
+    """
+    step_lens = _to_list(traj_step_lens)
+    view_lens = _to_list(traj_vp_view_lens)
+    B = len(step_lens)
+    N = sum(step_lens)
+    idx, start, scale = [], [0], []
+    n0 = 0
+    for b in range(B):
+        visited, unvisited = {}, {}
+        for t in range(step_lens[b]):
+            n = n0 + t
+            visited[traj_vpids[b][t]] = n
+            for j, vp in enumerate(traj_cand_vpids[b][t]):
+                if vp not in visited:
+                    unvisited.setdefault(vp, []).append(n * V + j)
+        n0 += step_lens[b]
+        for g in range(n_gmap):
+            vps = gmap_vpids[b]
+            if g == 0 or g >= len(vps):
+                scale.append(1.0)
+            else:
+                vp = vps[g]
+                if vp in visited:
+                    n = visited[vp]
+                    if fused:
+                        idx.append(N * V + n)
+                        scale.append(1.0)
+                    else:
+                        idx.extend(n * V + j for j in range(view_lens[n]))
+                        scale.append(1.0 / view_lens[n])
+                else:
+                    rows = unvisited[vp]
+                    idx.extend(rows)
+                    scale.append(1.0 / len(rows))
+            start.append(len(idx))
+    if not idx:
+        idx = [-1]
+    return (torch.tensor(idx, dtype=torch.int32), torch.tensor(start, dtype=torch.int32),
+            torch.tensor(scale, dtype=torch.float32))
+
+
+def build_vp_index(traj_step_lens, traj_vp_view_lens, V):
+    """Local-branch tokens: (b,0) = zero [stop]; (b,j>=1) = view j-1 of sample b's LAST panorama, for
+    j < max_b(view_len_last)+1 — padded view slots included, as in the reference (pad_tensors_wgrad of
+    x[-1] then [:max_vp_len], P/model/vilmodel_goat.py:378-388)."""
+    step_lens = _to_list(traj_step_lens)
+    view_lens = _to_list(traj_vp_view_lens)
+    B = len(step_lens)
+    last = np.cumsum(step_lens) - 1
+    vp_lens = [view_lens[n] + 1 for n in last]
+    width = max(vp_lens)
+    idx, start = [], [0]
+    for b in range(B):
+        for j in range(width):
+            if j >= 1:
+                idx.append(int(last[b]) * V + (j - 1))
+            start.append(len(idx))
+    return (torch.tensor(idx, dtype=torch.int32), torch.tensor(start, dtype=torch.int32),
+            torch.tensor(vp_lens, dtype=torch.int64), width)
+
+
+def build_sap_fusion(traj_cand_vpids, gmap_vpids, gmap_visited_masks, n_gmap, n_local):
+    """0/1 matrix M [B, n_gmap, n_local]: fused[b,g] = global[b,g] + sum_j M[b,g,j] * local[b,j]
+    (P/model/pretrain_goat.py:329-345)."""
+    vis = _to_list(gmap_visited_masks)
+    B = len(gmap_vpids)
+    M = np.zeros((B, n_gmap, n_local), dtype=np.float32)
+    for b in range(B):
+        M[b, 0, 0] = 1.0
+        visited = set(vp for vp, m in zip(gmap_vpids[b], vis[b]) if m)
+        tmp, bw = {}, []
+        for j, c in enumerate(traj_cand_vpids[b][-1]):
+            if c in visited:
+                bw.append(j + 1)
+            else:
+                tmp[c] = j + 1
+        for g, vp in enumerate(gmap_vpids[b]):
+            if g > 0 and vp not in visited:
+                if vp in tmp:
+                    M[b, g, tmp[vp]] += 1.0
+                else:
+                    for j in bw:
+                        M[b, g, j] += 1.0
+    return torch.from_numpy(M)

@@ -1,0 +1,597 @@
+"""torch.autograd.Function wrappers over the C ABI of libgoat_hip.so (hand-written backward passes).
+
+Every op here launches hand-written gfx950 kernels on the *current torch HIP stream* through ctypes
+(`_lib.py`); nothing synchronises or allocates outside torch's caching allocator, so a whole
+forward+backward step can be captured into a hipGraph (`torch.cuda.graph`).  There is no eager/CPU
+fallback: CPU tensors raise.
+
+Compute dtype: float32 (exact-f32 MFMA, the 1e-3 parity mode) or bfloat16 (bf16 storage, f32
+accumulate).  Parameters stay float32 masters; bf16 / transposed "shadows" of the weights are cached on
+the Parameter object and refreshed when its version counter moves (i.e. once per optimizer step).
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import GOAT_BF16, GOAT_F32, EPI_GELU, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_NONE, EPI_RELU
+
+_ACT_EPI = {None: EPI_NONE, 'none': EPI_NONE, 'gelu': EPI_GELU, 'relu': EPI_RELU}
+_ACT_DEPI = {'gelu': EPI_MUL_DGELU, 'relu': EPI_MUL_DRELU}
+
+
+# ----------------------------------------------------------------------------- plumbing
+def _dt(t):
+    if t.dtype == torch.float32:
+        return GOAT_F32
+    if t.dtype == torch.bfloat16:
+        return GOAT_BF16
+    raise RuntimeError('libgoat_hip supports float32 / bfloat16, got %s' % t.dtype)
+
+
+def _epc(t):
+    return 4 if t.dtype == torch.float32 else 8
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError('GOAT HIP ops need tensors on the GPU (no CPU fallback in the product path)')
+
+
+def _ptr(t, off=0):
+    return t.data_ptr() + off * t.element_size()
+
+
+class RngState:
+    """Dropout counter state.  Eager: host counter.  Graph capture: `dev` (uint64 on device) is bumped
+    by one in-graph add per replay so every replay draws fresh masks (see goat_hip.h)."""
+    seed = 0x5EED
+    counter = 0
+    dev = None
+
+    @classmethod
+    def next(cls, numel):
+        off = cls.counter
+        cls.counter += int(numel)
+        return cls.seed, off, (cls.dev.data_ptr() if cls.dev is not None else None)
+
+
+def manual_seed(seed):
+    RngState.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
+    RngState.counter = 0
+
+
+# ----------------------------------------------------------------------------- weight shadows
+def _shadow(param, dtype, transposed=False, pad_k=0):
+    """dtype-cast (and optionally transposed / K-padded) copy of a float32 master weight, cached."""
+    key = (dtype, transposed, pad_k)
+    cache = param.__dict__.setdefault('_goat_shadow', {})
+    ent = cache.get(key)
+    ver = param._version
+    if ent is not None and ent[0] == ver and ent[1].device == param.device:
+        return ent[1]
+    with torch.no_grad():
+        w = param.detach()
+        if pad_k:
+            w = torch.nn.functional.pad(w, (0, pad_k))
+        if transposed:
+            w = w.t()
+        w = w.to(dtype).contiguous()
+    cache[key] = (ver, w)
+    return w
+
+
+def _shadow_cat(params, dtype, transposed=False):
+    """Row-concatenation of several [N_i,K] weights (fused QKV / KV projection), cached on the first."""
+    key = ('cat', dtype, transposed, tuple(id(p) for p in params))
+    cache = params[0].__dict__.setdefault('_goat_shadow', {})
+    ver = tuple(p._version for p in params)
+    ent = cache.get(key)
+    if ent is not None and ent[0] == ver and ent[1].device == params[0].device:
+        return ent[1]
+    with torch.no_grad():
+        w = torch.cat([p.detach() for p in params], 0)
+        if transposed:
+            w = w.t()
+        w = w.to(dtype).contiguous()
+    cache[key] = (ver, w)
+    return w
+
+
+def _cat_bias(biases):
+    key = ('catb', tuple(id(b) for b in biases))
+    cache = biases[0].__dict__.setdefault('_goat_shadow', {})
+    ver = tuple(b._version for b in biases)
+    ent = cache.get(key)
+    if ent is not None and ent[0] == ver and ent[1].device == biases[0].device:
+        return ent[1]
+    with torch.no_grad():
+        b = torch.cat([x.detach().float() for x in biases], 0).contiguous()
+    cache[key] = (ver, b)
+    return b
+
+
+# ----------------------------------------------------------------------------- raw kernels
+def gemm_nt(a, b, out, bias=None, epi=EPI_NONE, aux=None, split_k=1):
+    """out[M,N] = epi(a[M,K] @ b[N,K]^T + bias)."""
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and out.shape[0] == M and out.shape[1] == N
+    st = _lib.lib().goat_gemm_nt(_stream(), _dt(a), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0),
+                                 _ptr(out), out.stride(0), M, N, K,
+                                 _ptr(bias) if bias is not None else None, epi,
+                                 _ptr(aux) if aux is not None else None,
+                                 aux.stride(0) if aux is not None else 0, split_k)
+    _lib.check(st, 'goat_gemm_nt(M=%d,N=%d,K=%d)' % (M, N, K))
+    return out
+
+
+def transpose_pad(x, colsum=None):
+    """x[R,C] -> out[C, ld] with ld = R rounded up to the 16-byte chunk, padding zero-filled."""
+    R, C = x.shape
+    e = _epc(x)
+    ld = (R + e - 1) // e * e
+    out = torch.empty((C, ld), dtype=x.dtype, device=x.device)
+    st = _lib.lib().goat_transpose(_stream(), _dt(x), _ptr(x), x.stride(0), _ptr(out), ld, R, C,
+                                   _ptr(colsum) if colsum is not None else None)
+    _lib.check(st, 'goat_transpose')
+    return out
+
+
+def _split_k(n_out_tiles, k_elems, bk):
+    kt = (k_elems + bk - 1) // bk
+    s = max(1, min(kt, int(round(512.0 / max(1, n_out_tiles)))))
+    return s
+
+
+def wgrad(dy, x, want_bias):
+    """dW[N,K] (f32) = dy[M,N]^T @ x[M,K] ; db[N] (f32) = colsum(dy).  TN product done as transposes + NT."""
+    M, N = dy.shape
+    K = x.shape[1]
+    db = torch.zeros(N, dtype=torch.float32, device=dy.device) if want_bias else None
+    dyT = transpose_pad(dy, db)
+    xT = transpose_pad(x)
+    dw = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    bk = 64 if dy.dtype == torch.bfloat16 else 32
+    gemm_nt(dyT, xT, dw, split_k=max(2, _split_k(tiles, dyT.shape[1], bk)))
+    return dw, db
+
+
+# ----------------------------------------------------------------------------- Linear
+def _pad_k(x, e):
+    K = x.shape[1]
+    pad = (-K) % e
+    if pad:
+        x = torch.nn.functional.pad(x, (0, pad))
+    return x, pad
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b)   (F.linear + activation; P/model/Bert_backbone.py:302,348-357,362)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, out_dtype):
+        _need_gpu(x)
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        x2, pad = _pad_k(x2, _epc(x2))
+        w = _shadow(weight, x2.dtype, False, pad)
+        N = w.shape[0]
+        out = torch.empty((x2.shape[0], N), dtype=out_dtype or x2.dtype, device=x2.device)
+        aux = None
+        epi = _ACT_EPI[act]
+        if epi != EPI_NONE and (ctx.needs_input_grad[0] or weight.requires_grad):
+            aux = torch.empty_like(out)
+        gemm_nt(x2, w, out, bias.detach() if bias is not None else None, epi, aux)
+        ctx.save_for_backward(x2, aux)
+        ctx.weight, ctx.has_bias, ctx.act, ctx.pad, ctx.xshape = weight, bias is not None, act, pad, x.shape
+        return out.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, aux = ctx.saved_tensors
+        weight = ctx.weight
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != x2.dtype:
+            dy2 = dy2.to(x2.dtype)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        if ctx.act not in (None, 'none'):
+            dy2 = act_bwd(dy2, aux, ctx.act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = _shadow(weight, x2.dtype, True, ctx.pad)  # [Kp, N]
+            dx = torch.empty_like(x2)
+            N = wt.shape[1]
+            dyp, padn = _pad_k(dy2, _epc(dy2))
+            if padn:
+                wt = torch.nn.functional.pad(wt, (0, padn))
+            gemm_nt(dyp, wt, dx)
+            if ctx.pad:
+                dx = dx[:, :x2.shape[1] - ctx.pad]
+            dx = dx.reshape(ctx.xshape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = wgrad(dy2, x2, ctx.has_bias)
+            if ctx.pad:
+                dw = dw[:, :x2.shape[1] - ctx.pad].contiguous()
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias=None, act=None, out_dtype=None):
+    return _LinearFn.apply(x, weight, bias, act, out_dtype)
+
+
+def act_bwd(dy, u, act, p=0.0, rng=(0, 0, None)):
+    """dx = dropmask_p(dy) * act'(u)  (goat_act_bwd)."""
+    dy = dy if dy.is_contiguous() else dy.contiguous()
+    dx = torch.empty_like(dy)
+    st = _lib.lib().goat_act_bwd(_stream(), _dt(dy), _ptr(dy), _ptr(u), _ptr(dx), dy.numel(), _ACT_EPI[act],
+                                 p, rng[0], rng[1], rng[2])
+    _lib.check(st, 'goat_act_bwd')
+    return dx
+
+
+class _FfnFn(torch.autograd.Function):
+    """y = dropout_p(act(x @ W1^T + b1)) @ W2^T + b2.  With p == 0 (BERT blocks: BertIntermediate +
+    BertOutput.dense, P/model/Bert_backbone.py:345-368) the activation derivative is fused into the dgrad
+    GEMM epilogue; with p > 0 (panorama encoder FFN, P/model/transformer.py:179) one elementwise kernel
+    applies mask and derivative."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act, p):
+        _need_gpu(x)
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        W1 = _shadow(w1, x2.dtype)
+        W2 = _shadow(w2, x2.dtype)
+        M, F_ = x2.shape[0], W1.shape[0]
+        u = torch.empty((M, F_), dtype=x2.dtype, device=x2.device)
+        h = torch.empty_like(u)
+        gemm_nt(x2, W1, h, b1.detach(), _ACT_EPI[act], u)
+        rng = (0, 0, None)
+        if p > 0:
+            rng = RngState.next(h.numel())
+            st = _lib.lib().goat_dropout_add_fwd(_stream(), _dt(h), _ptr(h), None, _ptr(h), h.numel(), p,
+                                                 rng[0], rng[1], rng[2])
+            _lib.check(st, 'goat_dropout_add_fwd')
+        y = torch.empty((M, W2.shape[0]), dtype=x2.dtype, device=x2.device)
+        gemm_nt(h, W2, y, b2.detach())
+        ctx.save_for_backward(x2, u, h)
+        ctx.w1, ctx.w2, ctx.act, ctx.xshape, ctx.p, ctx.rng = w1, w2, act, x.shape, p, rng
+        return y.view(*x.shape[:-1], W2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, h = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        W2t = _shadow(ctx.w2, x2.dtype, True)  # [F, H]
+        du = torch.empty_like(u)
+        if ctx.p > 0:
+            gemm_nt(dy2, W2t, du)
+            du = act_bwd(du, u, ctx.act, ctx.p, ctx.rng)
+        else:
+            gemm_nt(dy2, W2t, du, None, _ACT_DEPI[ctx.act], u)
+        dw2, db2 = wgrad(dy2, h, True)
+        W1t = _shadow(ctx.w1, x2.dtype, True)  # [H, F]
+        dx = torch.empty_like(x2)
+        gemm_nt(du, W1t, dx)
+        dw1, db1 = wgrad(du, x2, True)
+        return dx.view(ctx.xshape), dw1, db1, dw2, db2, None, None
+
+
+def ffn(x, w1, b1, w2, b2, act='gelu', p=0.0):
+    return _FfnFn.apply(x, w1, b1, w2, b2, act, float(p))
+
+
+# ----------------------------------------------------------------------------- fused multi-weight projection
+class _MultiLinearFn(torch.autograd.Function):
+    """y = x @ cat(W_i)^T + cat(b_i): one GEMM for the separate query/key/value Linears of a BERT block
+    (P/model/Bert_backbone.py:210,231-232).  Gradients are returned per original parameter."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        n = len(wb) // 2
+        ws, bs = wb[:n], wb[n:]
+        _need_gpu(x)
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        W = _shadow_cat(ws, x2.dtype)
+        b = _cat_bias(bs)
+        out = torch.empty((x2.shape[0], W.shape[0]), dtype=x2.dtype, device=x2.device)
+        gemm_nt(x2, W, out, b)
+        ctx.save_for_backward(x2)
+        ctx.ws, ctx.xshape = ws, x.shape
+        return out.view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        ws = ctx.ws
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Wt = _shadow_cat(ws, x2.dtype, True)
+            dx = torch.empty_like(x2)
+            gemm_nt(dy2, Wt, dx)
+            dx = dx.view(ctx.xshape)
+        dw, db = wgrad(dy2, x2, True)
+        sizes = [w.shape[0] for w in ws]
+        return (dx,) + tuple(torch.split(dw, sizes, 0)) + tuple(torch.split(db, sizes, 0))
+
+
+def multi_linear(x, weights, biases):
+    return _MultiLinearFn.apply(x, *weights, *biases)
+
+
+# ----------------------------------------------------------------------------- LayerNorm / dropout
+class _LnFn(torch.autograd.Function):
+    """y = LayerNorm(residual + dropout_p(x)) (P/model/Bert_backbone.py:306-310)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps, p):
+        _need_gpu(x)
+        H = x.shape[-1]
+        x2 = x.reshape(-1, H)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        r2 = None
+        if residual is not None:
+            r2 = residual.reshape(-1, H)
+            if not r2.is_contiguous():
+                r2 = r2.contiguous()
+        M = x2.shape[0]
+        y = torch.empty_like(x2)
+        need_z = (r2 is not None) or p > 0
+        z = torch.empty_like(x2) if need_z else None
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        seed, off, dev = RngState.next(x2.numel()) if p > 0 else (0, 0, None)
+        st = _lib.lib().goat_ln_fwd(_stream(), _dt(x2), _ptr(x2), _ptr(r2) if r2 is not None else None,
+                                    _ptr(gamma), _ptr(beta), eps, p, seed, off, dev,
+                                    _ptr(y), _ptr(z) if z is not None else None, _ptr(mean), _ptr(rstd), M, H)
+        _lib.check(st, 'goat_ln_fwd')
+        ctx.save_for_backward(z if z is not None else x2, gamma, mean, rstd)
+        ctx.rng = (p, seed, off, dev)
+        ctx.has_res = residual is not None
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, gamma, mean, rstd = ctx.saved_tensors
+        p, seed, off, dev = ctx.rng
+        H = z.shape[-1]
+        dy2 = dy.reshape(-1, H)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        M = z.shape[0]
+        L = _lib.lib()
+        dx = torch.empty_like(z)
+        dres = torch.empty_like(z) if (ctx.has_res and p > 0) else None
+        dg = torch.empty(H, dtype=torch.float32, device=z.device)
+        db = torch.empty(H, dtype=torch.float32, device=z.device)
+        ws = torch.empty(L.goat_ln_bwd_ws_floats(H), dtype=torch.float32, device=z.device)
+        st = L.goat_ln_bwd(_stream(), _dt(z), _ptr(dy2), _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd),
+                           p, seed, off, dev, _ptr(dx), _ptr(dres) if dres is not None else None,
+                           _ptr(dg), _ptr(db), _ptr(ws), M, H)
+        _lib.check(st, 'goat_ln_bwd')
+        dxv = dx.view(ctx.shape)
+        if ctx.has_res:
+            dr = dres.view(ctx.shape) if dres is not None else dxv
+        else:
+            dr = None
+        return dxv, dr, dg, db, None, None
+
+
+def layer_norm(x, gamma, beta, eps, residual=None, p=0.0):
+    return _LnFn.apply(x, residual, gamma, beta, float(eps), float(p))
+
+
+class _DropAddFn(torch.autograd.Function):
+    """y = residual + dropout_p(x)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p):
+        _need_gpu(x)
+        xc = x if x.is_contiguous() else x.contiguous()
+        rc = None
+        if residual is not None:
+            rc = residual if residual.is_contiguous() else residual.contiguous()
+        y = torch.empty_like(xc)
+        seed, off, dev = RngState.next(xc.numel()) if p > 0 else (0, 0, None)
+        st = _lib.lib().goat_dropout_add_fwd(_stream(), _dt(xc), _ptr(xc), _ptr(rc) if rc is not None else None,
+                                             _ptr(y), xc.numel(), p, seed, off, dev)
+        _lib.check(st, 'goat_dropout_add_fwd')
+        ctx.rng = (p, seed, off, dev)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, off, dev = ctx.rng
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        if p > 0:
+            dx = torch.empty_like(dyc)
+            st = _lib.lib().goat_dropout_bwd(_stream(), _dt(dyc), _ptr(dyc), _ptr(dx), dyc.numel(), p, seed, off, dev)
+            _lib.check(st, 'goat_dropout_bwd')
+        else:
+            dx = dyc
+        return dx, (dyc if ctx.has_res else None), None
+
+
+def dropout_add(x, residual, p):
+    if p <= 0 and residual is None:
+        return x
+    return _DropAddFn.apply(x, residual, float(p))
+
+
+def dropout(x, p):
+    return dropout_add(x, None, p)
+
+
+# ----------------------------------------------------------------------------- attention
+class _AttnFn(torch.autograd.Function):
+    """Masked MHA on packed projections.
+    mode 'self' : a = qkv [B,L,3H]              (q|k|v)
+    mode 'cross': a = q [B,Lq,H], b = kv [B,Lk,2H]   (k|v)
+    kmask: float32 [B,Lk] additive (0 / -10000 / -inf) or None; bias: float32 [B,Lq,Lk] or None."""
+
+    @staticmethod
+    def forward(ctx, a, b, kmask, bias, nh, p):
+        _need_gpu(a)
+        a = a if a.is_contiguous() else a.contiguous()
+        if b is not None:
+            b = b if b.is_contiguous() else b.contiguous()
+        if b is None:
+            B, Lq, H3 = a.shape
+            H = H3 // 3
+            Lk = Lq
+            q = (a, 0, H3, Lq * H3)
+            k = (a, H, H3, Lq * H3)
+            v = (a, 2 * H, H3, Lq * H3)
+        else:
+            B, Lq, H = a.shape
+            Lk = b.shape[1]
+            q = (a, 0, H, Lq * H)
+            k = (b, 0, 2 * H, Lk * 2 * H)
+            v = (b, H, 2 * H, Lk * 2 * H)
+        assert H == nh * 64, 'head_dim must be 64'
+        o = torch.empty((B, Lq, H), dtype=a.dtype, device=a.device)
+        lse = torch.empty((B, nh, Lq), dtype=torch.float32, device=a.device)
+        if kmask is not None:
+            kmask = kmask.contiguous().float()
+        if bias is not None:
+            bias = bias.contiguous().float()
+        seed, off, dev = RngState.next(B * nh * Lq * Lk) if p > 0 else (0, 0, None)
+        scale = 1.0 / math.sqrt(64.0)
+        st = _lib.lib().goat_attn_fwd(
+            _stream(), _dt(a),
+            _ptr(q[0], q[1]), q[2], q[3], _ptr(k[0], k[1]), k[2], k[3], _ptr(v[0], v[1]), v[2], v[3],
+            _ptr(o), H, Lq * H,
+            _ptr(kmask) if kmask is not None else None, _ptr(bias) if bias is not None else None, _ptr(lse),
+            B, nh, Lq, Lk, scale, p, seed, off, dev)
+        _lib.check(st, 'goat_attn_fwd(Lq=%d,Lk=%d)' % (Lq, Lk))
+        ctx.save_for_backward(a, b, kmask, bias, o, lse)
+        ctx.cfg = (nh, p, seed, off, dev, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        a, b, kmask, bias, o, lse = ctx.saved_tensors
+        nh, p, seed, off, dev, scale = ctx.cfg
+        do = do if do.is_contiguous() else do.contiguous()
+        da = torch.empty_like(a)
+        db = torch.empty_like(b) if b is not None else None
+        if b is None:
+            B, Lq, H3 = a.shape
+            H = H3 // 3
+            Lk = Lq
+            q, k, v = (a, 0, H3, Lq * H3), (a, H, H3, Lq * H3), (a, 2 * H, H3, Lq * H3)
+            dq, dk, dv = (da, 0, H3, Lq * H3), (da, H, H3, Lq * H3), (da, 2 * H, H3, Lq * H3)
+        else:
+            B, Lq, H = a.shape
+            Lk = b.shape[1]
+            q, k, v = (a, 0, H, Lq * H), (b, 0, 2 * H, Lk * 2 * H), (b, H, 2 * H, Lk * 2 * H)
+            dq, dk, dv = (da, 0, H, Lq * H), (db, 0, 2 * H, Lk * 2 * H), (db, H, 2 * H, Lk * 2 * H)
+        dbias = None
+        if bias is not None and ctx.needs_input_grad[3]:
+            dbias = torch.zeros_like(bias)
+        st = _lib.lib().goat_attn_bwd(
+            _stream(), _dt(a),
+            _ptr(q[0], q[1]), q[2], q[3], _ptr(k[0], k[1]), k[2], k[3], _ptr(v[0], v[1]), v[2], v[3],
+            _ptr(o), H, Lq * H, _ptr(do), H, Lq * H,
+            _ptr(dq[0], dq[1]), dq[2], dq[3], _ptr(dk[0], dk[1]), dk[2], dk[3], _ptr(dv[0], dv[1]), dv[2], dv[3],
+            _ptr(kmask) if kmask is not None else None, _ptr(bias) if bias is not None else None, _ptr(lse),
+            _ptr(dbias) if dbias is not None else None,
+            B, nh, Lq, Lk, scale, p, seed, off, dev)
+        _lib.check(st, 'goat_attn_bwd(Lq=%d,Lk=%d)' % (Lq, Lk))
+        return da, db, None, dbias, None, None
+
+
+def attention(a, b, kmask, bias, nh, p):
+    return _AttnFn.apply(a, b, kmask, bias, int(nh), float(p))
+
+
+# ----------------------------------------------------------------------------- pano fusion / gather
+class _PanoFusionFn(torch.autograd.Function):
+    """fused[n] = sum_v softmax_v(tanh(x[n,v]·a + a0)) x[n,v]  (P/model/vilmodel_goat.py:354-361)."""
+
+    @staticmethod
+    def forward(ctx, x, a_w, a_b):
+        _need_gpu(x)
+        x = x if x.is_contiguous() else x.contiguous()
+        N, V, H = x.shape
+        fused = torch.empty((N, H), dtype=x.dtype, device=x.device)
+        wsave = torch.empty((N, V), dtype=torch.float32, device=x.device)
+        av = a_w.detach().reshape(-1).contiguous()
+        st = _lib.lib().goat_pano_fusion_fwd(_stream(), _dt(x), _ptr(x), _ptr(av), _ptr(a_b), _ptr(fused),
+                                             _ptr(wsave), N, V, H)
+        _lib.check(st, 'goat_pano_fusion_fwd')
+        ctx.save_for_backward(x, av, a_b, wsave)
+        ctx.wshape = a_w.shape
+        return fused
+
+    @staticmethod
+    def backward(ctx, df):
+        x, av, a_b, wsave = ctx.saved_tensors
+        N, V, H = x.shape
+        df = df if df.is_contiguous() else df.contiguous()
+        dx = torch.empty_like(x)
+        da = torch.zeros(H, dtype=torch.float32, device=x.device)
+        da0 = torch.zeros(1, dtype=torch.float32, device=x.device)
+        st = _lib.lib().goat_pano_fusion_bwd(_stream(), _dt(x), _ptr(x), _ptr(av), _ptr(a_b), _ptr(wsave), _ptr(df),
+                                             _ptr(dx), _ptr(da), _ptr(da0), N, V, H)
+        _lib.check(st, 'goat_pano_fusion_bwd')
+        return dx, da.view(ctx.wshape), da0
+
+
+def pano_fusion(x, a_w, a_b):
+    return _PanoFusionFn.apply(x, a_w, a_b)
+
+
+class _GatherFn(torch.autograd.Function):
+    """out[i] = scale[i] * sum_{j in seg i} src[idx[j]]  (index tensors built on the host per batch)."""
+
+    @staticmethod
+    def forward(ctx, src, idx, start, scale, n_out):
+        _need_gpu(src)
+        src = src if src.is_contiguous() else src.contiguous()
+        H = src.shape[-1]
+        s2 = src.reshape(-1, H)
+        out = torch.empty((n_out, H), dtype=src.dtype, device=src.device)
+        st = _lib.lib().goat_gather_segmean_fwd(_stream(), _dt(s2), _ptr(s2), s2.shape[0], _ptr(idx), _ptr(start),
+                                                _ptr(scale) if scale is not None else None, _ptr(out), n_out, H)
+        _lib.check(st, 'goat_gather_segmean_fwd')
+        ctx.save_for_backward(idx, start, scale)
+        ctx.sshape, ctx.sdtype = src.shape, src.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, start, scale = ctx.saved_tensors
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        n_out, H = dout.shape
+        rows = 1
+        for s in ctx.sshape[:-1]:
+            rows *= s
+        d32 = torch.zeros((rows, H), dtype=torch.float32, device=dout.device)
+        st = _lib.lib().goat_gather_segmean_bwd(_stream(), _dt(dout), _ptr(dout), _ptr(idx), _ptr(start),
+                                                _ptr(scale) if scale is not None else None, _ptr(d32), n_out, H)
+        _lib.check(st, 'goat_gather_segmean_bwd')
+        return d32.to(ctx.sdtype).view(ctx.sshape), None, None, None, None
+
+
+def gather_segmean(src, idx, start, scale, n_out):
+    return _GatherFn.apply(src, idx, start, scale, int(n_out))

@@ -1,0 +1,355 @@
+"""BERT / RoBERTa / DETR-style blocks of GOAT with HIP forward+backward bodies.
+
+Module tree, attribute names and parameter shapes follow the reference exactly (state_dict keys are a
+drop-in contract); only the `forward` bodies differ: they call the hand-written gfx950
+kernels through `hipops`.  Reference classes mirrored here (P/ = pretrain_src/, M/ = map_nav_src/):
+  RobertaEmbeddings          P/model/Bert_backbone.py:56-121
+  BertSelfAttention/-Output  P/model/Bert_backbone.py:157-310   (Roberta* twins :373-543)
+  BertAttention              P/model/Bert_backbone.py:313-342
+  BertIntermediate/-Output   P/model/Bert_backbone.py:345-370
+  RobertaLayer               P/model/Bert_backbone.py:574-659
+  BertCrossLayer             P/model/Bert_backbone.py:661-754
+  CrossmodalEncoder          P/model/Bert_backbone.py:756-781
+  BertPredictionHeadTransform / BertLMPredictionHead / BertOnlyMLMHead   :797-838
+  TransformerEncoder(Layer)  P/model/transformer.py:62-89,133-191 (pre-LN, nn.MultiheadAttention)
+"""
+import torch
+from torch import nn
+
+from . import hipops
+
+_COMPUTE_DTYPE = [torch.float32]
+
+
+def set_compute_dtype(dtype):
+    """torch.float32 (exact-f32 MFMA parity mode) or torch.bfloat16 (bf16 storage, f32 accumulate)."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError('compute dtype must be float32 or bfloat16')
+    _COMPUTE_DTYPE[0] = dtype
+
+
+def compute_dtype():
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_gpu_dtype()
+        if dt == torch.bfloat16:
+            return torch.bfloat16
+        raise RuntimeError('GOAT HIP path supports bfloat16 autocast only (got %s)' % dt)
+    return _COMPUTE_DTYPE[0]
+
+
+def neg_mask(masks, value=-10000.0):
+    """bool [N,L] -> additive float32 key mask [N,L] (P/model/ops.py:25-34 without the broadcast dims)."""
+    return (1.0 - masks.float()) * value
+
+
+def inf_mask(masks):
+    """bool [N,L] (True = valid) -> 0 / -inf (nn.MultiheadAttention key_padding_mask semantics)."""
+    return torch.zeros(masks.shape, dtype=torch.float32, device=masks.device).masked_fill(~masks, float('-inf'))
+
+
+def gen_seq_masks(seq_lens, max_len=None):
+    # P/model/ops.py:36-44
+    if max_len is None:
+        max_len = int(seq_lens.max())
+    return torch.arange(max_len, device=seq_lens.device).unsqueeze(0) < seq_lens.unsqueeze(1)
+
+
+class Linear(nn.Linear):
+    def forward(self, x, act=None):
+        return hipops.linear(x, self.weight, self.bias, act)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x, residual=None, p=0.0):
+        return hipops.layer_norm(x, self.weight, self.bias, self.eps, residual, p)
+
+
+BertLayerNorm = LayerNorm
+
+
+def _p(drop):
+    """dropout probability of an nn.Dropout at call time (the reference's set_dropout mutates `.p`)."""
+    return drop.p if drop.training else 0.0
+
+
+def _check_act(config):
+    if getattr(config, 'hidden_act', 'gelu') != 'gelu':
+        raise NotImplementedError('GOAT HIP path implements hidden_act="gelu" (erf) only')
+
+
+class RobertaEmbeddings(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        pad = getattr(config, 'pad_token_id', None)
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=pad)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size, padding_idx=pad)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.register_buffer('position_ids', torch.arange(config.max_position_embeddings).expand((1, -1)))
+        self.register_buffer('token_type_ids', torch.zeros(self.position_ids.size(), dtype=torch.long), persistent=False)
+        self.padding_idx = pad
+
+    def forward(self, input_ids, token_type_ids=None):
+        L = input_ids.shape[1]
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        e = self.word_embeddings(input_ids) + self.token_type_embeddings(token_type_ids) \
+            + self.position_embeddings(self.position_ids[:, :L])      # position ids = arange(L) (:98-100)
+        e = self.LayerNorm(e.to(compute_dtype()))
+        return hipops.dropout(e, _p(self.dropout))
+
+
+class BertSelfAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = config.hidden_size // config.num_attention_heads
+        if self.attention_head_size != 64:
+            raise NotImplementedError('GOAT HIP attention kernels are specialised for head_dim 64')
+        self.all_head_size = config.hidden_size
+        self.query = Linear(config.hidden_size, self.all_head_size)
+        self.key = Linear(config.hidden_size, self.all_head_size)
+        self.value = Linear(config.hidden_size, self.all_head_size)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+
+    def forward(self, hidden, kmask=None, enc_hidden=None, enc_kmask=None, bias=None):
+        p = _p(self.dropout)
+        if enc_hidden is None:
+            qkv = hipops.multi_linear(hidden, [self.query.weight, self.key.weight, self.value.weight],
+                                      [self.query.bias, self.key.bias, self.value.bias])
+            return hipops.attention(qkv, None, kmask, bias, self.num_attention_heads, p)
+        # cross-attention: the query-side mask is ignored (P/model/Bert_backbone.py:221-224)
+        q = self.query(hidden)
+        kv = hipops.multi_linear(enc_hidden, [self.key.weight, self.value.weight], [self.key.bias, self.value.bias])
+        return hipops.attention(q, kv, enc_kmask, None, self.num_attention_heads, p)
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, config, in_size=None):
+        super().__init__()
+        self.dense = Linear(in_size or config.hidden_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, hidden, input_tensor):
+        return self.LayerNorm(self.dense(hidden), residual=input_tensor, p=_p(self.dropout))
+
+
+class BertAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertSelfAttention(config)
+        self.output = BertSelfOutput(config)
+
+    def forward(self, hidden, kmask=None, enc_hidden=None, enc_kmask=None, bias=None):
+        return self.output(self.self(hidden, kmask, enc_hidden, enc_kmask, bias), hidden)
+
+
+RobertaAttention = BertAttention
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        _check_act(config)
+        self.dense = Linear(config.hidden_size, config.intermediate_size)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+RobertaIntermediate, RobertaOutput = BertIntermediate, BertOutput
+
+
+def _ffn_block(inter, out, x):
+    """BertIntermediate -> BertOutput (dense, dropout, LayerNorm(+residual))."""
+    y = hipops.ffn(x, inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias, 'gelu', 0.0)
+    return out.LayerNorm(y, residual=x, p=_p(out.dropout))
+
+
+class RobertaLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        assert not getattr(config, 'is_decoder', False)
+        self.attention = RobertaAttention(config)
+        self.intermediate = RobertaIntermediate(config)
+        self.output = RobertaOutput(config)
+
+    def forward(self, hidden, kmask):
+        return _ffn_block(self.intermediate, self.output, self.attention(hidden, kmask))
+
+
+class BertCrossLayer(nn.Module):
+    """self-attn (+graph bias) -> cross-attn -> FFN.  `with_lang_branch` creates the reference's unused
+    lang_self_attn / lang_inter / lang_output parameters (pretrain checkpoints carry them)."""
+
+    def __init__(self, config, with_lang_branch=True):
+        super().__init__()
+        self.attention = BertAttention(config)
+        self.crossattention = BertAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+        if with_lang_branch and getattr(config, 'use_lang2visn_attn', False):
+            self.lang_self_attn = BertAttention(config)
+            self.lang_inter = RobertaIntermediate(config)
+            self.lang_output = RobertaOutput(config)
+
+    def forward(self, hidden, enc_hidden, kmask, enc_kmask, bias=None):
+        a = self.attention(hidden, kmask, bias=bias)
+        a = self.crossattention(a, None, enc_hidden, enc_kmask)
+        return _ffn_block(self.intermediate, self.output, a)
+
+
+def init_weights(module):
+    # P/model/Bert_backbone.py:840-848
+    if isinstance(module, (nn.Linear, nn.Embedding)):
+        module.weight.data.normal_(mean=0.0, std=0.02)
+    elif isinstance(module, nn.LayerNorm):
+        module.bias.data.zero_()
+        module.weight.data.fill_(1.0)
+    if isinstance(module, nn.Linear) and module.bias is not None:
+        module.bias.data.zero_()
+
+
+class CrossmodalEncoder(nn.Module):
+    def __init__(self, config, with_lang_branch=True):
+        super().__init__()
+        self.num_top_layer = config.num_top_layer
+        self.crossattention = nn.ModuleList([BertCrossLayer(config, with_lang_branch) for _ in range(self.num_top_layer)])
+        self.crossattention.apply(init_weights)
+
+    def forward(self, q_embeds, q_kmask, kv_embeds, kv_kmask, bias=None):
+        """q_kmask / kv_kmask: additive float32 [B,L] key masks (already -10000-style)."""
+        for layer in self.crossattention:
+            q_embeds = layer(q_embeds, kv_embeds, q_kmask, kv_kmask, bias)
+        return q_embeds
+
+
+class BertPooler(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.hidden_size, config.hidden_size)
+        self.activation = nn.Tanh()
+
+    def forward(self, hidden, location=0):
+        return torch.tanh(self.dense(hidden[:, location].contiguous()))
+
+
+class BertPredictionHeadTransform(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        _check_act(config)
+        self.dense = Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+    def forward(self, hidden):
+        return self.LayerNorm(self.dense(hidden, act='gelu'))
+
+
+class BertLMPredictionHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.transform = BertPredictionHeadTransform(config)
+        self.decoder = Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
+
+    def forward(self, hidden):
+        h = self.transform(hidden)
+        return hipops.linear(h, self.decoder.weight, self.bias, None, torch.float32)
+
+
+class BertOnlyMLMHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config)
+
+    def forward(self, sequence_output):
+        return self.predictions(sequence_output)
+
+
+# ----------------------------------------------------------------------------- panorama encoder (DETR style)
+class PanoSelfAttention(nn.Module):
+    """Parameter-compatible with nn.MultiheadAttention (in_proj_weight / in_proj_bias / out_proj)."""
+
+    def __init__(self, d_model, nhead, dropout):
+        super().__init__()
+        if d_model // nhead != 64:
+            raise NotImplementedError('GOAT HIP attention kernels are specialised for head_dim 64')
+        self.embed_dim, self.num_heads, self.dropout = d_model, nhead, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = Linear(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+    def forward(self, x, kmask, p):
+        qkv = hipops.linear(x, self.in_proj_weight, self.in_proj_bias)
+        return self.out_proj(hipops.attention(qkv, None, kmask, None, self.num_heads, p))
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward, dropout):
+        super().__init__()
+        self.self_attn = PanoSelfAttention(d_model, nhead, dropout)
+        self.linear1 = Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = Linear(dim_feedforward, d_model)
+        self.norm1 = LayerNorm(d_model)   # eps 1e-5 (torch default), P/model/transformer.py:143-144
+        self.norm2 = LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+
+    def forward(self, src, kmask):
+        # forward_pre (P/model/transformer.py:170-182); attention-prob dropout = the layer's dropout value
+        p_attn = self.self_attn.dropout if self.training else 0.0
+        a = self.self_attn(self.norm1(src), kmask, p_attn)
+        src = hipops.dropout_add(a, src, _p(self.dropout1))
+        y = hipops.ffn(self.norm2(src), self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                       'gelu', _p(self.dropout))
+        return hipops.dropout_add(y, src, _p(self.dropout2))
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, config, num_layers, norm=True):
+        super().__init__()
+        _check_act(config)
+        self.layers = nn.ModuleList([
+            TransformerEncoderLayer(config.hidden_size, config.num_attention_heads, config.intermediate_size,
+                                    config.hidden_dropout_prob) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = LayerNorm(config.hidden_size, eps=1e-12) if norm else None
+
+    def forward(self, src, valid_masks):
+        """src [N,V,H] batch-first; valid_masks bool [N,V] (True = real view)."""
+        kmask = inf_mask(valid_masks)
+        out = src
+        for layer in self.layers:
+            out = layer(out, kmask)
+        if self.norm is not None:
+            out = self.norm(out)
+        return out
+
+
+def create_transformer_encoder(config, num_layers, norm=False):
+    # P/model/ops.py:11-23
+    return TransformerEncoder(config, num_layers, norm=norm)
+
+
+class ClsPrediction(nn.Module):
+    # P/model/pretrain_goat.py:27-38
+    def __init__(self, hidden_size, input_size=None):
+        super().__init__()
+        if input_size is None:
+            input_size = hidden_size
+        self.net = nn.Sequential(Linear(input_size, hidden_size), nn.ReLU(),
+                                 LayerNorm(hidden_size, eps=1e-12), Linear(hidden_size, 1))
+
+    def forward(self, x):
+        h = self.net[2](self.net[0](x, act='relu'))
+        return self.net[3](h)

@@ -1,0 +1,400 @@
+"""GOAT pre-training model on the HIP kernels — drop-in for the reference's
+`model.pretrain_goat.GlocalTextPathCMTPreTraining` (P/model/pretrain_goat.py:40) and
+`model.vilmodel_goat.GlocalTextPathCMT` (P/model/vilmodel_goat.py:529).
+
+Same constructor (`config`), same `from_pretrained(None, config=, state_dict=)`, same
+`forward(batch, task, compute_loss)` return values, same parameter names/shapes (state_dict contract,
+including the parameters the reference creates but never trains).  Host-side Python loops over viewpoint
+strings are replaced by per-batch index tensors (graphmap.py) + one gather kernel.
+"""
+from collections import defaultdict
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import graphmap, hipops
+from .layers import (BertAttention, BertLayerNorm, BertOnlyMLMHead, BertPredictionHeadTransform, ClsPrediction,
+                     CrossmodalEncoder, LayerNorm, Linear, RobertaEmbeddings, RobertaLayer, _p, compute_dtype,
+                     create_transformer_encoder, gen_seq_masks, neg_mask)
+
+
+class GoatPreTrainedModel(nn.Module):
+    """The four behaviours of transformers' BertPreTrainedModel the reference relies on
+    (P/train_r2r_goat.py:192-197, P/model/pretrain_goat.py:83-89)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+
+    def _init_weights(self, module):
+        std = getattr(self.config, 'initializer_range', 0.02)
+        if isinstance(module, nn.Linear):
+            module.weight.data.normal_(mean=0.0, std=std)
+            if module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.Embedding):
+            module.weight.data.normal_(mean=0.0, std=std)
+            if module.padding_idx is not None:
+                module.weight.data[module.padding_idx].zero_()
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+
+    def init_weights(self):
+        self.apply(self._init_weights)
+        self.tie_weights()
+
+    def tie_weights(self):
+        pass
+
+    def _tie_or_clone_weights(self, output_embeddings, input_embeddings):
+        output_embeddings.weight = input_embeddings.weight
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, config=None, state_dict=None, **kwargs):
+        model = cls(config)
+        if state_dict:
+            own = model.state_dict()
+            keep = {k: v for k, v in state_dict.items() if k in own and own[k].shape == v.shape}
+            model.load_state_dict(keep, strict=False)
+            model.tie_weights()
+        return model
+
+
+def _cfg(config, name, default):
+    v = getattr(config, name, default)
+    return default if v is None else v
+
+
+class LanguageEncoder(nn.Module):
+    # P/model/vilmodel_goat.py:24-44
+    def __init__(self, config):
+        super().__init__()
+        self.num_l_layers = config.num_l_layers
+        self.update_lang_bert = config.update_lang_bert
+        self.layer = nn.ModuleList([RobertaLayer(config) for _ in range(self.num_l_layers)])
+        if not self.update_lang_bert:
+            for _, param in self.layer.named_parameters():
+                param.requires_grad = False
+
+    def forward(self, txt_embeds, txt_kmask):
+        for layer in self.layer:
+            txt_embeds = layer(txt_embeds, txt_kmask)
+        if not self.update_lang_bert:
+            txt_embeds = txt_embeds.detach()
+        return txt_embeds
+
+
+class CausalImageEmbeddings(nn.Module):
+    """P/model/vilmodel_goat.py:234-364 (R2R branch; shipped pre-train configs keep do_back_img off — the
+    upstream BACL-img pretrain branch is broken, SURVEY §8a-Q viii)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        if getattr(config, 'name', 'R2R') in ('REVERIE', 'SOON'):
+            raise NotImplementedError('REVERIE/SOON object branch of the pre-training model is not built yet')
+        if getattr(config, 'do_back_img', False):
+            raise NotImplementedError('pretrain do_back_img is broken upstream (undefined do_back_img_after_linear)')
+        self.img_linear = Linear(config.image_feat_size, config.hidden_size)
+        self.img_layer_norm = BertLayerNorm(config.hidden_size, eps=1e-12)
+        self.loc_linear = Linear(config.angle_feat_size + 3, config.hidden_size)
+        self.loc_layer_norm = BertLayerNorm(config.hidden_size, eps=1e-12)
+        self.img_self_attn = BertAttention(config)          # created, never used (checkpoint compat)
+        self.img_self_encoder = create_transformer_encoder(config, config.num_pano_layers, norm=True)
+        self.nav_type_embedding = nn.Embedding(2, config.hidden_size)   # unused on R2R
+        if config.adaptive_pano_fusion:
+            self.adaptive_pano_attn = Linear(config.hidden_size, 1)
+        self.layer_norm = BertLayerNorm(config.hidden_size, eps=1e-12)  # unused on R2R
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, traj_view_img_fts, traj_loc_fts, traj_vp_view_lens):
+        dt = compute_dtype()
+        x = self.img_layer_norm(self.img_linear(traj_view_img_fts.to(dt)))
+        x = x + self.loc_layer_norm(self.loc_linear(traj_loc_fts.to(dt)))
+        x = hipops.dropout(x, _p(self.dropout))
+        img_masks = gen_seq_masks(traj_vp_view_lens, traj_view_img_fts.shape[1])
+        x = self.img_self_encoder(x, img_masks)
+        fused = None
+        if self.config.adaptive_pano_fusion:
+            fused = hipops.pano_fusion(x, self.adaptive_pano_attn.weight, self.adaptive_pano_attn.bias)
+        return x, fused
+
+
+class LocalVPEncoder(nn.Module):
+    # P/model/vilmodel_goat.py:366-410
+    def __init__(self, config):
+        super().__init__()
+        self.vp_pos_embeddings = nn.Sequential(Linear(config.angle_feat_size * 2 + 6, config.hidden_size),
+                                               BertLayerNorm(config.hidden_size, eps=1e-12))
+        self.encoder = CrossmodalEncoder(config)
+        if 'cfp' in config.pretrain_tasks:
+            self.tim_self_encoder = BertAttention(config)
+
+    def vp_input_embedding(self, pano_embeds, idx, vp_pos_fts):
+        """pano_embeds [N,V,H]; idx = graphmap.build_vp_index(...) on device."""
+        vidx, vstart, vp_lens, width = idx
+        B = vp_pos_fts.shape[0]
+        vp_img = hipops.gather_segmean(pano_embeds, vidx, vstart, None, B * width).view(B, width, -1)
+        pos = self.vp_pos_embeddings[1](self.vp_pos_embeddings[0](vp_pos_fts[:, :width].to(vp_img.dtype)))
+        return vp_img + pos, gen_seq_masks(vp_lens, width)
+
+
+class GlobalMapEncoder(nn.Module):
+    # P/model/vilmodel_goat.py:412-527
+    def __init__(self, config):
+        super().__init__()
+        self.gmap_pos_embeddings = nn.Sequential(Linear(config.angle_feat_size + 3, config.hidden_size),
+                                                 BertLayerNorm(config.hidden_size, eps=1e-12))
+        self.gmap_step_embeddings = nn.Embedding(config.max_action_steps, config.hidden_size)
+        self.encoder = CrossmodalEncoder(config)
+        if 'cfp' in config.pretrain_tasks:
+            self.tim_self_encoder = BertAttention(config)
+        self.sprel_linear = Linear(1, 1) if config.graph_sprels else None
+
+    def gmap_input_embedding(self, src_rows, idx, gmap_step_ids, gmap_pos_fts, gmap_lens):
+        gidx, gstart, gscale = idx
+        B, G = gmap_step_ids.shape
+        img = hipops.gather_segmean(src_rows, gidx, gstart, gscale, B * G).view(B, G, -1)
+        pos = self.gmap_pos_embeddings[1](self.gmap_pos_embeddings[0](gmap_pos_fts.to(img.dtype)))
+        e = img + self.gmap_step_embeddings(gmap_step_ids).to(img.dtype) + pos
+        return e, gen_seq_masks(gmap_lens, G)
+
+    def sprels(self, gmap_pair_dists):
+        # Linear(1,1) on the distance matrix (:496-497); float32, gradient flows back through the attention bias
+        w, b = self.sprel_linear.weight.view(()), self.sprel_linear.bias.view(())
+        return gmap_pair_dists.float() * w + b
+
+
+class GlocalTextPathCMT(GoatPreTrainedModel):
+    def __init__(self, config):
+        super().__init__(config)
+        if getattr(config, 'do_back_txt', False):
+            raise NotImplementedError('pre-training BACL-txt (do_back_txt) is not built yet; shipped configs keep it off')
+        self.embeddings = RobertaEmbeddings(config)
+        self.lang_encoder = LanguageEncoder(config)
+        self.img_embeddings = CausalImageEmbeddings(config)
+        self.local_encoder = LocalVPEncoder(config)
+        self.global_encoder = GlobalMapEncoder(config)
+        self.init_weights()
+
+    # -- shared stems -----------------------------------------------------------------------
+    def _indices(self, batch):
+        """Per-batch host index tensors, cached on the caller's batch dict."""
+        cache = batch.get('_goat_cache')
+        if cache is None:
+            dev = batch['traj_view_img_fts'].device
+            V = batch['traj_view_img_fts'].shape[1]
+            G = batch['gmap_step_ids'].shape[1]
+            fused = bool(self.config.adaptive_pano_fusion)
+            lens_cpu = batch['traj_vp_view_lens'].cpu()
+            g = graphmap.build_gmap_index(batch['traj_step_lens'], lens_cpu, batch['traj_vpids'],
+                                          batch['traj_cand_vpids'], batch['gmap_vpids'], G, V, fused)
+            v = graphmap.build_vp_index(batch['traj_step_lens'], lens_cpu, V)
+            cache = {'gmap': tuple(t.to(dev) for t in g),
+                     'vp': (v[0].to(dev), v[1].to(dev), v[2].to(dev), v[3])}
+            batch['_goat_cache'] = cache
+        return cache
+
+    def _text(self, batch):
+        txt_masks = gen_seq_masks(batch['txt_lens'], batch['txt_ids'].shape[1])
+        txt_kmask = neg_mask(txt_masks)
+        txt = self.lang_encoder(self.embeddings(batch['txt_ids']), txt_kmask)
+        return txt, txt_kmask
+
+    def _pano(self, batch):
+        x, fused = self.img_embeddings(batch['traj_view_img_fts'], batch['traj_loc_fts'], batch['traj_vp_view_lens'])
+        N, V, H = x.shape
+        rows = x.view(N * V, H)
+        src = torch.cat([rows, fused], 0) if fused is not None else rows
+        return x, src
+
+    def _gmap_in(self, batch, src, cache):
+        return self.global_encoder.gmap_input_embedding(src, cache['gmap'], batch['gmap_step_ids'],
+                                                        batch['gmap_pos_fts'], batch['gmap_lens'])
+
+    def _vp_in(self, batch, x, cache):
+        return self.local_encoder.vp_input_embedding(x, cache['vp'], batch['vp_pos_fts'])
+
+    # -- the three reference entry points ---------------------------------------------------------
+    def forward(self, batch, return_gmap_embeds=True):
+        """GlocalTextPathCMT.forward (P/model/vilmodel_goat.py:546-594) -> (gmap_embeds, vp_embeds, txt_embeds)."""
+        cache = self._indices(batch)
+        txt, txt_kmask = self._text(batch)
+        x, src = self._pano(batch)
+        gmap = None
+        if return_gmap_embeds:
+            g, gm = self._gmap_in(batch, src, cache)
+            bias = self.global_encoder.sprels(batch['gmap_pair_dists']) if self.global_encoder.sprel_linear is not None else None
+            gmap = self.global_encoder.encoder(g, neg_mask(gm), txt, txt_kmask, bias)
+        v, vm = self._vp_in(batch, x, cache)
+        vp = self.local_encoder.encoder(v, neg_mask(vm), txt, txt_kmask)
+        return gmap, vp, txt
+
+    def forward_mlm(self, batch):
+        # P/model/vilmodel_goat.py:597-648: text queries attend to map / local tokens, outputs summed
+        cache = self._indices(batch)
+        txt, txt_kmask = self._text(batch)
+        x, src = self._pano(batch)
+        g, gm = self._gmap_in(batch, src, cache)
+        gt = self.global_encoder.encoder(txt, txt_kmask, g, neg_mask(gm))
+        v, vm = self._vp_in(batch, x, cache)
+        vt = self.local_encoder.encoder(txt, txt_kmask, v, neg_mask(vm))
+        return gt + vt
+
+    def forward_cfp(self, batch):
+        # P/model/vilmodel_goat.py:650-696: single self-attention blocks, no cross-modal encoders
+        cache = self._indices(batch)
+        txt, _ = self._text(batch)
+        x, src = self._pano(batch)
+        g, gm = self._gmap_in(batch, src, cache)
+        gmap = self.global_encoder.tim_self_encoder(g, neg_mask(gm))
+        v, vm = self._vp_in(batch, x, cache)
+        vp = self.local_encoder.tim_self_encoder(v, neg_mask(vm))
+        return gmap, vp, txt
+
+
+def attn_pool(x, w):
+    """tanh-attention pooling over ALL slots, no padding mask (P/model/pretrain_goat.py:502-515)."""
+    xf = x.float()
+    a = torch.softmax(torch.matmul(torch.tanh(xf), w), 1)
+    return torch.tanh(torch.sum(xf * a, 1))
+
+
+def cfp_losses(gmap_o, vp_o, fused_o, txt_o, temperature, gather=None):
+    """3 x symmetric InfoNCE (P/model/pretrain_goat.py:519-534).  `gather` (dp.CfpGather) extends the
+    negatives across data-parallel ranks; with world_size 1 / None it is exactly the reference."""
+    B = gmap_o.shape[0]
+    if gather is not None:
+        gmap_a, vp_a, fused_a, txt_a, off = gather(gmap_o, vp_o, fused_o, txt_o)
+    else:
+        gmap_a, vp_a, fused_a, txt_a, off = gmap_o, vp_o, fused_o, txt_o, 0
+    target = torch.arange(B, device=gmap_o.device) + off
+
+    def sym(x_loc, x_all):
+        row = F.cross_entropy((x_loc @ txt_a.T) / temperature, target, reduction='none')       # image -> all texts
+        col = F.cross_entropy((txt_o @ x_all.T) / temperature, target, reduction='none')        # text -> all images
+        return (row + col) / 2.0
+    return sym(gmap_o, gmap_a) + sym(vp_o, vp_a) + sym(fused_o, fused_a)
+
+
+class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
+    def __init__(self, config):
+        super().__init__(config)
+        self.bert = GlocalTextPathCMT(config)
+        tasks = config.pretrain_tasks
+        if 'mlm' in tasks:
+            self.mlm_head = BertOnlyMLMHead(config)
+        if 'mrc' in tasks:
+            raise NotImplementedError('MRC head is not part of the shipped GOAT pre-training tasks')
+        if 'sap' in tasks:
+            self.global_sap_head = ClsPrediction(config.hidden_size)
+            self.local_sap_head = ClsPrediction(config.hidden_size)
+            self.sap_fuse_linear = ClsPrediction(config.hidden_size, input_size=config.hidden_size * 2) \
+                if config.glocal_fuse else None
+        if 'og' in tasks:
+            self.og_head = ClsPrediction(config.hidden_size)
+        if 'cfp' in tasks:
+            self.tim_txt_head = BertPredictionHeadTransform(config)
+            self.tim_global_head = BertPredictionHeadTransform(config)
+            self.tim_local_head = BertPredictionHeadTransform(config)
+            self.tim_fused_head = BertPredictionHeadTransform(config)      # created, never used (checkpoint compat)
+            for n in ('tim_txt_attn', 'tim_global_attn', 'tim_local_attn', 'tim_fused_attn'):
+                prm = nn.Parameter(torch.empty(config.hidden_size, 1))
+                nn.init.uniform_(prm, -0.1, 0.1)
+                setattr(self, n, prm)
+            self.temperature = config.cfp_temperature
+        self.cfp_gather = None   # set by dp.GoatDataParallel to share CFP negatives across ranks
+        self.init_weights()
+        self.tie_weights()
+
+    def tie_weights(self):
+        if 'mlm' in self.config.pretrain_tasks:
+            self._tie_or_clone_weights(self.mlm_head.predictions.decoder, self.bert.embeddings.word_embeddings)
+
+    def forward(self, batch, task, compute_loss=True):
+        cache_host = batch  # index cache is stored on the caller's dict
+        if not isinstance(batch, defaultdict):
+            wrapped = defaultdict(lambda: None, batch)
+            wrapped['_goat_cache'] = batch.get('_goat_cache')
+            batch = wrapped
+        try:
+            if task.startswith('mlm'):
+                return self.forward_mlm(batch, compute_loss)
+            elif task.startswith('sap'):
+                return self.forward_sap(batch, compute_loss)
+            elif task.startswith('cfp'):
+                return self.forward_cfp(batch, compute_loss)
+            elif task.startswith('og') or task.startswith('mrc') or task.startswith('valid_sap_og'):
+                raise NotImplementedError('task %s needs the REVERIE object branch (not built yet)' % task)
+            else:
+                raise ValueError('invalid task')
+        finally:
+            if batch is not cache_host and batch.get('_goat_cache') is not None:
+                try:
+                    cache_host['_goat_cache'] = batch['_goat_cache']
+                except TypeError:
+                    pass
+
+    # -- MLM ---------------------------------------------------------------------------------------
+    def forward_mlm(self, batch, compute_loss):
+        txt = self.bert.forward_mlm(batch)
+        labels = batch['txt_labels']
+        cache = batch['_goat_cache']
+        if 'mlm_idx' not in cache:
+            cache['mlm_idx'] = (labels.reshape(-1) != -1).nonzero().squeeze(1)
+            cache['mlm_tgt'] = labels.reshape(-1)[cache['mlm_idx']]
+        masked = txt.reshape(-1, txt.shape[-1]).index_select(0, cache['mlm_idx'])
+        scores = self.mlm_head(masked)          # float32 logits
+        if compute_loss:
+            return F.cross_entropy(scores, cache['mlm_tgt'], reduction='none')
+        return scores
+
+    # -- SAP ---------------------------------------------------------------------------------------
+    def _fuse_weights(self, gmap_embeds, vp_embeds):
+        if self.sap_fuse_linear is None:
+            return 0.5
+        return torch.sigmoid(self.sap_fuse_linear(torch.cat([gmap_embeds[:, 0], vp_embeds[:, 0]], 1)).float())
+
+    def forward_sap(self, batch, compute_loss):
+        gmap, vp, _ = self.bert(batch)
+        cache = batch['_goat_cache']
+        B, G = gmap.shape[:2]
+        W = vp.shape[1]
+        fw = self._fuse_weights(gmap, vp)
+        gl = self.global_sap_head(gmap).squeeze(2).float() * fw
+        gl = gl.masked_fill(batch['gmap_visited_masks'], -float('inf'))
+        gl = gl.masked_fill(gen_seq_masks(batch['gmap_lens'], G).logical_not(), -float('inf'))
+        ll = self.local_sap_head(vp).squeeze(2).float() * (1 - fw)
+        if 'sap' not in cache:
+            step_lens = batch['traj_step_lens']
+            last = torch.as_tensor(step_lens).cumsum(0) - 1
+            nav = batch['traj_nav_types'][last.to(batch['traj_nav_types'].device)] != 1     # [B, V]
+            nav = torch.cat([torch.zeros(B, 1, dtype=torch.bool, device=nav.device), nav], 1)[:, :W]
+            M = graphmap.build_sap_fusion(batch['traj_cand_vpids'], batch['gmap_vpids'], batch['gmap_visited_masks'], G, W)
+            cache['sap'] = (nav, M.to(gl.device))
+        nav, M = cache['sap']
+        ll = ll.masked_fill(nav, -float('inf'))
+        fused = gl + torch.bmm(M, ll.masked_fill(nav, 0.0).unsqueeze(2)).squeeze(2)
+        if compute_loss:
+            ga, la = batch['global_act_labels'], batch['local_act_labels']
+            return F.cross_entropy(gl, ga, reduction='none') + F.cross_entropy(ll, la, reduction='none') \
+                + F.cross_entropy(fused, ga, reduction='none')
+        return gl, ll, fused, batch['global_act_labels'], batch['local_act_labels']
+
+    # -- CFP ---------------------------------------------------------------------------------------
+    def forward_cfp(self, batch, compute_loss):
+        gmap, vp, txt = self.bert.forward_cfp(batch)
+        if batch['extra_heads']:
+            gmap = self.tim_global_head(gmap)
+            vp = self.tim_local_head(vp)
+            txt = self.tim_txt_head(txt)
+        fw = self._fuse_weights(gmap, vp)
+        go = attn_pool(gmap, self.tim_global_attn)
+        vo = attn_pool(vp, self.tim_local_attn)
+        to = attn_pool(txt, self.tim_txt_attn)
+        fo = go * fw + vo * (1 - fw)
+        if compute_loss:
+            return cfp_losses(go, vo, fo, to, self.temperature, self.cfp_gather)
+        return go, vo, fo, to
