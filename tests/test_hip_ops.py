@@ -1,0 +1,328 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against plain PyTorch fp32
+references of the same op.  Tolerances: fp32 path 1e-3 relative-to-scale (north_star), bf16 path 2e-2."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def _tol(dtype):
+    return 1e-3 if dtype == torch.float32 else 2e-2
+
+
+def _close(got, ref, dtype, what=''):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    scale = ref.abs().max().clamp_min(1e-6)
+    err = (got - ref).abs().max() / scale
+    assert err < _tol(dtype), '%s: max err / scale = %.3e' % (what, err)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from vln_goat_amd import hipops
+    return hipops
+
+
+def test_library_loads_and_version():
+    from vln_goat_amd import _lib
+    assert _lib.lib().goat_version() >= 100
+
+
+def test_probe_tr16_semantics(ops):
+    """ds_read_b64_tr_b16 lane mapping (recorded for the TN-GEMM work; asserts the documented hypothesis:
+    within a 16-lane group, result(l, j) = source lane (4*j + (l&15)>>2), element (l&3))."""
+    from vln_goat_amd import _lib
+    out = torch.zeros(256, dtype=torch.int16, device=DEV)
+    st = _lib.lib().goat_probe_tr16(torch.cuda.current_stream().cuda_stream, out.data_ptr())
+    assert st == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.int64).reshape(64, 4)
+    import os
+    os.makedirs('gpurun_out', exist_ok=True)
+    np.savetxt('gpurun_out/tr16_probe.txt', got, fmt='%d')
+    exp = np.zeros((64, 4), dtype=np.int64)
+    for l in range(64):
+        g, i = l // 16, l % 16
+        for j in range(4):
+            src_lane = g * 16 + 4 * j + (i >> 2)
+            exp[l, j] = src_lane * 4 + (i & 3)
+    assert np.array_equal(got, exp), got[:16]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 768, 768), (37, 1, 768), (300, 2304, 768), (65, 50, 3072),
+                                   (1056, 768, 8)])
+def test_gemm_nt_plain_and_bias(ops, dtype, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g).to(DEV, dtype)
+    b = (torch.randn(N, K, generator=g) * 0.1).to(DEV, dtype)
+    bias = torch.randn(N, generator=g).to(DEV)
+    out = torch.empty(M, N, device=DEV, dtype=dtype)
+    ops.gemm_nt(a, b, out, bias)
+    ref = a.float() @ b.float().T + bias
+    _close(out, ref, dtype, 'gemm')
+    # asymmetric operands catch transposes: also check a single known element
+    i, j = M // 2, N // 3
+    assert abs(float(out[i, j]) - float(ref[i, j])) <= _tol(dtype) * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('act', ['gelu', 'relu'])
+def test_gemm_epilogues(ops, dtype, act):
+    from vln_goat_amd._lib import EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU
+    M, N, K = 257, 3072, 768
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g).to(DEV, dtype)
+    b = (torch.randn(N, K, generator=g) * 0.05).to(DEV, dtype)
+    bias = torch.randn(N, generator=g).to(DEV) * 0.1
+    out = torch.empty(M, N, device=DEV, dtype=dtype)
+    aux = torch.empty(M, N, device=DEV, dtype=dtype)
+    ops.gemm_nt(a, b, out, bias, EPI_GELU if act == 'gelu' else EPI_RELU, aux)
+    u = a.float() @ b.float().T + bias
+    ref = torch.nn.functional.gelu(u) if act == 'gelu' else torch.relu(u)
+    _close(aux, u, dtype, 'pre-activation')
+    _close(out, ref, dtype, 'activation')
+    # backward epilogue: C = (A·B^T) * act'(aux)
+    dy = torch.randn(M, K, generator=g).to(DEV, dtype)     # reuse shapes: dX[M,N'] with N' = N, K' = K
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV, dtype)
+    dxo = torch.empty(M, N, device=DEV, dtype=dtype)
+    ops.gemm_nt(dy, w, dxo, None, EPI_MUL_DGELU if act == 'gelu' else EPI_MUL_DRELU, aux)
+    uu = aux.float().requires_grad_(True)
+    (torch.nn.functional.gelu(uu) if act == 'gelu' else torch.relu(uu)).sum().backward()
+    ref2 = (dy.float() @ w.float().T) * uu.grad
+    _close(dxo, ref2, dtype, 'act-derivative epilogue')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_wgrad_splitk_and_bias_grad(ops, dtype):
+    M, N, K = 1003, 768, 3072
+    g = torch.Generator().manual_seed(11)
+    dy = (torch.randn(M, N, generator=g) * 0.1).to(DEV, dtype)
+    x = torch.randn(M, K, generator=g).to(DEV, dtype)
+    dw, db = ops.wgrad(dy, x, True)
+    _close(dw, dy.float().T @ x.float(), dtype, 'dW')
+    _close(db, dy.float().sum(0), dtype, 'db')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('R,C', [(64, 64), (100, 37), (3840, 768), (5, 3072)])
+def test_transpose_pad(ops, dtype, R, C):
+    x = torch.randn(R, C).to(DEV, dtype)
+    cs = torch.zeros(C, device=DEV)
+    out = ops.transpose_pad(x, cs)
+    assert out.shape[0] == C and out.shape[1] >= R
+    assert torch.equal(out[:, :R], x.T)
+    assert float(out[:, R:].abs().sum()) == 0.0
+    _close(cs, x.float().sum(0), dtype, 'colsum')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_layer_norm_fwd_bwd(ops, dtype, with_res):
+    M, H = 515, 768
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, H, generator=g).to(DEV, dtype).requires_grad_(True)
+    r = torch.randn(M, H, generator=g).to(DEV, dtype).requires_grad_(True) if with_res else None
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV).requires_grad_(True)
+    beta = (0.1 * torch.randn(H, generator=g)).to(DEV).requires_grad_(True)
+    y = ops.layer_norm(x, gamma, beta, 1e-12, r, 0.0)
+    dy = torch.randn(M, H, generator=g).to(DEV, dtype)
+    y.backward(dy)
+    xr = x.detach().float().requires_grad_(True)
+    rr = r.detach().float().requires_grad_(True) if with_res else None
+    gr, br = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    z = xr + rr if with_res else xr
+    yr = torch.nn.functional.layer_norm(z, (H,), gr, br, 1e-12)
+    yr.backward(dy.float())
+    _close(y, yr, dtype, 'ln y')
+    _close(x.grad, xr.grad, dtype, 'ln dx')
+    if with_res:
+        _close(r.grad, rr.grad, dtype, 'ln dres')
+    _close(gamma.grad, gr.grad, dtype, 'ln dgamma')
+    _close(beta.grad, br.grad, dtype, 'ln dbeta')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dropout_mask_consistency_and_rate(ops, dtype):
+    ops.manual_seed(123)
+    n = 1 << 20
+    x = torch.ones(n, device=DEV, dtype=dtype, requires_grad=True)
+    y = ops.dropout(x, 0.1)
+    keep = (y != 0)
+    rate = 1.0 - keep.float().mean().item()
+    assert abs(rate - 0.1) < 5e-3
+    assert torch.allclose(y[keep].float(), torch.full_like(y[keep].float(), 1 / 0.9), rtol=1e-2)
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad != 0, keep)          # backward regenerates the same mask
+    y2 = ops.dropout(x, 0.1)                        # a second call draws a different mask
+    assert not torch.equal(y2 != 0, keep)
+    # LayerNorm-fused dropout: residual path untouched, dropped path scaled
+    ops.manual_seed(7)
+    xx = torch.randn(256, 768, device=DEV).to(dtype).requires_grad_(True)
+    rr = torch.randn(256, 768, device=DEV).to(dtype).requires_grad_(True)
+    gmm = torch.ones(768, device=DEV, requires_grad=True)
+    bt = torch.zeros(768, device=DEV, requires_grad=True)
+    yy = ops.layer_norm(xx, gmm, bt, 1e-5, rr, 0.3)
+    yy.backward(torch.randn_like(yy))
+    frac_zero = (xx.grad == 0).float().mean().item()
+    assert abs(frac_zero - 0.3) < 2e-2
+    assert (rr.grad == 0).float().mean().item() < 1e-2
+
+
+def _attn_ref(q, k, v, kmask, bias, nh):
+    B, Lq, H = q.shape
+    Lk = k.shape[1]
+
+    def sp(x):
+        return x.view(x.shape[0], x.shape[1], nh, 64).permute(0, 2, 1, 3)
+    s = sp(q) @ sp(k).transpose(-1, -2) / 8.0
+    if kmask is not None:
+        s = s + kmask[:, None, None, :]
+    if bias is not None:
+        s = s + bias[:, None]
+    p = torch.softmax(s, -1)
+    return (p @ sp(v)).permute(0, 2, 1, 3).reshape(B, Lq, H)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('Lq,Lk,mode,use_bias,inf', [
+    (80, 80, 'self', False, False), (36, 36, 'self', False, True), (22, 22, 'self', True, False),
+    (37, 80, 'cross', False, False), (80, 23, 'cross', False, False), (130, 130, 'self', False, False),
+    (5, 200, 'cross', False, False), (33, 65, 'cross', False, False)])
+def test_attention_fwd_bwd(ops, dtype, Lq, Lk, mode, use_bias, inf):
+    B, nh, H = 3, 12, 768
+    g = torch.Generator().manual_seed(Lq * 131 + Lk)
+    klens = torch.tensor([Lk, max(1, Lk // 2), max(1, Lk - 3)])
+    valid = torch.arange(Lk)[None, :] < klens[:, None]
+    kmask = torch.zeros(B, Lk).masked_fill(~valid, float('-inf') if inf else -10000.0).to(DEV)
+    bias = (torch.randn(B, Lq, Lk, generator=g) * 0.5).to(DEV).requires_grad_(True) if use_bias else None
+    if mode == 'self':
+        a = (torch.randn(B, Lq, 3 * H, generator=g) * 0.7).to(DEV, dtype).requires_grad_(True)
+        b = None
+        o = ops.attention(a, None, kmask, bias, nh, 0.0)
+        af = a.detach().float().requires_grad_(True)
+        q, k, v = af.split(H, -1)
+    else:
+        a = (torch.randn(B, Lq, H, generator=g) * 0.7).to(DEV, dtype).requires_grad_(True)
+        b = (torch.randn(B, Lk, 2 * H, generator=g) * 0.7).to(DEV, dtype).requires_grad_(True)
+        o = ops.attention(a, b, kmask, bias, nh, 0.0)
+        af = a.detach().float().requires_grad_(True)
+        bf = b.detach().float().requires_grad_(True)
+        q = af
+        k, v = bf.split(H, -1)
+    biasf = bias.detach().clone().requires_grad_(True) if use_bias else None
+    ref = _attn_ref(q, k, v, kmask, biasf, nh)
+    do = torch.randn(B, Lq, H, generator=g).to(DEV)
+    o.backward(do.to(dtype))
+    ref.backward(do.to(dtype).float())
+    _close(o, ref, dtype, 'attn out')
+    _close(a.grad, af.grad, dtype, 'attn da')
+    if b is not None:
+        _close(b.grad, bf.grad, dtype, 'attn db')
+    if use_bias:
+        _close(bias.grad, biasf.grad, dtype, 'attn dbias')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_attention_dropout_is_unbiased_and_reproducible(ops, dtype):
+    B, L, nh, H = 4, 64, 12, 768
+    ops.manual_seed(99)
+    a = (torch.randn(B, L, 3 * H) * 0.5).to(DEV, dtype).requires_grad_(True)
+    base = ops.attention(a, None, None, None, nh, 0.0).float()
+    acc = torch.zeros_like(base)
+    n = 64
+    for _ in range(n):
+        acc += ops.attention(a, None, None, None, nh, 0.1).float()
+    mean = acc / n
+    assert (mean - base).abs().mean() / base.abs().mean() < 0.08
+    # backward with dropout: finite-difference-free check via linearity in dO
+    ops.manual_seed(5)
+    o1 = ops.attention(a, None, None, None, nh, 0.1)
+    o1.backward(torch.ones_like(o1))
+    g1 = a.grad.clone()
+    a.grad = None
+    ops.manual_seed(5)
+    o2 = ops.attention(a, None, None, None, nh, 0.1)
+    assert torch.equal(o1, o2)
+    o2.backward(torch.ones_like(o2))
+    assert torch.equal(g1, a.grad)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pano_fusion(ops, dtype):
+    N, V, H = 17, 36, 768
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(N, V, H, generator=g).to(DEV, dtype).requires_grad_(True)
+    w = (torch.randn(1, H, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    b0 = torch.randn(1, generator=g).to(DEV).requires_grad_(True)
+    f = ops.pano_fusion(x, w, b0)
+    df = torch.randn(N, H, generator=g).to(DEV)
+    f.backward(df.to(dtype))
+    xr = x.detach().float().requires_grad_(True)
+    wr, br = w.detach().clone().requires_grad_(True), b0.detach().clone().requires_grad_(True)
+    ws = torch.softmax(torch.tanh(xr @ wr.T + br), dim=1)
+    fr = (xr * ws).sum(1)
+    fr.backward(df.to(dtype).float())
+    _close(f, fr, dtype, 'fused')
+    _close(x.grad, xr.grad, dtype, 'dx')
+    _close(w.grad, wr.grad, dtype, 'da')
+    _close(b0.grad, br.grad, dtype, 'da0')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gather_segmean(ops, dtype):
+    rows, H, n_out = 50, 768, 9
+    g = torch.Generator().manual_seed(8)
+    src = torch.randn(rows, H, generator=g).to(DEV, dtype).requires_grad_(True)
+    segs = [[], [3], [4, 4, 7], [49, 0], [], [1, 2, 3, 5], [10], [11, 12], []]
+    idx = torch.tensor([i for s in segs for i in s] or [-1], dtype=torch.int32, device=DEV)
+    start = torch.tensor(np.cumsum([0] + [len(s) for s in segs]), dtype=torch.int32, device=DEV)
+    scale = torch.tensor([1.0 / max(1, len(s)) for s in segs], device=DEV)
+    out = ops.gather_segmean(src, idx, start, scale, n_out)
+    dout = torch.randn(n_out, H, generator=g).to(DEV, dtype)
+    out.backward(dout)
+    sr = src.detach().float().requires_grad_(True)
+    ref = torch.stack([sr[s].mean(0) if s else torch.zeros(H, device=DEV) for s in segs])
+    ref.backward(dout.float())
+    _close(out, ref, dtype, 'gather')
+    _close(src.grad, sr.grad, dtype, 'gather grad')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_linear_ffn_autograd(ops, dtype):
+    M, H, F_ = 300, 768, 3072
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(M, H, generator=g).to(DEV, dtype).requires_grad_(True)
+    w1 = torch.nn.Parameter((torch.randn(F_, H, generator=g) * 0.03).to(DEV))
+    b1 = torch.nn.Parameter((torch.randn(F_, generator=g) * 0.1).to(DEV))
+    w2 = torch.nn.Parameter((torch.randn(H, F_, generator=g) * 0.03).to(DEV))
+    b2 = torch.nn.Parameter((torch.randn(H, generator=g) * 0.1).to(DEV))
+    y = ops.ffn(x, w1, b1, w2, b2, 'gelu', 0.0)
+    dy = torch.randn(M, H, generator=g).to(DEV, dtype)
+    y.backward(dy)
+    xr = x.detach().float().requires_grad_(True)
+    ps = [p.detach().clone().requires_grad_(True) for p in (w1, b1, w2, b2)]
+    if dtype == torch.bfloat16:     # the kernels see bf16-rounded weights
+        wq = [ps[0].to(dtype).float(), ps[2].to(dtype).float()]
+    else:
+        wq = [ps[0], ps[2]]
+    yr = torch.nn.functional.gelu(xr @ wq[0].T + ps[1]) @ wq[1].T + ps[3]
+    yr.backward(dy.float())
+    _close(y, yr, dtype, 'ffn y')
+    _close(x.grad, xr.grad, dtype, 'ffn dx')
+    for p, r, n in zip((w1, b1, w2, b2), ps, ('dw1', 'db1', 'dw2', 'db2')):
+        _close(p.grad, r.grad, dtype, 'ffn ' + n)
+    # small-K / N=1 linears go through the same GEMM
+    xs = torch.randn(77, 7, generator=g).to(DEV, dtype).requires_grad_(True)
+    ws = torch.nn.Parameter((torch.randn(768, 7, generator=g)).to(DEV))
+    bs = torch.nn.Parameter(torch.randn(768, generator=g).to(DEV))
+    ys = ops.linear(xs, ws, bs)
+    ys.backward(torch.ones_like(ys))
+    _close(ys, xs.float() @ (ws.to(dtype).float()).T + bs, dtype, 'K=7 linear')
+    _close(ws.grad, torch.ones(77, 768, device=DEV).T @ xs.detach().float(), dtype, 'K=7 dW')
+    _close(xs.grad, torch.ones(77, 768, device=DEV) @ ws.detach().to(dtype).float(), dtype, 'K=7 dx')

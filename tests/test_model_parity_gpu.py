@@ -1,0 +1,114 @@
+"""End-to-end GPU parity: the HIP model (through the C ABI) against the CPU oracle on the same seeded
+inputs, and against the golden vectors of the imported reference.  fp32 path: 1e-3; bf16 path: 2e-2
+(relative to each tensor's scale), per BASELINE.json north_star."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, build_case, load_golden, oracle_run
+
+pytestmark = pytest.mark.gpu
+SMALL = ['pretrain_small_fixed', 'pretrain_small_ragged']
+
+
+def _rel(a, b):
+    a, b = a.double().cpu().reshape(-1), b.double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('task', ['mlm', 'sap', 'cfp'])
+@pytest.mark.parametrize('case', SMALL)
+def test_losses_and_grads_match_oracle(case, task, dtype):
+    import vln_goat_amd
+    from vln_goat_amd import synth
+    cfg, model, batch = build_case(case)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ref_loss, ref_grads = oracle_run(cfg, sd, batch, task)
+    gold = load_golden(case)
+    vln_goat_amd.set_compute_dtype(dtype)
+    try:
+        model = model.cuda().eval()
+        gb = synth.batch_to(batch, 'cuda')
+        loss = model(gb, task, compute_loss=True)
+        loss.mean().backward()
+        torch.cuda.synchronize()
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)
+    tol = 1e-3 if dtype == torch.float32 else 2e-2
+    scale = max(1.0, float(ref_loss.abs().max()))
+    lossc = loss.detach().float().cpu()
+    assert float((lossc - ref_loss).abs().max()) / scale < tol
+    assert float(np.abs(lossc.numpy() - gold[task + '_loss_vec']).max()) / scale < tol
+    # gradients: every parameter tensor, relative L2 error.  Gradients that are mathematically zero
+    # (e.g. key biases: softmax is shift-invariant) are checked on an absolute scale instead.
+    gmax = max(float(g.norm()) for g in ref_grads.values() if g is not None)
+    rtol = 1e-3 if dtype == torch.float32 else 0.25       # per tensor
+    agg_tol = 1e-4 if dtype == torch.float32 else 3e-2    # sum |err| / sum |ref| over all tensors
+    bad, num, den = [], 0.0, 0.0
+    for n, p in model.named_parameters():
+        rg = ref_grads.get(n)
+        if rg is None or float(rg.norm()) <= 1e-6 * gmax:
+            if p.grad is not None:
+                assert float(p.grad.float().norm()) <= 1e-4 * gmax, n
+            continue
+        assert p.grad is not None, n
+        d = float((p.grad.double().cpu() - rg.double()).norm())
+        num += d
+        den += float(rg.double().norm())
+        if d / float(rg.double().norm()) > rtol:
+            bad.append((n, d / float(rg.double().norm())))
+    assert not bad, bad[:10]
+    assert num / den < agg_tol, num / den
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', SMALL)
+def test_logits_match_reference_golden(case, dtype):
+    import vln_goat_amd
+    from vln_goat_amd import synth
+    cfg, model, batch = build_case(case)
+    gold = load_golden(case)
+    vln_goat_amd.set_compute_dtype(dtype)
+    try:
+        model = model.cuda().eval()
+        gb = synth.batch_to(batch, 'cuda')
+        with torch.no_grad():
+            gl, ll, fl, _, _ = model(gb, 'sap', compute_loss=False)
+            go, vo, fo, to = model(gb, 'cfp', compute_loss=False)
+            gm, vp, tx = model.bert(gb)
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)
+    tol = 1e-3 if dtype == torch.float32 else 2e-2
+    for got, key in ((gl, 'sap_global_logits'), (ll, 'sap_local_logits'), (fl, 'sap_fused_logits')):
+        ref = gold[key]
+        g = got.float().cpu().numpy()
+        assert np.array_equal(np.isinf(g), np.isinf(ref)), key
+        m = ~np.isinf(ref)
+        assert np.abs(g[m] - ref[m]).max() / max(1.0, np.abs(ref[m]).max()) < tol, key
+    for got, key in ((go, 'cfp_gmap_out'), (vo, 'cfp_vp_out'), (fo, 'cfp_fused_out'), (to, 'cfp_txt_out')):
+        assert np.abs(got.float().cpu().numpy() - gold[key]).max() < tol, key
+    for got, key in ((gm, 'bert_gmap_embeds'), (vp, 'bert_vp_embeds'), (tx, 'bert_txt_embeds')):
+        ref = gold[key]
+        g = got[:, :, :16].float().cpu().numpy()
+        assert np.abs(g - ref).max() / np.abs(ref).max() < tol * 2, key
+
+
+def test_training_mode_runs_with_dropout_and_is_finite():
+    import vln_goat_amd
+    from vln_goat_amd import synth
+    cfg, model, batch = build_case('pretrain_small_ragged')
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        model = model.cuda().train()
+        gb = synth.batch_to(batch, 'cuda')
+        for task in ('mlm', 'sap', 'cfp'):
+            model.zero_grad(set_to_none=True)
+            loss = model(gb, task, compute_loss=True)
+            loss.mean().backward()
+            assert torch.isfinite(loss).all()
+            for n, p in model.named_parameters():
+                if p.grad is not None:
+                    assert torch.isfinite(p.grad).all(), n
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)
