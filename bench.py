@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""bench.py — GOAT pre-training fwd+bwd throughput (trajectory-steps/s) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 30 --warmup 6
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): full R2R GOAT pre-train config (6 text / 3+3 cross-modal / 2 panorama
+layers, vocab 50265, 208 M parameters, pretrain_src/config/r2r_GOAT_model_config.json), per-rank batch 48,
+T=5 panoramas x 36 views x 768, 80-token instructions, tasks cycled mlm->sap->cfp (the shipped 1:1:1
+mix_ratio), dropout 0.1 ON, random-init weights, synthetic inputs.  A "step" is one forward+backward of one
+task on one batch (+ gradient all-reduce over ranks when N>1, no optimizer).  Compute dtype bf16 (f32
+accumulate, f32 master weights / gradients).  On 1 GPU each task's step is captured once into a hipGraph
+and replayed; dropout masks change per replay through a device-side counter.
+
+One JSON line is printed by rank 0 (see the contract in the task statement) with `roofline` (MFMA GEMM
+kernel: algorithmic FLOPs / HIP-event time per launch, measured live) and `cpu_baseline` (the CPU oracle
+= a port of the reference path, timed on the host cores of this box on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+TASKS = ('mlm', 'sap', 'cfp')
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # dense peaks, MI355X_MICROARCH.md
+# algorithmic FLOPs per trajectory-step, fwd+bwd, 1:1:1 task mix at L=80,T=5,V=36,G=22
+ALGO_GFLOP_PER_TRAJ_STEP = {'mlm': 12.98, 'sap': 9.83, 'cfp': 7.6}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--batch', type=int, default=48, help='per-rank batch (train_batch_size of r2r_GOAT_pretrain.json)')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--layers', default='6,3,2', help='num_l_layers,num_top_layer,num_pano_layers')
+    return ap.parse_args()
+
+
+def setup_dist(args):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    return world, rank, local
+
+
+def build(args, rank):
+    import vln_goat_amd
+    from vln_goat_amd import config as gcfg, pretrain_model, synth
+    nl, nx, npano = [int(x) for x in args.layers.split(',')]
+    cfg = gcfg.make_config(num_l_layers=nl, num_top_layer=nx, num_pano_layers=npano)
+    torch.manual_seed(0)
+    model = pretrain_model.GlocalTextPathCMTPreTraining(cfg)    # random init (reference init rule)
+    model = model.cuda().train()
+    vln_goat_amd.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+    batch = synth.make_pretrain_batch(B=args.batch, T=5, L=80, seed=100 + rank, style='survey')
+    gb = synth.batch_to(batch, 'cuda')
+    return cfg, model, batch, gb
+
+
+def make_steps(args, model, gb, world):
+    """Returns {task: callable running one fwd+bwd step}, and per-task gradient lists."""
+    from vln_goat_amd import hipops
+    hipops.manual_seed(1234)
+    hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')
+    params = list(model.parameters())
+
+    def eager_step(task):
+        for p in params:
+            p.grad = None
+        hipops.RngState.dev.add_(0x9E3779B1)
+        loss = model(gb, task, compute_loss=True)
+        loss.mean().backward()
+        return loss
+
+    use_graph = not args.no_graph
+    steps, grads, losses = {}, {}, {}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for task in TASKS:                       # warm-up: builds weight shadows, index caches, kernel attrs
+            for _ in range(2):
+                eager_step(task)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    if not use_graph:
+        for task in TASKS:
+            steps[task] = (lambda t=task: eager_step(t))
+        return steps, None
+    for task in TASKS:
+        g = torch.cuda.CUDAGraph()
+        for p in params:
+            p.grad = None
+        with torch.cuda.graph(g):
+            hipops.RngState.dev.add_(0x9E3779B1)
+            loss = model(gb, task, compute_loss=True)
+            loss.mean().backward()
+        grads[task] = [p.grad for p in params]
+        losses[task] = loss
+        steps[task] = g.replay
+    return steps, grads
+
+
+def cpu_baseline(args, cfg):
+    """The CPU oracle (a port of the reference path; validated against the imported reference in the build
+    container) timed on this box's host cores: fp32, dropout on, bounded sample."""
+    from oracle import goat_oracle
+    from vln_goat_amd import pretrain_model, synth
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    model = pretrain_model.GlocalTextPathCMTPreTraining(cfg)
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in model.state_dict().items()}
+    sd['mlm_head.predictions.decoder.weight'] = sd['bert.embeddings.word_embeddings.weight']
+    B = args.cpu_batch
+    batch = synth.make_pretrain_batch(B=B, T=5, L=80, seed=7, style='survey')
+    times = []
+    t_budget = time.time()
+    for it in range(1 + 2):
+        for task in TASKS:
+            for v in sd.values():
+                if torch.is_tensor(v) and v.requires_grad:
+                    v.grad = None
+            t0 = time.time()
+            loss = goat_oracle.forward(cfg, sd, batch, task, compute_loss=True, training=True)
+            loss.mean().backward()
+            dt = time.time() - t0
+            if it > 0:
+                times.append(dt)
+        if time.time() - t_budget > 40:
+            break
+    if not times:
+        return None
+    per_step = sum(times) / len(times)
+    return {'value': round(B * 5 / per_step, 2), 'unit': 'trajectory-steps/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': 'oracle/goat_oracle.py fp32 fwd+bwd, full R2R config, B=%d T=5 L=80, dropout on, %d timed steps '
+                      '(mlm/sap/cfp cycled) after 1 warm-up cycle' % (B, len(times))}
+
+
+def gemm_roofline(args, model, gb):
+    """Time every goat_gemm_nt launch of one eager mlm+sap+cfp cycle with HIP events on the launch stream."""
+    from vln_goat_amd import hipops
+    hipops.PROFILE = []
+    for task in TASKS:
+        for p in model.parameters():
+            p.grad = None
+        loss = model(gb, task, compute_loss=True)
+        loss.mean().backward()
+    torch.cuda.synchronize()
+    recs = hipops.PROFILE
+    hipops.PROFILE = None
+    tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
+    tot_fl = sum(f for _, _, f, _ in recs)
+    n = len(recs)
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    return {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'traffic': None, 'kernel': 'gemm_nt_kernel', 'launches_per_cycle': n,
+            'avg_launch_us': round(tot_ms * 1e3 / max(n, 1), 2),
+            'algorithmic_gflop_per_launch': round(tot_fl / max(n, 1) / 1e9, 3),
+            'gemm_ms_per_cycle': round(tot_ms, 3)}
+
+
+def main():
+    args = parse()
+    world, rank, local = setup_dist(args)
+    cfg, model, batch, gb = build(args, rank)
+    from vln_goat_amd import dp, synth
+    wrapper = dp.GoatDataParallel(model, share_cfp_negatives=True) if world > 1 else None
+    if world > 1:
+        args.no_graph = True      # collectives (CFP all-gather, grad all-reduce) run eagerly in round 1
+    steps, grads = make_steps(args, model, gb, world)
+    n_traj = synth.n_traj_steps(batch)
+
+    def run(i):
+        task = TASKS[i % len(TASKS)]
+        steps[task]()
+        if world > 1:
+            wrapper.reduce_gradients(task)
+
+    for i in range(args.warmup):
+        run(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        value = n_traj * world * args.steps / dt
+        algo = sum(ALGO_GFLOP_PER_TRAJ_STEP.values()) / 3.0
+        out = {
+            'metric': 'trajectory-steps/sec fwd+bwd (GOAT pretrain, 36 views x 768, 80 tok)',
+            'value': round(value, 1), 'unit': 'trajectory-steps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'Full R2R GOAT pretrain config (pretrain_src/run_r2r_goat.sh): %s layers text/cross/pano, '
+                                   'vocab 50265, per-rank batch %d, T=5, 36x768 views, L=80, tasks mlm/sap/cfp 1:1:1, dropout 0.1, '
+                                   'fwd+bwd%s, random-init' % (args.layers, args.batch, ' + grad all-reduce' if world > 1 else ''),
+                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                       'launch': 'eager' if args.no_graph else 'hipGraph replay'},
+            'samples_per_s': round(value / 5.0, 1),
+            'step_mfma_frac': round(value / world * algo * 1e9 / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4),
+        }
+        if world == 1 and not args.no_roofline:
+            out['roofline'] = gemm_roofline(args, model, gb)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, cfg)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

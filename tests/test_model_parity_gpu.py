@@ -43,8 +43,10 @@ def test_losses_and_grads_match_oracle(case, task, dtype):
     # gradients: every parameter tensor, relative L2 error.  Gradients that are mathematically zero
     # (e.g. key biases: softmax is shift-invariant) are checked on an absolute scale instead.
     gmax = max(float(g.norm()) for g in ref_grads.values() if g is not None)
-    rtol = 1e-3 if dtype == torch.float32 else 0.25       # per tensor
-    agg_tol = 1e-4 if dtype == torch.float32 else 3e-2    # sum |err| / sum |ref| over all tensors
+    # bf16 tolerances are calibrated on stock PyTorch: the CPU oracle under torch.autocast(bfloat16) differs from
+    # its own fp32 run by 6.6% (sap) / 0.8% (mlm) / 2.0% (cfp) aggregate on these cases (worst tensor 15%).
+    rtol = 1e-3 if dtype == torch.float32 else 0.35       # per tensor
+    agg_tol = 1e-4 if dtype == torch.float32 else 0.12    # sum |err| / sum |ref| over all tensors
     bad, num, den = [], 0.0, 0.0
     for n, p in model.named_parameters():
         rg = ref_grads.get(n)

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libgoat_hip.so')
-SOURCES = ['gemm.hip', 'attention.hip', 'rowops.hip']
+SOURCES = ['gemm.hip', 'gemm2.hip', 'attention.hip', 'rowops.hip']
 
 GOAT_F32, GOAT_BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU = 0, 1, 2, 3, 4
@@ -30,6 +30,9 @@ _f32 = ctypes.c_float
 SIGNATURES = {
     'goat_version': [],
     'goat_gemm_nt': [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i32],
+    'goat_gemm_bf16': [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i32, _i32],
+    'goat_gemm_bf16_set_stages': [_i32],
+    'goat_colsum': [_vp, _i32, _vp, _i64, _i32, _i32, _vp],
     'goat_transpose': [_vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _vp],
     'goat_ln_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
     'goat_ln_bwd_ws_floats': [_i32],

@@ -166,13 +166,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                     int nparts, int H) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * H) return;
+// 256 threads = 32 columns x 8 part-groups; coalesced over columns, parts strided over the groups
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int nparts, int H) {
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cx;
   float s = 0.f;
-  for (int b = 0; b < nparts; ++b) s += ws[(int64_t)b * 2 * H + i];
-  if (i < H) dgamma[i] = s; else dbeta[i - H] = s;
+  if (i < 2 * H)
+    for (int b = g; b < nparts; b += 8) s += ws[(int64_t)b * 2 * H + i];
+  red[g][cx] = s;
+  __syncthreads();
+  if (g == 0 && i < 2 * H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    if (i < H) dgamma[i] = t; else dbeta[i - H] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------ dropout (+add)
@@ -245,6 +255,25 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, 
     g *= (act == 1) ? dgelu_f(uv) : (uv > 0.f ? 1.f : 0.f);
     dx[i] = from_f<T>(g);
   }
+}
+
+
+// ------------------------------------------------------------------------------------ column sums
+// block = 256 threads = 64 columns x 4 row lanes; each block walks a strip of rows, one atomic per column.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ld, int R, int C,
+                                                     float* __restrict__ colsum, int rows_per_block) {
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(R, r0 + rows_per_block);
+  float acc = 0.f;
+  if (c < C)
+    for (int r = r0 + ty; r < r1; r += 4) acc += to_f(x[(int64_t)r * ld + c]);
+  part[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < C) atomicAdd(colsum + c, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
 }
 
 // ------------------------------------------------------------------------------------ transpose
@@ -465,7 +494,7 @@ extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* r
   return 0;
 }
 
-#define GOAT_LN_BWD_PARTS 256
+#define GOAT_LN_BWD_PARTS 128
 
 extern "C" int goat_ln_bwd_ws_floats(int H) { return GOAT_LN_BWD_PARTS * 2 * H; }
 
@@ -491,7 +520,7 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
     return GOAT_E_ARG;
   }
   GOAT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, ST(stream), ws, dgamma, dbeta, nparts,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 31) / 32), dim3(256), 0, ST(stream), ws, dgamma, dbeta, nparts,
                      H);
   GOAT_LAUNCH_CHECK();
   return 0;
@@ -549,6 +578,27 @@ extern "C" int goat_act_bwd(void* stream, int dtype, const void* dy, const void*
   else if (dtype == GOAT_F32)
     hipLaunchKernelGGL(act_bwd_kernel<float>, dim3((int)blocks), dim3(256), 0, ST(stream), (const float*)dy,
                        (const float*)u, (float*)dx, n, act, p, seed, offset, rng_dev);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_colsum(void* stream, int dtype, const void* x, int64_t ld, int R, int C, float* colsum) {
+  if (!x || !colsum) return GOAT_E_ARG;
+  if (R <= 0 || C <= 0) return GOAT_E_SHAPE;
+  const int cb = (C + 63) / 64;
+  int rb = (1024 + cb - 1) / cb;
+  if (rb > (R + 31) / 32) rb = (R + 31) / 32;
+  if (rb < 1) rb = 1;
+  const int rows_per_block = (R + rb - 1) / rb;
+  dim3 grid(cb, (R + rows_per_block - 1) / rows_per_block);
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)x, ld, R, C, colsum,
+                       rows_per_block);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)x, ld, R, C, colsum,
+                       rows_per_block);
   else
     return GOAT_E_ARG;
   GOAT_LAUNCH_CHECK();

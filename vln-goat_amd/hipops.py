@@ -116,17 +116,26 @@ def _cat_bias(biases):
 
 
 # ----------------------------------------------------------------------------- raw kernels
+PROFILE = None   # bench.py sets this to a list to time every goat_gemm_nt launch with HIP events
+
+
 def gemm_nt(a, b, out, bias=None, epi=EPI_NONE, aux=None, split_k=1):
     """out[M,N] = epi(a[M,K] @ b[N,K]^T + bias)."""
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K and out.shape[0] == M and out.shape[1] == N
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     st = _lib.lib().goat_gemm_nt(_stream(), _dt(a), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0),
                                  _ptr(out), out.stride(0), M, N, K,
                                  _ptr(bias) if bias is not None else None, epi,
                                  _ptr(aux) if aux is not None else None,
                                  aux.stride(0) if aux is not None else 0, split_k)
     _lib.check(st, 'goat_gemm_nt(M=%d,N=%d,K=%d)' % (M, N, K))
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, epi, split_k, str(a.dtype))))
     return out
 
 
@@ -142,23 +151,78 @@ def transpose_pad(x, colsum=None):
     return out
 
 
-def _split_k(n_out_tiles, k_elems, bk):
-    kt = (k_elems + bk - 1) // bk
-    s = max(1, min(kt, int(round(512.0 / max(1, n_out_tiles)))))
-    return s
+def _split_k(n_out_tiles, k_tiles, target=384):
+    return max(1, min(k_tiles, int(round(float(target) / max(1, n_out_tiles)))))
+
+
+def colsum(x, out=None):
+    """float32 column sums of x[R,C] (bias gradient)."""
+    R, C = x.shape
+    if out is None:
+        out = torch.zeros(C, dtype=torch.float32, device=x.device)
+    st = _lib.lib().goat_colsum(_stream(), _dt(x), _ptr(x), x.stride(0), R, C, _ptr(out))
+    _lib.check(st, 'goat_colsum')
+    return out
+
+
+def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split_k=1):
+    """out[M,N] = epi(op(a) @ op(b)^T + bias); ta: a is [Kc,M] (else [M,Kc]); tb: b is [Kc,N] (else [N,Kc]).
+    bf16 -> pipelined LDS-DMA kernel (goat_gemm_bf16) whenever its layout rules hold; otherwise (f32 parity
+    path, odd contraction lengths) explicit transposes + goat_gemm_nt."""
+    Kc = a.shape[0] if ta else a.shape[1]
+    M = a.shape[1] if ta else a.shape[0]
+    N = b.shape[1] if tb else b.shape[0]
+    assert (b.shape[0] if tb else b.shape[1]) == Kc and out.shape[0] == M and out.shape[1] == N
+    fast = (a.dtype == torch.bfloat16 and not (ta and not tb) and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
+            and ((ta and tb) or Kc % 64 == 0) and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+            and a.stride(1) == 1 and b.stride(1) == 1)
+    if not fast:
+        if ta:
+            a = transpose_pad(a)
+            if tb:
+                b = transpose_pad(b)
+            elif b.shape[1] != a.shape[1]:
+                b = torch.nn.functional.pad(b, (0, a.shape[1] - b.shape[1]))
+        elif tb:
+            b = transpose_pad(b)
+            if b.shape[1] != a.shape[1]:
+                a = torch.nn.functional.pad(a, (0, b.shape[1] - a.shape[1]))
+        if split_k > 1:
+            bk = 64 if a.dtype == torch.bfloat16 else 32
+            split_k = max(2, min(split_k, (a.shape[1] + bk - 1) // bk))
+        return gemm_nt(a, b, out, bias, epi, aux, split_k)
+    # M-tile: 128 rows for long contractions / big grids (arithmetic intensity), 64 rows otherwise (3 workgroups
+    # per CU overlap the short pipelines' prologue/epilogue) — measured with scripts/gemm_bench.py
+    tiles128 = ((M + 127) // 128) * ((N + 127) // 128) * max(1, split_k)
+    kper = Kc // max(1, split_k)
+    bm = 128 if ((kper >= 2048 and tiles128 >= 256) or tiles128 >= 1024) else 64
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    st = _lib.lib().goat_gemm_bf16(_stream(), int(ta), int(tb), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0),
+                                   _ptr(out), out.stride(0), M, N, Kc,
+                                   _ptr(bias) if bias is not None else None, epi,
+                                   _ptr(aux) if aux is not None else None,
+                                   aux.stride(0) if aux is not None else 0, split_k, bm)
+    _lib.check(st, 'goat_gemm_bf16(ta=%d,tb=%d,M=%d,N=%d,Kc=%d)' % (ta, tb, M, N, Kc))
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * M * N * Kc, (M, N, Kc, epi, split_k, 'v2 t%d%d bm%d' % (ta, tb, bm))))
+    return out
 
 
 def wgrad(dy, x, want_bias):
-    """dW[N,K] (f32) = dy[M,N]^T @ x[M,K] ; db[N] (f32) = colsum(dy).  TN product done as transposes + NT."""
+    """dW[N,K] (f32) = dy[M,N]^T @ x[M,K] ; db[N] (f32) = colsum(dy)."""
     M, N = dy.shape
     K = x.shape[1]
-    db = torch.zeros(N, dtype=torch.float32, device=dy.device) if want_bias else None
-    dyT = transpose_pad(dy, db)
-    xT = transpose_pad(x)
-    dw = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+    db = colsum(dy) if want_bias else None
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    bk = 64 if dy.dtype == torch.bfloat16 else 32
-    gemm_nt(dyT, xT, dw, split_k=max(2, _split_k(tiles, dyT.shape[1], bk)))
+    split = _split_k(tiles, (M + 63) // 64)
+    if split > 1:
+        dw = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+    else:
+        dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    gemm(dy, x, dw, ta=True, tb=True, split_k=split)
     return dw, db
 
 
@@ -188,7 +252,7 @@ class _LinearFn(torch.autograd.Function):
         epi = _ACT_EPI[act]
         if epi != EPI_NONE and (ctx.needs_input_grad[0] or weight.requires_grad):
             aux = torch.empty_like(out)
-        gemm_nt(x2, w, out, bias.detach() if bias is not None else None, epi, aux)
+        gemm(x2, w, out, bias=bias.detach() if bias is not None else None, epi=epi, aux=aux)
         ctx.save_for_backward(x2, aux)
         ctx.weight, ctx.has_bias, ctx.act, ctx.pad, ctx.xshape = weight, bias is not None, act, pad, x.shape
         return out.view(*x.shape[:-1], N)
@@ -206,13 +270,9 @@ class _LinearFn(torch.autograd.Function):
             dy2 = act_bwd(dy2, aux, ctx.act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = _shadow(weight, x2.dtype, True, ctx.pad)  # [Kp, N]
+            w = _shadow(weight, x2.dtype, False, ctx.pad)  # [N, Kp]
             dx = torch.empty_like(x2)
-            N = wt.shape[1]
-            dyp, padn = _pad_k(dy2, _epc(dy2))
-            if padn:
-                wt = torch.nn.functional.pad(wt, (0, padn))
-            gemm_nt(dyp, wt, dx)
+            gemm(dy2, w, dx, ta=False, tb=True)        # dx[M,Kp] = dy[M,N] @ W[N,Kp]
             if ctx.pad:
                 dx = dx[:, :x2.shape[1] - ctx.pad]
             dx = dx.reshape(ctx.xshape)
@@ -254,7 +314,7 @@ class _FfnFn(torch.autograd.Function):
         M, F_ = x2.shape[0], W1.shape[0]
         u = torch.empty((M, F_), dtype=x2.dtype, device=x2.device)
         h = torch.empty_like(u)
-        gemm_nt(x2, W1, h, b1.detach(), _ACT_EPI[act], u)
+        gemm(x2, W1, h, bias=b1.detach(), epi=_ACT_EPI[act], aux=u)
         rng = (0, 0, None)
         if p > 0:
             rng = RngState.next(h.numel())
@@ -262,7 +322,7 @@ class _FfnFn(torch.autograd.Function):
                                                  rng[0], rng[1], rng[2])
             _lib.check(st, 'goat_dropout_add_fwd')
         y = torch.empty((M, W2.shape[0]), dtype=x2.dtype, device=x2.device)
-        gemm_nt(h, W2, y, b2.detach())
+        gemm(h, W2, y, bias=b2.detach())
         ctx.save_for_backward(x2, u, h)
         ctx.w1, ctx.w2, ctx.act, ctx.xshape, ctx.p, ctx.rng = w1, w2, act, x.shape, p, rng
         return y.view(*x.shape[:-1], W2.shape[0])
@@ -273,17 +333,17 @@ class _FfnFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        W2t = _shadow(ctx.w2, x2.dtype, True)  # [F, H]
+        W2 = _shadow(ctx.w2, x2.dtype)  # [H, F]
         du = torch.empty_like(u)
         if ctx.p > 0:
-            gemm_nt(dy2, W2t, du)
+            gemm(dy2, W2, du, tb=True)
             du = act_bwd(du, u, ctx.act, ctx.p, ctx.rng)
         else:
-            gemm_nt(dy2, W2t, du, None, _ACT_DEPI[ctx.act], u)
+            gemm(dy2, W2, du, tb=True, epi=_ACT_DEPI[ctx.act], aux=u)
         dw2, db2 = wgrad(dy2, h, True)
-        W1t = _shadow(ctx.w1, x2.dtype, True)  # [H, F]
+        W1 = _shadow(ctx.w1, x2.dtype)  # [F, H]
         dx = torch.empty_like(x2)
-        gemm_nt(du, W1t, dx)
+        gemm(du, W1, dx, tb=True)
         dw1, db1 = wgrad(du, x2, True)
         return dx.view(ctx.xshape), dw1, db1, dw2, db2, None, None
 
@@ -308,7 +368,7 @@ class _MultiLinearFn(torch.autograd.Function):
         W = _shadow_cat(ws, x2.dtype)
         b = _cat_bias(bs)
         out = torch.empty((x2.shape[0], W.shape[0]), dtype=x2.dtype, device=x2.device)
-        gemm_nt(x2, W, out, b)
+        gemm(x2, W, out, bias=b)
         ctx.save_for_backward(x2)
         ctx.ws, ctx.xshape = ws, x.shape
         return out.view(*x.shape[:-1], W.shape[0])
@@ -322,9 +382,9 @@ class _MultiLinearFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            Wt = _shadow_cat(ws, x2.dtype, True)
+            W = _shadow_cat(ws, x2.dtype)
             dx = torch.empty_like(x2)
-            gemm_nt(dy2, Wt, dx)
+            gemm(dy2, W, dx, tb=True)
             dx = dx.view(ctx.xshape)
         dw, db = wgrad(dy2, x2, True)
         sizes = [w.shape[0] for w in ws]
