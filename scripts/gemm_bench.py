@@ -27,7 +27,7 @@ for ta, tb, M, N, Kc, epi, split in SHAPES:
         def run():
             s_ = L.goat_gemm_bf16(st, ta, tb, hipops._dt(out), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
                                  out.data_ptr(), out.stride(0), M, N, Kc, bias.data_ptr() if bias is not None else None, epi,
-                                 aux.data_ptr() if aux is not None else None, N if aux is not None else 0, split, bm)
+                                 aux.data_ptr() if aux is not None else None, N if aux is not None else 0, split, bm, None)
             assert s_ == 0, s_
         for _ in range(5):
             run()

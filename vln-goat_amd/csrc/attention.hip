@@ -93,7 +93,7 @@ __device__ __forceinline__ void stage_rows(T* lds, const T* g, int64_t rs, int r
 
 // ======================================================================================== forward
 template <typename T, int NKT>
-__global__ void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename AT<T>::Frag Frag;
   constexpr int KSTEPS = AT<T>::KSTEPS, LSTR = AT<T>::LSTR, TSTEPS = AT<T>::TSTEPS;
@@ -211,7 +211,7 @@ __global__ void attn_fwd_kernel(AttnArgs p) {
 // ======================================================================================== backward
 // One workgroup per (b, h); wave w owns key tile w and loops over the query tiles.
 template <typename T, int NKT>
-__global__ void attn_bwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NKT * 64) void attn_bwd_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename AT<T>::Frag Frag;
   constexpr int KSTEPS = AT<T>::KSTEPS, LSTR = AT<T>::LSTR, TSTEPS = AT<T>::TSTEPS, PSTR = AT<T>::PSTR;

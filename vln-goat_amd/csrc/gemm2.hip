@@ -28,6 +28,7 @@ struct G2Args {
   int tiles_m, tiles_n;
   int k_tiles_per_split;
   uint32_t a_bytes, b_bytes;  // buffer sizes for the bounds check
+  float* colsum;              // TA only: colsum[m] += sum_k A[k,m]  (bias gradient fused into wgrad)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -158,6 +159,10 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(G2Args p) {
 
   const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_void*)smem;  // LDS byte offset of the dynamic region
   const int t15 = lane & 15, g = lane >> 4;
+  const bool do_colsum = TA && p.colsum != nullptr && tn == 0 && wn == 0;
+  float bsum[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
 
   for (int t = 0; t < nkt; ++t) {
     wait_vm<(NSTAGE - 2) * LOADS>();
@@ -204,6 +209,12 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(G2Args p) {
       if (ks + 1 < BK / 16) {
         if ((ks & 1) == 0) GOAT_LOAD_FRAGS(ks + 1, 1); else GOAT_LOAD_FRAGS(ks + 1, 0);
       }
+      if (TA && do_colsum) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[ks & 1][i][e];
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -212,6 +223,15 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(G2Args p) {
   }
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
+
+  if (TA && do_colsum) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      const int row = m0 + wm * (BM / 2) + i * 32 + l31;
+      if (hi == 0 && row < p.M) atomicAdd(p.colsum + row, v);
+    }
+  }
 
   // ------------------------------------------------------------------ epilogue (as gemm.hip)
   const int wrow0 = wm * (BM / 2), wcol0 = wn * 64;
@@ -407,8 +427,9 @@ extern "C" int goat_gemm_bf16_set_stages(int n) {
 extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_out,
                               const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                               int M, int N, int Kc, const float* bias, int epilogue,
-                              void* aux, int64_t ldaux, int split_k, int bm) {
+                              void* aux, int64_t ldaux, int split_k, int bm, float* colsum) {
   if (!A || !B || !C) return GOAT_E_ARG;
+  if (colsum && !trans_a) return GOAT_E_ARG;
   if (M <= 0 || N <= 0 || Kc <= 0) return GOAT_E_SHAPE;
   if ((lda % 8) || (ldb % 8)) return GOAT_E_SHAPE;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return GOAT_E_SHAPE;
@@ -430,6 +451,7 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   a.tiles_m = (M + bm - 1) / bm;
   a.tiles_n = (N + BN - 1) / BN;
   a.a_bytes = (uint32_t)a_bytes; a.b_bytes = (uint32_t)b_bytes;
+  a.colsum = colsum;
   const int kt = (Kc + BK - 1) / BK;
   if (split_k < 1) split_k = 1;
   if (split_k > kt) split_k = kt;

@@ -5,10 +5,10 @@
 
 namespace {
 
-constexpr int MAXC = 8;  // 16-B chunks per lane kept in registers: H <= 64*MAXC*EPC
+constexpr int MAXC_MAX = 8;  // 16-B chunks per lane kept in registers: H <= 64*MAXC*EPC (MAXC is a template parameter)
 
 // ------------------------------------------------------------------------------------ LayerNorm fwd
-template <typename T>
+template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float p, uint64_t seed, uint64_t offset,
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // ------------------------------------------------------------------------------------ LayerNorm bwd
 // grid = NPART blocks of 4 waves; wave w of block b walks rows (b*4+w), +4*NPART, ...
 // partial dgamma/dbeta per block -> ws[block][2][H]; ln_bwd_reduce sums them.
-template <typename T>
+template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float p, uint64_t seed,
@@ -462,9 +462,22 @@ template <typename T>
 int ln_check(int H) {
   const int epc = DT<T>::EPC;
   if (H % epc) return GOAT_E_SHAPE;
-  if (H > 64 * MAXC * epc) return GOAT_E_SHAPE;
+  if (H > 64 * MAXC_MAX * epc) return GOAT_E_SHAPE;
   return 0;
 }
+template <typename T>
+int ln_maxc(int H) {  // smallest instantiated chunk count covering H
+  const int need = (H / DT<T>::EPC + 63) / 64;
+  return need <= 1 ? 1 : need <= 2 ? 2 : need <= 3 ? 3 : need <= 4 ? 4 : 8;
+}
+#define GOAT_LN_DISPATCH(T_, H_, ...)                        \
+  switch (ln_maxc<T_>(H_)) {                                 \
+    case 1: { constexpr int MC = 1; __VA_ARGS__; } break;    \
+    case 2: { constexpr int MC = 2; __VA_ARGS__; } break;    \
+    case 3: { constexpr int MC = 3; __VA_ARGS__; } break;    \
+    case 4: { constexpr int MC = 4; __VA_ARGS__; } break;    \
+    default: { constexpr int MC = 8; __VA_ARGS__; } break;   \
+  }
 
 }  // namespace
 
@@ -481,12 +494,14 @@ extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* r
   dim3 grid((M + 3) / 4);
   if (dtype == GOAT_BF16) {
     if (int e = ln_check<bf16_t>(H)) return e;
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)x, (const bf16_t*)residual,
-                       gamma, beta, eps, p, seed, offset, rng_dev, (bf16_t*)y, (bf16_t*)z_out, mean, rstd, M, H);
+    GOAT_LN_DISPATCH(bf16_t, H, hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, MC>), grid, dim3(256), 0, ST(stream),
+                                                    (const bf16_t*)x, (const bf16_t*)residual, gamma, beta, eps, p, seed,
+                                                    offset, rng_dev, (bf16_t*)y, (bf16_t*)z_out, mean, rstd, M, H));
   } else if (dtype == GOAT_F32) {
     if (int e = ln_check<float>(H)) return e;
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)x, (const float*)residual,
-                       gamma, beta, eps, p, seed, offset, rng_dev, (float*)y, (float*)z_out, mean, rstd, M, H);
+    GOAT_LN_DISPATCH(float, H, hipLaunchKernelGGL((ln_fwd_kernel<float, MC>), grid, dim3(256), 0, ST(stream),
+                                                   (const float*)x, (const float*)residual, gamma, beta, eps, p, seed,
+                                                   offset, rng_dev, (float*)y, (float*)z_out, mean, rstd, M, H));
   } else {
     return GOAT_E_ARG;
   }
@@ -494,7 +509,7 @@ extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* r
   return 0;
 }
 
-#define GOAT_LN_BWD_PARTS 128
+#define GOAT_LN_BWD_PARTS 512
 
 extern "C" int goat_ln_bwd_ws_floats(int H) { return GOAT_LN_BWD_PARTS * 2 * H; }
 
@@ -510,12 +525,14 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
   if (sm > 64 * 1024) return GOAT_E_SHAPE;
   if (dtype == GOAT_BF16) {
     if (int e = ln_check<bf16_t>(H)) return e;
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nparts), dim3(256), sm, ST(stream), (const bf16_t*)dy,
-                       (const bf16_t*)z, gamma, mean, rstd, p, seed, offset, rng_dev, (bf16_t*)dx, (bf16_t*)d_res, ws, M, H);
+    GOAT_LN_DISPATCH(bf16_t, H, hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, MC>), dim3(nparts), dim3(256), sm, ST(stream),
+                                                    (const bf16_t*)dy, (const bf16_t*)z, gamma, mean, rstd, p, seed, offset,
+                                                    rng_dev, (bf16_t*)dx, (bf16_t*)d_res, ws, M, H));
   } else if (dtype == GOAT_F32) {
     if (int e = ln_check<float>(H)) return e;
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nparts), dim3(256), sm, ST(stream), (const float*)dy, (const float*)z,
-                       gamma, mean, rstd, p, seed, offset, rng_dev, (float*)dx, (float*)d_res, ws, M, H);
+    GOAT_LN_DISPATCH(float, H, hipLaunchKernelGGL((ln_bwd_kernel<float, MC>), dim3(nparts), dim3(256), sm, ST(stream),
+                                                   (const float*)dy, (const float*)z, gamma, mean, rstd, p, seed, offset,
+                                                   rng_dev, (float*)dx, (float*)d_res, ws, M, H));
   } else {
     return GOAT_E_ARG;
   }

@@ -165,7 +165,7 @@ def colsum(x, out=None):
     return out
 
 
-def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split_k=1):
+def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split_k=1, colsum_out=None):
     """out[M,N] = epi(op(a) @ op(b)^T + bias); ta: a is [Kc,M] (else [M,Kc]); tb: b is [Kc,N] (else [N,Kc]).
     bf16 -> pipelined LDS-DMA kernel (goat_gemm_bf16) whenever its layout rules hold; otherwise (f32 parity
     path, odd contraction lengths) explicit transposes + goat_gemm_nt."""
@@ -177,6 +177,8 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
             and ((ta and tb) or Kc % 64 == 0) and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
             and a.stride(1) == 1 and b.stride(1) == 1)
     if not fast:
+        if colsum_out is not None:
+            colsum(a, colsum_out)
         if ta:
             a = transpose_pad(a)
             if tb:
@@ -195,7 +197,7 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
     # per CU overlap the short pipelines' prologue/epilogue) — measured with scripts/gemm_bench.py
     tiles128 = ((M + 127) // 128) * ((N + 127) // 128) * max(1, split_k)
     kper = Kc // max(1, split_k)
-    bm = 128 if ((kper >= 2048 and tiles128 >= 256) or tiles128 >= 1024) else 64
+    bm = 128 if (not ta and ((kper >= 2048 and tiles128 >= 256) or tiles128 >= 1024)) else 64
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -203,7 +205,8 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
                                    _ptr(out), out.stride(0), M, N, Kc,
                                    _ptr(bias) if bias is not None else None, epi,
                                    _ptr(aux) if aux is not None else None,
-                                   aux.stride(0) if aux is not None else 0, split_k, bm)
+                                   aux.stride(0) if aux is not None else 0, split_k, bm,
+                                   _ptr(colsum_out) if colsum_out is not None else None)
     _lib.check(st, 'goat_gemm_bf16(ta=%d,tb=%d,M=%d,N=%d,Kc=%d)' % (ta, tb, M, N, Kc))
     if PROFILE is not None:
         e1.record()
@@ -212,17 +215,26 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
 
 
 def wgrad(dy, x, want_bias):
-    """dW[N,K] (f32) = dy[M,N]^T @ x[M,K] ; db[N] (f32) = colsum(dy)."""
+    """dW[N,K] (f32) = dy[M,N]^T @ x[M,K] ; db[N] (f32) = colsum(dy), fused into the same kernel.
+    One zero-fill covers both outputs (split-K partial tiles and the bias sums are accumulated atomically)."""
     M, N = dy.shape
     K = x.shape[1]
-    db = colsum(dy) if want_bias else None
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    split = _split_k(tiles, (M + 63) // 64)
+    # (bm 64, split) tuned with scripts/wgrad_sweep.py on GOAT's weight shapes
+    tiles = ((N + 63) // 64) * ((K + 127) // 128)
+    kt = (M + 63) // 64
+    if tiles < 128:
+        split = max(1, min(int(round(250.0 / tiles)), kt // 8))
+    else:
+        split = max(1, min(int(round(500.0 / tiles)), kt // 24))
+    nb = N if want_bias else 0
     if split > 1:
-        dw = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+        buf = torch.zeros(N * K + nb, dtype=torch.float32, device=dy.device)
+        dw = buf[:N * K].view(N, K)
+        db = buf[N * K:] if want_bias else None
     else:
         dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-    gemm(dy, x, dw, ta=True, tb=True, split_k=split)
+        db = torch.zeros(N, dtype=torch.float32, device=dy.device) if want_bias else None
+    gemm(dy, x, dw, ta=True, tb=True, split_k=split, colsum_out=db)
     return dw, db
 
 
