@@ -1,0 +1,115 @@
+"""world_size-2 tests (gloo, CPU) of the data-parallel engine: bucketed gradient averaging and the CFP
+all-gather whose result must equal the single-process loss/gradients on the concatenated batch."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+
+def _worker_buckets(rank, world, port, q):
+    _init(rank, world, port)
+    from vln_goat_amd import dp
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Linear(32, 8), torch.nn.Linear(8, 4))
+    unused = torch.nn.Linear(3, 3)          # never receives a gradient (task-dependent parameter subsets)
+    holder = torch.nn.ModuleList([model, unused])
+    w = dp.GoatDataParallel(holder, bucket_bytes=1024)     # tiny buckets -> several all-reduces
+    torch.manual_seed(100 + rank)
+    x = torch.randn(5, 16)
+    model(x).pow(2).mean().backward()
+    local = [p.grad.clone() for p in model.parameters()]
+    w.reduce_gradients('sap')
+    w.reduce_gradients('sap')   # second call reuses the cached bucket plan; averaging an average is a no-op
+    got = [p.grad.clone() for p in model.parameters()]
+    q.put((rank, local, got, [p.grad is None for p in unused.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_grad_allreduce_mean():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_buckets, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    mean = [(a + b) / 2 for a, b in zip(res[0][1], res[1][1])]
+    for r in range(world):
+        for g, m in zip(res[r][2], mean):
+            assert torch.allclose(g, m, atol=1e-6)
+        assert all(res[r][3])
+
+
+def _cfp_inputs(n, h=32):
+    g = torch.Generator().manual_seed(7)
+    return [torch.tanh(torch.randn(n, h, generator=g)) for _ in range(4)]
+
+
+def _worker_cfp(rank, world, port, q):
+    _init(rank, world, port)
+    from vln_goat_amd import dp
+    from vln_goat_amd.pretrain_model import cfp_losses
+    B = 3
+    full = _cfp_inputs(world * B)
+    loc = [t[rank * B:(rank + 1) * B].clone().requires_grad_(True) for t in full]
+    loss = cfp_losses(loc[0], loc[1], loc[2], loc[3], 0.7, dp.CfpGather())
+    loss.mean().backward()
+    grads = [t.grad.clone() for t in loc]
+    for g in grads:                      # what GoatDataParallel.reduce_gradients does for parameters
+        dist.all_reduce(g)
+        g /= world
+    q.put((rank, loss.detach(), [t.grad.clone() for t in loc]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cfp_gather_equals_single_process_on_concatenated_batch():
+    from vln_goat_amd.pretrain_model import cfp_losses
+    world, port, B = 2, _free_port(), 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_cfp, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    full = [t.clone().requires_grad_(True) for t in _cfp_inputs(world * B)]
+    ref = cfp_losses(full[0], full[1], full[2], full[3], 0.7, None)     # reference formula, one process
+    ref.mean().backward()
+    got = torch.cat([r[1] for r in res])
+    assert torch.allclose(got, ref.detach(), atol=1e-5)
+    # d(mean over the global batch)/d(local embeddings) = (1/W) * local grads of the local-mean loss
+    for k in range(4):
+        g = torch.cat([r[2][k] for r in res]) / world
+        assert torch.allclose(g, full[k].grad, atol=1e-6), k
+
+
+def test_world_size_one_is_the_reference_formula():
+    from vln_goat_amd import dp
+    from vln_goat_amd.pretrain_model import cfp_losses
+    x = _cfp_inputs(4)
+    a = cfp_losses(x[0], x[1], x[2], x[3], 1.0, None)
+    b = cfp_losses(x[0], x[1], x[2], x[3], 1.0, dp.CfpGather())
+    assert torch.equal(a, b)

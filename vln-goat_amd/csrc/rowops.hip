@@ -166,21 +166,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-// 256 threads = 32 columns x 8 part-groups; coalesced over columns, parts strided over the groups
+// 256 threads = 16 columns x 16 part-groups; every thread sums nparts/16 partials with 4 independent chains
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int nparts, int H) {
-  __shared__ float red[8][33];
-  const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + cx;
-  float s = 0.f;
-  if (i < 2 * H)
-    for (int b = g; b < nparts; b += 8) s += ws[(int64_t)b * 2 * H + i];
-  red[g][cx] = s;
+  __shared__ float red[16][17];
+  const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < 2 * H) {
+    int b = g;
+    for (; b + 48 < nparts; b += 64) {
+      s0 += ws[(int64_t)b * 2 * H + i];
+      s1 += ws[(int64_t)(b + 16) * 2 * H + i];
+      s2 += ws[(int64_t)(b + 32) * 2 * H + i];
+      s3 += ws[(int64_t)(b + 48) * 2 * H + i];
+    }
+    for (; b < nparts; b += 16) s0 += ws[(int64_t)b * 2 * H + i];
+  }
+  red[g][cx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g == 0 && i < 2 * H) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    for (int k = 0; k < 16; ++k) t += red[k][cx];
     if (i < H) dgamma[i] = t; else dbeta[i - H] = t;
   }
 }
@@ -509,7 +517,7 @@ extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* r
   return 0;
 }
 
-#define GOAT_LN_BWD_PARTS 512
+#define GOAT_LN_BWD_PARTS 256
 
 extern "C" int goat_ln_bwd_ws_floats(int H) { return GOAT_LN_BWD_PARTS * 2 * H; }
 
@@ -537,7 +545,7 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
     return GOAT_E_ARG;
   }
   GOAT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 31) / 32), dim3(256), 0, ST(stream), ws, dgamma, dbeta, nparts,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 15) / 16), dim3(256), 0, ST(stream), ws, dgamma, dbeta, nparts,
                      H);
   GOAT_LAUNCH_CHECK();
   return 0;

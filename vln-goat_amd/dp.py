@@ -35,9 +35,9 @@ class _AllGatherCat(torch.autograd.Function):
     def forward(ctx, x):
         W = _world()
         ctx.shape = x.shape
-        out = torch.empty((W,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x.contiguous())
-        return out
+        out = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous())       # concatenated along dim 0
+        return out.view((W,) + tuple(x.shape))
 
     @staticmethod
     def backward(ctx, dy):
@@ -48,7 +48,7 @@ class _AllGatherCat(torch.autograd.Function):
             dist.all_reduce(dy)
             dx.copy_(dy[_rank()])
         else:
-            dist.reduce_scatter_tensor(dx, dy)
+            dist.reduce_scatter_tensor(dx, dy.view((W * ctx.shape[0],) + tuple(ctx.shape[1:])))
         return dx
 
 
