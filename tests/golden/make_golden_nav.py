@@ -1,0 +1,79 @@
+"""Golden vectors for the fine-tuning (navigation) path FROM THE IMPORTED REFERENCE (this container only):
+`GlocalTextPathNavCMT` (/root/reference/map_nav_src/models/vilmodel_GOAT.py:556) with BACL (type_2 + door and
+type_1) and FACL on, driven through language -> (panorama -> navigation) x 3 steps with BPTT through [MEM]
+by vln_goat_amd.synth.run_nav_episode.  Run in its own process (the pre-training tree
+defines clashing top-level packages):   python tests/golden/make_golden_nav.py
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_shim  # noqa: E402
+
+CASES = {
+    'nav_type2_door': dict(do_back_txt_type='type_2', do_back_img_type='type_1', do_add_method='door'),
+    'nav_type1_add': dict(do_back_txt_type='type_1', do_back_img_type='type_2', do_add_method='add'),
+}
+WEIGHT_SEED = 11
+VOCAB = 1200
+
+
+def fingerprint(g):
+    if g is None:
+        return np.zeros(9, dtype=np.float32)
+    flat = g.detach().float().reshape(-1)
+    first = torch.zeros(8)
+    first[:min(8, flat.numel())] = flat[:8]
+    return np.concatenate([[float(flat.double().norm())], first.numpy()]).astype(np.float32)
+
+
+def main():
+    vg = ref_shim.import_nav()
+    from vln_goat_amd import nav_model, synth
+    for name, over in CASES.items():
+        args = SimpleNamespace(num_l_layers=2, num_x_layers=2, num_pano_layers=2, dropout=0.5, feat_dropout=0.4,
+                               do_back_img=True, do_back_txt=True, do_front_img=True, do_front_his=True, do_front_txt=True,
+                               vocab_size=VOCAB, mode='train', **over)
+        cfg = nav_model.nav_config_from_args(args)
+        torch.manual_seed(0)
+        ref = vg.GlocalTextPathNavCMT(cfg)
+        ours = nav_model.GlocalTextPathNavCMT(cfg)
+        sd = synth.seeded_state_dict(ours, seed=WEIGHT_SEED)
+        rk, ok = set(ref.state_dict().keys()), set(sd.keys())
+        assert rk == ok, (sorted(rk - ok)[:8], sorted(ok - rk)[:8])
+        for k, v in ref.state_dict().items():
+            assert tuple(v.shape) == tuple(sd[k].shape), k
+        ref.load_state_dict(sd)
+        ref.eval()
+        ep = synth.make_nav_episode(B=2, L=44, n_steps=3, seed=5, vocab_size=VOCAB)
+        for k in ('front_txt_feats', 'front_vp_feats', 'front_gmap_feats', 'instr_z_direction_features', 'instr_z_landmark_features',
+                  'z_img_features'):
+            ep[k].requires_grad_(True)
+        loss, rec = synth.run_nav_episode(lambda m, b: ref(m, b), ep)
+        loss.backward()
+        store = {'loss': np.array([float(loss)], dtype=np.float32),
+                 'param_names': np.array([n for n, _ in ref.named_parameters()]),
+                 'grad_fp': np.stack([fingerprint(p.grad) for _, p in ref.named_parameters()]),
+                 'txt_embeds': rec['txt_embeds'][:, :, :16].detach().numpy()}
+        for k in ('front_txt_feats', 'front_gmap_feats', 'z_img_features', 'instr_z_direction_features'):
+            store['dinput_' + k] = fingerprint(ep[k].grad)
+        for t, s in enumerate(rec['steps']):
+            for k in ('global_logits', 'local_logits', 'fused_logits', 'cls_embeds'):
+                store['s%d_%s' % (t, k)] = s[k].detach().numpy()
+            store['s%d_gmap_embeds' % t] = s['gmap_embeds'][:, :, :16].detach().numpy()
+            store['s%d_vp_embeds' % t] = s['vp_embeds'][:, :, :16].detach().numpy()
+            store['s%d_pano_fused' % t] = s['pano_fused'][:, :32].detach().numpy()
+        path = os.path.join(HERE, name + '.npz')
+        np.savez_compressed(path, **store)
+        print('wrote', path, os.path.getsize(path) // 1024, 'KiB', 'loss', float(loss))
+
+
+if __name__ == '__main__':
+    main()

@@ -181,3 +181,135 @@ def seeded_state_dict(model, seed=0, perturb=True):
             v = 0.02 * rs.standard_normal(shape)
         out[name] = torch.from_numpy(np.asarray(v, dtype=np.float32)).reshape(shape).to(ref.dtype)
     return out
+
+
+# ======================================================================================= fine-tune episode
+def make_nav_episode(B=2, L=44, V=36, n_steps=3, n_cand=4, seed=0, vocab_size=50265, dict_sizes=(35, 39, 50, 24)):
+    """Synthetic stand-in for one DAgger rollout of the fine-tuning loop (M/r2r/agent.py:515-592; shapes of
+    M/utils/efficiency_count.py:16-137): text once, then per step a panorama and the graph inputs.  Returns a
+    dict of CPU tensors / lists; `run_nav_episode` drives any model exposing `model(mode, batch)`."""
+    rs = np.random.RandomState(seed)
+    Kd, Kl, Kr, Kf = dict_sizes
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    txt_lens = rs.randint(L // 2, L + 1, B)
+    txt_lens[0] = L
+    txt_ids = np.ones((B, L), dtype=np.int64)
+    for b in range(B):
+        txt_ids[b, :txt_lens[b]] = rs.randint(3, vocab_size, txt_lens[b])
+
+    def pz(k):
+        p = rs.uniform(0.1, 1.0, (B, k, 1))
+        return f32(p / p.sum(1, keepdims=True))
+    ep = {
+        'txt_ids': torch.from_numpy(txt_ids),
+        'txt_masks': torch.from_numpy(np.arange(L)[None, :] < txt_lens[:, None]),
+        'instr_z_direction_features': f32(rs.uniform(0, 1, (B, Kd, 768))), 'instr_z_direction_pzs': pz(Kd),
+        'instr_z_landmark_features': f32(rs.uniform(0, 1, (B, Kl, 768))), 'instr_z_landmark_pzs': pz(Kl),
+        'front_txt_feats': f32(rs.uniform(0, 1, (B, Kf, 768))),
+        'front_vp_feats': f32(rs.uniform(0, 1, (B, Kf, 768))), 'front_gmap_feats': f32(rs.uniform(0, 1, (B, Kf, 768))),
+        'z_img_features': f32(rs.uniform(0, 1, (B, Kr, 768))), 'z_img_pzs': pz(Kr),
+        'steps': [],
+    }
+    for t in range(n_steps):
+        view_lens = rs.randint(V - 4, V + 1, B)
+        view_lens[0] = V
+        fts = rs.standard_normal((B, V, 768)).astype(np.float32)
+        loc = np.stack([_angle_fts(rs, V) for _ in range(B)], 0)
+        nav_types = np.zeros((B, V), dtype=np.int64)
+        nav_types[:, :n_cand] = 1
+        for b in range(B):
+            fts[b, view_lens[b]:] = 0
+            loc[b, view_lens[b]:] = 0
+        G = 2 + (t + 1) + n_cand                      # [stop], [MEM], visited nodes, current candidates
+        gmap_vpids, vp_cand_vpids = [], []
+        gvis = np.zeros((B, G), dtype=bool)
+        for b in range(B):
+            visited = ['b%d_p%d' % (b, s) for s in range(t + 1)]
+            cands = ['b%d_c%d_%d' % (b, t, j) for j in range(n_cand)]
+            if t > 0:
+                cands[1] = visited[t - 1]             # a back-edge: candidate already visited
+            unv = [c for c in cands if c not in visited]
+            ids = [None, 'MEM'] + visited + unv
+            ids += [None] * (G - len(ids))
+            gmap_vpids.append(ids[:G])
+            gvis[b, 2:2 + len(visited)] = True
+            vp_cand_vpids.append([None, 'MEM'] + cands + [None] * (V - n_cand))
+        gmasks = np.ones((B, G), dtype=bool)
+        gmasks[:, 1] = False                          # gmap [MEM] slot is masked out (M/r2r/agent.py:209)
+        for b in range(B):
+            n_valid = sum(1 for x in gmap_vpids[b][2:] if x is not None) + 2
+            gmasks[b, n_valid:] = False
+        d = rs.uniform(0, 1, (B, G, G)).astype(np.float32)
+        d = np.triu(d, 1)
+        d = d + d.transpose(0, 2, 1)
+        d[:, :2, :] = 0
+        d[:, :, :2] = 0
+        vp_masks = np.zeros((B, V + 2), dtype=bool)
+        vp_nav = np.zeros((B, V + 2), dtype=bool)
+        for b in range(B):
+            vp_masks[b, :view_lens[b] + 2] = True
+            vp_nav[b, 0] = True
+            vp_nav[b, 2:2 + n_cand] = True
+        target = np.array([2 + (t + 1) + rs.randint(0, max(1, n_cand - 1)) if t + 1 < n_steps else 0 for _ in range(B)])
+        ep['steps'].append({
+            'view_img_fts': f32(fts), 'loc_fts': f32(loc), 'nav_types': torch.from_numpy(nav_types),
+            'view_lens': torch.from_numpy(view_lens.astype(np.int64)),
+            'gmap_step_ids': torch.from_numpy(np.tile(np.arange(G), (B, 1)).astype(np.int64) % 5),
+            'gmap_pos_fts': f32(rs.standard_normal((B, G, 7))), 'gmap_masks': torch.from_numpy(gmasks),
+            'gmap_pair_dists': f32(d), 'gmap_visited_masks': torch.from_numpy(gvis), 'gmap_vpids': gmap_vpids,
+            'vp_pos_fts': f32(rs.standard_normal((B, V + 2, 14))), 'vp_masks': torch.from_numpy(vp_masks),
+            'vp_nav_masks': torch.from_numpy(vp_nav), 'vp_cand_vpids': vp_cand_vpids,
+            'target': torch.from_numpy(target.astype(np.int64)),
+            'gmap_cand_view': n_cand,
+        })
+    return ep
+
+
+def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_float=True):
+    """language once, then panorama + navigation per step with the [MEM] token carrying `cls_embeds` of the
+    previous step (not detached: back-propagation through time, M/r2r/agent.py:592).  Returns (loss, records)."""
+    from collections import defaultdict
+    dd = lambda d: defaultdict(lambda: None, d)
+    mv = lambda x: x.to(device) if torch.is_tensor(x) else x
+    lang = {'txt_ids': mv(ep['txt_ids']), 'txt_masks': mv(ep['txt_masks'])}
+    if use_bacl:
+        for k in ('instr_z_direction_features', 'instr_z_direction_pzs', 'instr_z_landmark_features', 'instr_z_landmark_pzs'):
+            lang[k] = mv(ep[k])
+    if use_facl:
+        lang['front_txt_feats'] = mv(ep['front_txt_feats'])
+    txt = model('language', dd(lang))
+    B = txt.shape[0]
+    mem = None
+    loss = 0.0
+    rec = {'txt_embeds': txt, 'steps': []}
+    fused_hist = []
+    for t, st in enumerate(ep['steps']):
+        pin = {'view_img_fts': mv(st['view_img_fts']), 'loc_fts': mv(st['loc_fts']), 'nav_types': mv(st['nav_types']),
+               'view_lens': mv(st['view_lens']), 'already_dropout': True}
+        if use_bacl:
+            pin['z_img_features'], pin['z_img_pzs'] = mv(ep['z_img_features']), mv(ep['z_img_pzs'])
+        pano, pmask, fused = model('panorama', dd(pin))
+        fused_hist.append(fused)
+        H = pano.shape[-1]
+        zero = pano.new_zeros(B, 1, H)
+        memtok = zero if mem is None else mem.unsqueeze(1).to(pano.dtype)
+        nc = st['gmap_cand_view']
+        G = st['gmap_step_ids'].shape[1]
+        parts = [zero, memtok] + [f.unsqueeze(1) for f in fused_hist] + [pano[:, :nc]]
+        gimg = torch.cat(parts, 1)
+        gimg = gimg[:, :G] if gimg.shape[1] >= G else torch.cat([gimg, pano.new_zeros(B, G - gimg.shape[1], H)], 1)
+        vimg = torch.cat([zero, memtok, pano], 1)
+        nin = {'txt_embeds': txt, 'txt_masks': mv(ep['txt_masks']), 'gmap_img_embeds': gimg,
+               'gmap_step_ids': mv(st['gmap_step_ids']), 'gmap_pos_fts': mv(st['gmap_pos_fts']), 'gmap_masks': mv(st['gmap_masks']),
+               'gmap_pair_dists': mv(st['gmap_pair_dists']), 'gmap_visited_masks': mv(st['gmap_visited_masks']),
+               'gmap_vpids': st['gmap_vpids'], 'vp_img_embeds': vimg, 'vp_pos_fts': mv(st['vp_pos_fts']),
+               'vp_masks': mv(st['vp_masks']), 'vp_nav_masks': mv(st['vp_nav_masks']), 'vp_obj_masks': None,
+               'vp_cand_vpids': st['vp_cand_vpids'], 'flops_count': False}
+        if use_facl:
+            nin['front_vp_feats'], nin['front_gmap_feats'] = mv(ep['front_vp_feats']), mv(ep['front_gmap_feats'])
+        out = model('navigation', dd(nin))
+        mem = out['cls_embeds']
+        logits = out['fused_logits'].float() if to_float else out['fused_logits']
+        loss = loss + torch.nn.functional.cross_entropy(logits, mv(st['target']), reduction='sum', ignore_index=-100)
+        rec['steps'].append({'pano_embeds': pano, 'pano_fused': fused, **out})
+    return loss, rec
