@@ -78,6 +78,29 @@ __device__ __forceinline__ typename AT<T>::Frag acc_frag(const f32x16& a, int st
   return f;
 }
 
+// B fragment "fixed column, accumulator-pattern rows" of a row-major [row][64] LDS tile.
+//   f32 : four ds_read_b32 (rows 8*step + 4*hi + e)
+//   bf16: two ds_read_b64_tr_b16 (hardware 4x16 transpose): rows 16*step + 4*hi + {0..3} and +8
+template <typename T>
+__device__ __forceinline__ typename AT<T>::Frag bfrag_crow(const T* lds, int stride, int row_base, int step, int dt, int lane);
+template <>
+__device__ __forceinline__ f32x4 bfrag_crow<float>(const float* lds, int stride, int row_base, int step, int dt, int lane) {
+  return gather_crow<float>(lds, stride, row_base, step, dt * 32 + (lane & 31), lane);
+}
+template <>
+__device__ __forceinline__ bf16x8 bfrag_crow<bf16_t>(const bf16_t* lds, int stride, int row_base, int step, int dt, int lane) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+  const int g = lane >> 4, t15 = lane & 15;
+  const int col = dt * 32 + (g & 1) * 16 + (t15 & 3) * 4;
+  const int r0 = row_base + 16 * step + 4 * (g >> 1) + (t15 >> 2);
+  bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(lds + r0 * stride + col));
+  bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(lds + (r0 + 8) * stride + col));
+  bf16x8 f;
+  f[0] = v0[0]; f[1] = v0[1]; f[2] = v0[2]; f[3] = v0[3];
+  f[4] = v1[0]; f[5] = v1[1]; f[6] = v1[2]; f[7] = v1[3];
+  return f;
+}
+
 // cooperative copy of `nrows` 64-wide rows (global, strided) into LDS [rows_pad][LSTR]; rows >= nrows zero
 template <typename T>
 __device__ __forceinline__ void stage_rows(T* lds, const T* g, int64_t rs, int row0, int nrows_valid, int rows_pad,
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
       Frag pa = acc_frag<T>(s[jt], st);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        Frag vb = gather_crow<T>(vl, LSTR, jt * 32, st, dt * 32 + l31, lane);
+        Frag vb = bfrag_crow<T>(vl, LSTR, jt * 32, st, dt, lane);
         mma32(o[dt], pa, vb);
       }
     }
@@ -415,6 +438,240 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_kernel(AttnArgs p) {
     }
 }
 
+// ======================================================================================== backward v2
+// Two barrier-free single-wave roles per (b, h); S and dP are recomputed in each (cheap next to the removed
+// cross-wave reductions, LDS transposes and barriers of attn_bwd_kernel above, which is kept for reference):
+//   dQ role  (b, h, q-tile):  lane = query;  S^T = K·Q^T, dP^T = V·dO^T per key tile; dQ += dS·K
+//   dKV role (b, h, key-tile): lane = key;   S = Q·K^T, dP = dO·V^T per query tile; dV += Pd^T·dO, dK += dS^T·Q
+// "Transposed" B operands (K, dO, Q with the contraction index as the LDS row) come from bfrag_crow.
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename AT<T>::Frag Frag;
+  constexpr int KSTEPS = AT<T>::KSTEPS, LSTR = AT<T>::LSTR, TSTEPS = AT<T>::TSTEPS, NE = AT<T>::NE;
+  T* kl = reinterpret_cast<T*>(smem);  // [nkt*32][LSTR]
+  const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+  const int q0 = blockIdx.y * 32, q = q0 + l31;
+  const bool qv = q < p.Lq;
+  const int nkt = (p.Lk + 31) / 32;
+  const T* Qb = reinterpret_cast<const T*>(p.Q) + b * p.q_bs + h * HD;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + b * p.k_bs + h * HD;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + b * p.v_bs + h * HD;
+  const T* Ob = reinterpret_cast<const T*>(p.O) + b * p.o_bs + h * HD;
+  const T* dOb = reinterpret_cast<const T*>(p.dO) + b * p.do_bs + h * HD;
+  T* dQb = reinterpret_cast<T*>(p.dQ) + b * p.dq_bs + h * HD;
+
+  stage_rows<T>(kl, Kb, p.k_rs, 0, p.Lk, nkt * 32, lane, 64);
+  Frag qf[KSTEPS], dof[KSTEPS];
+  float dsum = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    qf[ks] = gfrag<T>(Qb + (int64_t)q * p.q_rs, qv, ks, hi);
+    dof[ks] = gfrag<T>(dOb + (int64_t)q * p.do_rs, qv, ks, hi);
+    Frag of = gfrag<T>(Ob + (int64_t)q * p.o_rs, qv, ks, hi);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) dsum += to_f(dof[ks][e]) * to_f(of[e]);
+  }
+  dsum += __shfl_xor(dsum, 32, 64);
+  const float lse_q = qv ? p.lse[((int64_t)b * p.nh + h) * p.Lq + q] : 0.f;
+  const bool lse_ok = (lse_q != -INFINITY);
+  const bool drop = p.p > 0.f;
+  const uint32_t thr = goat_thr24(p.p);
+  const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
+  const uint64_t seed = p.seed + (p.rng_dev ? *p.rng_dev : 0ull);
+  const uint64_t ctr0 = p.offset + (((uint64_t)b * p.nh + h) * p.Lq + q) * (uint64_t)p.Lk;
+  __syncthreads();
+
+  f32x16 dq[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+  for (int jt = 0; jt < nkt; ++jt) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    const int key_l = jt * 32 + l31;
+    const bool kvl = key_l < p.Lk;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      Frag kf = *reinterpret_cast<const Frag*>(kl + key_l * LSTR + (ks * 2 + hi) * NE);
+      Frag vf = gfrag<T>(Vb + (int64_t)key_l * p.v_rs, kvl, ks, hi);
+      mma32(s, kf, qf[ks]);
+      mma32(dp, vf, dof[ks]);
+    }
+    f32x16 ds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = jt * 32 + c_row(r, lane);
+      float pr = 0.f;
+      if (qv && key < p.Lk && lse_ok) {
+        float v = s[r] * p.scale;
+        if (p.kmask) v += p.kmask[(int64_t)b * p.Lk + key];
+        if (p.bias) v += p.bias[((int64_t)b * p.Lq + q) * p.Lk + key];
+        pr = __expf(v - lse_q);
+      }
+      float keep = 1.f;
+      if (drop) keep = goat_keep(seed, ctr0 + key, thr) ? keep_scale : 0.f;
+      const float d = pr * (dp[r] * keep - dsum);
+      if (p.dbias && qv && key < p.Lk) atomicAdd(p.dbias + ((int64_t)b * p.Lq + q) * p.Lk + key, d);
+      ds[r] = d * p.scale;
+    }
+#pragma unroll
+    for (int st = 0; st < TSTEPS; ++st) {
+      Frag a = acc_frag<T>(ds, st);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        Frag kb = bfrag_crow<T>(kl, LSTR, jt * 32, st, dt, lane);
+        mma32(dq[dt], a, kb);
+      }
+    }
+  }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = q0 + c_row(r, lane);
+      if (qq < p.Lq) dQb[(int64_t)qq * p.dq_rs + dt * 32 + l31] = from_f<T>(dq[dt][r]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnArgs p) {
+  typedef typename AT<T>::Frag Frag;
+  constexpr int KSTEPS = AT<T>::KSTEPS, LSTR = AT<T>::LSTR, TSTEPS = AT<T>::TSTEPS, NE = AT<T>::NE;
+  __shared__ __attribute__((aligned(16))) T ql[32 * AT<T>::LSTR];
+  __shared__ __attribute__((aligned(16))) T dol[32 * AT<T>::LSTR];
+  __shared__ float rowd[32], rowl[32];
+  const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+  const int k0 = blockIdx.y * 32, key = k0 + l31;
+  const bool kv = key < p.Lk;
+  const T* Qb = reinterpret_cast<const T*>(p.Q) + b * p.q_bs + h * HD;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + b * p.k_bs + h * HD;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + b * p.v_bs + h * HD;
+  const T* Ob = reinterpret_cast<const T*>(p.O) + b * p.o_bs + h * HD;
+  const T* dOb = reinterpret_cast<const T*>(p.dO) + b * p.do_bs + h * HD;
+  T* dKb = reinterpret_cast<T*>(p.dK) + b * p.dk_bs + h * HD;
+  T* dVb = reinterpret_cast<T*>(p.dV) + b * p.dv_bs + h * HD;
+
+  Frag kf[KSTEPS], vf[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    kf[ks] = gfrag<T>(Kb + (int64_t)key * p.k_rs, kv, ks, hi);
+    vf[ks] = gfrag<T>(Vb + (int64_t)key * p.v_rs, kv, ks, hi);
+  }
+  const float kmv = kv ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + key] : 0.f) : -INFINITY;
+  const bool drop = p.p > 0.f;
+  const uint32_t thr = goat_thr24(p.p);
+  const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
+  const uint64_t seed = p.seed + (p.rng_dev ? *p.rng_dev : 0ull);
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+
+  const int nqt = (p.Lq + 31) / 32;
+  for (int it = 0; it < nqt; ++it) {
+    const int q0 = it * 32;
+    __syncthreads();
+    stage_rows<T>(ql, Qb, p.q_rs, q0, p.Lq, 32, lane, 64);
+    stage_rows<T>(dol, dOb, p.do_rs, q0, p.Lq, 32, lane, 64);
+    {  // D_q and lse_q for row l31 of this query tile
+      const int qq = q0 + l31;
+      float dsum = 0.f;
+      if (qq < p.Lq) {
+        const T* orow = Ob + (int64_t)qq * p.o_rs + hi * 32;
+        const T* drow = dOb + (int64_t)qq * p.do_rs + hi * 32;
+#pragma unroll
+        for (int c = 0; c < 32 / NE; ++c) {
+          Chunk<T> a, d2;
+          a.load(orow + c * NE);
+          d2.load(drow + c * NE);
+#pragma unroll
+          for (int e = 0; e < NE; ++e) dsum += a.v[e] * d2.v[e];
+        }
+      }
+      dsum += __shfl_xor(dsum, 32, 64);
+      if (hi == 0) {
+        rowd[l31] = dsum;
+        rowl[l31] = (qq < p.Lq) ? p.lse[((int64_t)b * p.nh + h) * p.Lq + qq] : -INFINITY;
+      }
+    }
+    __syncthreads();
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      Frag qa = *reinterpret_cast<const Frag*>(ql + l31 * LSTR + (ks * 2 + hi) * NE);
+      Frag da = *reinterpret_cast<const Frag*>(dol + l31 * LSTR + (ks * 2 + hi) * NE);
+      mma32(s, qa, kf[ks]);
+      mma32(dp, da, vf[ks]);
+    }
+    f32x16 pd, ds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = c_row(r, lane);
+      const int q = q0 + qr;
+      const float lse_q = rowl[qr];
+      float pr = 0.f;
+      if (q < p.Lq && kv && lse_q != -INFINITY) {
+        float v = s[r] * p.scale + kmv;
+        if (p.bias) v += p.bias[((int64_t)b * p.Lq + q) * p.Lk + key];
+        pr = __expf(v - lse_q);
+      }
+      float keep = 1.f;
+      if (drop) keep = goat_keep(seed, p.offset + (((uint64_t)b * p.nh + h) * p.Lq + q) * (uint64_t)p.Lk + key, thr) ? keep_scale : 0.f;
+      pd[r] = pr * keep;
+      ds[r] = pr * (dp[r] * keep - rowd[qr]) * p.scale;
+    }
+#pragma unroll
+    for (int st = 0; st < TSTEPS; ++st) {
+      Frag ap = acc_frag<T>(pd, st);
+      Frag as = acc_frag<T>(ds, st);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        Frag bo = bfrag_crow<T>(dol, LSTR, 0, st, dt, lane);
+        mma32(dv[dt], ap, bo);
+        Frag bq = bfrag_crow<T>(ql, LSTR, 0, st, dt, lane);
+        mma32(dk[dt], as, bq);
+      }
+    }
+  }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = k0 + c_row(r, lane);
+      if (kk < p.Lk) {
+        dKb[(int64_t)kk * p.dk_rs + dt * 32 + l31] = from_f<T>(dk[dt][r]);
+        dVb[(int64_t)kk * p.dv_rs + dt * 32 + l31] = from_f<T>(dv[dt][r]);
+      }
+    }
+}
+
+template <typename T>
+int launch_bwd2(hipStream_t st, const AttnArgs& a) {
+  const int nkt = (a.Lk + 31) / 32, nqt = (a.Lq + 31) / 32;
+  const size_t sm = (size_t)nkt * 32 * AT<T>::LSTR * sizeof(T);
+  static size_t attr = 0;
+  if (sm > 64 * 1024 && sm > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    if (e != hipSuccess) return (int)e;
+    attr = sm;
+  }
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(a.B * a.nh, nqt), dim3(64), sm, st, a);
+  GOAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, dim3(a.B * a.nh, nkt), dim3(64), 0, st, a);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T>
 size_t fwd_smem(int nkt) { return (size_t)nkt * 32 * AT<T>::LSTR * sizeof(T); }
 template <typename T>
@@ -516,5 +773,5 @@ extern "C" int goat_attn_bwd(void* stream, int dtype, const void* Q, int64_t q_r
   a.kmask = kmask; a.bias = bias; a.lse = const_cast<float*>(lse); a.dbias = dbias;
   a.B = B; a.nh = nh; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.p = p; a.seed = seed; a.offset = offset; a.rng_dev = rng_dev;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  return dtype == GOAT_BF16 ? dispatch<bf16_t>(st, a, true) : dispatch<float>(st, a, true);
+  return dtype == GOAT_BF16 ? launch_bwd2<bf16_t>(st, a) : launch_bwd2<float>(st, a);
 }
