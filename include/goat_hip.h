@@ -63,16 +63,14 @@ int goat_gemm_nt(void* stream, int dtype_in, int dtype_out,
  * bf16 inputs; dtype_out GOAT_BF16 or GOAT_F32 (F32 only with GOAT_EPI_NONE).  K-contiguous operands need
  * Kc % 64 == 0 (transposed operands: any Kc, the tail is zero-filled by the buffer bounds check); lda/ldb
  * multiples of 8, bases 16-B aligned, each operand < 2 GiB.  split_k>1: f32 atomic accumulation into C.
- * bm: 128 or 64 (M-tile; 64 fills the chip on small-M problems).
+ * bm: 128 or 64 (M-tile; 64 fills the chip on small-M problems).  nstage: 2..4 LDS ring stages (2 = most
+ * workgroups per CU, 3-4 = deeper prefetch for long/cold contractions).
  * colsum (trans_a only, may be NULL): colsum[m] += sum_k A[k,m] (float32, atomic; caller zero-fills) — the bias
  * gradient of the Linear, accumulated from the A fragments the wgrad already holds in registers. */
 int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_out,
                    const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                    int M, int N, int Kc, const float* bias, int epilogue,
-                   void* aux, int64_t ldaux, int split_k, int bm, float* colsum);
-
-/* tuning knob: LDS ring depth (2..4 stages of the LDS-DMA pipeline; default 2 = most workgroups per CU). */
-int goat_gemm_bf16_set_stages(int n);
+                   void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum);
 
 /* colsum[c] += sum_r x[r,c] (float32, atomic; caller zero-fills): bias gradient of a Linear. */
 int goat_colsum(void* stream, int dtype, const void* x, int64_t ld, int R, int C, float* colsum);

@@ -15,19 +15,26 @@ bms = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [128, 6
 stages = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [4]
 L = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
+ROT = int(os.environ.get('ROT', '1'))   # >1: rotate over ROT operand sets (cold caches, as inside a training step)
 for ta, tb, M, N, Kc, epi, split in SHAPES:
-    a = torch.randn((Kc, M) if ta else (M, Kc), device='cuda').to(torch.bfloat16)
-    b = (torch.randn((Kc, N) if tb else (N, Kc), device='cuda') * 0.1).to(torch.bfloat16)
-    out = torch.zeros(M, N, device='cuda', dtype=torch.float32 if split > 1 else torch.bfloat16)
+    if ROT > 1 and M * N * Kc > 2e11:
+        continue
+    As = [torch.randn((Kc, M) if ta else (M, Kc), device='cuda').to(torch.bfloat16) for _ in range(ROT)]
+    Bs = [(torch.randn((Kc, N) if tb else (N, Kc), device='cuda') * 0.1).to(torch.bfloat16) for _ in range(ROT)]
+    Os = [torch.zeros(M, N, device='cuda', dtype=torch.float32 if split > 1 else torch.bfloat16) for _ in range(ROT)]
+    a, b, out = As[0], Bs[0], Os[0]
     aux = torch.randn(M, N, device='cuda').to(torch.bfloat16) if epi else None
     bias = torch.zeros(N, device='cuda') if (split == 1) else None
     res = []
     for bm, ns in [(b_, n_) for b_ in bms for n_ in stages]:
-        L.goat_gemm_bf16_set_stages(ns)
+        cnt = [0]
         def run():
+            i = cnt[0] % ROT
+            cnt[0] += 1
+            a, b, out = As[i], Bs[i], Os[i]
             s_ = L.goat_gemm_bf16(st, ta, tb, hipops._dt(out), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
                                  out.data_ptr(), out.stride(0), M, N, Kc, bias.data_ptr() if bias is not None else None, epi,
-                                 aux.data_ptr() if aux is not None else None, N if aux is not None else 0, split, bm, None)
+                                 aux.data_ptr() if aux is not None else None, N if aux is not None else 0, split, bm, ns if 'ns' in dir() else 2, None)
             assert s_ == 0, s_
         for _ in range(5):
             run()

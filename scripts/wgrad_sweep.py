@@ -20,7 +20,7 @@ for M, N, Kc in SHAPES:
             cs = torch.zeros(M, device='cuda')
             def run():
                 s_ = L.goat_gemm_bf16(st, 1, 1, 0, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), N,
-                                      M, N, Kc, None, 0, None, 0, split, bm, cs.data_ptr())
+                                      M, N, Kc, None, 0, None, 0, split, bm, 2, cs.data_ptr())
                 assert s_ == 0
             for _ in range(3): run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -33,10 +33,10 @@ def test_argument_validation_without_gpu():
     h = _lib.lib()
     assert h.goat_version() >= 100
     assert h.goat_gemm_nt(None, 1, 1, None, 0, None, 0, None, 0, 4, 4, 8, None, 0, None, 0, 1) == -1      # GOAT_E_ARG
-    assert h.goat_gemm_bf16(None, 0, 0, 1, None, 0, None, 0, None, 0, 4, 4, 64, None, 0, None, 0, 1, 128, None) == -1
+    assert h.goat_gemm_bf16(None, 0, 0, 1, None, 0, None, 0, None, 0, 4, 4, 64, None, 0, None, 0, 1, 128, 2, None) == -1
     buf = (ctypes.c_char * 256)()
     p = ctypes.addressof(buf) & ~15
-    assert h.goat_gemm_bf16(None, 0, 0, 1, p, 8, p, 8, p, 8, 4, 4, 8, None, 0, None, 0, 1, 128, None) == -2   # Kc % 64
+    assert h.goat_gemm_bf16(None, 0, 0, 1, p, 8, p, 8, p, 8, 4, 4, 8, None, 0, None, 0, 1, 128, 2, None) == -2   # Kc % 64
     assert h.goat_ln_fwd(None, 1, None, None, None, None, 1e-5, 0.0, 0, 0, None, None, None, None, None, 4, 768) == -1
     assert h.goat_attn_fwd(None, 1, p, 64, 64, p, 64, 64, p, 64, 64, p, 64, 64, None, None, p, 1, 1, 4, 300, 0.125,
                            0.0, 0, 0, None) == -2                                                             # Lk > 256

@@ -390,7 +390,9 @@ int launch2s(hipStream_t st, const G2Args& a, int split) {
   return 0;
 }
 
-int g_nstage = 2;  // LDS ring depth; 2 stages = 64 KiB (bm 128) / 48 KiB (bm 64) -> 2-3 workgroups per CU (measured best)
+// LDS ring depth: 2 stages = 64 KiB (bm 128) / 48 KiB (bm 64) -> 2-3 workgroups per CU (best on short, hot
+// contractions); 3-4 stages = deeper prefetch, 1-2 workgroups per CU (best on long / cold contractions)
+thread_local int g_nstage = 2;
 
 template <bool TA, bool TB, typename OutT, int EPI, bool SPLITK, int BM>
 int launch2(hipStream_t st, const G2Args& a, int split) {
@@ -418,17 +420,13 @@ int dispatch2(hipStream_t st, const G2Args& a, int dtype_out, int epi, int split
 
 }  // namespace
 
-extern "C" int goat_gemm_bf16_set_stages(int n) {
-  if (n < 2 || n > 4) return GOAT_E_ARG;
-  g_nstage = n;
-  return 0;
-}
-
 extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_out,
                               const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                               int M, int N, int Kc, const float* bias, int epilogue,
-                              void* aux, int64_t ldaux, int split_k, int bm, float* colsum) {
+                              void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum) {
   if (!A || !B || !C) return GOAT_E_ARG;
+  if (nstage < 2 || nstage > 4) return GOAT_E_ARG;
+  g_nstage = nstage;
   if (colsum && !trans_a) return GOAT_E_ARG;
   if (M <= 0 || N <= 0 || Kc <= 0) return GOAT_E_SHAPE;
   if ((lda % 8) || (ldb % 8)) return GOAT_E_SHAPE;

@@ -135,7 +135,11 @@ def gemm_nt(a, b, out, bias=None, epi=EPI_NONE, aux=None, split_k=1):
     _lib.check(st, 'goat_gemm_nt(M=%d,N=%d,K=%d)' % (M, N, K))
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, epi, split_k, str(a.dtype))))
+        PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, epi, split_k, str(a.dtype)),
+                        ('goat_gemm_nt', (_dt(a), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0),
+                                          M, N, K, _ptr(bias) if bias is not None else None, epi,
+                                          _ptr(aux) if aux is not None else None, aux.stride(0) if aux is not None else 0,
+                                          split_k), (a, b, out, bias, aux))))
     return out
 
 
@@ -165,10 +169,81 @@ def colsum(x, out=None):
     return out
 
 
-def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split_k=1, colsum_out=None):
+# ----------------------------------------------------------------------------- GEMM configuration / autotuner
+AUTOTUNE = False        # bench.py / trainers may switch this on: first sight of a shape times the candidate configs
+_TUNED = {}             # (ta, tb, M, N, Kc, epi, f32out, split_req) -> (bm, nstage, split)
+_FLUSH = [None]
+
+
+def _heuristic_cfg(ta, tb, M, N, Kc, split_k):
+    """(bm, nstage) measured with scripts/gemm_bench.py (hot and cold operands)."""
+    tiles128 = ((M + 127) // 128) * ((N + 127) // 128) * max(1, split_k)
+    kper = Kc // max(1, split_k)
+    if ta:
+        return 64, 2
+    if kper >= 2048 and tiles128 >= 150:
+        return 128, 3
+    if tiles128 >= 1024:
+        return 128, 2
+    return 64, 2
+
+
+def _launch_gemm_bf16(a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_k, bm, nstage, colsum_out):
+    st = _lib.lib().goat_gemm_bf16(_stream(), int(ta), int(tb), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0),
+                                   _ptr(out), out.stride(0), M, N, Kc,
+                                   _ptr(bias) if bias is not None else None, epi,
+                                   _ptr(aux) if aux is not None else None,
+                                   aux.stride(0) if aux is not None else 0, split_k, bm, nstage,
+                                   _ptr(colsum_out) if colsum_out is not None else None)
+    _lib.check(st, 'goat_gemm_bf16(ta=%d,tb=%d,M=%d,N=%d,Kc=%d,bm=%d,ns=%d,split=%d)' % (ta, tb, M, N, Kc, bm, nstage, split_k))
+
+
+def _time_cfg(fn, reps=4):
+    """median HIP-event time of fn() with the L2 / Infinity Cache flushed before every repetition (inside a
+    training step the operands of a GEMM are cold: they were just produced by another kernel)."""
+    if _FLUSH[0] is None:
+        _FLUSH[0] = torch.empty(320 << 20, dtype=torch.uint8, device='cuda')
+    ts = []
+    for _ in range(reps):
+        _FLUSH[0].zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def _tune_gemm(key, a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_opts, colsum_out):
+    kt = (Kc + 63) // 64
+    best = None
+    scratch = torch.empty_like(out) if out.dtype == torch.float32 else out
+    cs = torch.zeros_like(colsum_out) if colsum_out is not None else None
+    for split in split_opts:
+        if split > kt:
+            continue
+        for bm in (64, 128):
+            for ns in (2, 3, 4):
+                if bm == 128 and ns == 4 and out.dtype == torch.bfloat16 and epi != EPI_NONE:
+                    continue
+                try:
+                    t = _time_cfg(lambda: _launch_gemm_bf16(a, b, scratch, ta, tb, M, N, Kc, bias, epi, aux, split, bm, ns, cs))
+                except RuntimeError:
+                    continue
+                if best is None or t < best[0]:
+                    best = (t, bm, ns, split)
+    _TUNED[key] = best[1:]
+    return best[1:]
+
+
+def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split_k=1, colsum_out=None, split_opts=None):
     """out[M,N] = epi(op(a) @ op(b)^T + bias); ta: a is [Kc,M] (else [M,Kc]); tb: b is [Kc,N] (else [N,Kc]).
     bf16 -> pipelined LDS-DMA kernel (goat_gemm_bf16) whenever its layout rules hold; otherwise (f32 parity
-    path, odd contraction lengths) explicit transposes + goat_gemm_nt."""
+    path, odd contraction lengths) explicit transposes + goat_gemm_nt.
+    split_opts: candidate split-K factors the autotuner may choose from (the caller must have zero-filled
+    `out` if any of them is > 1); returns `out`."""
     Kc = a.shape[0] if ta else a.shape[1]
     M = a.shape[1] if ta else a.shape[0]
     N = b.shape[1] if tb else b.shape[0]
@@ -193,33 +268,58 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
             bk = 64 if a.dtype == torch.bfloat16 else 32
             split_k = max(2, min(split_k, (a.shape[1] + bk - 1) // bk))
         return gemm_nt(a, b, out, bias, epi, aux, split_k)
-    # M-tile: 128 rows for long contractions / big grids (arithmetic intensity), 64 rows otherwise (3 workgroups
-    # per CU overlap the short pipelines' prologue/epilogue) — measured with scripts/gemm_bench.py
-    tiles128 = ((M + 127) // 128) * ((N + 127) // 128) * max(1, split_k)
-    kper = Kc // max(1, split_k)
-    bm = 128 if (not ta and ((kper >= 2048 and tiles128 >= 256) or tiles128 >= 1024)) else 64
+    key = (ta, tb, M, N, Kc, epi, out.dtype == torch.float32, split_k, bias is not None)
+    cfg = _TUNED.get(key)
+    if cfg is None:
+        if AUTOTUNE and not torch.cuda.is_current_stream_capturing() and PROFILE is None:
+            cfg = _tune_gemm(key, a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_opts or (split_k,), colsum_out)
+        else:
+            cfg = _heuristic_cfg(ta, tb, M, N, Kc, split_k) + (split_k,)
+    bm, nstage, split_k = cfg
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    st = _lib.lib().goat_gemm_bf16(_stream(), int(ta), int(tb), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0),
-                                   _ptr(out), out.stride(0), M, N, Kc,
-                                   _ptr(bias) if bias is not None else None, epi,
-                                   _ptr(aux) if aux is not None else None,
-                                   aux.stride(0) if aux is not None else 0, split_k, bm,
-                                   _ptr(colsum_out) if colsum_out is not None else None)
-    _lib.check(st, 'goat_gemm_bf16(ta=%d,tb=%d,M=%d,N=%d,Kc=%d)' % (ta, tb, M, N, Kc))
+    _launch_gemm_bf16(a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_k, bm, nstage, colsum_out)
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * Kc, (M, N, Kc, epi, split_k, 'v2 t%d%d bm%d' % (ta, tb, bm))))
+        PROFILE.append((e0, e1, 2.0 * M * N * Kc, (M, N, Kc, epi, split_k, 'v2 t%d%d bm%d s%d' % (ta, tb, bm, nstage)),
+                        ('goat_gemm_bf16', (int(ta), int(tb), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out),
+                                            out.stride(0), M, N, Kc, _ptr(bias) if bias is not None else None, epi,
+                                            _ptr(aux) if aux is not None else None, aux.stride(0) if aux is not None else 0,
+                                            split_k, bm, nstage, _ptr(colsum_out) if colsum_out is not None else None),
+                         (a, b, out, bias, aux, colsum_out))))
     return out
 
 
-def wgrad(dy, x, want_bias):
-    """dW[N,K] (f32) = dy[M,N]^T @ x[M,K] ; db[N] (f32) = colsum(dy), fused into the same kernel.
-    One zero-fill covers both outputs (split-K partial tiles and the bias sums are accumulated atomically)."""
+class WgradOverlap:
+    """Optional: run every weight-gradient GEMM on a side HIP stream so it overlaps the data-gradient chain
+    (dgrad -> LayerNorm-bwd -> attention-bwd ...) that autograd keeps issuing on the main stream.  GOAT's
+    GEMMs are small (180-360 workgroups on 256 CUs), so two independent GEMM streams fill the chip better than
+    one.  Weight gradients are only consumed after backward, so one join at the end suffices:
+        hipops.WgradOverlap.enable();  loss.backward();  hipops.WgradOverlap.join()
+    Works eagerly and inside torch.cuda.graph capture (fork/join inside the captured region).  Off by default
+    (torch DDP's reducer reads .grad as soon as autograd hooks fire)."""
+    stream = None
+
+    @classmethod
+    def enable(cls):
+        if cls.stream is None:
+            cls.stream = torch.cuda.Stream()
+
+    @classmethod
+    def disable(cls):
+        cls.stream = None
+
+    @classmethod
+    def join(cls):
+        if cls.stream is not None:
+            torch.cuda.current_stream().wait_stream(cls.stream)
+
+
+def _wgrad_impl(dy, x, want_bias):
     M, N = dy.shape
     K = x.shape[1]
-    # (bm 64, split) tuned with scripts/wgrad_sweep.py on GOAT's weight shapes
+    # default (bm 64, split) from scripts/wgrad_sweep.py; the autotuner may pick another split (output is zero-filled)
     tiles = ((N + 63) // 64) * ((K + 127) // 128)
     kt = (M + 63) // 64
     if tiles < 128:
@@ -227,15 +327,33 @@ def wgrad(dy, x, want_bias):
     else:
         split = max(1, min(int(round(500.0 / tiles)), kt // 24))
     nb = N if want_bias else 0
-    if split > 1:
+    tunable = AUTOTUNE and dy.dtype == torch.bfloat16
+    if split > 1 or tunable:
         buf = torch.zeros(N * K + nb, dtype=torch.float32, device=dy.device)
         dw = buf[:N * K].view(N, K)
         db = buf[N * K:] if want_bias else None
+        split = max(split, 2) if not tunable else split
     else:
         dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
         db = torch.zeros(N, dtype=torch.float32, device=dy.device) if want_bias else None
-    gemm(dy, x, dw, ta=True, tb=True, split_k=split, colsum_out=db)
+    gemm(dy, x, dw, ta=True, tb=True, split_k=split, colsum_out=db,
+         split_opts=(1, 2, 3, 4, 6, 8) if tunable else None)
     return dw, db
+
+
+def wgrad(dy, x, want_bias):
+    """dW[N,K] (f32) = dy[M,N]^T @ x[M,K] ; db[N] (f32) = colsum(dy), fused into the same kernel.
+    One zero-fill covers both outputs (split-K partial tiles and the bias sums are accumulated atomically)."""
+    side = WgradOverlap.stream
+    if side is None:
+        return _wgrad_impl(dy, x, want_bias)
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)                       # dy / x are ready on the main stream
+    with torch.cuda.stream(side):
+        out = _wgrad_impl(dy, x, want_bias)
+    dy.record_stream(side)                      # keep the operands alive until the side-stream GEMM has read them
+    x.record_stream(side)
+    return out
 
 
 # ----------------------------------------------------------------------------- Linear
