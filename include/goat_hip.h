@@ -147,6 +147,15 @@ int goat_attn_bwd(void* stream, int dtype,
                   int B, int nh, int Lq, int Lk, float scale,
                   float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev);
 
+/* Softmax cross-entropy (reduction none) on float32 logits [M, ld] with N valid columns (ld >= N may be padded):
+ * loss[m] = logsumexp(logits[m,:N]) - logits[m,target[m]], lse saved.  Replaces F.cross_entropy on the 576 x 50265
+ * MLM scores (P/model/pretrain_goat.py:213-215).  Backward writes dlogits (GOAT_BF16 or GOAT_F32) with row stride
+ * ld_out, zeros in the padding columns [N, ld_out), ready to be the K-padded operand of the decoder's dgrad/wgrad. */
+int goat_ce_fwd(void* stream, const float* logits, int64_t ld, int M, int N, const int64_t* targets,
+                float* loss, float* lse);
+int goat_ce_bwd(void* stream, int dtype_out, const float* logits, int64_t ld, int M, int N,
+                const int64_t* targets, const float* lse, const float* dloss, void* dlogits, int64_t ld_out);
+
 /* Adaptive panorama fusion: w = softmax_v(tanh(x[n,v,:]·a + a0)) over ALL V slots (no mask);
  * fused[n,:] = sum_v w_v x[n,v,:]    (P/model/vilmodel_goat.py:354-361).  a: float32[H], a0: float32[1].
  * wsave: float32 [N,V] softmax weights saved for backward. */

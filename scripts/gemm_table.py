@@ -10,6 +10,7 @@ args = A(); args.batch = int(sys.argv[1]) if len(sys.argv) > 1 else 48; args.dty
 torch.cuda.set_device(0)
 cfg, model, batch, gb = bench.build(args, 0)
 hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')
+hipops.AUTOTUNE = True
 for rep in range(3):
     hipops.PROFILE = [] if rep == 2 else None
     for task in bench.TASKS:
@@ -18,9 +19,24 @@ for rep in range(3):
         model(gb, task, compute_loss=True).mean().backward()
     torch.cuda.synchronize()
 recs = hipops.PROFILE
+hipops.PROFILE = None
+# time every recorded launch individually with a cache flush in front (in-step conditions), 3 reps, median
+from vln_goat_amd import _lib
+L = _lib.lib()
+flush = torch.empty(320 << 20, dtype=torch.uint8, device='cuda')
 agg = collections.OrderedDict()
-for e0, e1, fl, key in recs:
-    t = e0.elapsed_time(e1) * 1e3
+for rec in recs:
+    fl, key = rec[2], rec[3]
+    name, cargs, keep = rec[4]
+    ts = []
+    for _ in range(3):
+        flush.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); rc = getattr(L, name)(torch.cuda.current_stream().cuda_stream, *cargs); e1.record(); e1.synchronize()
+        assert rc == 0
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    t = ts[1] * 1e3
     a = agg.setdefault(key, [0, 0.0, fl])
     a[0] += 1; a[1] += t
 tot = sum(a[1] for a in agg.values())

@@ -383,3 +383,27 @@ def test_gemm_bf16_epilogues_match_v1(ops):
     uu = aux.float().requires_grad_(True)
     torch.nn.functional.gelu(uu).sum().backward()
     _close(du, (dy.float() @ w2.float()) * uu.grad, torch.bfloat16, 'dgelu epilogue')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N', [(37, 1000), (576, 50265)])
+def test_decoder_cross_entropy_fused(ops, dtype, M, N):
+    K = 768
+    g = torch.Generator().manual_seed(N + M)
+    h = torch.randn(M, K, generator=g).to(DEV, dtype).requires_grad_(True)
+    w = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.05).to(DEV))
+    b = torch.nn.Parameter((torch.randn(N, generator=g) * 0.1).to(DEV))
+    tgt = torch.randint(0, N, (M,), generator=g).to(DEV)
+    loss = ops.decoder_cross_entropy(h, w, b, tgt)
+    gl = torch.rand(M, generator=g).to(DEV)
+    loss.backward(gl)
+    hr = h.detach().float().requires_grad_(True)
+    wr = w.detach().clone().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True)
+    wq = wr.to(dtype).float() if dtype == torch.bfloat16 else wr
+    ref = torch.nn.functional.cross_entropy(hr @ wq.T + br, tgt, reduction='none')
+    ref.backward(gl)
+    _close(loss, ref, dtype, 'ce loss')
+    _close(h.grad, hr.grad, dtype, 'ce dh')
+    _close(w.grad, wr.grad, dtype, 'ce dW')
+    _close(b.grad, br.grad, dtype, 'ce db')

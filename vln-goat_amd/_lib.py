@@ -41,6 +41,8 @@ SIGNATURES = {
     'goat_act_bwd': [_vp, _i32, _vp, _vp, _vp, _i64, _i32, _f32, _u64, _u64, _vp],
     'goat_attn_fwd': [_vp, _i32] + [_vp, _i64, _i64] * 4 + [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _u64, _vp],
     'goat_attn_bwd': [_vp, _i32] + [_vp, _i64, _i64] * 8 + [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _u64, _vp],
+    'goat_ce_fwd': [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
+    'goat_ce_bwd': [_vp, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64],
     'goat_pano_fusion_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_pano_fusion_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_gather_segmean_fwd': [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32],

@@ -284,6 +284,73 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   if (ty == 0 && c < C) atomicAdd(colsum + c, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
 }
 
+
+// ------------------------------------------------------------------------------------ softmax cross-entropy
+// One 256-thread block per row of f32 logits [M, ld] with N valid columns (ld may be padded).
+//   fwd: lse[m] = logsumexp(logits[m,:N]) ; loss[m] = lse - logits[m, target]       (F.cross_entropy, reduction none;
+//        P/model/pretrain_goat.py:213-215 on the 576 x 50265 MLM scores)
+//   bwd: dlogits[m,n] = (exp(l - lse) - [n == target]) * dloss[m] for n < N, 0 for the padding columns n in [N, ld_out)
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int64_t ld, int N,
+                                                     const int64_t* __restrict__ targets, float* __restrict__ loss,
+                                                     float* __restrict__ lse) {
+  __shared__ float red[4];
+  const int m = blockIdx.x;
+  const float* row = logits + (int64_t)m * ld;
+  float mx = -INFINITY;
+  const int n4 = N >> 2;
+  for (int c = threadIdx.x; c < n4; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + c * 4);
+    mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  for (int c = n4 * 4 + threadIdx.x; c < N; c += 256) mx = fmaxf(mx, row[c]);
+  mx = block_reduce(mx, red, true);
+  float sum = 0.f;
+  for (int c = threadIdx.x; c < n4; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + c * 4);
+    sum += __expf(v[0] - mx) + __expf(v[1] - mx) + __expf(v[2] - mx) + __expf(v[3] - mx);
+  }
+  for (int c = n4 * 4 + threadIdx.x; c < N; c += 256) sum += __expf(row[c] - mx);
+  sum = block_reduce(sum, red, false);
+  if (threadIdx.x == 0) {
+    const float l = mx + __logf(sum);
+    lse[m] = l;
+    loss[m] = l - row[targets[m]];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int64_t ld, int N,
+                                                     const int64_t* __restrict__ targets, const float* __restrict__ lse,
+                                                     const float* __restrict__ dloss, T* __restrict__ dlogits, int64_t ld_out) {
+  const int m = blockIdx.x;
+  const float* row = logits + (int64_t)m * ld;
+  T* out = dlogits + (int64_t)m * ld_out;
+  const float l = lse[m], g = dloss[m];
+  const int t = (int)targets[m];
+  for (int c = threadIdx.x * 4; c < (int)ld_out; c += 256 * 4) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = c + e;
+      v[e] = (n < N) ? (__expf(row[n] - l) - (n == t ? 1.f : 0.f)) * g : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < (int)ld_out) out[c + e] = from_f<T>(v[e]);
+  }
+}
+
 // ------------------------------------------------------------------------------------ transpose
 // 64x64 tiles through LDS; each block walks RT consecutive row tiles of one column tile so the column
 // sums (bias gradient) cost one atomic per column per block.
@@ -624,6 +691,31 @@ extern "C" int goat_colsum(void* stream, int dtype, const void* x, int64_t ld, i
   else if (dtype == GOAT_F32)
     hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)x, ld, R, C, colsum,
                        rows_per_block);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_ce_fwd(void* stream, const float* logits, int64_t ld, int M, int N, const int64_t* targets,
+                           float* loss, float* lse) {
+  if (!logits || !targets || !loss || !lse) return GOAT_E_ARG;
+  if (M <= 0 || N <= 0 || ld < N || (ld & 3) || (reinterpret_cast<uintptr_t>(logits) & 15)) return GOAT_E_SHAPE;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(M), dim3(256), 0, ST(stream), logits, ld, N, targets, loss, lse);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_ce_bwd(void* stream, int dtype_out, const float* logits, int64_t ld, int M, int N,
+                           const int64_t* targets, const float* lse, const float* dloss, void* dlogits, int64_t ld_out) {
+  if (!logits || !targets || !lse || !dloss || !dlogits) return GOAT_E_ARG;
+  if (M <= 0 || N <= 0 || ld < N || ld_out < N) return GOAT_E_SHAPE;
+  if (dtype_out == GOAT_BF16)
+    hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(M), dim3(256), 0, ST(stream), logits, ld, N, targets, lse, dloss,
+                       (bf16_t*)dlogits, ld_out);
+  else if (dtype_out == GOAT_F32)
+    hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(M), dim3(256), 0, ST(stream), logits, ld, N, targets, lse, dloss,
+                       (float*)dlogits, ld_out);
   else
     return GOAT_E_ARG;
   GOAT_LAUNCH_CHECK();

@@ -482,6 +482,77 @@ def ffn(x, w1, b1, w2, b2, act='gelu', p=0.0):
     return _FfnFn.apply(x, w1, b1, w2, b2, act, float(p))
 
 
+# ----------------------------------------------------------------------------- tied decoder + cross-entropy (MLM)
+def _shadow_rows_padded(param, dtype, rows):
+    """[rows, K] copy of a [N, K] weight (N <= rows, extra rows zero), cached like _shadow."""
+    key = ('rowpad', dtype, rows)
+    cache = param.__dict__.setdefault('_goat_shadow', {})
+    ent = cache.get(key)
+    if ent is not None and ent[0] == param._version and ent[1].device == param.device:
+        return ent[1]
+    with torch.no_grad():
+        w = torch.zeros((rows, param.shape[1]), dtype=dtype, device=param.device)
+        w[:param.shape[0]] = param.detach().to(dtype)
+    cache[key] = (param._version, w)
+    return w
+
+
+class _DecoderCeFn(torch.autograd.Function):
+    """loss[m] = CE(h[m] @ W^T + b, target[m])  — BertLMPredictionHead.decoder + F.cross_entropy
+    (P/model/Bert_backbone.py:826-829, P/model/pretrain_goat.py:210-216).  The vocabulary dimension is padded
+    to a multiple of 64 (zero weight rows) so the logits GEMM, its dgrad (contraction over the vocabulary,
+    split-K) and its wgrad all run on the LDS-DMA kernel; cross-entropy forward/backward are two row kernels
+    that never materialise a softmax."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, targets):
+        _need_gpu(h)
+        h2 = h.reshape(-1, h.shape[-1])
+        h2 = h2 if h2.is_contiguous() else h2.contiguous()
+        M, K = h2.shape
+        N = weight.shape[0]
+        Np = (N + 63) // 64 * 64
+        W = _shadow_rows_padded(weight, h2.dtype, Np)
+        Nl = W.shape[0]
+        bpad = torch.zeros(Nl, dtype=torch.float32, device=h.device)
+        bpad[:N] = bias.detach()
+        logits = torch.empty((M, Nl), dtype=torch.float32, device=h.device)
+        gemm(h2, W, logits, bias=bpad)
+        loss = torch.empty(M, dtype=torch.float32, device=h.device)
+        lse = torch.empty(M, dtype=torch.float32, device=h.device)
+        tg = targets.contiguous()
+        st = _lib.lib().goat_ce_fwd(_stream(), _ptr(logits), Nl, M, N, _ptr(tg), _ptr(loss), _ptr(lse))
+        _lib.check(st, 'goat_ce_fwd')
+        ctx.save_for_backward(h2, logits, lse, tg)
+        ctx.weight, ctx.N, ctx.hshape = weight, N, h.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        h2, logits, lse, tg = ctx.saved_tensors
+        weight, N = ctx.weight, ctx.N
+        M, K = h2.shape
+        Nl = logits.shape[1]
+        dl = torch.empty((M, Nl), dtype=h2.dtype, device=h2.device)
+        dloss = dloss.contiguous().float()
+        st = _lib.lib().goat_ce_bwd(_stream(), _dt(dl), _ptr(logits), Nl, M, N, _ptr(tg), _ptr(lse), _ptr(dloss), _ptr(dl), Nl)
+        _lib.check(st, 'goat_ce_bwd')
+        if h2.dtype == torch.bfloat16:
+            W = _shadow_rows_padded(weight, h2.dtype, Nl)
+            dh32 = torch.zeros((M, K), dtype=torch.float32, device=h2.device)
+            gemm(dl, W, dh32, tb=True, split_k=8, split_opts=(4, 6, 8, 12, 16))     # contraction over the vocabulary
+            dh = dh32.to(h2.dtype)
+        else:
+            dh = torch.empty_like(h2)
+            gemm(dl, _shadow_rows_padded(weight, h2.dtype, Nl), dh, tb=True)
+        dw, db = wgrad(dl, h2, True)
+        return dh.view(ctx.hshape), dw[:N], db[:N], None
+
+
+def decoder_cross_entropy(h, weight, bias, targets):
+    return _DecoderCeFn.apply(h, weight, bias, targets)
+
+
 # ----------------------------------------------------------------------------- fused multi-weight projection
 class _MultiLinearFn(torch.autograd.Function):
     """y = x @ cat(W_i)^T + cat(b_i): one GEMM for the separate query/key/value Linears of a BERT block

@@ -264,6 +264,10 @@ class BertLMPredictionHead(nn.Module):
         h = self.transform(hidden)
         return hipops.linear(h, self.decoder.weight, self.bias, None, torch.float32)
 
+    def loss(self, hidden, targets):
+        """per-token cross-entropy without materialising softmax / f32 dlogits (fused decoder + CE)."""
+        return hipops.decoder_cross_entropy(self.transform(hidden), self.decoder.weight, self.bias, targets)
+
 
 class BertOnlyMLMHead(nn.Module):
     def __init__(self, config):

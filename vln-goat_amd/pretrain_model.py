@@ -346,10 +346,9 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
             cache['mlm_idx'] = (labels.reshape(-1) != -1).nonzero().squeeze(1)
             cache['mlm_tgt'] = labels.reshape(-1)[cache['mlm_idx']]
         masked = txt.reshape(-1, txt.shape[-1]).index_select(0, cache['mlm_idx'])
-        scores = self.mlm_head(masked)          # float32 logits
         if compute_loss:
-            return F.cross_entropy(scores, cache['mlm_tgt'], reduction='none')
-        return scores
+            return self.mlm_head.predictions.loss(masked, cache['mlm_tgt'])
+        return self.mlm_head(masked)            # float32 logits
 
     # -- SAP ---------------------------------------------------------------------------------------
     def _fuse_weights(self, gmap_embeds, vp_embeds):
