@@ -57,10 +57,15 @@ def setup_dist(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        backend = os.environ.get('GOAT_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm; 'gloo' only for single-GPU self-tests
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     return world, rank, local
 
 
@@ -113,22 +118,33 @@ def make_steps(args, model, gb, world):
             steps[task] = (lambda t=task: eager_step(t))
         return steps, None
     for task in TASKS:
-        if world > 1 and task == 'cfp':
+        if (world > 1 or os.environ.get('GOAT_BENCH_EAGER_CFP')) and task == 'cfp':
             # the CFP step contains a collective (all-gather of the contrastive negatives): launched eagerly
             steps[task] = (lambda t=task: eager_step(t))
             grads[task] = None
             continue
-        g = torch.cuda.CUDAGraph()
         for p in params:
             p.grad = None
-        with torch.cuda.graph(g):
-            hipops.RngState.dev.add_(0x9E3779B1)
-            loss = model(gb, task, compute_loss=True)
-            loss.mean().backward()
-            hipops.WgradOverlap.join()
-        grads[task] = [p.grad for p in params]
-        losses[task] = loss
-        steps[task] = g.replay
+        try:
+            if world > 1:
+                torch.cuda.synchronize()
+                dist.barrier()
+            g = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
+            with torch.cuda.graph(g, capture_error_mode='thread_local' if world > 1 else 'global'):
+                hipops.RngState.dev.add_(0x9E3779B1)
+                loss = model(gb, task, compute_loss=True)
+                loss.mean().backward()
+                hipops.WgradOverlap.join()
+            grads[task] = [p.grad for p in params]
+            losses[task] = loss.detach()     # (not the autograd graph: stale AccumulateGrad nodes would pin the capture stream)
+            del loss
+            steps[task] = g.replay
+        except Exception as e:       # never lose the run to a capture problem: fall back to eager launches for this task
+            print('[bench] hipGraph capture of %s failed (%s: %s); running it eagerly' % (task, type(e).__name__, e), file=sys.stderr)
+            torch.cuda.synchronize()
+            steps[task] = (lambda t=task: eager_step(t))
+            grads[task] = None
     return steps, grads
 
 

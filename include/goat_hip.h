@@ -179,6 +179,22 @@ int goat_gather_segmean_bwd(void* stream, int dtype, const void* dout,
                             const int32_t* idx, const int32_t* start, const float* scale,
                             float* dsrc32, int n_out, int H);
 
+/* Embedding tables (float32 masters):  out[r,:] = word[ids[r],:] + type[type_ids ? type_ids[r] : 0,:] + pos[r % L,:]
+ * cast to `dtype` — the three nn.Embedding lookups and two adds of BertEmbeddings.forward
+ * (P/model/Bert_backbone.py:98-113; the reference's position ids are arange(L) for every sample), and with
+ * type_tab = pos_tab = NULL the single lookup of gmap_step_embeddings (P/model/vilmodel_goat.py:474) /
+ * nav_type_embedding.  ids/type_ids are int64 [rows] (torch LongTensor).  An id outside [0,vocab) sets bit 0 of
+ * *err_flag (if given) and reads row 0 instead of faulting. */
+int goat_embed_fwd(void* stream, int dtype, const float* word, const int64_t* ids, const float* type_tab,
+                   const int64_t* type_ids, const float* pos_tab, int L, void* out, int rows, int H, int vocab,
+                   int* err_flag);
+/* backward: scatter-add of dout[rows,H] into the PRE-ZEROED float32 table gradients (float atomics).  Any of
+ * dword / dtype_tab / dpos may be NULL.  Rows with ids[r] == word_pad and positions l == pos_pad contribute
+ * nothing (nn.Embedding(padding_idx) semantics, Bert_backbone.py:85-87; pass -1 for "no padding row").
+ * dtype_tab is only written when type_ids != NULL: the all-zero-type case is a column sum (goat_colsum). */
+int goat_embed_bwd(void* stream, int dtype, const void* dout, const int64_t* ids, const int64_t* type_ids, int L,
+                   float* dword, float* dtype_tab, float* dpos, int rows, int H, int vocab, int word_pad, int pos_pad);
+
 /* Debug/probe helper used by tests: fills out[64*4] with the element indices returned by
  * ds_read_b64_tr_b16 when lane l points at elements 4l..4l+3 of an LDS array holding 0,1,2,... */
 int goat_probe_tr16(void* stream, uint16_t* out);

@@ -43,7 +43,8 @@ def _worker_buckets(rank, world, port, q):
     w.reduce_gradients('sap')
     w.reduce_gradients('sap')   # second call reuses the cached bucket plan; averaging an average is a no-op
     got = [p.grad.clone() for p in model.parameters()]
-    q.put((rank, local, got, [p.grad is None for p in unused.parameters()]))
+    # numpy payloads are pickled by value (torch tensors travel as shared-memory fds that die with this process)
+    q.put((rank, [t.numpy() for t in local], [t.numpy() for t in got], [p.grad is None for p in unused.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,10 +57,10 @@ def test_bucketed_grad_allreduce_mean():
     [p.start() for p in ps]
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
     [p.join(60) for p in ps]
-    mean = [(a + b) / 2 for a, b in zip(res[0][1], res[1][1])]
+    mean = [(torch.from_numpy(a) + torch.from_numpy(b)) / 2 for a, b in zip(res[0][1], res[1][1])]
     for r in range(world):
         for g, m in zip(res[r][2], mean):
-            assert torch.allclose(g, m, atol=1e-6)
+            assert torch.allclose(torch.from_numpy(g), m, atol=1e-6)
         assert all(res[r][3])
 
 
@@ -81,7 +82,7 @@ def _worker_cfp(rank, world, port, q):
     for g in grads:                      # what GoatDataParallel.reduce_gradients does for parameters
         dist.all_reduce(g)
         g /= world
-    q.put((rank, loss.detach(), [t.grad.clone() for t in loc]))
+    q.put((rank, loss.detach().numpy(), [t.grad.numpy() for t in loc]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -98,11 +99,11 @@ def test_cfp_gather_equals_single_process_on_concatenated_batch():
     full = [t.clone().requires_grad_(True) for t in _cfp_inputs(world * B)]
     ref = cfp_losses(full[0], full[1], full[2], full[3], 0.7, None)     # reference formula, one process
     ref.mean().backward()
-    got = torch.cat([r[1] for r in res])
+    got = torch.cat([torch.from_numpy(r[1]) for r in res])
     assert torch.allclose(got, ref.detach(), atol=1e-5)
     # d(mean over the global batch)/d(local embeddings) = (1/W) * local grads of the local-mean loss
     for k in range(4):
-        g = torch.cat([r[2][k] for r in res]) / world
+        g = torch.cat([torch.from_numpy(r[2][k]) for r in res]) / world
         assert torch.allclose(g, full[k].grad, atol=1e-6), k
 
 

@@ -294,6 +294,48 @@ def test_gather_segmean(ops, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('with_types', [False, True])
+def test_embedding_tables(ops, dtype, with_types):
+    """word + type + position lookups in one kernel; scatter-add backward with nn.Embedding(padding_idx) semantics
+    (the gradient of the padding row of the word table AND of position row `pad` is zero, as in the reference)."""
+    import torch.nn.functional as F
+    B, L, H, V, P, pad = 7, 19, 768, 300, 40, 1
+    g = torch.Generator().manual_seed(33)
+    word = torch.nn.Parameter(torch.randn(V, H, generator=g).to(DEV))
+    typ = torch.nn.Parameter(torch.randn(2, H, generator=g).to(DEV))
+    pos = torch.nn.Parameter(torch.randn(P, H, generator=g).to(DEV))
+    ids = torch.randint(0, V, (B, L), generator=g).to(DEV)
+    ids[:, -4:] = pad                          # padded tail
+    ids[0, :5] = 17                            # repeated ids (atomics accumulate)
+    tids = torch.randint(0, 2, (B, L), generator=g).to(DEV) if with_types else None
+    out = ops.embedding(ids, word, typ, tids, pos, out_dtype=dtype, word_pad=pad, pos_pad=pad)
+    dout = torch.randn(B, L, H, generator=g).to(DEV, dtype)
+    out.backward(dout)
+    ops.check_embed_errors()
+    wr, tr, pr = [p.detach().clone().requires_grad_(True) for p in (word, typ, pos)]
+    ref = F.embedding(ids, wr, padding_idx=pad) + F.embedding(tids if with_types else torch.zeros_like(ids), tr) \
+        + F.embedding(torch.arange(L, device=DEV)[None], pr, padding_idx=pad)
+    ref.backward(dout.float())
+    _close(out, ref, dtype, 'embedding')
+    for a, b, n in ((word, wr, 'word'), (typ, tr, 'type'), (pos, pr, 'pos')):
+        assert a.grad.dtype == torch.float32
+        _close(a.grad, b.grad, torch.float32, 'embedding grad ' + n)      # f32 accumulation of the same dout values
+    assert float(word.grad[pad].abs().max()) == 0.0 and float(pos.grad[pad].abs().max()) == 0.0
+    # single-table form (gmap_step_embeddings) + out-of-range detection
+    step = torch.nn.Parameter(torch.randn(15, H, generator=g).to(DEV))
+    sid = torch.randint(0, 15, (4, 22), generator=g).to(DEV)
+    o2 = ops.embedding(sid, step, out_dtype=dtype)
+    _close(o2, F.embedding(sid, step), dtype, 'embedding single')
+    o2.backward(torch.ones_like(o2))
+    _close(step.grad, torch.bincount(sid.reshape(-1), minlength=15).float()[:, None].expand(15, H), torch.float32, 'step grad')
+    bad = sid.clone()
+    bad[0, 0] = 15
+    ops.embedding(bad, step, out_dtype=dtype)
+    with pytest.raises(IndexError):
+        ops.check_embed_errors()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_linear_ffn_autograd(ops, dtype):
     M, H, F_ = 300, 768, 3072
     g = torch.Generator().manual_seed(21)

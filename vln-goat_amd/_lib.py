@@ -47,6 +47,8 @@ SIGNATURES = {
     'goat_pano_fusion_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_gather_segmean_fwd': [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32],
     'goat_gather_segmean_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
+    'goat_embed_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],
+    'goat_embed_bwd': [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],
     'goat_probe_tr16': [_vp, _vp],
 }
 

@@ -520,6 +520,93 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const T* __restrict__ d
   }
 }
 
+// ------------------------------------------------------------------------------------ embedding tables
+// out[r] = word[ids[r]] (+ type[tids ? tids[r] : 0]) (+ pos[r % L]) — the three lookups and two adds of
+// BertEmbeddings (P/model/Bert_backbone.py:98-113; position ids are arange(L)) in one pass; tables are the f32 masters.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ word, const int64_t* __restrict__ ids,
+                                                        const float* __restrict__ type_tab, const int64_t* __restrict__ tids,
+                                                        const float* __restrict__ pos_tab, int L, T* __restrict__ out,
+                                                        int rows, int H, int vocab, int* __restrict__ err) {
+  constexpr int EPC = DT<T>::EPC;
+  const int nchunk = H / EPC;
+  const int64_t total = (int64_t)rows * nchunk;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(t / nchunk), c = (int)(t % nchunk);
+    int64_t id = ids[r];
+    if (id < 0 || id >= vocab) {  // torch raises on an out-of-range index; flag it and read row 0
+      if (err) atomicOr(err, 1);
+      id = 0;
+    }
+    float acc[EPC];
+    {
+      const float* w = word + id * H + c * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; e += 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(w + e);
+        acc[e] = v[0]; acc[e + 1] = v[1]; acc[e + 2] = v[2]; acc[e + 3] = v[3];
+      }
+    }
+    if (type_tab) {
+      const float* w = type_tab + (tids ? tids[r] : 0) * H + c * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; e += 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(w + e);
+        acc[e] += v[0]; acc[e + 1] += v[1]; acc[e + 2] += v[2]; acc[e + 3] += v[3];
+      }
+    }
+    if (pos_tab) {
+      const float* w = pos_tab + (int64_t)(r % L) * H + c * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; e += 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(w + e);
+        acc[e] += v[0]; acc[e + 1] += v[1]; acc[e + 2] += v[2]; acc[e + 3] += v[3];
+      }
+    }
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = acc[e];
+    o.store(out + (int64_t)r * H + c * EPC);
+  }
+}
+
+// scatter-add of d(out) into the (pre-zeroed) f32 table gradients.  Rows whose id equals the table's
+// padding index contribute nothing (nn.Embedding(padding_idx=…) semantics, Bert_backbone.py:85-87 — this
+// also zeroes the gradient of position row `pos_pad`, as in the reference).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids,
+                                                        const int64_t* __restrict__ tids, int L, float* __restrict__ dword,
+                                                        float* __restrict__ dtype_tab, float* __restrict__ dpos, int rows,
+                                                        int H, int vocab, int word_pad, int pos_pad) {
+  constexpr int EPC = DT<T>::EPC;
+  const int nchunk = H / EPC;
+  const int64_t total = (int64_t)rows * nchunk;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(t / nchunk), c = (int)(t % nchunk);
+    Chunk<T> g;
+    g.load(dout + (int64_t)r * H + c * EPC);
+    const int64_t id = ids[r];
+    if (dword && id >= 0 && id < vocab && id != word_pad) {
+      float* d = dword + id * H + c * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) atomicAdd(d + e, g.v[e]);
+    }
+    if (dtype_tab && tids) {  // (all-zero type ids are reduced by goat_colsum instead: no atomics on one row)
+      float* d = dtype_tab + tids[r] * H + c * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) atomicAdd(d + e, g.v[e]);
+    }
+    if (dpos) {
+      const int l = r % L;
+      if (l != pos_pad) {
+        float* d = dpos + (int64_t)l * H + c * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) atomicAdd(d + e, g.v[e]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ tr16 probe
 __global__ void probe_tr16_kernel(uint16_t* out) {
   __shared__ __attribute__((aligned(16))) uint16_t sm[64 * 4];
@@ -811,6 +898,50 @@ extern "C" int goat_gather_segmean_bwd(void* stream, int dtype, const void* dout
   else if (dtype == GOAT_F32)
     hipLaunchKernelGGL(gather_bwd_kernel<float>, dim3(blocks), dim3(256), 0, ST(stream), (const float*)dout, idx, start,
                        scale, dsrc32, n_out, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_embed_fwd(void* stream, int dtype, const float* word, const int64_t* ids, const float* type_tab,
+                             const int64_t* type_ids, const float* pos_tab, int L, void* out, int rows, int H, int vocab,
+                             int* err_flag) {
+  if (!word || !ids || !out) return GOAT_E_ARG;
+  if (rows <= 0 || H <= 0 || vocab <= 0 || (pos_tab && L <= 0)) return GOAT_E_SHAPE;
+  const int epc = dtype == GOAT_BF16 ? 8 : 4;
+  if (H % epc) return GOAT_E_SHAPE;
+  int64_t total = (int64_t)rows * (H / epc);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST(stream), word, ids, type_tab, type_ids,
+                       pos_tab, L, (bf16_t*)out, rows, H, vocab, err_flag);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(blocks), dim3(256), 0, ST(stream), word, ids, type_tab, type_ids,
+                       pos_tab, L, (float*)out, rows, H, vocab, err_flag);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_embed_bwd(void* stream, int dtype, const void* dout, const int64_t* ids, const int64_t* type_ids,
+                             int L, float* dword, float* dtype_tab, float* dpos, int rows, int H, int vocab, int word_pad,
+                             int pos_pad) {
+  if (!dout || !ids) return GOAT_E_ARG;
+  if (rows <= 0 || H <= 0 || vocab <= 0 || (dpos && L <= 0)) return GOAT_E_SHAPE;
+  const int epc = dtype == GOAT_BF16 ? 8 : 4;
+  if (H % epc) return GOAT_E_SHAPE;
+  int64_t total = (int64_t)rows * (H / epc);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST(stream), (const bf16_t*)dout, ids, type_ids,
+                       L, dword, dtype_tab, dpos, rows, H, vocab, word_pad, pos_pad);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(blocks), dim3(256), 0, ST(stream), (const float*)dout, ids, type_ids,
+                       L, dword, dtype_tab, dpos, rows, H, vocab, word_pad, pos_pad);
   else
     return GOAT_E_ARG;
   GOAT_LAUNCH_CHECK();

@@ -35,6 +35,11 @@ class _AllGatherCat(torch.autograd.Function):
     def forward(ctx, x):
         W = _world()
         ctx.shape = x.shape
+        if dist.get_backend() == 'gloo' and x.is_cuda:          # gloo has no GPU all-gather: zero-padded all-reduce
+            out = torch.zeros((W,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+            out[_rank()] = x
+            dist.all_reduce(out)
+            return out
         out = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x.contiguous())       # concatenated along dim 0
         return out.view((W,) + tuple(x.shape))

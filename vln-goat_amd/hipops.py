@@ -856,3 +856,79 @@ class _GatherFn(torch.autograd.Function):
 
 def gather_segmean(src, idx, start, scale, n_out):
     return _GatherFn.apply(src, idx, start, scale, int(n_out))
+
+
+# ----------------------------------------------------------------------------- embedding tables
+_EMBED_ERR = {}
+
+
+def _embed_err(dev):
+    t = _EMBED_ERR.get(dev)
+    if t is None:
+        t = _EMBED_ERR[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
+def check_embed_errors():
+    """Raises if any embedding lookup since the last call saw an id outside its table (synchronises)."""
+    for dev, t in _EMBED_ERR.items():
+        if int(t.item()):
+            t.zero_()
+            raise IndexError('embedding id out of range on %s' % (dev,))
+
+
+class _EmbedFn(torch.autograd.Function):
+    """out = word[ids] (+ type[type_ids or 0]) (+ pos[arange(L)]) in one pass; backward scatters into f32 table
+    gradients (P/model/Bert_backbone.py:98-113).  Replaces three F.embedding calls and torch's sort-based
+    embedding backward."""
+
+    @staticmethod
+    def forward(ctx, ids, word, type_tab, type_ids, pos_tab, out_dtype, word_pad, pos_pad):
+        _need_gpu(word)
+        ids = ids if ids.is_contiguous() else ids.contiguous()
+        if ids.dtype != torch.int64:
+            ids = ids.long()
+        if type_ids is not None:
+            type_ids = type_ids.long().contiguous()
+        V, H = word.shape
+        rows = ids.numel()
+        L = ids.shape[-1]
+        if pos_tab is not None and L > pos_tab.shape[0]:
+            raise IndexError('sequence length %d exceeds the position table (%d rows)' % (L, pos_tab.shape[0]))
+        out = torch.empty(tuple(ids.shape) + (H,), dtype=out_dtype, device=word.device)
+        st = _lib.lib().goat_embed_fwd(_stream(), _dt(out), _ptr(word), _ptr(ids), _ptr(type_tab) if type_tab is not None else None,
+                                       _ptr(type_ids) if type_ids is not None else None,
+                                       _ptr(pos_tab) if pos_tab is not None else None, L, _ptr(out), rows, H, V,
+                                       _ptr(_embed_err(word.device)))
+        _lib.check(st, 'goat_embed_fwd')
+        ctx.save_for_backward(ids, type_ids)
+        ctx.meta = (V, H, L, None if type_tab is None else type_tab.shape[0], None if pos_tab is None else pos_tab.shape[0],
+                    -1 if word_pad is None else int(word_pad), -1 if pos_pad is None else int(pos_pad))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, type_ids = ctx.saved_tensors
+        V, H, L, TV, P, word_pad, pos_pad = ctx.meta
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        d2 = dout.view(-1, H)
+        rows = d2.shape[0]
+        need_w, need_t, need_p = ctx.needs_input_grad[1], TV is not None and ctx.needs_input_grad[2], \
+            P is not None and ctx.needs_input_grad[4]
+        dev = dout.device
+        dword = torch.zeros((V, H), dtype=torch.float32, device=dev) if need_w else None
+        dtab = torch.zeros((TV, H), dtype=torch.float32, device=dev) if need_t else None
+        dpos = torch.zeros((P, H), dtype=torch.float32, device=dev) if need_p else None
+        if need_w or need_p or (need_t and type_ids is not None):
+            st = _lib.lib().goat_embed_bwd(_stream(), _dt(d2), _ptr(d2), _ptr(ids), _ptr(type_ids) if type_ids is not None else None,
+                                           L, _ptr(dword) if need_w else None,
+                                           _ptr(dtab) if (need_t and type_ids is not None) else None,
+                                           _ptr(dpos) if need_p else None, rows, H, V, word_pad, pos_pad)
+            _lib.check(st, 'goat_embed_bwd')
+        if need_t and type_ids is None:
+            colsum(d2, out=dtab[0])            # every token has type 0: one column sum instead of `rows` atomics per column
+        return None, dword, dtab, None, dpos, None, None, None
+
+
+def embedding(ids, word, type_tab=None, type_ids=None, pos_tab=None, out_dtype=None, word_pad=None, pos_pad=None):
+    return _EmbedFn.apply(ids, word, type_tab, type_ids, pos_tab, out_dtype or word.dtype, word_pad, pos_pad)

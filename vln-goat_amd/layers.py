@@ -92,12 +92,11 @@ class RobertaEmbeddings(nn.Module):
         self.padding_idx = pad
 
     def forward(self, input_ids, token_type_ids=None):
-        L = input_ids.shape[1]
-        if token_type_ids is None:
-            token_type_ids = torch.zeros_like(input_ids)
-        e = self.word_embeddings(input_ids) + self.token_type_embeddings(token_type_ids) \
-            + self.position_embeddings(self.position_ids[:, :L])      # position ids = arange(L) (:98-100)
-        e = self.LayerNorm(e.to(compute_dtype()))
+        # one gather-sum kernel for the three tables; position ids = arange(L) for every sample (:98-100)
+        e = hipops.embedding(input_ids, self.word_embeddings.weight, self.token_type_embeddings.weight, token_type_ids,
+                             self.position_embeddings.weight, out_dtype=compute_dtype(),
+                             word_pad=self.word_embeddings.padding_idx, pos_pad=self.position_embeddings.padding_idx)
+        e = self.LayerNorm(e)
         return hipops.dropout(e, _p(self.dropout))
 
 

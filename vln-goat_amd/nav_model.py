@@ -316,7 +316,7 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
         B, G = gmap_step_ids.shape
         ge = self.global_encoder
         pos = ge.gmap_pos_embeddings[1](ge.gmap_pos_embeddings[0](gmap_pos_fts.to(dt)))
-        gmap = gmap_img_embeds.to(dt) + ge.gmap_step_embeddings(gmap_step_ids.long()).to(dt) + pos
+        gmap = gmap_img_embeds.to(dt) + hipops.embedding(gmap_step_ids, ge.gmap_step_embeddings.weight, out_dtype=dt) + pos
         bias = None
         if ge.sprel_linear is not None:
             bias = gmap_pair_dists.float() * ge.sprel_linear.weight.view(()) + ge.sprel_linear.bias.view(())
@@ -371,7 +371,7 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
         B = batch['gmap_step_ids'].shape[0]
         ge, le = self.global_encoder, self.local_encoder
         gimg = hipops.gather_segmean(src, gi[0].to(dev), gi[1].to(dev), gi[2].to(dev), B * G).view(B, G, H)
-        gmap = gimg + ge.gmap_step_embeddings(batch['gmap_step_ids']).to(x.dtype) \
+        gmap = gimg + hipops.embedding(batch['gmap_step_ids'], ge.gmap_step_embeddings.weight, out_dtype=x.dtype) \
             + ge.gmap_pos_embeddings[1](ge.gmap_pos_embeddings[0](batch['gmap_pos_fts'].to(x.dtype)))
         gmap = ge.tim_self_encoder(gmap, neg_mask(gen_seq_masks(batch['gmap_lens'], G)))
         W = vi[3]

@@ -158,7 +158,7 @@ class GlobalMapEncoder(nn.Module):
         B, G = gmap_step_ids.shape
         img = hipops.gather_segmean(src_rows, gidx, gstart, gscale, B * G).view(B, G, -1)
         pos = self.gmap_pos_embeddings[1](self.gmap_pos_embeddings[0](gmap_pos_fts.to(img.dtype)))
-        e = img + self.gmap_step_embeddings(gmap_step_ids).to(img.dtype) + pos
+        e = img + hipops.embedding(gmap_step_ids, self.gmap_step_embeddings.weight, out_dtype=img.dtype) + pos
         return e, gen_seq_masks(gmap_lens, G)
 
     def sprels(self, gmap_pair_dists):
