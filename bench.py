@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-autotune', action='store_true', help='use the static GEMM tile/stage heuristics')
     ap.add_argument('--overlap', action='store_true', help='weight-gradient GEMMs on a side stream (measured: no gain)')
+    ap.add_argument('--no-arena', action='store_true', help='per-parameter gradient tensors instead of the flat gradient arena')
     ap.add_argument('--cpu-batch', type=int, default=4)
     ap.add_argument('--layers', default='6,3,2', help='num_l_layers,num_top_layer,num_pano_layers')
     return ap.parse_args()
@@ -83,20 +84,24 @@ def build(args, rank):
     return cfg, model, batch, gb
 
 
-def make_steps(args, model, gb, world):
-    """Returns {task: callable running one fwd+bwd step}, and per-task gradient lists."""
+def make_steps(args, model, gb, world, wrapper):
+    """Returns {task: callable running one fwd+bwd step} (and, without the arena, per-task gradient lists)."""
     from vln_goat_amd import hipops
     hipops.manual_seed(1234)
     hipops.AUTOTUNE = not args.no_autotune     # first sight of a GEMM shape times (tile, LDS stages, split-K) candidates
     hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')
     params = list(model.parameters())
+    arena = [None]
 
     if args.overlap:
         hipops.WgradOverlap.enable()            # weight-gradient GEMMs on a side stream (joined after backward)
 
-    def eager_step(task):
-        for p in params:
-            p.grad = None
+    def step_body(task):
+        if arena[0] is not None:
+            arena[0].zero(task)                 # one fill per contiguous range of the task's gradient slices
+        else:
+            for p in params:
+                p.grad = None
         hipops.RngState.dev.add_(0x9E3779B1)
         loss = model(gb, task, compute_loss=True)
         loss.mean().backward()
@@ -108,23 +113,27 @@ def make_steps(args, model, gb, world):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for task in TASKS:                       # warm-up: builds weight shadows, index caches, kernel attrs
-            for _ in range(2):
-                eager_step(task)
+        for task in TASKS:                       # warm-up: builds weight shadows, index caches, kernel attrs, GEMM tuning
+            step_body(task)
+            wrapper.record_usage(task)           # which parameters this task produces gradients for (static)
+        if not args.no_arena:
+            for p in params:
+                p.grad = None
+            arena[0] = wrapper.build_arena()     # .grad of every used parameter = view into one flat HBM buffer
+        for task in TASKS:
+            step_body(task)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     if not use_graph:
         for task in TASKS:
-            steps[task] = (lambda t=task: eager_step(t))
+            steps[task] = (lambda t=task: step_body(t))
         return steps, None
     for task in TASKS:
         if (world > 1 or os.environ.get('GOAT_BENCH_EAGER_CFP')) and task == 'cfp':
             # the CFP step contains a collective (all-gather of the contrastive negatives): launched eagerly
-            steps[task] = (lambda t=task: eager_step(t))
+            steps[task] = (lambda t=task: step_body(t))
             grads[task] = None
             continue
-        for p in params:
-            p.grad = None
         try:
             if world > 1:
                 torch.cuda.synchronize()
@@ -132,18 +141,15 @@ def make_steps(args, model, gb, world):
             g = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
             with torch.cuda.graph(g, capture_error_mode='thread_local' if world > 1 else 'global'):
-                hipops.RngState.dev.add_(0x9E3779B1)
-                loss = model(gb, task, compute_loss=True)
-                loss.mean().backward()
-                hipops.WgradOverlap.join()
-            grads[task] = [p.grad for p in params]
+                loss = step_body(task)
+            grads[task] = [p.grad for p in params] if arena[0] is None else None
             losses[task] = loss.detach()     # (not the autograd graph: stale AccumulateGrad nodes would pin the capture stream)
             del loss
             steps[task] = g.replay
         except Exception as e:       # never lose the run to a capture problem: fall back to eager launches for this task
             print('[bench] hipGraph capture of %s failed (%s: %s); running it eagerly' % (task, type(e).__name__, e), file=sys.stderr)
             torch.cuda.synchronize()
-            steps[task] = (lambda t=task: eager_step(t))
+            steps[task] = (lambda t=task: step_body(t))
             grads[task] = None
     return steps, grads
 
@@ -250,8 +256,8 @@ def main():
     world, rank, local = setup_dist(args)
     cfg, model, batch, gb = build(args, rank)
     from vln_goat_amd import dp, synth
-    wrapper = dp.GoatDataParallel(model, share_cfp_negatives=True) if world > 1 else None
-    steps, grads = make_steps(args, model, gb, world)
+    wrapper = dp.GoatDataParallel(model, share_cfp_negatives=True)
+    steps, grads = make_steps(args, model, gb, world, wrapper)
     n_traj = synth.n_traj_steps(batch)
 
     def run(i):
@@ -299,6 +305,9 @@ def main():
             out['roofline'] = gemm_roofline(args, model, gb)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, cfg)
+        if os.environ.get('GOAT_SAVE_TUNED'):      # persist the autotuned GEMM table (copied to vln-goat_amd/tuned_gfx950.json)
+            from vln_goat_amd import hipops
+            hipops.save_tuned(os.environ['GOAT_SAVE_TUNED'])
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -37,6 +37,8 @@ extern "C" {
 #define GOAT_EPI_RELU 2       /* same with relu                                   P/model/pretrain_goat.py:32-35 */
 #define GOAT_EPI_MUL_DGELU 3  /* C = (A·Bᵀ) * gelu'(aux)   (backward of the GELU epilogue) */
 #define GOAT_EPI_MUL_DRELU 4  /* C = (A·Bᵀ) * [aux>0] */
+#define GOAT_EPI_ACCUM 5      /* C += A·Bᵀ  (float32 C only, no bias): weight gradients accumulated in place into the
+                                flat gradient arena, i.e. autograd's `param.grad += dW` without the temporary */
 
 /* library/version probe: returns 100*major+minor */
 int goat_version(void);
@@ -93,13 +95,13 @@ int goat_ln_fwd(void* stream, int dtype, const void* x, const void* residual,
                 void* y, void* z_out, float* mean, float* rstd, int M, int H);
 
 /* backward of goat_ln_fwd.  dz = LN-backward(dy) ; d_res<-dz (if non-NULL) ; dx<-dz*mask/(1-p) (if non-NULL).
- * dgamma/dbeta: float32[H], OVERWRITTEN.  ws: float32 scratch of goat_ln_bwd_ws_floats(H) elements
+ * dgamma/dbeta: float32[H], overwritten (accumulate=0) or added to (accumulate=1: gradient-arena slices).  ws: float32 scratch of goat_ln_bwd_ws_floats(H) elements
  * (per-block column partials; a second tiny kernel reduces them — no atomics, deterministic). */
 int goat_ln_bwd_ws_floats(int H);
 int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* z,
                 const float* gamma, const float* mean, const float* rstd,
                 float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev,
-                void* dx, void* d_res, float* dgamma, float* dbeta, float* ws, int M, int H);
+                void* dx, void* d_res, float* dgamma, float* dbeta, float* ws, int M, int H, int accumulate);
 
 /* y = residual + dropout_p(x)  (residual may be NULL, y may alias x).  nn.Dropout + pre-LN residual adds
  * (P/model/transformer.py:177,181; P/model/vilmodel_goat.py:316). n = element count. */

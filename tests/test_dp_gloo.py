@@ -64,6 +64,64 @@ def test_bucketed_grad_allreduce_mean():
         assert all(res[r][3])
 
 
+def _worker_arena(rank, world, port, q):
+    _init(rank, world, port)
+    from vln_goat_amd import dp
+    torch.manual_seed(0)
+    shared = torch.nn.Linear(16, 32)
+    head_a, head_b = torch.nn.Linear(32, 8), torch.nn.Linear(32, 4)
+    unused = torch.nn.Linear(3, 3)
+    holder = torch.nn.ModuleList([shared, head_a, head_b, unused])
+    w = dp.GoatDataParallel(holder)
+    torch.manual_seed(100 + rank)
+    x = torch.randn(5, 16)
+
+    def run(task):
+        h = shared(x)
+        return (head_a(h) if task == 'sap' else head_b(h)).pow(2).mean()
+    for task in ('sap', 'mlm'):                  # discovery: ordinary backward per task
+        for p in holder.parameters():
+            p.grad = None
+        run(task).backward()
+        w.record_usage(task)
+    for p in holder.parameters():
+        p.grad = None
+    arena = w.build_arena(bucket_bytes=256)      # tiny buckets -> several all-reduces per range
+    out = {}
+    for task in ('sap', 'mlm', 'sap'):
+        arena.bind(task)                         # .grad = arena view for this task's parameters, None for the others
+        arena.zero(task)
+        run(task).backward()
+        local = {n: p.grad.clone().numpy() for n, p in holder.named_parameters() if p.grad is not None}
+        w.reduce_gradients(task)
+        got = {n: (p.grad.clone().numpy() if p.grad is not None else None) for n, p in holder.named_parameters()}
+        out[task] = (local, got)
+    q.put((rank, out, [len(arena.ranges(t)) for t in ('sap', 'mlm')], arena.numel))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_arena_allreduce_and_task_binding():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_arena, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    import numpy as np
+    for task, used_head, other_head in (('sap', '1.', '2.'), ('mlm', '2.', '1.')):
+        l0, g0 = res[0][1][task]
+        l1, g1 = res[1][1][task]
+        for n in g0:
+            if n.startswith('3.') or n.startswith(other_head):
+                assert g0[n] is None and g1[n] is None, (task, n)      # unused / other task's parameters: .grad None
+                continue
+            want = (l0[n] + l1[n]) / 2
+            assert np.allclose(g0[n], want, atol=1e-6) and np.allclose(g1[n], want, atol=1e-6), (task, n)
+    assert res[0][2] == res[1][2] and max(res[0][2]) <= 2       # a task's slices form at most 2 contiguous ranges here
+
+
 def _cfp_inputs(n, h=32):
     g = torch.Generator().manual_seed(7)
     return [torch.tanh(torch.randn(n, h, generator=g)) for _ in range(4)]

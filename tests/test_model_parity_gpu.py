@@ -114,3 +114,52 @@ def test_training_mode_runs_with_dropout_and_is_finite():
                     assert torch.isfinite(p.grad).all(), n
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('task', ['mlm', 'sap', 'cfp'])
+def test_gradient_arena_equals_autograd(task, dtype):
+    """dp.GradArena: gradients accumulated by the kernels straight into the flat arena (hipops._sink) must equal
+    the ordinary autograd result — once after zero(), and doubled after a second backward (accumulation)."""
+    import vln_goat_amd
+    from vln_goat_amd import dp, synth
+    cfg, model, batch = build_case('pretrain_small_ragged')
+    vln_goat_amd.set_compute_dtype(dtype)
+    try:
+        model = model.cuda().eval()
+        gb = synth.batch_to(batch, 'cuda')
+        model(gb, task, compute_loss=True).mean().backward()
+        ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        wrapper = dp.GoatDataParallel(model)
+        wrapper.record_usage(task)
+        for p in model.parameters():
+            p.grad = None
+        arena = wrapper.build_arena()
+        assert {n for n, p in model.named_parameters() if p.grad is not None} == set(ref)
+        gmax = max(float(g.norm()) for g in ref.values())
+
+        def check(mult, what):
+            torch.cuda.synchronize()
+            for n, p in model.named_parameters():
+                if n not in ref:
+                    assert p.grad is None, n
+                    continue
+                assert p.grad is arena.views[id(p)], n        # still bound: nothing replaced the sink
+                d = float((p.grad.double() - mult * ref[n].double()).norm())
+                assert d <= 2e-5 * max(mult * float(ref[n].norm()), 1e-3 * gmax), (what, n, d, float(ref[n].norm()))
+        arena.flat.fill_(123.0)                    # stale garbage everywhere
+        for step in range(3):                      # step 0 clears everything; later steps rely on the learned owner sets
+            arena.zero(task)
+            model(gb, task, compute_loss=True).mean().backward()
+            check(1, 'step %d' % step)
+        model(gb, task, compute_loss=True).mean().backward()      # no zero(): gradients accumulate, as .backward() does
+        check(2, 'accumulate')
+        # unbinding one sink restores the ordinary path for that parameter
+        name, par = next((n, p) for n, p in model.named_parameters() if n.endswith('query.weight') and n in ref)
+        arena.zero(task)
+        par.grad = None
+        model(gb, task, compute_loss=True).mean().backward()
+        assert par.grad is not None and par.grad is not arena.views[id(par)]
+        assert float((par.grad.double() - ref[name].double()).norm()) <= 2e-5 * float(ref[name].norm())
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, 'libgoat_hip.so')
 SOURCES = ['gemm.hip', 'gemm2.hip', 'attention.hip', 'rowops.hip']
 
 GOAT_F32, GOAT_BF16 = 0, 1
-EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ACCUM = 0, 1, 2, 3, 4, 5
 
 _lib = None
 
@@ -35,7 +35,7 @@ SIGNATURES = {
     'goat_transpose': [_vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _vp],
     'goat_ln_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
     'goat_ln_bwd_ws_floats': [_i32],
-    'goat_ln_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
+    'goat_ln_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_dropout_add_fwd': [_vp, _i32, _vp, _vp, _vp, _i64, _f32, _u64, _u64, _vp],
     'goat_dropout_bwd': [_vp, _i32, _vp, _vp, _i64, _f32, _u64, _u64, _vp],
     'goat_act_bwd': [_vp, _i32, _vp, _vp, _vp, _i64, _i32, _f32, _u64, _u64, _vp],

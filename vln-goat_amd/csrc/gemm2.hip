@@ -29,6 +29,7 @@ struct G2Args {
   int k_tiles_per_split;
   uint32_t a_bytes, b_bytes;  // buffer sizes for the bounds check
   float* colsum;              // TA only: colsum[m] += sum_k A[k,m]  (bias gradient fused into wgrad)
+  int accum;                  // f32 output, no split: C += A·B (read-modify-write) instead of C = A·B
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -344,7 +345,10 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(G2Args p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + wrow0 + i * 32 + c_row(r, lane);
-          if (row < p.M && col < p.N) C[(int64_t)row * p.ldc + col] = from_f<OutT>(acc[i][j][r]);
+          if (row < p.M && col < p.N) {
+            OutT* dst = C + (int64_t)row * p.ldc + col;
+            *dst = from_f<OutT>(p.accum ? acc[i][j][r] + to_f(*dst) : acc[i][j][r]);
+          }
         }
       }
     return;
@@ -405,7 +409,7 @@ template <bool TA, bool TB, int BM>
 int dispatch2(hipStream_t st, const G2Args& a, int dtype_out, int epi, int split) {
   if (split > 1) return launch2<TA, TB, float, GOAT_EPI_NONE, true, BM>(st, a, split);
   if (dtype_out == GOAT_F32) {
-    if (epi != GOAT_EPI_NONE) return GOAT_E_ARG;
+    if (epi != GOAT_EPI_NONE && epi != GOAT_EPI_ACCUM) return GOAT_E_ARG;
     return launch2<TA, TB, float, GOAT_EPI_NONE, false, BM>(st, a, 1);
   }
   switch (epi) {
@@ -436,7 +440,8 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   if ((!trans_a || !trans_b) && (Kc % BK)) return GOAT_E_SHAPE;
   if (trans_a && !trans_b) return GOAT_E_ARG;
   if ((epilogue == GOAT_EPI_MUL_DGELU || epilogue == GOAT_EPI_MUL_DRELU) && !aux) return GOAT_E_ARG;
-  if (split_k > 1 && (dtype_out != GOAT_F32 || epilogue != GOAT_EPI_NONE || bias)) return GOAT_E_ARG;
+  if (epilogue == GOAT_EPI_ACCUM && (dtype_out != GOAT_F32 || bias)) return GOAT_E_ARG;
+  if (split_k > 1 && (dtype_out != GOAT_F32 || (epilogue != GOAT_EPI_NONE && epilogue != GOAT_EPI_ACCUM) || bias)) return GOAT_E_ARG;
   if (bm != 64 && bm != 128) return GOAT_E_ARG;
   const int64_t a_rows = trans_a ? Kc : M, b_rows = trans_b ? Kc : N;
   const int64_t a_bytes = a_rows * lda * 2, b_bytes = b_rows * ldb * 2;
@@ -450,6 +455,7 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   a.tiles_n = (N + BN - 1) / BN;
   a.a_bytes = (uint32_t)a_bytes; a.b_bytes = (uint32_t)b_bytes;
   a.colsum = colsum;
+  a.accum = epilogue == GOAT_EPI_ACCUM;
   const int kt = (Kc + BK - 1) / BK;
   if (split_k < 1) split_k = 1;
   if (split_k > kt) split_k = kt;

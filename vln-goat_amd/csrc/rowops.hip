@@ -100,47 +100,73 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       const int c = lane + 64 * i;
       g[i][e] = (c < nchunk) ? gamma[c * EPC + e] : 0.f;
     }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    Chunk<T> vdy[MAXC], vz[MAXC];
-    float c1 = 0.f, c2 = 0.f;
+  // two rows per wave in flight: the loads of both rows are issued before the first reduction (this kernel is
+  // latency-bound on its 16-B loads, not on the shuffles)
+  const int rstride = gridDim.x * 4;
+  for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += 2 * rstride) {
+    Chunk<T> vdy[2][MAXC], vz[2][MAXC];
+    float mu[2], rs[2], c1[2] = {0.f, 0.f}, c2[2] = {0.f, 0.f};
+    bool live[2];
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nchunk) {
-        const int64_t base = (int64_t)row * H + c * EPC;
-        vdy[i].load(dy + base);
-        vz[i].load(z + base);
+    for (int u = 0; u < 2; ++u) {
+      const int row = row0 + u * rstride;
+      live[u] = row < M;
+      mu[u] = live[u] ? mean[row] : 0.f;
+      rs[u] = live[u] ? rstd[row] : 0.f;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          const float xh = (vz[i].v[e] - mu) * rs;
-          const float d = vdy[i].v[e];
-          dg[i][e] += d * xh;
-          db[i][e] += d;
-          const float dxh = d * g[i][e];
-          c1 += dxh;
-          c2 += dxh * xh;
-          vz[i].v[e] = xh;
-          vdy[i].v[e] = dxh;
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (live[u] && c < nchunk) {
+          const int64_t base = (int64_t)row * H + c * EPC;
+          vdy[u][i].load(dy + base);
+          vz[u][i].load(z + base);
         }
       }
     }
-    c1 = wave_sum(c1) / H;
-    c2 = wave_sum(c2) / H;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nchunk) {
-        const int64_t base = (int64_t)row * H + c * EPC;
-        Chunk<T> o;
+    for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) o.v[e] = (vdy[i].v[e] - c1 - vz[i].v[e] * c2) * rs;
-        if (dres) o.store(dres + base);
-        if (drop) {
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (live[u] && c < nchunk) {
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) o.v[e] = goat_keep(seed, offset + base + e, thr) ? o.v[e] * ks : 0.f;
+          for (int e = 0; e < EPC; ++e) {
+            const float xh = (vz[u][i].v[e] - mu[u]) * rs[u];
+            const float d = vdy[u][i].v[e];
+            dg[i][e] += d * xh;
+            db[i][e] += d;
+            const float dxh = d * g[i][e];
+            c1[u] += dxh;
+            c2[u] += dxh * xh;
+            vz[u][i].v[e] = xh;
+            vdy[u][i].v[e] = dxh;
+          }
         }
-        if (dx) o.store(dx + base);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      c1[u] = wave_sum(c1[u]) / H;
+      c2[u] = wave_sum(c2[u]) / H;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = row0 + u * rstride;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (live[u] && c < nchunk) {
+          const int64_t base = (int64_t)row * H + c * EPC;
+          Chunk<T> o;
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) o.v[e] = (vdy[u][i].v[e] - c1[u] - vz[u][i].v[e] * c2[u]) * rs[u];
+          if (dres) o.store(dres + base);
+          if (drop) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.v[e] = goat_keep(seed, offset + base + e, thr) ? o.v[e] * ks : 0.f;
+          }
+          if (dx) o.store(dx + base);
+        }
       }
     }
   }
@@ -168,7 +194,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 
 // 256 threads = 16 columns x 16 part-groups; every thread sums nparts/16 partials with 4 independent chains
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int nparts, int H) {
+                                                            float* __restrict__ dbeta, int nparts, int H, int accumulate) {
   __shared__ float red[16][17];
   const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + cx;
@@ -189,7 +215,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][cx];
-    if (i < H) dgamma[i] = t; else dbeta[i - H] = t;
+    float* dst = (i < H) ? dgamma + i : dbeta + (i - H);
+    *dst = accumulate ? *dst + t : t;
   }
 }
 
@@ -578,31 +605,24 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ do
                                                         const int64_t* __restrict__ tids, int L, float* __restrict__ dword,
                                                         float* __restrict__ dtype_tab, float* __restrict__ dpos, int rows,
                                                         int H, int vocab, int word_pad, int pos_pad) {
-  constexpr int EPC = DT<T>::EPC;
-  const int nchunk = H / EPC;
-  const int64_t total = (int64_t)rows * nchunk;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(t / nchunk), c = (int)(t % nchunk);
-    Chunk<T> g;
-    g.load(dout + (int64_t)r * H + c * EPC);
+  // one wave per row; lane l owns columns l, l+64, ...: every atomic instruction of a wave covers 256 contiguous
+  // bytes of one table row (the memory-side atomic units coalesce those; 32-B-strided lanes do not).
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nwave = gridDim.x * (blockDim.x >> 6);
+  for (int r = wave; r < rows; r += nwave) {
     const int64_t id = ids[r];
-    if (dword && id >= 0 && id < vocab && id != word_pad) {
-      float* d = dword + id * H + c * EPC;
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) atomicAdd(d + e, g.v[e]);
-    }
-    if (dtype_tab && tids) {  // (all-zero type ids are reduced by goat_colsum instead: no atomics on one row)
-      float* d = dtype_tab + tids[r] * H + c * EPC;
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) atomicAdd(d + e, g.v[e]);
-    }
-    if (dpos) {
-      const int l = r % L;
-      if (l != pos_pad) {
-        float* d = dpos + (int64_t)l * H + c * EPC;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) atomicAdd(d + e, g.v[e]);
-      }
+    float* dw = (dword && id >= 0 && id < vocab && id != word_pad) ? dword + id * H : nullptr;
+    float* dt = (dtype_tab && tids) ? dtype_tab + tids[r] * H : nullptr;
+    const int l = r % L;
+    float* dp = (dpos && l != pos_pad) ? dpos + (int64_t)l * H : nullptr;
+    if (!dw && !dt && !dp) continue;
+    const T* g = dout + (int64_t)r * H;
+    for (int c = lane; c < H; c += 64) {
+      const float v = to_f(g[c]);
+      if (dw) atomicAdd(dw + c, v);
+      if (dt) atomicAdd(dt + c, v);
+      if (dp) atomicAdd(dp + c, v);
     }
   }
 }
@@ -671,17 +691,17 @@ extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* r
   return 0;
 }
 
-#define GOAT_LN_BWD_PARTS 256
+#define GOAT_LN_BWD_PARTS 512
 
 extern "C" int goat_ln_bwd_ws_floats(int H) { return GOAT_LN_BWD_PARTS * 2 * H; }
 
 extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* z, const float* gamma,
                            const float* mean, const float* rstd, float p, uint64_t seed, uint64_t offset,
                            const uint64_t* rng_dev, void* dx, void* d_res, float* dgamma, float* dbeta, float* ws,
-                           int M, int H) {
+                           int M, int H, int accumulate) {
   if (!dy || !z || !gamma || !mean || !rstd || !dgamma || !dbeta || !ws) return GOAT_E_ARG;
   if (M <= 0) return GOAT_E_SHAPE;
-  int nparts = (M + 3) / 4;
+  int nparts = (M + 7) / 8;   // 4 waves x 2 rows in flight per block
   if (nparts > GOAT_LN_BWD_PARTS) nparts = GOAT_LN_BWD_PARTS;
   const size_t sm = (size_t)8 * H * sizeof(float);
   if (sm > 64 * 1024) return GOAT_E_SHAPE;
@@ -700,7 +720,7 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
   }
   GOAT_LAUNCH_CHECK();
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 15) / 16), dim3(256), 0, ST(stream), ws, dgamma, dbeta, nparts,
-                     H);
+                     H, accumulate);
   GOAT_LAUNCH_CHECK();
   return 0;
 }
@@ -933,9 +953,8 @@ extern "C" int goat_embed_bwd(void* stream, int dtype, const void* dout, const i
   if (rows <= 0 || H <= 0 || vocab <= 0 || (dpos && L <= 0)) return GOAT_E_SHAPE;
   const int epc = dtype == GOAT_BF16 ? 8 : 4;
   if (H % epc) return GOAT_E_SHAPE;
-  int64_t total = (int64_t)rows * (H / epc);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = (rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
   if (dtype == GOAT_BF16)
     hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST(stream), (const bf16_t*)dout, ids, type_ids,
                        L, dword, dtype_tab, dpos, rows, H, vocab, word_pad, pos_pad);

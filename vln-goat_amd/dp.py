@@ -133,6 +133,161 @@ class GradBuckets:
             torch._foreach_copy_(gs, views)                      # unpack reduced values back into the grads
 
 
+class GradArena:
+    """Flat float32 gradient storage in HBM: every parameter's `.grad` is a view into ONE buffer.
+
+    * the HIP autograd Functions (hipops._sink) accumulate weight / bias / LayerNorm / embedding-table gradients
+      straight into these views — no per-parameter zero-fill, no temporaries, no `grad += dW` kernels; anything that
+      still comes back through autograd is added in place by AccumulateGrad, so the result is always `.grad` as
+      torch would have produced it;
+    * one fill per step zeroes the slices a task touches (`zero(task)`), and the gradient all-reduce runs in place
+      on a few large contiguous ranges (`all_reduce_mean(task)`), without pack/unpack copies;
+    * parameters are ordered by the set of tasks that use them (`usage`), so a task's parameters form a handful of
+      contiguous ranges; within a group matrices come first, in registration order, so the query/key/value weights of
+      a block stay adjacent (one fused wgrad GEMM writes all three).
+    Parameters that no task uses are left out (their .grad stays None, as under the reference's
+    DDP(find_unused_parameters=True), P/utils/misc.py:52-65).
+    Call `zero()` instead of `optimizer.zero_grad(set_to_none=True)`; if some code does set a .grad to None, the
+    Functions notice (the sink is no longer bound) and fall back to returning ordinary gradients."""
+
+    ALIGN = 64          # elements (256 B): slices stay 16-B aligned for the GEMM epilogue and vector fills
+
+    def __init__(self, params, usage=None, bucket_bytes=128 << 20):
+        params = [p for p in params if p.requires_grad]
+        seen, uniq = set(), []
+        for p in params:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        if usage is not None:
+            uniq = [p for p in uniq if usage.get(id(p))]
+            key = lambda p: tuple(sorted(usage[id(p)]))
+        else:
+            key = lambda p: ()
+        groups = {}
+        for p in uniq:
+            groups.setdefault(key(p), []).append(p)
+        self.params, self.offsets, self.tasks_of = [], {}, {}
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        off = 0
+        for k in sorted(groups):
+            plist = groups[k]
+            for p in [q for q in plist if q.dim() >= 2] + [q for q in plist if q.dim() < 2]:
+                self.params.append(p)
+                self.offsets[id(p)] = off
+                self.tasks_of[id(p)] = frozenset(k) if usage is not None else None
+                off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.numel = off
+        dev = self.params[0].device if self.params else torch.device('cpu')
+        self.flat = torch.zeros(max(off, 1), dtype=torch.float32, device=dev)
+        self.views = {id(p): self.flat[self.offsets[id(p)]:self.offsets[id(p)] + p.numel()].view_as(p) for p in self.params}
+        self._ranges, self._owned, self._fills, self._cur = {}, {}, {}, None
+        self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+
+    # -- binding ---------------------------------------------------------------------------------
+    def attach(self):
+        for p in self.params:
+            v = self.views[id(p)]
+            p.grad = v
+            p.__dict__['_goat_sink'] = v
+        return self
+
+    def detach(self):
+        for p in self.params:
+            p.grad = None
+            p.__dict__.pop('_goat_sink', None)
+
+    def bind(self, task):
+        """Call before the backward of a step when an optimizer consumes .grad: .grad = arena view (sink re-bound) for the
+        parameters `task` uses, None for the others — what the reference's optimizer sees after zero_grad + a step
+        of that task.  Replayed hipGraphs write into the arena regardless of this host-side binding."""
+        key = task.split('_')[0]
+        for p in self.params:
+            t = self.tasks_of[id(p)]
+            used = t is None or key in t
+            p.grad = self.views[id(p)] if used else None
+            if used:
+                p.__dict__['_goat_sink'] = self.views[id(p)]
+
+    # -- ranges ----------------------------------------------------------------------------------
+    def ranges(self, task=None):
+        key = task.split('_')[0] if task is not None else None
+        r = self._ranges.get(key)
+        if r is None:
+            r = []
+            for p in self.params:
+                t = self.tasks_of[id(p)]
+                if key is not None and t is not None and key not in t:
+                    continue
+                a = self.offsets[id(p)]
+                b = a + (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+                if r and r[-1][1] == a:
+                    r[-1][1] = b
+                else:
+                    r.append([a, b])
+            r = self._ranges[key] = [tuple(x) for x in r]
+        return r
+
+    def zero(self, task=None):
+        """Start of a step.  The HIP Functions clear (or overwrite) a slice themselves the first time they write it in a
+        step — right before the kernel that accumulates into it, so the lines are still in the Infinity Cache — and
+        this call only has to zero the slices that are NOT written that way (gradients that arrive through plain
+        autograd).  Which slices the Functions own is learned per task from the previous step of that task (per-task
+        data flow is static; the first step of a task clears everything)."""
+        from . import hipops
+        key = task.split('_')[0] if task is not None else None
+        if self._cur is not None:                       # close the previous step: remember what its Functions wrote
+            prev, epoch = self._cur
+            self._owned[prev] = {id(p) for p in self.params if p.__dict__.get('_goat_epoch') == epoch}
+        hipops.ARENA_EPOCH[0] += 1
+        self._cur = (key, hipops.ARENA_EPOCH[0])
+        owned = self._owned.get(key)
+        if owned is None:
+            for a, b in self.ranges(task):
+                self.flat[a:b].zero_()
+            return
+        fills = self._fills.get(key)
+        if fills is None or fills[0] != len(owned):
+            r = []
+            for p in self.params:
+                t = self.tasks_of[id(p)]
+                if (key is not None and t is not None and key not in t) or id(p) in owned:
+                    continue
+                a = self.offsets[id(p)]
+                b = a + (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+                if r and r[-1][1] == a:
+                    r[-1][1] = b
+                else:
+                    r.append([a, b])
+            fills = self._fills[key] = (len(owned), r)
+        for a, b in fills[1]:
+            self.flat[a:b].zero_()
+
+    # -- communication ---------------------------------------------------------------------------
+    def all_reduce_mean(self, task=None):
+        """Average the task's gradient ranges over ranks, in place, on the communication stream."""
+        W = _world()
+        if W == 1:
+            return
+        chunks = []
+        for a, b in self.ranges(task):
+            while a < b:
+                e = min(b, a + self.bucket_elems)
+                chunks.append(self.flat[a:e])
+                a = e
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                for c in chunks:
+                    dist.all_reduce(c)
+                    c.div_(W)
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        else:
+            for c in chunks:
+                dist.all_reduce(c)
+                c.div_(W)
+
+
 class GoatDataParallel(torch.nn.Module):
     """model wrapper: forward = model.forward; `reduce_gradients(task)` averages grads over ranks."""
 
@@ -141,6 +296,8 @@ class GoatDataParallel(torch.nn.Module):
         self.module = model
         self.bucket_bytes, self.wire_dtype = bucket_bytes, wire_dtype
         self._buckets = {}
+        self._usage = {}
+        self.arena = None
         if share_cfp_negatives and hasattr(model, 'cfp_gather'):
             model.cfp_gather = CfpGather()
         if _world() > 1:
@@ -151,7 +308,21 @@ class GoatDataParallel(torch.nn.Module):
     def forward(self, *a, **k):
         return self.module(*a, **k)
 
+    def record_usage(self, task):
+        """Call after an ordinary (arena-less) backward of `task`: remembers which parameters it produced gradients for."""
+        key = task.split('_')[0]
+        for p in self.module.parameters():
+            if p.grad is not None:
+                self._usage.setdefault(id(p), set()).add(key)
+
+    def build_arena(self, bucket_bytes=128 << 20):
+        """Flat gradient arena over the parameters seen by record_usage (all parameters if it was never called)."""
+        self.arena = GradArena(self.module.parameters(), self._usage or None, bucket_bytes).attach()
+        return self.arena
+
     def reduce_gradients(self, task, grads=None):
+        if self.arena is not None and grads is None:
+            return self.arena.all_reduce_mean(task)
         key = task.split('_')[0]
         gb = self._buckets.get(key)
         if gb is None:

@@ -9,12 +9,14 @@ Compute dtype: float32 (exact-f32 MFMA, the 1e-3 parity mode) or bfloat16 (bf16 
 accumulate).  Parameters stay float32 masters; bf16 / transposed "shadows" of the weights are cached on
 the Parameter object and refreshed when its version counter moves (i.e. once per optimizer step).
 """
+import json
 import math
+import os
 
 import torch
 
 from . import _lib
-from ._lib import GOAT_BF16, GOAT_F32, EPI_GELU, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_NONE, EPI_RELU
+from ._lib import GOAT_BF16, GOAT_F32, EPI_ACCUM, EPI_GELU, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_NONE, EPI_RELU
 
 _ACT_EPI = {None: EPI_NONE, 'none': EPI_NONE, 'gelu': EPI_GELU, 'relu': EPI_RELU}
 _ACT_DEPI = {'gelu': EPI_MUL_DGELU, 'relu': EPI_MUL_DRELU}
@@ -173,6 +175,28 @@ def colsum(x, out=None):
 AUTOTUNE = False        # bench.py / trainers may switch this on: first sight of a shape times the candidate configs
 _TUNED = {}             # (ta, tb, M, N, Kc, epi, f32out, split_req) -> (bm, nstage, split)
 _FLUSH = [None]
+TUNED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_gfx950.json')
+
+
+def load_tuned(path=None):
+    """Merge a saved table of autotuned GEMM configurations (measured on an MI355X by bench.py) into _TUNED."""
+    path = path or TUNED_FILE
+    if not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        tab = json.load(f)
+    for k, v in tab.items():
+        kk = json.loads(k)
+        _TUNED.setdefault(tuple(bool(x) if i in (0, 1, 6, 8) else int(x) for i, x in enumerate(kk)), tuple(int(x) for x in v))
+    return len(tab)
+
+
+def save_tuned(path):
+    tab = {json.dumps([int(x) for x in k]): list(v) for k, v in sorted(_TUNED.items())}
+    with open(path, 'w') as f:
+        json.dump(tab, f, indent=0, sort_keys=True)
+    return len(tab)
+
 
 
 def _heuristic_cfg(ta, tb, M, N, Kc, split_k):
@@ -238,12 +262,16 @@ def _tune_gemm(key, a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_opts, col
     return best[1:]
 
 
-def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split_k=1, colsum_out=None, split_opts=None):
+def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split_k=1, colsum_out=None, split_opts=None,
+         accumulate=False, zero_first=False):
     """out[M,N] = epi(op(a) @ op(b)^T + bias); ta: a is [Kc,M] (else [M,Kc]); tb: b is [Kc,N] (else [N,Kc]).
     bf16 -> pipelined LDS-DMA kernel (goat_gemm_bf16) whenever its layout rules hold; otherwise (f32 parity
     path, odd contraction lengths) explicit transposes + goat_gemm_nt.
     split_opts: candidate split-K factors the autotuner may choose from (the caller must have zero-filled
-    `out` if any of them is > 1); returns `out`."""
+    `out` if any of them is > 1); returns `out`.
+    accumulate: out (float32) += product — split-K launches add atomically anyway, unsplit ones use the
+    read-modify-write epilogue GOAT_EPI_ACCUM (gradient-arena sinks).
+    zero_first: `out` holds stale data: clear it here if (and only if) the launch ends up split (atomics)."""
     Kc = a.shape[0] if ta else a.shape[1]
     M = a.shape[1] if ta else a.shape[0]
     N = b.shape[1] if tb else b.shape[0]
@@ -252,6 +280,12 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
             and ((ta and tb) or Kc % 64 == 0) and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
             and a.stride(1) == 1 and b.stride(1) == 1)
     if not fast:
+        if accumulate:       # f32 parity path / odd shapes: product into a temporary, then one add
+            tmp = torch.zeros_like(out) if split_k > 1 else torch.empty_like(out)
+            gemm(a, b, tmp, ta, tb, bias, epi, aux, split_k, colsum_out, None, False)
+            return out.add_(tmp)
+        if zero_first and split_k > 1:
+            out.zero_()
         if colsum_out is not None:
             colsum(a, colsum_out)
         if ta:
@@ -276,6 +310,11 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
         else:
             cfg = _heuristic_cfg(ta, tb, M, N, Kc, split_k) + (split_k,)
     bm, nstage, split_k = cfg
+    if zero_first and split_k > 1:
+        out.zero_()
+    if accumulate and split_k == 1:
+        assert epi == EPI_NONE and out.dtype == torch.float32 and bias is None
+        epi = EPI_ACCUM
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -316,7 +355,56 @@ class WgradOverlap:
             torch.cuda.current_stream().wait_stream(cls.stream)
 
 
-def _wgrad_impl(dy, x, want_bias):
+def _sink(param):
+    """Gradient-arena slice bound to `param` (dp.GradArena.attach), or None.  When it is bound — i.e. still the
+    object behind param.grad — backward passes accumulate the parameter's gradient straight into it and return
+    None to autograd (no temporary, no zero-fill, no `grad += dW` kernel).  Setting param.grad = None (or to any
+    other tensor) silently restores the ordinary autograd path."""
+    if param is None:
+        return None
+    s = param.__dict__.get('_goat_sink')
+    return s if (s is not None and param.grad is s) else None
+
+
+def _sink_cat(params):
+    """One [sum(rows), ...] view over the arena slices of several parameters if they are adjacent in the arena
+    (query/key/value weights of a block), else None."""
+    sinks = [_sink(p) for p in params]
+    if any(t is None for t in sinks):
+        return None
+    for a, b in zip(sinks, sinks[1:]):
+        if a.data_ptr() + a.numel() * a.element_size() != b.data_ptr() or a.shape[1:] != b.shape[1:]:
+            return None
+    s0 = sinks[0]
+    return torch.as_strided(s0, (sum(t.shape[0] for t in sinks),) + tuple(s0.shape[1:]), s0.stride())
+
+
+ARENA_EPOCH = [0]       # bumped by dp.GradArena.zero(): a sink's first use in a step overwrites / clears its slice
+
+
+def _first_touch(*params):
+    """True if none of `params` has been written through its sink yet in this step (marks them written).
+    Mixed states (some written, some not) cannot be served by one kernel launch: the unwritten slices are cleared
+    here and the call is treated as an accumulation."""
+    cur = ARENA_EPOCH[0]
+    seen = [p.__dict__.get('_goat_epoch') == cur for p in params]
+    for p, was in zip(params, seen):
+        p.__dict__['_goat_epoch'] = cur
+        if not was and any(seen):
+            p.__dict__['_goat_sink'].zero_()
+    return not any(seen)
+
+
+def _prep_fallback(*params):
+    """A Function is about to return ordinary gradients for `params` (autograd will add them into .grad): if a
+    .grad is an arena slice nobody has written yet in this step it still holds the previous step's values."""
+    for p in params:
+        t = _sink(p)
+        if t is not None and _first_touch(p):
+            t.zero_()
+
+
+def _wgrad_impl(dy, x, want_bias, w_sink=None, b_sink=None, first=False):
     M, N = dy.shape
     K = x.shape[1]
     # default (bm 64, split) from scripts/wgrad_sweep.py; the autotuner may pick another split (output is zero-filled)
@@ -328,6 +416,17 @@ def _wgrad_impl(dy, x, want_bias):
         split = max(1, min(int(round(500.0 / tiles)), kt // 24))
     nb = N if want_bias else 0
     tunable = AUTOTUNE and dy.dtype == torch.bfloat16
+    if w_sink is not None:
+        # gradient-arena slice.  First use in this step: clear it right here (the fill leaves the lines in the
+        # Infinity Cache for the split-K atomics) or, unsplit, simply overwrite it; later uses accumulate.
+        db = b_sink
+        if want_bias and db is None:
+            db = torch.zeros(N, dtype=torch.float32, device=dy.device)
+        elif want_bias and first:
+            db.zero_()
+        gemm(dy, x, w_sink, ta=True, tb=True, split_k=split, colsum_out=db if want_bias else None,
+             split_opts=(1, 2, 3, 4, 6, 8) if tunable else None, accumulate=not first, zero_first=first)
+        return None, (db if (want_bias and b_sink is None) else None)
     if split > 1 or tunable:
         buf = torch.zeros(N * K + nb, dtype=torch.float32, device=dy.device)
         dw = buf[:N * K].view(N, K)
@@ -341,16 +440,17 @@ def _wgrad_impl(dy, x, want_bias):
     return dw, db
 
 
-def wgrad(dy, x, want_bias):
+def wgrad(dy, x, want_bias, w_sink=None, b_sink=None, first=False):
     """dW[N,K] (f32) = dy[M,N]^T @ x[M,K] ; db[N] (f32) = colsum(dy), fused into the same kernel.
-    One zero-fill covers both outputs (split-K partial tiles and the bias sums are accumulated atomically)."""
+    One zero-fill covers both outputs (split-K partial tiles and the bias sums are accumulated atomically).
+    With sinks (gradient-arena slices) the results are accumulated in place and (None, None) is returned."""
     side = WgradOverlap.stream
     if side is None:
-        return _wgrad_impl(dy, x, want_bias)
+        return _wgrad_impl(dy, x, want_bias, w_sink, b_sink, first)
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)                       # dy / x are ready on the main stream
     with torch.cuda.stream(side):
-        out = _wgrad_impl(dy, x, want_bias)
+        out = _wgrad_impl(dy, x, want_bias, w_sink, b_sink, first)
     dy.record_stream(side)                      # keep the operands alive until the side-stream GEMM has read them
     x.record_stream(side)
     return out
@@ -384,7 +484,7 @@ class _LinearFn(torch.autograd.Function):
             aux = torch.empty_like(out)
         gemm(x2, w, out, bias=bias.detach() if bias is not None else None, epi=epi, aux=aux)
         ctx.save_for_backward(x2, aux)
-        ctx.weight, ctx.has_bias, ctx.act, ctx.pad, ctx.xshape = weight, bias is not None, act, pad, x.shape
+        ctx.weight, ctx.bias, ctx.has_bias, ctx.act, ctx.pad, ctx.xshape = weight, bias, bias is not None, act, pad, x.shape
         return out.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -407,7 +507,11 @@ class _LinearFn(torch.autograd.Function):
                 dx = dx[:, :x2.shape[1] - ctx.pad]
             dx = dx.reshape(ctx.xshape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = wgrad(dy2, x2, ctx.has_bias)
+            w_sink = None if ctx.pad else _sink(weight)
+            b_sink = _sink(ctx.bias) if w_sink is not None else None
+            first = w_sink is not None and _first_touch(*([weight] + ([ctx.bias] if b_sink is not None else [])))
+            _prep_fallback(*(([] if w_sink is not None else [weight]) + ([] if b_sink is not None else [ctx.bias])))
+            dw, db = wgrad(dy2, x2, ctx.has_bias, w_sink, b_sink, first)
             if ctx.pad:
                 dw = dw[:, :x2.shape[1] - ctx.pad].contiguous()
         return dx, dw, db, None, None
@@ -455,6 +559,7 @@ class _FfnFn(torch.autograd.Function):
         gemm(h, W2, y, bias=b2.detach())
         ctx.save_for_backward(x2, u, h)
         ctx.w1, ctx.w2, ctx.act, ctx.xshape, ctx.p, ctx.rng = w1, w2, act, x.shape, p, rng
+        ctx.b1, ctx.b2 = b1, b2
         return y.view(*x.shape[:-1], W2.shape[0])
 
     @staticmethod
@@ -470,11 +575,19 @@ class _FfnFn(torch.autograd.Function):
             du = act_bwd(du, u, ctx.act, ctx.p, ctx.rng)
         else:
             gemm(dy2, W2, du, tb=True, epi=_ACT_DEPI[ctx.act], aux=u)
-        dw2, db2 = wgrad(dy2, h, True)
+        s2 = _sink(ctx.w2)
+        sb2 = _sink(ctx.b2) if s2 is not None else None
+        f2 = s2 is not None and _first_touch(*([ctx.w2] + ([ctx.b2] if sb2 is not None else [])))
+        _prep_fallback(*(([] if s2 is not None else [ctx.w2]) + ([] if sb2 is not None else [ctx.b2])))
+        dw2, db2 = wgrad(dy2, h, True, s2, sb2, f2)
         W1 = _shadow(ctx.w1, x2.dtype)  # [F, H]
         dx = torch.empty_like(x2)
         gemm(du, W1, dx, tb=True)
-        dw1, db1 = wgrad(du, x2, True)
+        s1 = _sink(ctx.w1)
+        sb1 = _sink(ctx.b1) if s1 is not None else None
+        f1 = s1 is not None and _first_touch(*([ctx.w1] + ([ctx.b1] if sb1 is not None else [])))
+        _prep_fallback(*(([] if s1 is not None else [ctx.w1]) + ([] if sb1 is not None else [ctx.b1])))
+        dw1, db1 = wgrad(du, x2, True, s1, sb1, f1)
         return dx.view(ctx.xshape), dw1, db1, dw2, db2, None, None
 
 
@@ -524,7 +637,7 @@ class _DecoderCeFn(torch.autograd.Function):
         st = _lib.lib().goat_ce_fwd(_stream(), _ptr(logits), Nl, M, N, _ptr(tg), _ptr(loss), _ptr(lse))
         _lib.check(st, 'goat_ce_fwd')
         ctx.save_for_backward(h2, logits, lse, tg)
-        ctx.weight, ctx.N, ctx.hshape = weight, N, h.shape
+        ctx.weight, ctx.bias, ctx.N, ctx.hshape = weight, bias, N, h.shape
         return loss
 
     @staticmethod
@@ -545,6 +658,15 @@ class _DecoderCeFn(torch.autograd.Function):
         else:
             dh = torch.empty_like(h2)
             gemm(dl, _shadow_rows_padded(weight, h2.dtype, Nl), dh, tb=True)
+        w_sink = _sink(weight)
+        if w_sink is not None:      # the tied word-embedding table: accumulate next to the embedding scatter-add
+            b_sink = _sink(ctx.bias)
+            first = _first_touch(*([weight] + ([ctx.bias] if b_sink is not None else [])))
+            if b_sink is None:
+                _prep_fallback(ctx.bias)
+            dw, db = wgrad(dl[:, :N], h2, True, w_sink, b_sink, first)
+            return dh.view(ctx.hshape), None, db, None
+        _prep_fallback(weight, ctx.bias)
         dw, db = wgrad(dl, h2, True)
         return dh.view(ctx.hshape), dw[:N], db[:N], None
 
@@ -571,7 +693,7 @@ class _MultiLinearFn(torch.autograd.Function):
         out = torch.empty((x2.shape[0], W.shape[0]), dtype=x2.dtype, device=x2.device)
         gemm(x2, W, out, bias=b)
         ctx.save_for_backward(x2)
-        ctx.ws, ctx.xshape = ws, x.shape
+        ctx.ws, ctx.bs, ctx.xshape = ws, bs, x.shape
         return out.view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
@@ -587,9 +709,15 @@ class _MultiLinearFn(torch.autograd.Function):
             dx = torch.empty_like(x2)
             gemm(dy2, W, dx, tb=True)
             dx = dx.view(ctx.xshape)
-        dw, db = wgrad(dy2, x2, True)
+        w_sink = _sink_cat(ws)
+        b_sink = _sink_cat(ctx.bs) if w_sink is not None else None
+        first = w_sink is not None and _first_touch(*(list(ws) + (list(ctx.bs) if b_sink is not None else [])))
+        _prep_fallback(*(([] if w_sink is not None else list(ws)) + ([] if b_sink is not None else list(ctx.bs))))
+        dw, db = wgrad(dy2, x2, True, w_sink, b_sink, first)
         sizes = [w.shape[0] for w in ws]
-        return (dx,) + tuple(torch.split(dw, sizes, 0)) + tuple(torch.split(db, sizes, 0))
+        none = (None,) * len(ws)
+        return (dx,) + (tuple(torch.split(dw, sizes, 0)) if dw is not None else none) \
+            + (tuple(torch.split(db, sizes, 0)) if db is not None else none)
 
 
 def multi_linear(x, weights, biases):
@@ -626,6 +754,7 @@ class _LnFn(torch.autograd.Function):
         ctx.save_for_backward(z if z is not None else x2, gamma, mean, rstd)
         ctx.rng = (p, seed, off, dev)
         ctx.has_res = residual is not None
+        ctx.gb = (gamma, beta)
         ctx.shape = x.shape
         return y.view(x.shape)
 
@@ -641,13 +770,19 @@ class _LnFn(torch.autograd.Function):
         L = _lib.lib()
         dx = torch.empty_like(z)
         dres = torch.empty_like(z) if (ctx.has_res and p > 0) else None
-        dg = torch.empty(H, dtype=torch.float32, device=z.device)
-        db = torch.empty(H, dtype=torch.float32, device=z.device)
+        sg, sb = _sink(ctx.gb[0]), _sink(ctx.gb[1])
+        sunk = sg is not None and sb is not None
+        if not sunk:
+            _prep_fallback(*ctx.gb)
+        dg = sg if sunk else torch.empty(H, dtype=torch.float32, device=z.device)
+        db = sb if sunk else torch.empty(H, dtype=torch.float32, device=z.device)
         ws = torch.empty(L.goat_ln_bwd_ws_floats(H), dtype=torch.float32, device=z.device)
         st = L.goat_ln_bwd(_stream(), _dt(z), _ptr(dy2), _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd),
                            p, seed, off, dev, _ptr(dx), _ptr(dres) if dres is not None else None,
-                           _ptr(dg), _ptr(db), _ptr(ws), M, H)
+                           _ptr(dg), _ptr(db), _ptr(ws), M, H, int(sunk and not _first_touch(*ctx.gb)))
         _lib.check(st, 'goat_ln_bwd')
+        if sunk:
+            dg = db = None
         dxv = dx.view(ctx.shape)
         if ctx.has_res:
             dr = dres.view(ctx.shape) if dres is not None else dxv
@@ -901,6 +1036,7 @@ class _EmbedFn(torch.autograd.Function):
                                        _ptr(pos_tab) if pos_tab is not None else None, L, _ptr(out), rows, H, V,
                                        _ptr(_embed_err(word.device)))
         _lib.check(st, 'goat_embed_fwd')
+        ctx.tabs = (word, type_tab, pos_tab)
         ctx.save_for_backward(ids, type_ids)
         ctx.meta = (V, H, L, None if type_tab is None else type_tab.shape[0], None if pos_tab is None else pos_tab.shape[0],
                     -1 if word_pad is None else int(word_pad), -1 if pos_pad is None else int(pos_pad))
@@ -916,19 +1052,38 @@ class _EmbedFn(torch.autograd.Function):
         need_w, need_t, need_p = ctx.needs_input_grad[1], TV is not None and ctx.needs_input_grad[2], \
             P is not None and ctx.needs_input_grad[4]
         dev = dout.device
-        dword = torch.zeros((V, H), dtype=torch.float32, device=dev) if need_w else None
-        dtab = torch.zeros((TV, H), dtype=torch.float32, device=dev) if need_t else None
-        dpos = torch.zeros((P, H), dtype=torch.float32, device=dev) if need_p else None
-        if need_w or need_p or (need_t and type_ids is not None):
+        sw, st_, sp = (_sink(t) for t in ctx.tabs)
+        for t, sk, need in zip(ctx.tabs, (sw, st_, sp), (need_w, need_t, need_p)):
+            if sk is not None and need and _first_touch(t):
+                sk.zero_()              # first writer of this slice in the step: clear it (scatter-adds follow)
+        dword = (sw if sw is not None else torch.zeros((V, H), dtype=torch.float32, device=dev)) if need_w else None
+        dtab = (st_ if st_ is not None else torch.zeros((TV, H), dtype=torch.float32, device=dev)) if need_t else None
+        dpos = (sp if sp is not None else torch.zeros((P, H), dtype=torch.float32, device=dev)) if need_p else None
+        if need_w or (need_t and type_ids is not None):
             st = _lib.lib().goat_embed_bwd(_stream(), _dt(d2), _ptr(d2), _ptr(ids), _ptr(type_ids) if type_ids is not None else None,
                                            L, _ptr(dword) if need_w else None,
                                            _ptr(dtab) if (need_t and type_ids is not None) else None,
-                                           _ptr(dpos) if need_p else None, rows, H, V, word_pad, pos_pad)
+                                           None, rows, H, V, word_pad, pos_pad)
             _lib.check(st, 'goat_embed_bwd')
+        if need_p:
+            # position ids are arange(L) for every sample: d pos[:L] = column sums of dout viewed as [rows/L, L*H]
+            # (the padding row, if any, is skipped: nn.Embedding(padding_idx) gives it no gradient)
+            flat, of = d2.view(rows // L, L * H), dpos.view(-1)
+            if 0 <= pos_pad < L:
+                if pos_pad > 0:
+                    colsum(flat[:, :pos_pad * H], out=of[:pos_pad * H])
+                if pos_pad + 1 < L:
+                    colsum(flat[:, (pos_pad + 1) * H:], out=of[(pos_pad + 1) * H:L * H])
+            else:
+                colsum(flat, out=of[:L * H])
         if need_t and type_ids is None:
             colsum(d2, out=dtab[0])            # every token has type 0: one column sum instead of `rows` atomics per column
-        return None, dword, dtab, None, dpos, None, None, None
+        return (None, None if dword is sw else dword, None if dtab is st_ else dtab, None, None if dpos is sp else dpos,
+                None, None, None)
 
 
 def embedding(ids, word, type_tab=None, type_ids=None, pos_tab=None, out_dtype=None, word_pad=None, pos_pad=None):
     return _EmbedFn.apply(ids, word, type_tab, type_ids, pos_tab, out_dtype or word.dtype, word_pad, pos_pad)
+
+
+load_tuned()
