@@ -187,18 +187,39 @@ def pano_encoder(ctx, sd, pre, x, key_pad):
 
 
 def image_embeddings(ctx, sd, pre, batch):
-    """CausalImageEmbeddings.forward, R2R branch, no BACL (P/model/vilmodel_goat.py:289-364)."""
+    """CausalImageEmbeddings.forward, no BACL (P/model/vilmodel_goat.py:289-364): R2R branch, or the REVERIE/SOON
+    branch that appends object tokens to every panorama (:322-349)."""
+    reverie = getattr(ctx.cfg, 'name', 'R2R') in ('REVERIE', 'SOON')
     x = _ln(sd, pre + '.img_layer_norm', _lin(sd, pre + '.img_linear', batch['traj_view_img_fts']), 1e-12)
-    x = x + _ln(sd, pre + '.loc_layer_norm', _lin(sd, pre + '.loc_linear', batch['traj_loc_fts']), 1e-12)
-    img_masks = gen_seq_masks(batch['traj_vp_view_lens'])
-    x = ctx.drop(x, ctx.cfg.hidden_dropout_prob)
-    x = pano_encoder(ctx, sd, pre + '.img_self_encoder', x, img_masks.logical_not())
+    lens = batch['traj_vp_view_lens']
+    if not reverie:
+        x = x + _ln(sd, pre + '.loc_layer_norm', _lin(sd, pre + '.loc_linear', batch['traj_loc_fts']), 1e-12)
+        img_masks = gen_seq_masks(lens)
+        x = ctx.drop(x, ctx.cfg.hidden_dropout_prob)
+        x = pano_encoder(ctx, sd, pre + '.img_self_encoder', x, img_masks.logical_not())
+    if batch['traj_obj_img_fts'] is not None:
+        # positional call at :567-572 binds traj_obj_img_fts / traj_vp_obj_lens to the reverie_obj_* arguments
+        o = _lin(sd, pre + '.obj_reverie_linear', batch['traj_obj_img_fts'])
+        if ctx.cfg.use_obj_name:
+            o = o + sd[pre + '.obj_name_linear.weight'][batch['traj_reverie_obj_names']]
+        o = _ln(sd, pre + '.obj_reverie_layer_norm', o, 1e-12)
+        obj_lens = batch['traj_vp_obj_lens']
+        rows = []
+        for xv, xo, vl, ol in zip(x, o, lens, obj_lens):
+            rows.append(torch.cat([xv[:vl], xo[:ol]], 0) if ol > 0 else xv[:vl])
+        x = pad_tensors_wgrad(rows)
+        lens = lens + obj_lens
+        x = x + sd[pre + '.nav_type_embedding.weight'][batch['traj_nav_types']] \
+            + _ln(sd, pre + '.loc_layer_norm', _lin(sd, pre + '.loc_linear', batch['traj_loc_fts']), 1e-12)
+        x = _ln(sd, pre + '.layer_norm', x, 1e-12)
+        x = ctx.drop(x, ctx.cfg.hidden_dropout_prob)
+        x = pano_encoder(ctx, sd, pre + '.pano_encoder', x, gen_seq_masks(lens).logical_not())
     step_lens = batch['traj_step_lens']
     split_embeds = torch.split(x, step_lens, 0)
-    split_lens = torch.split(batch['traj_vp_view_lens'], step_lens, 0)
+    split_lens = torch.split(lens, step_lens, 0)
     fused = None
     if ctx.cfg.adaptive_pano_fusion:
-        w = torch.softmax(torch.tanh(_lin(sd, pre + '.adaptive_pano_attn', x)), dim=1)  # all V slots, no mask
+        w = torch.softmax(torch.tanh(_lin(sd, pre + '.adaptive_pano_attn', x)), dim=1)  # all slots, no mask
         fused = torch.split(torch.sum(x * w, dim=1), step_lens, 0)
     return split_embeds, split_lens, fused
 
@@ -401,14 +422,67 @@ def forward_cfp(ctx, sd, batch, compute_loss=True):
     return go, vo, fo, to
 
 
+def _last_step(batch, key):
+    return [x[-1] for x in torch.split(batch[key], batch['traj_step_lens'], 0)]
+
+
+def forward_og(ctx, sd, batch, compute_loss=True):
+    # GlocalTextPathCMTPreTraining.forward_og (P/model/pretrain_goat.py:356-391)
+    _, vp, _ = bert_forward(ctx, sd, batch, return_gmap=False)
+    view_lens, obj_lens = _last_step(batch, 'traj_vp_view_lens'), _last_step(batch, 'traj_vp_obj_lens')
+    obj = pad_tensors_wgrad([x[1 + vl:1 + vl + ol] for x, vl, ol in zip(vp, view_lens, obj_lens)])
+    obj_masks = gen_seq_masks(torch.stack(obj_lens, 0))
+    logits = cls_prediction(sd, 'og_head', obj).squeeze(2).masked_fill(obj_masks.logical_not(), -float('inf'))
+    if compute_loss:
+        return F.cross_entropy(logits, batch['obj_labels'], reduction='none')
+    return logits
+
+
+def region_classification(sd, pre, x):
+    # RegionClassification (P/model/pretrain_goat.py:14-25)
+    h = _ln(sd, pre + '.net.2', F.relu(_lin(sd, pre + '.net.0', x)), 1e-12)
+    return _lin(sd, pre + '.net.3', h)
+
+
+def _masked_hidden(hidden, mask):
+    # _compute_masked_hidden (P/model/pretrain_goat.py:543-547)
+    return hidden[mask.unsqueeze(-1).expand_as(hidden)].contiguous().view(-1, hidden.size(-1))
+
+
+def forward_mrc(ctx, sd, batch, compute_loss=True):
+    # GlocalTextPathCMTPreTraining.forward_mrc (P/model/pretrain_goat.py:226-284)
+    _, vp, _ = bert_forward(ctx, sd, batch, return_gmap=False)
+    view_lens = _last_step(batch, 'traj_vp_view_lens')
+    view = pad_tensors_wgrad([x[1:vl + 1] for x, vl in zip(vp, view_lens)])
+    v_pred = region_classification(sd, 'image_classifier', _masked_hidden(view, batch['vp_view_mrc_masks']))
+    v_tgt = _masked_hidden(batch['vp_view_probs'], batch['vp_view_mrc_masks'])
+    o_pred = o_tgt = None
+    if batch['traj_obj_img_fts'] is not None:
+        obj_lens = _last_step(batch, 'traj_vp_obj_lens')
+        obj = pad_tensors_wgrad([x[vl + 1:vl + ol + 1] for x, vl, ol in zip(vp, view_lens, obj_lens)])
+        head = 'obj_classifier' if ('obj_classifier.net.0.weight' in sd) else 'image_classifier'
+        o_pred = region_classification(sd, head, _masked_hidden(obj, batch['vp_obj_mrc_masks']))
+        o_tgt = _masked_hidden(batch['vp_obj_probs'], batch['vp_obj_mrc_masks'])
+    if not compute_loss:
+        return v_pred, v_tgt, o_pred, o_tgt
+    loss = F.kl_div(F.log_softmax(v_pred, dim=-1), v_tgt, reduction='none').sum(dim=1)
+    if o_pred is not None:
+        loss = torch.cat([loss, F.kl_div(F.log_softmax(o_pred, dim=-1), o_tgt, reduction='none').sum(dim=1)], 0)
+    return loss
+
+
 def forward(cfg, sd, batch, task, compute_loss=True, training=False):
     """GlocalTextPathCMTPreTraining.forward dispatch (P/model/pretrain_goat.py:91-186)."""
     ctx = Ctx(cfg, training)
     batch = defaultdict(lambda: None, batch)
     if task.startswith('mlm'):
         return forward_mlm(ctx, sd, batch, compute_loss)
+    if task.startswith('mrc'):
+        return forward_mrc(ctx, sd, batch, compute_loss)
     if task.startswith('sap'):
         return forward_sap(ctx, sd, batch, compute_loss)
+    if task.startswith('og'):
+        return forward_og(ctx, sd, batch, compute_loss)
     if task.startswith('cfp'):
         return forward_cfp(ctx, sd, batch, compute_loss)
     raise ValueError('invalid task')

@@ -20,7 +20,11 @@ import ref_shim  # noqa: E402
 CASES = {
     'nav_type2_door': dict(do_back_txt_type='type_2', do_back_img_type='type_1', do_add_method='door'),
     'nav_type1_add': dict(do_back_txt_type='type_1', do_back_img_type='type_2', do_add_method='add'),
+    # REVERIE: object tokens in every panorama + object-grounding head
+    'nav_reverie_objects': dict(do_back_txt_type='type_2', do_back_img_type='type_1', do_add_method='door', dataset='reverie',
+                                obj_feat_size=768),
 }
+EPISODE = {'nav_reverie_objects': dict(objects=5, seed=9)}
 WEIGHT_SEED = 11
 VOCAB = 1200
 
@@ -34,10 +38,12 @@ def fingerprint(g):
     return np.concatenate([[float(flat.double().norm())], first.numpy()]).astype(np.float32)
 
 
-def main():
+def main(only=None):
     vg = ref_shim.import_nav()
     from vln_goat_amd import nav_model, synth
     for name, over in CASES.items():
+        if only and name not in only:
+            continue
         args = SimpleNamespace(num_l_layers=2, num_x_layers=2, num_pano_layers=2, dropout=0.5, feat_dropout=0.4,
                                do_back_img=True, do_back_txt=True, do_front_img=True, do_front_his=True, do_front_txt=True,
                                vocab_size=VOCAB, mode='train', **over)
@@ -52,7 +58,7 @@ def main():
             assert tuple(v.shape) == tuple(sd[k].shape), k
         ref.load_state_dict(sd)
         ref.eval()
-        ep = synth.make_nav_episode(B=2, L=44, n_steps=3, seed=5, vocab_size=VOCAB)
+        ep = synth.make_nav_episode(**{**dict(B=2, L=44, n_steps=3, seed=5, vocab_size=VOCAB), **EPISODE.get(name, {})})
         for k in ('front_txt_feats', 'front_vp_feats', 'front_gmap_feats', 'instr_z_direction_features', 'instr_z_landmark_features',
                   'z_img_features'):
             ep[k].requires_grad_(True)
@@ -70,10 +76,12 @@ def main():
             store['s%d_gmap_embeds' % t] = s['gmap_embeds'][:, :, :16].detach().numpy()
             store['s%d_vp_embeds' % t] = s['vp_embeds'][:, :, :16].detach().numpy()
             store['s%d_pano_fused' % t] = s['pano_fused'][:, :32].detach().numpy()
+            if s.get('obj_logits') is not None:
+                store['s%d_obj_logits' % t] = s['obj_logits'].detach().numpy()
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **store)
         print('wrote', path, os.path.getsize(path) // 1024, 'KiB', 'loss', float(loss))
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1:] or None)

@@ -24,18 +24,10 @@ sys.path.insert(0, ROOT)
 
 import ref_shim  # noqa: E402
 
-CASES = {
-    # name: (config overrides, batch kwargs)
-    'pretrain_small_fixed': (dict(num_l_layers=2, num_top_layer=2, num_pano_layers=2, vocab_size=1000),
-                             dict(B=4, T=5, L=80, seed=1, vocab_size=1000, style='survey')),
-    'pretrain_small_ragged': (dict(num_l_layers=2, num_top_layer=2, num_pano_layers=2, vocab_size=1000),
-                              dict(B=4, T=[1, 3, 5, 2], L=[80, 33, 20, 57], seed=2, vocab_size=1000, style='rich',
-                                   ragged_views=True)),
-    'pretrain_config1': (dict(num_l_layers=2, num_top_layer=2, num_pano_layers=2),
-                         dict(B=4, T=5, L=80, seed=3, style='survey')),
-}
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from helpers import CASES, case_tasks  # noqa: E402  (single source of the case definitions)
+
 WEIGHT_SEED = 7
-TASKS = ('mlm', 'sap', 'cfp')
 REF_CFG_JSON = '/root/reference/pretrain_src/config/r2r_GOAT_model_config.json'
 
 
@@ -72,7 +64,11 @@ def main(only=None):
         if only and name not in only:
             continue
         torch.manual_seed(0)
-        ref_cfg = ref_shim.make_config(REF_CFG_JSON, pretrain_tasks={'mlm', 'sap', 'cfp'}, name='R2R', **cfg_over)
+        over = dict(cfg_over)
+        tasks = case_tasks(name)
+        over['pretrain_tasks'] = set(tasks)
+        over.setdefault('name', 'R2R')
+        ref_cfg = ref_shim.make_config(REF_CFG_JSON, **over)
         ref = pg.GlocalTextPathCMTPreTraining(ref_cfg)
         ours = pretrain_model.GlocalTextPathCMTPreTraining(gcfg.make_config(**cfg_over))
         sd = synth.seeded_state_dict(ours, seed=WEIGHT_SEED)
@@ -86,7 +82,7 @@ def main(only=None):
         ref.eval()
         batch = synth.make_pretrain_batch(**bkw)
         store = {'param_names': np.array([n for n, _ in ref.named_parameters()])}
-        for task in TASKS:
+        for task in tasks:
             ref.zero_grad(set_to_none=True)
             if task == 'cfp':
                 go, vo, fo, to = ref(batch, task, compute_loss=False)
@@ -104,6 +100,13 @@ def main(only=None):
                     gl, ll, fl, _, _ = ref(batch, task, compute_loss=False)
                     store['sap_global_logits'], store['sap_local_logits'], store['sap_fused_logits'] = \
                         gl.numpy(), ll.numpy(), fl.numpy()
+                if task == 'og':
+                    store['og_logits'] = ref(batch, task, compute_loss=False).numpy()
+                if task == 'mrc':
+                    vp_, vt_, op_, ot_ = ref(batch, task, compute_loss=False)
+                    store['mrc_view_pred'] = vp_.numpy()
+                    if op_ is not None:
+                        store['mrc_obj_pred'] = op_.numpy()
                 if task == 'mlm':
                     sc = ref(batch, task, compute_loss=False)
                     store['mlm_scores_head'] = sc[:, :64].numpy()
@@ -111,11 +114,12 @@ def main(only=None):
         # intermediate activations of the backbone (small slices) for debugging / per-module parity
         with torch.no_grad():
             b2 = dict(batch)
-            gm, vp, tx = ref.bert(b2['txt_ids'], b2['txt_lens'], b2['traj_view_img_fts'], None, b2['traj_loc_fts'],
-                                  b2['traj_nav_types'], b2['traj_step_lens'], b2['traj_vp_view_lens'], None,
-                                  b2['traj_vpids'], b2['traj_cand_vpids'], b2['gmap_lens'], b2['gmap_step_ids'],
-                                  b2['gmap_pos_fts'], b2['gmap_pair_dists'], b2['gmap_vpids'], b2['vp_pos_fts'],
-                                  return_txt_embeds=True)
+            gm, vp, tx = ref.bert(b2['txt_ids'], b2['txt_lens'], b2['traj_view_img_fts'], b2.get('traj_obj_img_fts'),
+                                  b2['traj_loc_fts'], b2['traj_nav_types'], b2['traj_step_lens'], b2['traj_vp_view_lens'],
+                                  b2.get('traj_vp_obj_lens'), b2['traj_vpids'], b2['traj_cand_vpids'], b2['gmap_lens'],
+                                  b2['gmap_step_ids'], b2['gmap_pos_fts'], b2['gmap_pair_dists'], b2['gmap_vpids'],
+                                  b2['vp_pos_fts'], return_txt_embeds=True,
+                                  traj_reverie_obj_names=b2.get('traj_reverie_obj_names'))
             store['bert_gmap_embeds'] = gm[:, :, :16].numpy()
             store['bert_vp_embeds'] = vp[:, :, :16].numpy()
             store['bert_txt_embeds'] = tx[:, :, :16].numpy()

@@ -18,7 +18,22 @@ CASES = {
                                    ragged_views=True)),
     'pretrain_config1': (dict(num_l_layers=2, num_top_layer=2, num_pano_layers=2),
                          dict(B=4, T=5, L=80, seed=3, style='survey')),
+    # REVERIE/SOON object branch (objects appended to every panorama), OG head, MRC on views and objects
+    'pretrain_reverie_small': (dict(num_l_layers=2, num_top_layer=2, num_pano_layers=2, vocab_size=1000, name='REVERIE',
+                                    obj_feat_size=768, image_prob_size=100, obj_prob_size=100, obj_name_vocab_size=45,
+                                    use_obj_name=True, pretrain_tasks=['mlm', 'mrc', 'sap', 'og', 'cfp']),
+                               dict(B=4, T=[2, 4, 1, 3], L=[40, 33, 20, 57], seed=5, vocab_size=1000, style='rich',
+                                    ragged_views=True, objects=6, mrc=True, prob_size=100)),
+    # MRC head on an R2R batch (views only; separate object classifier configured but unused)
+    'pretrain_r2r_mrc': (dict(num_l_layers=2, num_top_layer=2, num_pano_layers=2, vocab_size=1000, image_prob_size=100,
+                              obj_prob_size=50, pretrain_tasks=['mlm', 'mrc', 'sap', 'cfp']),
+                         dict(B=3, T=[3, 1, 2], L=[30, 24, 16], seed=6, vocab_size=1000, style='survey', mrc=True,
+                              prob_size=100)),
 }
+
+
+def case_tasks(name):
+    return tuple(CASES[name][0].get('pretrain_tasks', ('mlm', 'sap', 'cfp')))
 WEIGHT_SEED = 7
 
 

@@ -5,10 +5,12 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CASES, build_case, load_golden, oracle_run
+from helpers import CASES, build_case, case_tasks, load_golden, oracle_run
 
 pytestmark = pytest.mark.gpu
 SMALL = ['pretrain_small_fixed', 'pretrain_small_ragged']
+EXTRA = ['pretrain_reverie_small', 'pretrain_r2r_mrc']      # REVERIE object branch + OG head; MRC head
+CASE_TASKS = [(c, t) for c in SMALL + EXTRA for t in case_tasks(c)]
 
 
 def _rel(a, b):
@@ -17,8 +19,7 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('task', ['mlm', 'sap', 'cfp'])
-@pytest.mark.parametrize('case', SMALL)
+@pytest.mark.parametrize('case,task', CASE_TASKS)
 def test_losses_and_grads_match_oracle(case, task, dtype):
     import vln_goat_amd
     from vln_goat_amd import synth
@@ -47,12 +48,17 @@ def test_losses_and_grads_match_oracle(case, task, dtype):
     # its own fp32 run by 6.6% (sap) / 0.8% (mlm) / 2.0% (cfp) aggregate on these cases (worst tensor 15%).
     rtol = 1e-3 if dtype == torch.float32 else 0.35       # per tensor
     agg_tol = 1e-4 if dtype == torch.float32 else 0.12    # sum |err| / sum |ref| over all tensors
+    # gradients far below the scale of the others (sums of cancelling terms, e.g. the scalar bias of the fusion score)
+    # sit inside the bf16 rounding noise of the big terms: those are held to an absolute bound instead
+    tiny = (1e-6 if dtype == torch.float32 else 2e-3) * gmax
+    abs_tol = (1e-4 if dtype == torch.float32 else 5e-3) * gmax
     bad, num, den = [], 0.0, 0.0
     for n, p in model.named_parameters():
         rg = ref_grads.get(n)
-        if rg is None or float(rg.norm()) <= 1e-6 * gmax:
+        if rg is None or float(rg.norm()) <= tiny:
             if p.grad is not None:
-                assert float(p.grad.float().norm()) <= 1e-4 * gmax, n
+                ref0 = rg.double() if rg is not None else 0.0
+                assert float((p.grad.double().cpu() - ref0).norm()) <= abs_tol, n
             continue
         assert p.grad is not None, n
         d = float((p.grad.double().cpu() - rg.double()).norm())
@@ -163,3 +169,34 @@ def test_gradient_arena_equals_autograd(task, dtype):
         assert float((par.grad.double() - ref[name].double()).norm()) <= 2e-5 * float(ref[name].norm())
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', EXTRA)
+def test_og_and_mrc_outputs_match_reference_golden(case, dtype):
+    import vln_goat_amd
+    from vln_goat_amd import synth
+    cfg, model, batch = build_case(case)
+    gold = load_golden(case)
+    tol = 1e-3 if dtype == torch.float32 else 2e-2
+    vln_goat_amd.set_compute_dtype(dtype)
+    try:
+        model = model.cuda().eval()
+        gb = synth.batch_to(batch, 'cuda')
+        with torch.no_grad():
+            vp, vt, op, ot = model(gb, 'mrc', compute_loss=False)
+            lg = model(gb, 'og', compute_loss=False).float().cpu().numpy() if 'og' in case_tasks(case) else None
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)
+    ref = gold['mrc_view_pred']
+    assert float(np.abs(vp.float().cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max())) < tol
+    if 'mrc_obj_pred' in gold:
+        ref = gold['mrc_obj_pred']
+        assert float(np.abs(op.float().cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max())) < tol
+    else:
+        assert op is None
+    if lg is not None:
+        ref = gold['og_logits']
+        assert np.array_equal(np.isinf(lg), np.isinf(ref))
+        m = ~np.isinf(ref)
+        assert float(np.abs(lg[m] - ref[m]).max()) / max(1.0, float(np.abs(ref[m]).max())) < tol

@@ -14,10 +14,14 @@ pytestmark = pytest.mark.gpu
 CASES = {
     'nav_type2_door': dict(do_back_txt_type='type_2', do_back_img_type='type_1', do_add_method='door'),
     'nav_type1_add': dict(do_back_txt_type='type_1', do_back_img_type='type_2', do_add_method='add'),
+    # REVERIE: object tokens in every panorama + object-grounding head (must match tests/golden/make_golden_nav.py)
+    'nav_reverie_objects': dict(do_back_txt_type='type_2', do_back_img_type='type_1', do_add_method='door', dataset='reverie',
+                                obj_feat_size=768),
 }
+EPISODE = {'nav_reverie_objects': dict(objects=5, seed=9)}
 
 
-def _build(over):
+def _build(over, epkw=None):
     from vln_goat_amd import nav_model, synth
     args = SimpleNamespace(num_l_layers=2, num_x_layers=2, num_pano_layers=2, dropout=0.5, feat_dropout=0.4,
                            do_back_img=True, do_back_txt=True, do_front_img=True, do_front_his=True, do_front_txt=True,
@@ -25,7 +29,7 @@ def _build(over):
     cfg = nav_model.nav_config_from_args(args)
     model = nav_model.GlocalTextPathNavCMT(cfg)
     model.load_state_dict(synth.seeded_state_dict(model, seed=11))
-    ep = synth.make_nav_episode(B=2, L=44, n_steps=3, seed=5, vocab_size=1200)
+    ep = synth.make_nav_episode(**{**dict(B=2, L=44, n_steps=3, seed=5, vocab_size=1200), **(epkw or {})})
     return model, ep
 
 
@@ -35,7 +39,7 @@ def test_nav_episode_matches_reference_golden(case, dtype):
     import vln_goat_amd
     from vln_goat_amd import synth
     gold = load_golden(case)
-    model, ep = _build(CASES[case])
+    model, ep = _build(CASES[case], EPISODE.get(case))
     vln_goat_amd.set_compute_dtype(dtype)
     try:
         model = model.cuda().eval()
@@ -55,6 +59,12 @@ def test_nav_episode_matches_reference_golden(case, dtype):
             assert np.array_equal(np.isinf(got), np.isinf(ref)), (t, k)
             m = ~np.isinf(ref)
             assert np.abs(got[m] - ref[m]).max() / max(1.0, np.abs(ref[m]).max()) < tol, (t, k)
+        if ('s%d_obj_logits' % t) in gold:
+            ref = gold['s%d_obj_logits' % t]
+            got = s['obj_logits'].detach().float().cpu().numpy()
+            assert np.array_equal(np.isinf(got), np.isinf(ref)), (t, 'obj_logits')
+            m = ~np.isinf(ref)
+            assert np.abs(got[m] - ref[m]).max() / max(1.0, np.abs(ref[m]).max()) < tol, (t, 'obj_logits')
         for k, sl in (('cls_embeds', None), ('gmap_embeds', 16), ('vp_embeds', 16), ('pano_fused', 32)):
             ref = gold['s%d_%s' % (t, k)]
             got = s[k].detach().float().cpu().numpy()

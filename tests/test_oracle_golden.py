@@ -7,14 +7,17 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CASES, build_case, fingerprint, load_golden, oracle_run, ROOT
+from helpers import CASES, build_case, case_tasks, fingerprint, load_golden, oracle_run, ROOT
 
 SMALL = ['pretrain_small_fixed', 'pretrain_small_ragged']
 ALL = SMALL + (['pretrain_config1'] if os.path.exists(os.path.join(ROOT, 'tests/golden/pretrain_config1.npz')) else [])
 
 
-@pytest.mark.parametrize('case', ALL)
-@pytest.mark.parametrize('task', ['mlm', 'sap', 'cfp'])
+EXTRA = ['pretrain_reverie_small', 'pretrain_r2r_mrc']      # REVERIE object branch + OG head, MRC head
+CASE_TASKS = [(c, t) for c in ALL + EXTRA for t in case_tasks(c)]
+
+
+@pytest.mark.parametrize('case,task', CASE_TASKS)
 def test_oracle_matches_reference_golden(case, task):
     gold = load_golden(case)
     cfg, model, batch = build_case(case)
@@ -53,3 +56,23 @@ def test_oracle_logits_and_pooled_vectors(case):
         np.testing.assert_allclose(got.numpy(), gold[key], rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(sc[:, :64].numpy(), gold['mlm_scores_head'], rtol=1e-5, atol=5e-5)
     np.testing.assert_allclose(torch.logsumexp(sc, 1).numpy(), gold['mlm_scores_lse'], rtol=1e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize('case', EXTRA)
+def test_oracle_og_and_mrc_outputs(case):
+    from oracle import goat_oracle
+    gold = load_golden(case)
+    cfg, model, batch = build_case(case)
+    sd = model.state_dict()
+    with torch.no_grad():
+        vp, vt, op, ot = goat_oracle.forward(cfg, sd, batch, 'mrc', compute_loss=False)
+        np.testing.assert_allclose(vp.numpy(), gold['mrc_view_pred'], rtol=1e-5, atol=5e-5)
+        if 'mrc_obj_pred' in gold:
+            np.testing.assert_allclose(op.numpy(), gold['mrc_obj_pred'], rtol=1e-5, atol=5e-5)
+        else:
+            assert op is None
+        if 'og' in case_tasks(case):
+            lg = goat_oracle.forward(cfg, sd, batch, 'og', compute_loss=False).numpy()
+            ref = gold['og_logits']
+            assert np.array_equal(np.isinf(lg), np.isinf(ref))
+            np.testing.assert_allclose(lg[~np.isinf(ref)], ref[~np.isinf(ref)], rtol=1e-5, atol=2e-5)

@@ -109,3 +109,24 @@ def build_sap_fusion(traj_cand_vpids, gmap_vpids, gmap_visited_masks, n_gmap, n_
                     for j in bw:
                         M[b, g, j] += 1.0
     return torch.from_numpy(M)
+
+
+def build_obj_concat_index(view_lens, obj_lens, V, O, W):
+    """REVERIE/SOON panorama rows: token j of row n is view j (j < view_len), object j - view_len
+    (view_len <= j < view_len + obj_len) or padding — the per-row torch.cat + pad_tensors_wgrad of
+    P/model/vilmodel_goat.py:331-340 as one gather.  Source rows: [0, N*V) views, [N*V, N*V + N*O) objects.
+    -> (idx int32 [n_tokens], start int32 [N*W + 1]); padding slots are empty segments (zeros)."""
+    view_lens, obj_lens = _to_list(view_lens), _to_list(obj_lens)
+    N = len(view_lens)
+    idx, start = [], [0]
+    for n in range(N):
+        vl, ol = int(view_lens[n]), int(obj_lens[n])
+        if vl + ol > W:
+            raise ValueError('row %d: %d views + %d objects exceed the padded width %d' % (n, vl, ol, W))
+        for j in range(W):
+            if j < vl:
+                idx.append(n * V + j)
+            elif j < vl + ol:
+                idx.append(N * V + n * O + (j - vl))
+            start.append(len(idx))
+    return torch.tensor(idx or [-1], dtype=torch.int32), torch.tensor(start, dtype=torch.int32)

@@ -344,6 +344,17 @@ def create_transformer_encoder(config, num_layers, norm=False):
     return TransformerEncoder(config, num_layers, norm=norm)
 
 
+class RegionClassification(nn.Module):
+    # MRC head (P/model/pretrain_goat.py:14-25)
+    def __init__(self, hidden_size, label_dim):
+        super().__init__()
+        self.net = nn.Sequential(Linear(hidden_size, hidden_size), nn.ReLU(),
+                                 LayerNorm(hidden_size, eps=1e-12), Linear(hidden_size, label_dim))
+
+    def forward(self, x):
+        return self.net[3](self.net[2](self.net[0](x, act='relu')))
+
+
 class ClsPrediction(nn.Module):
     # P/model/pretrain_goat.py:27-38
     def __init__(self, hidden_size, input_size=None):

@@ -128,19 +128,20 @@ class LanguageEncoderDo(nn.Module):
 
 
 class CausalImageEmbeddings(nn.Module):
-    """M/models/vilmodel_GOAT.py:164-316 (R2R branch)."""
+    """M/models/vilmodel_GOAT.py:164-316: R2R/RxR branch and the REVERIE/SOON branch (object tokens appended to the
+    panorama, M:693-720)."""
 
     def __init__(self, config):
         super().__init__()
         self.config = config
-        if config.name in ('REVERIE', 'SOON'):
-            raise NotImplementedError('REVERIE/SOON object tokens are not built yet')
+        self.reverie = config.name in ('REVERIE', 'SOON')
         H = config.hidden_size
         self.img_linear = Linear(config.image_feat_size, H)
         self.img_layer_norm = BertLayerNorm(H, eps=1e-12)
         self.loc_linear = Linear(config.angle_feat_size + 3, H)
         self.loc_layer_norm = BertLayerNorm(H, eps=1e-12)
-        self.img_self_encoder = create_transformer_encoder(config, config.num_pano_layers, norm=True)
+        if not self.reverie:
+            self.img_self_encoder = create_transformer_encoder(config, config.num_pano_layers, norm=True)
         self.do_back_img = config.do_back_img
         if self.do_back_img:
             self.do_img_before_linear = Linear(config.image_feat_size, H)
@@ -154,7 +155,15 @@ class CausalImageEmbeddings(nn.Module):
                     self.sigmoid = nn.Sigmoid()
                 elif config.do_add_method == 'concat':
                     self.do_concat_img_linear = Linear(H * 2, H)
-        self.nav_type_embedding = nn.Embedding(2, H)
+        if self.reverie:
+            if config.use_obj_name:
+                self.obj_name_linear = nn.Embedding(config.obj_name_vocab_size, H)
+            self.obj_reverie_linear = Linear(config.obj_feat_size, H)
+            self.obj_reverie_layer_norm = BertLayerNorm(H, eps=1e-12)
+            self.nav_type_embedding = nn.Embedding(3, H)
+            self.pano_encoder = create_transformer_encoder(config, config.num_pano_layers, norm=True)
+        else:
+            self.nav_type_embedding = nn.Embedding(2, H)
         if config.adaptive_pano_fusion:
             self.adaptive_pano_attn = Linear(H, 1)
         self.layer_norm = BertLayerNorm(H, eps=1e-12)
@@ -179,21 +188,41 @@ class CausalImageEmbeddings(nn.Module):
                 x = self.do_concat_img_linear(torch.cat((x, z), -1))
         return self.do_img_concat_layernorm(x)
 
-    def encode(self, view_img_fts, loc_fts, view_lens, z_img_features=None, z_img_pzs=None, loc_before=False):
-        """-> (embeds [N,V,H], masks [N,V] bool, fused [N,H] | None).  `loc_before` = pre-training order
-        (location added before the intervention, M:225-252); per-step navigation adds it after (M:688-691)."""
+    def encode(self, view_img_fts, loc_fts, view_lens, z_img_features=None, z_img_pzs=None, loc_before=False,
+               nav_types=None, obj_fts=None, obj_lens=None, obj_names=None):
+        """-> (embeds [N,W,H], masks [N,W] bool, fused [N,H] | None).  `loc_before` = pre-training order
+        (location added before the intervention, M:225-252); per-step navigation adds it after (M:688-691).
+        REVERIE/SOON (M:693-720): object tokens follow the views of every row; loc_fts / nav_types are [N,W,...]."""
         dt = compute_dtype()
         x = self.img_layer_norm(self.img_linear(view_img_fts.to(dt)))
-        loc = self.loc_layer_norm(self.loc_linear(loc_fts.to(dt)))
-        if loc_before:
-            x = x + loc
-        if z_img_features is not None:
-            x = self.intervene(x, z_img_features, z_img_pzs)
-        if not loc_before:
-            x = x + loc
-        x = hipops.dropout(x, _p(self.dropout))
-        masks = gen_seq_masks(view_lens, view_img_fts.shape[1])
-        x = self.img_self_encoder(x, masks)
+        if self.reverie:
+            if z_img_features is not None:
+                x = self.intervene(x, z_img_features, z_img_pzs)
+            o = self.obj_reverie_linear(obj_fts.to(dt))
+            if self.config.use_obj_name:
+                o = o + hipops.embedding(obj_names, self.obj_name_linear.weight, out_dtype=dt)
+            o = self.obj_reverie_layer_norm(o)
+            N, V, H = x.shape
+            W = nav_types.shape[1]
+            ci = graphmap.build_obj_concat_index(view_lens, obj_lens, V, o.shape[1], W)
+            src = torch.cat([x.reshape(N * V, H), o.reshape(-1, H)], 0)
+            x = hipops.gather_segmean(src, ci[0].to(x.device), ci[1].to(x.device), None, N * W).view(N, W, H)
+            x = x + self.loc_layer_norm(self.loc_linear(loc_fts.to(dt))) \
+                + hipops.embedding(nav_types, self.nav_type_embedding.weight, out_dtype=dt)
+            x = hipops.dropout(self.layer_norm(x), _p(self.dropout))
+            masks = gen_seq_masks(view_lens + obj_lens, W)
+            x = self.pano_encoder(x, masks)
+        else:
+            loc = self.loc_layer_norm(self.loc_linear(loc_fts.to(dt)))
+            if loc_before:
+                x = x + loc
+            if z_img_features is not None:
+                x = self.intervene(x, z_img_features, z_img_pzs)
+            if not loc_before:
+                x = x + loc
+            x = hipops.dropout(x, _p(self.dropout))
+            masks = gen_seq_masks(view_lens, view_img_fts.shape[1])
+            x = self.img_self_encoder(x, masks)
         fused = None
         if self.config.adaptive_pano_fusion:
             fused = hipops.pano_fusion(x, self.adaptive_pano_attn.weight, self.adaptive_pano_attn.bias)
@@ -301,8 +330,11 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
         return self.lang_encoder(e, txt_masks, z_direc, z_direc_pzs, z_landm, z_landm_pzs, front_txt)
 
     # ---- panorama -------------------------------------------------------------------------------------
-    def forward_panorama_do_per_step(self, view_img_fts, loc_fts, nav_types, view_lens, z_img_features=None, z_img_pzs=None):
-        return self.img_embeddings.encode(view_img_fts, loc_fts, view_lens, z_img_features, z_img_pzs, loc_before=False)
+    def forward_panorama_do_per_step(self, view_img_fts, loc_fts, nav_types, view_lens, z_img_features=None, z_img_pzs=None,
+                                     reverie_obj_fts=None, reverie_obj_lens=None, reverie_obj_names=None):
+        return self.img_embeddings.encode(view_img_fts, loc_fts, view_lens, z_img_features, z_img_pzs, loc_before=False,
+                                          nav_types=nav_types, obj_fts=reverie_obj_fts, obj_lens=reverie_obj_lens,
+                                          obj_names=reverie_obj_names)
 
     # ---- navigation -------------------------------------------------------------------------------------
     def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
@@ -389,7 +421,9 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
                                      batch['instr_z_landmark_pzs'], batch['front_txt_feats'])
         if mode == 'panorama':
             return self.forward_panorama_do_per_step(batch['view_img_fts'], batch['loc_fts'], batch['nav_types'],
-                                                     batch['view_lens'], batch['z_img_features'], batch['z_img_pzs'])
+                                                     batch['view_lens'], batch['z_img_features'], batch['z_img_pzs'],
+                                                     batch['reverie_obj_img_fts'], batch['reverie_obj_lens'],
+                                                     batch['reverie_obj_names'])
         if mode == 'navigation':
             return self.forward_navigation_per_step(
                 batch['txt_embeds'], batch['txt_masks'], batch['gmap_img_embeds'], batch['gmap_step_ids'], batch['gmap_pos_fts'],
@@ -444,6 +478,10 @@ class VLNBert(nn.Module):
         if mode == 'panorama':
             if not batch['already_dropout']:
                 batch['view_img_fts'] = hipops.dropout(batch['view_img_fts'].to(compute_dtype()).contiguous(), _p(self.drop_env))
+            if 'reverie_obj_img_fts' in batch and batch['reverie_obj_img_fts'] is not None:
+                # object features are dropped regardless of `already_dropout` (M/models/model.py:31-32)
+                batch['reverie_obj_img_fts'] = hipops.dropout(batch['reverie_obj_img_fts'].to(compute_dtype()).contiguous(),
+                                                              _p(self.drop_env))
         return self.vln_bert(mode, batch)
 
 
@@ -480,7 +518,8 @@ def nav_config_from_args(args):
         num_top_layer=g('num_x_layers', 3), hidden_size=768, num_attention_heads=12, num_hidden_layers=g('num_l_layers', 6),
         hidden_dropout_prob=g('dropout', 0.5), attention_probs_dropout_prob=0.1, intermediate_size=3072, hidden_act='gelu',
         layer_norm_eps=1e-5, pad_token_id=1, initializer_range=0.02, is_decoder=False, add_cross_attention=False,
-        chunk_size_feed_forward=0, name='R2R', use_lang2visn_attn=False)
+        chunk_size_feed_forward=0, use_lang2visn_attn=False,
+        name={'reverie': 'REVERIE', 'soon': 'SOON'}.get(g('dataset', 'r2r'), 'R2R'), use_obj_name=g('dataset', 'r2r') == 'reverie')
 
 
 def remap_pretrain_checkpoint(ckpt_weights):

@@ -15,7 +15,7 @@ from torch import nn
 
 from . import graphmap, hipops
 from .layers import (BertAttention, BertLayerNorm, BertOnlyMLMHead, BertPredictionHeadTransform, ClsPrediction,
-                     CrossmodalEncoder, LayerNorm, Linear, RobertaEmbeddings, RobertaLayer, _p, compute_dtype,
+                     CrossmodalEncoder, LayerNorm, Linear, RegionClassification, RobertaEmbeddings, RobertaLayer, _p, compute_dtype,
                      create_transformer_encoder, gen_seq_masks, neg_mask)
 
 
@@ -87,35 +87,60 @@ class LanguageEncoder(nn.Module):
 
 
 class CausalImageEmbeddings(nn.Module):
-    """P/model/vilmodel_goat.py:234-364 (R2R branch; shipped pre-train configs keep do_back_img off — the
-    upstream BACL-img pretrain branch is broken, SURVEY §8a-Q viii)."""
+    """P/model/vilmodel_goat.py:234-364: the R2R branch (view + location embeddings through the panorama encoder)
+    and the REVERIE/SOON branch (object tokens appended to every panorama, :322-349).  Shipped pre-train configs
+    keep do_back_img off — the upstream BACL-img pretrain branch is broken, SURVEY §8a-Q viii."""
 
     def __init__(self, config):
         super().__init__()
         self.config = config
-        if getattr(config, 'name', 'R2R') in ('REVERIE', 'SOON'):
-            raise NotImplementedError('REVERIE/SOON object branch of the pre-training model is not built yet')
+        self.reverie = getattr(config, 'name', 'R2R') in ('REVERIE', 'SOON')
         if getattr(config, 'do_back_img', False):
             raise NotImplementedError('pretrain do_back_img is broken upstream (undefined do_back_img_after_linear)')
-        self.img_linear = Linear(config.image_feat_size, config.hidden_size)
-        self.img_layer_norm = BertLayerNorm(config.hidden_size, eps=1e-12)
-        self.loc_linear = Linear(config.angle_feat_size + 3, config.hidden_size)
-        self.loc_layer_norm = BertLayerNorm(config.hidden_size, eps=1e-12)
-        self.img_self_attn = BertAttention(config)          # created, never used (checkpoint compat)
-        self.img_self_encoder = create_transformer_encoder(config, config.num_pano_layers, norm=True)
-        self.nav_type_embedding = nn.Embedding(2, config.hidden_size)   # unused on R2R
+        H = config.hidden_size
+        self.img_linear = Linear(config.image_feat_size, H)
+        self.img_layer_norm = BertLayerNorm(H, eps=1e-12)
+        self.loc_linear = Linear(config.angle_feat_size + 3, H)
+        self.loc_layer_norm = BertLayerNorm(H, eps=1e-12)
+        if not self.reverie:
+            self.img_self_attn = BertAttention(config)          # created, never used (checkpoint compat)
+            self.img_self_encoder = create_transformer_encoder(config, config.num_pano_layers, norm=True)
+        if self.reverie:
+            self.obj_name_linear = nn.Embedding(config.obj_name_vocab_size, H)
+            self.obj_reverie_linear = Linear(config.obj_feat_size, H)
+            self.obj_reverie_layer_norm = BertLayerNorm(H, eps=1e-12)
+            self.nav_type_embedding = nn.Embedding(3, H)
+            self.pano_encoder = create_transformer_encoder(config, config.num_pano_layers, norm=True)
+        else:
+            self.nav_type_embedding = nn.Embedding(2, H)    # unused on R2R
         if config.adaptive_pano_fusion:
-            self.adaptive_pano_attn = Linear(config.hidden_size, 1)
-        self.layer_norm = BertLayerNorm(config.hidden_size, eps=1e-12)  # unused on R2R
+            self.adaptive_pano_attn = Linear(H, 1)
+        self.layer_norm = BertLayerNorm(H, eps=1e-12)       # unused on R2R
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
-    def forward(self, traj_view_img_fts, traj_loc_fts, traj_vp_view_lens):
+    def forward(self, traj_view_img_fts, traj_loc_fts, traj_vp_view_lens, traj_nav_types=None, obj_fts=None, obj_lens=None,
+                obj_names=None, cat_index=None):
+        """-> (tokens [N,W,H], fused [N,H] | None).  cat_index = graphmap.build_obj_concat_index(...) on device."""
         dt = compute_dtype()
         x = self.img_layer_norm(self.img_linear(traj_view_img_fts.to(dt)))
-        x = x + self.loc_layer_norm(self.loc_linear(traj_loc_fts.to(dt)))
-        x = hipops.dropout(x, _p(self.dropout))
-        img_masks = gen_seq_masks(traj_vp_view_lens, traj_view_img_fts.shape[1])
-        x = self.img_self_encoder(x, img_masks)
+        if not self.reverie:
+            x = x + self.loc_layer_norm(self.loc_linear(traj_loc_fts.to(dt)))
+            x = hipops.dropout(x, _p(self.dropout))
+            img_masks = gen_seq_masks(traj_vp_view_lens, traj_view_img_fts.shape[1])
+            x = self.img_self_encoder(x, img_masks)
+        if obj_fts is not None:
+            o = self.obj_reverie_linear(obj_fts.to(dt))
+            if self.config.use_obj_name:
+                o = o + hipops.embedding(obj_names, self.obj_name_linear.weight, out_dtype=dt)
+            o = self.obj_reverie_layer_norm(o)
+            N, V, H = x.shape
+            W = traj_nav_types.shape[1]
+            src = torch.cat([x.reshape(N * V, H), o.reshape(-1, H)], 0)
+            x = hipops.gather_segmean(src, cat_index[0], cat_index[1], None, N * W).view(N, W, H)
+            x = x + hipops.embedding(traj_nav_types, self.nav_type_embedding.weight, out_dtype=dt) \
+                + self.loc_layer_norm(self.loc_linear(traj_loc_fts.to(dt)))
+            x = hipops.dropout(self.layer_norm(x), _p(self.dropout))
+            x = self.pano_encoder(x, gen_seq_masks(traj_vp_view_lens + obj_lens, W))
         fused = None
         if self.config.adaptive_pano_fusion:
             fused = hipops.pano_fusion(x, self.adaptive_pano_attn.weight, self.adaptive_pano_attn.bias)
@@ -189,11 +214,20 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
             G = batch['gmap_step_ids'].shape[1]
             fused = bool(self.config.adaptive_pano_fusion)
             lens_cpu = batch['traj_vp_view_lens'].cpu()
+            cache = {}
+            if batch.get('traj_obj_img_fts') is not None:
+                # REVERIE/SOON: every panorama row becomes [views | objects], W slots wide (P/model/vilmodel_goat.py:331-341)
+                obj_cpu = batch['traj_vp_obj_lens'].cpu()
+                W = batch['traj_nav_types'].shape[1]
+                ci = graphmap.build_obj_concat_index(lens_cpu, obj_cpu, V, batch['traj_obj_img_fts'].shape[1], W)
+                cache['objcat'] = (ci[0].to(dev), ci[1].to(dev))
+                cache['view_lens_cpu'], cache['obj_lens_cpu'] = lens_cpu, obj_cpu
+                lens_cpu, V = lens_cpu + obj_cpu, W
             g = graphmap.build_gmap_index(batch['traj_step_lens'], lens_cpu, batch['traj_vpids'],
                                           batch['traj_cand_vpids'], batch['gmap_vpids'], G, V, fused)
             v = graphmap.build_vp_index(batch['traj_step_lens'], lens_cpu, V)
-            cache = {'gmap': tuple(t.to(dev) for t in g),
-                     'vp': (v[0].to(dev), v[1].to(dev), v[2].to(dev), v[3])}
+            cache['gmap'] = tuple(t.to(dev) for t in g)
+            cache['vp'] = (v[0].to(dev), v[1].to(dev), v[2].to(dev), v[3])
             batch['_goat_cache'] = cache
         return cache
 
@@ -204,7 +238,11 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
         return txt, txt_kmask
 
     def _pano(self, batch):
-        x, fused = self.img_embeddings(batch['traj_view_img_fts'], batch['traj_loc_fts'], batch['traj_vp_view_lens'])
+        cache = self._indices(batch)
+        x, fused = self.img_embeddings(batch['traj_view_img_fts'], batch['traj_loc_fts'], batch['traj_vp_view_lens'],
+                                       batch.get('traj_nav_types'), batch.get('traj_obj_img_fts'),
+                                       batch.get('traj_vp_obj_lens'), batch.get('traj_reverie_obj_names'),
+                                       cache.get('objcat'))
         N, V, H = x.shape
         rows = x.view(N * V, H)
         src = torch.cat([rows, fused], 0) if fused is not None else rows
@@ -287,7 +325,11 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
         if 'mlm' in tasks:
             self.mlm_head = BertOnlyMLMHead(config)
         if 'mrc' in tasks:
-            raise NotImplementedError('MRC head is not part of the shipped GOAT pre-training tasks')
+            self.image_classifier = RegionClassification(config.hidden_size, config.image_prob_size)
+            if config.obj_prob_size > 0 and config.obj_prob_size != config.image_prob_size:
+                self.obj_classifier = RegionClassification(config.hidden_size, config.obj_prob_size)
+            else:
+                self.obj_classifier = None
         if 'sap' in tasks:
             self.global_sap_head = ClsPrediction(config.hidden_size)
             self.local_sap_head = ClsPrediction(config.hidden_size)
@@ -326,8 +368,13 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
                 return self.forward_sap(batch, compute_loss)
             elif task.startswith('cfp'):
                 return self.forward_cfp(batch, compute_loss)
-            elif task.startswith('og') or task.startswith('mrc') or task.startswith('valid_sap_og'):
-                raise NotImplementedError('task %s needs the REVERIE object branch (not built yet)' % task)
+            elif task.startswith('mrc'):
+                return self.forward_mrc(batch, compute_loss)
+            elif task.startswith('og'):
+                return self.forward_og(batch, compute_loss)
+            elif task.startswith('valid_sap_og'):
+                # upstream passes more arguments than forward_sap_og accepts (SURVEY §8a-Q ix): dead in the reference
+                raise NotImplementedError('valid_sap_og is dead code in the reference (signature mismatch at pretrain_goat.py:155-169)')
             else:
                 raise ValueError('invalid task')
         finally:
@@ -381,6 +428,80 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
             return F.cross_entropy(gl, ga, reduction='none') + F.cross_entropy(ll, la, reduction='none') \
                 + F.cross_entropy(fused, ga, reduction='none')
         return gl, ll, fused, batch['global_act_labels'], batch['local_act_labels']
+
+    # -- OG / MRC (local stream only) ---------------------------------------------------------------
+    def _last_lens(self, batch):
+        """(view_len, obj_len) of each sample's LAST panorama, as python lists (host index bookkeeping)."""
+        cache = batch['_goat_cache']
+        if 'last_lens' not in cache:
+            last = torch.as_tensor(batch['traj_step_lens']).cumsum(0) - 1
+            vl = batch['traj_vp_view_lens'].cpu()[last].tolist()
+            ol = batch['traj_vp_obj_lens'].cpu()[last].tolist() if batch['traj_vp_obj_lens'] is not None else [0] * len(vl)
+            cache['last_lens'] = (vl, ol)
+        return cache['last_lens']
+
+    def forward_og(self, batch, compute_loss):
+        """P/model/pretrain_goat.py:356-391: ClsPrediction on the object tokens of the local stream, -inf outside.
+        The head is per token, so it runs on all local tokens and the object logits are gathered from the result
+        (same values as pad_tensors_wgrad of the object slices followed by the head)."""
+        _, vp, _ = self.bert(batch, return_gmap_embeds=False)
+        cache = batch['_goat_cache']
+        if 'og_idx' not in cache:
+            vl, ol = self._last_lens(batch)
+            O = max(1, max(ol))
+            idx = torch.zeros(len(vl), O, dtype=torch.int64)
+            msk = torch.zeros(len(vl), O, dtype=torch.bool)
+            for b, (v, o) in enumerate(zip(vl, ol)):
+                idx[b, :o] = torch.arange(1 + v, 1 + v + o)
+                msk[b, :o] = True
+            cache['og_idx'] = (idx.to(vp.device), msk.to(vp.device))
+        idx, msk = cache['og_idx']
+        logits = self.og_head(vp).squeeze(2).float().gather(1, idx).masked_fill(msk.logical_not(), -float('inf'))
+        if compute_loss:
+            return F.cross_entropy(logits, batch['obj_labels'], reduction='none')
+        return logits
+
+    def _mrc_rows(self, batch, which, width):
+        """flat row indices (into vp.view(B*W1, H)) of the masked view / object tokens, in the reference's order."""
+        cache = batch['_goat_cache']
+        key = 'mrc_' + which
+        if key not in cache:
+            vl, ol = self._last_lens(batch)
+            mask = batch['vp_view_mrc_masks' if which == 'view' else 'vp_obj_mrc_masks'].cpu()
+            rows = []
+            for b in range(mask.shape[0]):
+                n = vl[b] if which == 'view' else ol[b]
+                off = 1 if which == 'view' else 1 + vl[b]
+                for j in range(mask.shape[1]):
+                    if mask[b, j]:
+                        if j >= n:
+                            raise ValueError('MRC mask selects a padded %s slot (sample %d, slot %d)' % (which, b, j))
+                        rows.append(b * width + off + j)
+            dev = batch['traj_view_img_fts'].device
+            cache[key] = (torch.tensor(rows, dtype=torch.int64, device=dev), mask.to(dev))
+        return cache[key]
+
+    def forward_mrc(self, batch, compute_loss):
+        """P/model/pretrain_goat.py:226-284: region classification (KL to soft labels) on the masked view tokens —
+        and object tokens, REVERIE — of the local stream; only the masked rows go through the classifier."""
+        _, vp, _ = self.bert(batch, return_gmap_embeds=False)
+        B, W1, H = vp.shape
+        flat = vp.reshape(B * W1, H)
+        rows, vmask = self._mrc_rows(batch, 'view', W1)
+        v_pred = self.image_classifier(flat.index_select(0, rows)).float()
+        v_tgt = batch['vp_view_probs'][vmask]
+        o_pred = o_tgt = None
+        if batch['traj_obj_img_fts'] is not None:
+            orow, omask = self._mrc_rows(batch, 'obj', W1)
+            head = self.obj_classifier if self.obj_classifier is not None else self.image_classifier
+            o_pred = head(flat.index_select(0, orow)).float()
+            o_tgt = batch['vp_obj_probs'][omask]
+        if not compute_loss:
+            return v_pred, v_tgt, o_pred, o_tgt
+        loss = F.kl_div(F.log_softmax(v_pred, dim=-1), v_tgt.float(), reduction='none').sum(dim=1)
+        if o_pred is not None:
+            loss = torch.cat([loss, F.kl_div(F.log_softmax(o_pred, dim=-1), o_tgt.float(), reduction='none').sum(dim=1)], 0)
+        return loss
 
     # -- CFP ---------------------------------------------------------------------------------------
     def forward_cfp(self, batch, compute_loss):

@@ -18,13 +18,17 @@ def _angle_fts(rs, n):
 
 
 def make_pretrain_batch(B=4, T=5, L=80, seed=0, vocab_size=50265, n_views=36, n_cand=4, style='survey',
-                        ragged_views=False, mask_prob=0.15, feat_dim=768):
+                        ragged_views=False, mask_prob=0.15, feat_dim=768, objects=0, obj_dim=768, mrc=False,
+                        prob_size=1000):
     """One batch usable for all of mlm / sap / cfp.
 
     T, L: int (fixed) or list of per-sample values.  style='survey': every step sees `n_cand` fresh
     candidates, one of which is the next path node (G = 2 + 4T - ... = 22 at T=5).
     style='rich': additionally a back-edge to the previous node and an unvisited node shared between
     consecutive steps (exercises the visited-candidate and multi-view-mean branches of the reference loops).
+    objects > 0: REVERIE/SOON-style batch (P/data/tasks.py og_collate): up to `objects` object tokens per panorama
+    (0 allowed except on a sample's last step), loc/nav-type tensors [N, max(view+obj)], nav type 2 = object,
+    `obj_labels`.  mrc=True adds the masked-region inputs (soft labels over `prob_size` classes).
     """
     rs = np.random.RandomState(seed)
     Ts = [T] * B if isinstance(T, int) else list(T)
@@ -115,13 +119,57 @@ def make_pretrain_batch(B=4, T=5, L=80, seed=0, vocab_size=50265, n_views=36, n_
         local_lab[b] = (last_c.index(vp) + 1) if (gi > 0 and vp in last_c) else 0
 
     last = np.cumsum(Ts) - 1
-    vp_w = int(view_lens[last].max()) + 1
+    extra = {}
+    tot_lens = view_lens.copy()
+    if objects > 0:
+        obj_lens = rs.randint(0, objects + 1, N)
+        obj_lens[last] = np.maximum(obj_lens[last], 1)
+        O = int(obj_lens.max())
+        obj_fts = rs.standard_normal((N, O, obj_dim)).astype(np.float32)
+        obj_names = rs.randint(0, 45, (N, O)).astype(np.int64)
+        tot_lens = view_lens + obj_lens
+        W = int(tot_lens.max())
+        loc2 = np.zeros((N, W, 7), dtype=np.float32)
+        nav2 = np.zeros((N, W), dtype=np.int64)
+        for n_ in range(N):
+            obj_fts[n_, obj_lens[n_]:] = 0
+            obj_names[n_, obj_lens[n_]:] = 0
+            loc2[n_, :view_lens[n_]] = loc[n_, :view_lens[n_]]
+            loc2[n_, view_lens[n_]:tot_lens[n_]] = _angle_fts(rs, int(obj_lens[n_]))
+            nav2[n_, :view_lens[n_]] = nav_types[n_, :view_lens[n_]]
+            nav2[n_, view_lens[n_]:tot_lens[n_]] = 2
+        loc, nav_types = loc2, nav2
+        extra.update({'traj_obj_img_fts': torch.from_numpy(obj_fts), 'traj_vp_obj_lens': torch.from_numpy(obj_lens.astype(np.int64)),
+                      'traj_reverie_obj_names': torch.from_numpy(obj_names),
+                      'obj_labels': torch.from_numpy(np.array([rs.randint(obj_lens[n_]) for n_ in last], dtype=np.int64))})
+    vp_w = int(tot_lens[last].max()) + 1
     vp_pos = rs.standard_normal((B, vp_w, 14)).astype(np.float32)
     for b in range(B):
-        vp_pos[b, view_lens[last[b]] + 1:] = 0
+        vp_pos[b, tot_lens[last[b]] + 1:] = 0
+    if mrc:
+        def soft(n_rows):
+            p = rs.uniform(0, 1, (n_rows, prob_size)).astype(np.float32) ** 4
+            return p / p.sum(1, keepdims=True)
+        vmax = int(view_lens[last].max())
+        vm = np.zeros((B, vmax), dtype=bool)
+        vprob = np.zeros((B, vmax, prob_size), dtype=np.float32)
+        for b in range(B):
+            k = view_lens[last[b]]
+            vm[b, rs.choice(k, max(1, int(round(mask_prob * k))), replace=False)] = True
+            vprob[b, :k] = soft(k)
+        extra.update({'vp_view_mrc_masks': torch.from_numpy(vm), 'vp_view_probs': torch.from_numpy(vprob)})
+        if objects > 0:
+            omax = int(obj_lens[last].max())
+            om = np.zeros((B, omax), dtype=bool)
+            oprob = np.zeros((B, omax, prob_size), dtype=np.float32)
+            for b in range(B):
+                k = obj_lens[last[b]]
+                om[b, rs.choice(k, max(1, int(round(mask_prob * k))), replace=False)] = True
+                oprob[b, :k] = soft(k)
+            extra.update({'vp_obj_mrc_masks': torch.from_numpy(om), 'vp_obj_probs': torch.from_numpy(oprob)})
 
     t = torch.from_numpy
-    return {
+    out = {
         'txt_ids': t(txt_ids), 'txt_lens': torch.tensor(Ls, dtype=torch.int64), 'txt_labels': t(txt_labels),
         'traj_view_img_fts': t(fts), 'traj_loc_fts': t(loc), 'traj_nav_types': t(nav_types),
         'traj_step_lens': list(Ts), 'traj_vp_view_lens': t(view_lens.astype(np.int64)),
@@ -131,6 +179,8 @@ def make_pretrain_batch(B=4, T=5, L=80, seed=0, vocab_size=50265, n_views=36, n_
         'global_act_labels': t(global_lab), 'local_act_labels': t(local_lab),
         'extra_heads': [True] * B, 'traj_reverie_loc_fts': None,
     }
+    out.update(extra)
+    return out
 
 
 def batch_to(batch, device):
@@ -184,10 +234,13 @@ def seeded_state_dict(model, seed=0, perturb=True):
 
 
 # ======================================================================================= fine-tune episode
-def make_nav_episode(B=2, L=44, V=36, n_steps=3, n_cand=4, seed=0, vocab_size=50265, dict_sizes=(35, 39, 50, 24)):
+def make_nav_episode(B=2, L=44, V=36, n_steps=3, n_cand=4, seed=0, vocab_size=50265, dict_sizes=(35, 39, 50, 24),
+                     objects=0):
     """Synthetic stand-in for one DAgger rollout of the fine-tuning loop (M/r2r/agent.py:515-592; shapes of
     M/utils/efficiency_count.py:16-137): text once, then per step a panorama and the graph inputs.  Returns a
-    dict of CPU tensors / lists; `run_nav_episode` drives any model exposing `model(mode, batch)`."""
+    dict of CPU tensors / lists; `run_nav_episode` drives any model exposing `model(mode, batch)`.
+    objects > 0: REVERIE-style steps — up to `objects` object tokens after the views of every panorama (at least one
+    on the last step), nav type 2, `vp_obj_masks`, and an object-grounding target on the last step."""
     rs = np.random.RandomState(seed)
     Kd, Kl, Kr, Kf = dict_sizes
     f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
@@ -251,16 +304,51 @@ def make_nav_episode(B=2, L=44, V=36, n_steps=3, n_cand=4, seed=0, vocab_size=50
             vp_nav[b, 0] = True
             vp_nav[b, 2:2 + n_cand] = True
         target = np.array([2 + (t + 1) + rs.randint(0, max(1, n_cand - 1)) if t + 1 < n_steps else 0 for _ in range(B)])
+        obj = {}
+        if objects > 0:
+            obj_lens = rs.randint(0, objects + 1, B)
+            if t + 1 == n_steps:
+                obj_lens = np.maximum(obj_lens, 1)
+            O = max(1, int(obj_lens.max()))
+            tot = view_lens + obj_lens
+            W = int(tot.max())
+            ofts = rs.standard_normal((B, O, 768)).astype(np.float32)
+            onames = rs.randint(0, 45, (B, O)).astype(np.int64)
+            loc2 = np.zeros((B, W, 7), dtype=np.float32)
+            nav2 = np.zeros((B, W), dtype=np.int64)
+            vp_masks = np.zeros((B, W + 2), dtype=bool)
+            vp_nav = np.zeros((B, W + 2), dtype=bool)
+            vp_obj = np.zeros((B, W + 2), dtype=bool)
+            for b in range(B):
+                ofts[b, obj_lens[b]:] = 0
+                onames[b, obj_lens[b]:] = 0
+                loc2[b, :view_lens[b]] = loc[b, :view_lens[b]]
+                loc2[b, view_lens[b]:tot[b]] = _angle_fts(rs, int(obj_lens[b]))
+                nav2[b, :n_cand] = 1
+                nav2[b, view_lens[b]:tot[b]] = 2
+                vp_masks[b, :tot[b] + 2] = True
+                vp_nav[b, 0] = True
+                vp_nav[b, 2:2 + n_cand] = True
+                vp_obj[b, 2 + view_lens[b]:2 + tot[b]] = True
+                vp_cand_vpids[b] = [None, 'MEM'] + vp_cand_vpids[b][2:2 + n_cand] + [None] * (W - n_cand)
+            loc, nav_types = loc2, nav2
+            obj = {'reverie_obj_img_fts': f32(ofts), 'reverie_obj_lens': torch.from_numpy(obj_lens.astype(np.int64)),
+                   'reverie_obj_names': torch.from_numpy(onames), 'vp_obj_masks': torch.from_numpy(vp_obj),
+                   'obj_target': torch.from_numpy(np.array([2 + view_lens[b] + rs.randint(obj_lens[b]) if t + 1 == n_steps else -100
+                                                            for b in range(B)], dtype=np.int64))}
+            vp_w = W + 2
+        else:
+            vp_w = V + 2
         ep['steps'].append({
             'view_img_fts': f32(fts), 'loc_fts': f32(loc), 'nav_types': torch.from_numpy(nav_types),
             'view_lens': torch.from_numpy(view_lens.astype(np.int64)),
             'gmap_step_ids': torch.from_numpy(np.tile(np.arange(G), (B, 1)).astype(np.int64) % 5),
             'gmap_pos_fts': f32(rs.standard_normal((B, G, 7))), 'gmap_masks': torch.from_numpy(gmasks),
             'gmap_pair_dists': f32(d), 'gmap_visited_masks': torch.from_numpy(gvis), 'gmap_vpids': gmap_vpids,
-            'vp_pos_fts': f32(rs.standard_normal((B, V + 2, 14))), 'vp_masks': torch.from_numpy(vp_masks),
+            'vp_pos_fts': f32(rs.standard_normal((B, vp_w, 14))), 'vp_masks': torch.from_numpy(vp_masks),
             'vp_nav_masks': torch.from_numpy(vp_nav), 'vp_cand_vpids': vp_cand_vpids,
             'target': torch.from_numpy(target.astype(np.int64)),
-            'gmap_cand_view': n_cand,
+            'gmap_cand_view': n_cand, **obj,
         })
     return ep
 
@@ -288,6 +376,10 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
                'view_lens': mv(st['view_lens']), 'already_dropout': True}
         if use_bacl:
             pin['z_img_features'], pin['z_img_pzs'] = mv(ep['z_img_features']), mv(ep['z_img_pzs'])
+        has_obj = 'reverie_obj_img_fts' in st
+        if has_obj:
+            for k in ('reverie_obj_img_fts', 'reverie_obj_lens', 'reverie_obj_names'):
+                pin[k] = mv(st[k])
         pano, pmask, fused = model('panorama', dd(pin))
         fused_hist.append(fused)
         H = pano.shape[-1]
@@ -303,7 +395,8 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
                'gmap_step_ids': mv(st['gmap_step_ids']), 'gmap_pos_fts': mv(st['gmap_pos_fts']), 'gmap_masks': mv(st['gmap_masks']),
                'gmap_pair_dists': mv(st['gmap_pair_dists']), 'gmap_visited_masks': mv(st['gmap_visited_masks']),
                'gmap_vpids': st['gmap_vpids'], 'vp_img_embeds': vimg, 'vp_pos_fts': mv(st['vp_pos_fts']),
-               'vp_masks': mv(st['vp_masks']), 'vp_nav_masks': mv(st['vp_nav_masks']), 'vp_obj_masks': None,
+               'vp_masks': mv(st['vp_masks']), 'vp_nav_masks': mv(st['vp_nav_masks']),
+               'vp_obj_masks': mv(st['vp_obj_masks']) if has_obj else None,
                'vp_cand_vpids': st['vp_cand_vpids'], 'flops_count': False}
         if use_facl:
             nin['front_vp_feats'], nin['front_gmap_feats'] = mv(ep['front_vp_feats']), mv(ep['front_gmap_feats'])
@@ -311,5 +404,8 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
         mem = out['cls_embeds']
         logits = out['fused_logits'].float() if to_float else out['fused_logits']
         loss = loss + torch.nn.functional.cross_entropy(logits, mv(st['target']), reduction='sum', ignore_index=-100)
+        if has_obj and t + 1 == len(ep['steps']):        # object grounding at the stop step (M/reverie/agent_obj.py)
+            ol = out['obj_logits'].float() if to_float else out['obj_logits']
+            loss = loss + torch.nn.functional.cross_entropy(ol, mv(st['obj_target']), reduction='sum', ignore_index=-100)
         rec['steps'].append({'pano_embeds': pano, 'pano_fused': fused, **out})
     return loss, rec
