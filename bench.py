@@ -243,8 +243,24 @@ def gemm_roofline(args, model, gb):
     n = len(recs)
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    # HBM-side traffic per launch of this kernel family: PMC counters cannot be read from inside the process, so the value
+    # comes from the committed rocprofv3 --pmc passes of this same step mix (scripts/collect_profiles.sh; FETCH_SIZE and
+    # WRITE_SIZE in separate passes, gfx950 corrections applied as MI355X_MICROARCH.md prescribes) — null if absent.
+    traffic, tsrc = None, None
+    tpath = os.path.join(ROOT, 'profiles', 'round1_pmc_gemm_traffic.json')
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic, tsrc = round(tj['traffic_bytes_per_launch']), 'profiles/round1_pmc_gemm_traffic.json'
+    algo_bytes = 0.0
+    for r in recs:
+        M_, N_, K_, epi_, split_ = r[3][:5]
+        f32out = r[4][1][2] == 0 if r[4][0] == 'goat_gemm_bf16' else False
+        algo_bytes += (M_ * K_ + N_ * K_) * 2 + M_ * N_ * (4 if f32out else 2) * (2 if epi_ in (1, 2) else 1) \
+            + (M_ * N_ * 2 if epi_ in (3, 4) else 0)
     return {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'traffic': None, 'kernel': 'gemm2_kernel (goat_gemm_bf16) + gemm_nt_kernel', 'launches_per_cycle': n,
+            'traffic': traffic, 'traffic_unit': 'bytes/launch (L2-miss reads x2-corrected + writes; rocprofv3 --pmc)',
+            'traffic_source': tsrc, 'algorithmic_bytes_per_launch': round(algo_bytes / max(n, 1)), 'kernel': 'gemm2_kernel (goat_gemm_bf16) + gemm_nt_kernel', 'launches_per_cycle': n,
             'avg_launch_us': round(tot_ms * 1e3 / max(n, 1), 2),
             'algorithmic_gflop_per_launch': round(tot_fl / max(n, 1) / 1e9, 3),
             'gemm_ms_per_cycle': round(tot_ms, 3),

@@ -1,0 +1,44 @@
+#!/bin/bash
+# Collects the evidence the bench line is judged against (run on the GPU box through gpurun):
+#   1. rocprofv3 --kernel-trace --stats of the default bench command   -> kernel_stats
+#   2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same step mix (eager launches) -> HBM-side traffic per launch
+#   3. per-shape PMC traffic of the GEMM kernel (scripts/gemm_pmc.py) and the per-shape timing table
+# Everything lands in gpurun_out/final/; summaries are then copied into profiles/ (tracked).
+set -u
+OUT=/root/repo/gpurun_out/final
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python /root/repo/bench.py --steps 30 --warmup 6 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python /root/repo/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-graph > $OUT/pmc_$c.log 2>&1
+  GEMM_PMC_ORDER=$OUT/gemm_pmc_order.json timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/gpmc_$c -- python /root/repo/scripts/gemm_pmc.py > $OUT/gpmc_$c.log 2>&1
+done
+cd /root/repo
+python scripts/prof_stats.py $OUT/trace 60 > $OUT/kernel_stats.txt
+grep '^{"metric"' $OUT/bench_under_rocprof.log > $OUT/bench_line_under_rocprof.json
+{ python scripts/pmc_summary.py $OUT/pmc_FETCH_SIZE 25; python scripts/pmc_summary.py $OUT/pmc_WRITE_SIZE 25; } > $OUT/pmc_step_summary.txt
+python scripts/gemm_pmc_report.py $OUT/gemm_pmc_order.json $OUT/gpmc_FETCH_SIZE $OUT/gpmc_WRITE_SIZE > $OUT/gemm_pmc_per_shape.txt
+python scripts/gemm_table.py > $OUT/gemm_shape_table.txt 2>&1
+python - <<'PY'
+import csv, glob, json
+out = '/root/repo/gpurun_out/final'
+def fam_avg(d, counter):
+    n = s = 0
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            if ('gemm2_kernel' in r['Kernel_Name'] or 'gemm_nt_kernel' in r['Kernel_Name']) and r['Counter_Name'] == counter:
+                n += 1; s += float(r['Counter_Value'])
+    return n, (s / n if n else None)
+nf, f = fam_avg(out + '/pmc_FETCH_SIZE', 'FETCH_SIZE')
+nw, w = fam_avg(out + '/pmc_WRITE_SIZE', 'WRITE_SIZE')
+json.dump({'kernel': 'gemm2_kernel + gemm_nt_kernel', 'launches_counted': nf,
+           'fetch_kb_per_launch_reported': f, 'write_kb_per_launch_reported': w,
+           'read_bytes_per_launch': f * 1024 * 2, 'write_bytes_per_launch': w * 1024,
+           'traffic_bytes_per_launch': f * 1024 * 2 + w * 1024,
+           'corrections': 'FETCH_SIZE (KB) doubled: gfx950 rocprofv3 tallies 128-B requests at 64 B for 16-B/lane reads (MI355X_MICROARCH.md, HBM); '
+                          'WRITE_SIZE (KB) x1, calibrated on act_bwd (23,307 KB reported for a 23,040 KB store). FETCH_SIZE counts L2-miss requests on the '
+                          'fabric side, Infinity-Cache hits included: an upper bound on HBM bytes.',
+           'command': 'rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 6 --warmup 3 --no-graph (two separate passes)'},
+          open(out + '/pmc_gemm_traffic.json', 'w'), indent=1)
+PY
+cat $OUT/pmc_gemm_traffic.json | head -12

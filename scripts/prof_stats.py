@@ -11,3 +11,13 @@ print("%-100s %8s %12s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "pc
 for r in rows[: int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
     print("%-100s %8s %12.1f %10.2f %6.2f" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e3,
                                              float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+
+fam = {}
+for r in rows:
+    n = r["Name"]
+    k = "GEMM family (gemm2_kernel* + gemm_nt_kernel*)" if ("gemm2_kernel" in n or "gemm_nt_kernel" in n) else None
+    if k:
+        a = fam.setdefault(k, [0, 0.0])
+        a[0] += int(r["Calls"]); a[1] += float(r["TotalDurationNs"])
+for k, (c, t) in fam.items():
+    print("%-100s %8d %12.1f %10.2f %6.2f" % (k, c, t / 1e3, t / 1e3 / c, 100 * t / tot))
