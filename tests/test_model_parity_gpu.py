@@ -10,7 +10,8 @@ from helpers import CASES, build_case, case_tasks, load_golden, oracle_run
 pytestmark = pytest.mark.gpu
 SMALL = ['pretrain_small_fixed', 'pretrain_small_ragged']
 EXTRA = ['pretrain_reverie_small', 'pretrain_r2r_mrc']      # REVERIE object branch + OG head; MRC head
-CASE_TASKS = [(c, t) for c in SMALL + EXTRA for t in case_tasks(c)]
+CONFIG1 = ['pretrain_config1']          # SURVEY config 1: full 50 265-token vocabulary (tied decoder + fused CE at real size)
+CASE_TASKS = [(c, t) for c in SMALL + EXTRA + CONFIG1 for t in case_tasks(c)]
 
 
 def _rel(a, b):
