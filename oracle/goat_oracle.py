@@ -153,6 +153,43 @@ def lang_encoder(ctx, sd, pre, txt_embeds, txt_masks):
     return txt_embeds
 
 
+def lang_encoder_do(ctx, sd, pre, txt_embeds, txt_masks, batch):
+    """LanguageEncoderDo.forward — BACL-txt in pre-training (P/model/vilmodel_goat.py:104-159); no front-door
+    dictionary is passed on this path (:549)."""
+    cfg = ctx.cfg
+    ext = extend_neg_masks(txt_masks)
+    for i in range(cfg.num_l_layers):
+        txt_embeds = roberta_layer(ctx, sd, f'{pre}.layer.{i}', txt_embeds, ext)
+    zd = batch['instr_z_direction_features']
+    if zd is None:
+        return txt_embeds
+    zd = zd.to(torch.float32)                               # RobertaEmbeddings passes them through (Bert_backbone.py:117-120)
+    zl = batch['instr_z_landmark_features'].to(torch.float32)
+    eps = cfg.layer_norm_eps
+    if cfg.do_back_txt_type == 'type_1':
+        if cfg.z_cross_attn:
+            zd = bert_attention(ctx, sd, pre + '.z_direc_cross_attn', zd, None, txt_embeds, ext)
+            zl = bert_attention(ctx, sd, pre + '.z_landm_cross_attn', zl, None, txt_embeds, ext)
+        sum_d = torch.sum(zd * batch['instr_z_direction_pzs'].to(torch.float32), 1).unsqueeze(1)
+        sum_l = torch.sum(zl * batch['instr_z_landmark_pzs'].to(torch.float32), 1).unsqueeze(1)
+        txt_embeds = _lin(sd, pre + '.z_txt_linear', txt_embeds) + _lin(sd, pre + '.z_direct_linear', sum_d) \
+            + _lin(sd, pre + '.z_landm_linear', sum_l)
+        return _ln(sd, pre + '.z_concat_layernorm', txt_embeds, eps)
+    zd = bert_attention(ctx, sd, pre + '.z_direc_cross_attn', txt_embeds, None, zd, None)
+    zd = _ln(sd, pre + '.z_direct_ln', _lin(sd, pre + '.z_direct_linear', zd), eps)
+    zl = bert_attention(ctx, sd, pre + '.z_landm_cross_attn', txt_embeds, None, zl, None)
+    zl = _ln(sd, pre + '.z_landm_ln', _lin(sd, pre + '.z_landm_linear', zl), eps)
+    if cfg.do_add_method == 'door':
+        aug = zd + zl
+        w = torch.sigmoid(_lin(sd, pre + '.instr_aug_linear', aug) + _lin(sd, pre + '.instr_ori_linear', txt_embeds))
+        txt_embeds = w * aug + (1 - w) * txt_embeds
+    elif cfg.do_add_method == 'add':
+        txt_embeds = txt_embeds + zd + zl
+    elif cfg.do_add_method == 'concat':
+        txt_embeds = _lin(sd, pre + '.concat_linear', torch.cat((txt_embeds, zd, zl), -1))
+    return _ln(sd, pre + '.z_concat_layernorm', txt_embeds, eps)
+
+
 # ----------------------------------------------------------------------------- panorama encoder
 def pano_layer(ctx, sd, pre, src, key_pad):
     """TransformerEncoderLayer.forward_pre (P/model/transformer.py:170-182) with
@@ -282,6 +319,8 @@ def _sprels(sd, pre, batch):
 def _text(ctx, sd, batch):
     txt_masks = gen_seq_masks(batch['txt_lens'])
     e = embeddings(ctx, sd, 'bert.embeddings', batch['txt_ids'])
+    if getattr(ctx.cfg, 'do_back_txt', False):
+        return lang_encoder_do(ctx, sd, 'bert.lang_encoder', e, txt_masks, batch), txt_masks
     return lang_encoder(ctx, sd, 'bert.lang_encoder', e, txt_masks), txt_masks
 
 

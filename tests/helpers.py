@@ -29,6 +29,13 @@ CASES = {
                               obj_prob_size=50, pretrain_tasks=['mlm', 'mrc', 'sap', 'cfp']),
                          dict(B=3, T=[3, 1, 2], L=[30, 24, 16], seed=6, vocab_size=1000, style='survey', mrc=True,
                               prob_size=100)),
+    # BACL-txt in pre-training (do_back_txt): type_2 + door, and type_1 with dictionary->text cross-attention
+    'pretrain_bacl_type2_door': (dict(num_l_layers=2, num_top_layer=2, num_pano_layers=2, vocab_size=1000, do_back_txt=True,
+                                      do_back_txt_type='type_2', do_add_method='door', do_front_txt=True),
+                                 dict(B=3, T=[2, 1, 3], L=[30, 24, 16], seed=8, vocab_size=1000, style='rich', zdict=(35, 39))),
+    'pretrain_bacl_type1_xattn': (dict(num_l_layers=2, num_top_layer=2, num_pano_layers=2, vocab_size=1000, do_back_txt=True,
+                                       do_back_txt_type='type_1', z_cross_attn=True),
+                                  dict(B=3, T=[2, 1, 3], L=[30, 24, 16], seed=9, vocab_size=1000, style='survey', zdict=(35, 39))),
 }
 
 

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 SMALL = ['pretrain_small_fixed', 'pretrain_small_ragged']
 EXTRA = ['pretrain_reverie_small', 'pretrain_r2r_mrc']      # REVERIE object branch + OG head; MRC head
 CONFIG1 = ['pretrain_config1']          # SURVEY config 1: full 50 265-token vocabulary (tied decoder + fused CE at real size)
-CASE_TASKS = [(c, t) for c in SMALL + EXTRA + CONFIG1 for t in case_tasks(c)]
+BACL = ['pretrain_bacl_type2_door', 'pretrain_bacl_type1_xattn']      # BACL-txt in pre-training (do_back_txt)
+CASE_TASKS = [(c, t) for c in SMALL + EXTRA + CONFIG1 + BACL for t in case_tasks(c)]
 
 
 def _rel(a, b):

@@ -14,7 +14,8 @@ ALL = SMALL + (['pretrain_config1'] if os.path.exists(os.path.join(ROOT, 'tests/
 
 
 EXTRA = ['pretrain_reverie_small', 'pretrain_r2r_mrc']      # REVERIE object branch + OG head, MRC head
-CASE_TASKS = [(c, t) for c in ALL + EXTRA for t in case_tasks(c)]
+BACL = ['pretrain_bacl_type2_door', 'pretrain_bacl_type1_xattn']      # BACL-txt in pre-training (do_back_txt)
+CASE_TASKS = [(c, t) for c in ALL + EXTRA + BACL for t in case_tasks(c)]
 
 
 @pytest.mark.parametrize('case,task', CASE_TASKS)

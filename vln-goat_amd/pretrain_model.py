@@ -86,6 +86,86 @@ class LanguageEncoder(nn.Module):
         return txt_embeds
 
 
+def _door(aug_lin, ori_lin, aug, ori):
+    """door gate: w = sigmoid(Linear_a(aug) + Linear_o(ori)); out = w*aug + (1-w)*ori (P/model/vilmodel_goat.py:137-143)."""
+    w = torch.sigmoid(aug_lin(aug).float() + ori_lin(ori).float()).to(aug.dtype)
+    return w * aug + (1 - w) * ori
+
+
+class LanguageEncoderDo(nn.Module):
+    """BACL-txt in pre-training (P/model/vilmodel_goat.py:46-159): after the RoBERTa layers the text is intervened
+    with the direction / landmark confounder dictionaries — type_1: probability-weighted dictionary sums through
+    three Linears (optionally dictionary->text cross-attention first, z_cross_attn); type_2: text->dictionary
+    cross-attention, then door / add / concat — followed by LayerNorm.  Module set mirrors the reference's
+    constructor (state_dict keys), including modules it creates and never calls (txt_self_attn, z_front_*)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.num_l_layers = config.num_l_layers
+        self.update_lang_bert = config.update_lang_bert
+        self.layer = nn.ModuleList([RobertaLayer(config) for _ in range(self.num_l_layers)])
+        if not self.update_lang_bert:
+            for _, param in self.layer.named_parameters():
+                param.requires_grad = False
+        H = config.hidden_size
+        if config.do_back_txt:
+            if config.z_cross_attn:
+                self.z_direc_cross_attn = BertAttention(config)
+                self.z_landm_cross_attn = BertAttention(config)
+            self.z_txt_linear = Linear(H, H)
+            self.z_direct_linear = Linear(H, H)
+            self.z_landm_linear = Linear(H, H)
+            self.z_concat_layernorm = BertLayerNorm(H, eps=config.layer_norm_eps)
+            self.z_direct_ln = BertLayerNorm(H, eps=config.layer_norm_eps)
+            self.z_landm_ln = BertLayerNorm(H, eps=config.layer_norm_eps)
+            if config.do_back_txt_type == 'type_2':
+                self.z_direc_cross_attn = BertAttention(config)
+                self.z_landm_cross_attn = BertAttention(config)
+                self.txt_self_attn = BertAttention(config)
+                self.instr_aug_linear = Linear(H, 1)
+                self.instr_ori_linear = Linear(H, 1)
+                self.instr_sigmoid = nn.Sigmoid()
+                self.concat_linear = Linear(H * 3, H)
+        if getattr(config, 'do_front_txt', False):
+            self.z_front_cross_attn = BertAttention(config)
+            self.z_front_linear = Linear(H, H)
+            self.z_front_ln = BertLayerNorm(H, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, txt_embeds, txt_kmask, z_direc=None, z_direc_pzs=None, z_landm=None, z_landm_pzs=None):
+        cfg = self.config
+        for layer in self.layer:
+            txt_embeds = layer(txt_embeds, txt_kmask)
+        if not self.update_lang_bert:
+            txt_embeds = txt_embeds.detach()
+        if z_direc is None:
+            return txt_embeds
+        dt = txt_embeds.dtype
+        z_direc, z_landm = z_direc.to(dt), (z_landm.to(dt) if z_landm is not None else None)
+        if cfg.do_back_txt_type == 'type_1':
+            if cfg.z_cross_attn:       # dictionary entries attend to the (key-masked) text
+                z_direc = self.z_direc_cross_attn(z_direc, None, txt_embeds, txt_kmask)
+                z_landm = self.z_landm_cross_attn(z_landm, None, txt_embeds, txt_kmask)
+            sd = torch.sum(z_direc.float() * z_direc_pzs.float(), 1, keepdim=True).to(dt)
+            sl = torch.sum(z_landm.float() * z_landm_pzs.float(), 1, keepdim=True).to(dt)
+            txt_embeds = self.z_txt_linear(txt_embeds) + self.z_direct_linear(sd) + self.z_landm_linear(sl)
+            return self.z_concat_layernorm(txt_embeds)
+        # type_2: the text attends to each dictionary (no key mask on dictionary entries)
+        zd = self.z_direct_ln(self.z_direct_linear(self.z_direc_cross_attn(txt_embeds, None, z_direc, None)))
+        zl = None
+        if z_landm is not None:
+            zl = self.z_landm_ln(self.z_landm_linear(self.z_landm_cross_attn(txt_embeds, None, z_landm, None)))
+        if cfg.do_add_method == 'door':
+            aug = zd if zl is None else zd + zl
+            txt_embeds = _door(self.instr_aug_linear, self.instr_ori_linear, aug, txt_embeds)
+        elif cfg.do_add_method == 'add':
+            txt_embeds = txt_embeds + zd + zl
+        elif cfg.do_add_method == 'concat':
+            txt_embeds = self.concat_linear(torch.cat((txt_embeds, zd, zl), -1))
+        return self.z_concat_layernorm(txt_embeds)
+
+
 class CausalImageEmbeddings(nn.Module):
     """P/model/vilmodel_goat.py:234-364: the R2R branch (view + location embeddings through the panorama encoder)
     and the REVERIE/SOON branch (object tokens appended to every panorama, :322-349).  Shipped pre-train configs
@@ -195,10 +275,8 @@ class GlobalMapEncoder(nn.Module):
 class GlocalTextPathCMT(GoatPreTrainedModel):
     def __init__(self, config):
         super().__init__(config)
-        if getattr(config, 'do_back_txt', False):
-            raise NotImplementedError('pre-training BACL-txt (do_back_txt) is not built yet; shipped configs keep it off')
         self.embeddings = RobertaEmbeddings(config)
-        self.lang_encoder = LanguageEncoder(config)
+        self.lang_encoder = LanguageEncoderDo(config) if getattr(config, 'do_back_txt', False) else LanguageEncoder(config)
         self.img_embeddings = CausalImageEmbeddings(config)
         self.local_encoder = LocalVPEncoder(config)
         self.global_encoder = GlobalMapEncoder(config)
@@ -234,7 +312,13 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
     def _text(self, batch):
         txt_masks = gen_seq_masks(batch['txt_lens'], batch['txt_ids'].shape[1])
         txt_kmask = neg_mask(txt_masks)
-        txt = self.lang_encoder(self.embeddings(batch['txt_ids']), txt_kmask)
+        e = self.embeddings(batch['txt_ids'])
+        if getattr(self.config, 'do_back_txt', False):
+            # the embeddings pass the dictionaries through as float32 (P/model/Bert_backbone.py:117-120)
+            txt = self.lang_encoder(e, txt_kmask, batch['instr_z_direction_features'], batch['instr_z_direction_pzs'],
+                                    batch['instr_z_landmark_features'], batch['instr_z_landmark_pzs'])
+        else:
+            txt = self.lang_encoder(e, txt_kmask)
         return txt, txt_kmask
 
     def _pano(self, batch):

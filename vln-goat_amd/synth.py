@@ -19,7 +19,7 @@ def _angle_fts(rs, n):
 
 def make_pretrain_batch(B=4, T=5, L=80, seed=0, vocab_size=50265, n_views=36, n_cand=4, style='survey',
                         ragged_views=False, mask_prob=0.15, feat_dim=768, objects=0, obj_dim=768, mrc=False,
-                        prob_size=1000):
+                        prob_size=1000, zdict=None):
     """One batch usable for all of mlm / sap / cfp.
 
     T, L: int (fixed) or list of per-sample values.  style='survey': every step sees `n_cand` fresh
@@ -179,6 +179,15 @@ def make_pretrain_batch(B=4, T=5, L=80, seed=0, vocab_size=50265, n_views=36, n_
         'global_act_labels': t(global_lab), 'local_act_labels': t(local_lab),
         'extra_heads': [True] * B, 'traj_reverie_loc_fts': None,
     }
+    if zdict:                                   # BACL dictionaries (P/data/tasks.py:156-164): (K_direction, K_landmark)
+        def pz(k):
+            p = rs.uniform(0.1, 1.0, (B, k, 1))
+            return torch.from_numpy((p / p.sum(1, keepdims=True)).astype(np.float32))
+        kd, kl = zdict
+        extra.update({'instr_z_direction_features': torch.from_numpy(rs.uniform(0, 1, (B, kd, 768)).astype(np.float32)),
+                      'instr_z_direction_pzs': pz(kd),
+                      'instr_z_landmark_features': torch.from_numpy(rs.uniform(0, 1, (B, kl, 768)).astype(np.float32)),
+                      'instr_z_landmark_pzs': pz(kl)})
     out.update(extra)
     return out
 
