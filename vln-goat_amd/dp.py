@@ -143,14 +143,17 @@ class GradArena:
     * one fill per step zeroes the slices a task touches (`zero(task)`), and the gradient all-reduce runs in place
       on a few large contiguous ranges (`all_reduce_mean(task)`), without pack/unpack copies;
     * parameters are ordered by the set of tasks that use them (`usage`), so a task's parameters form a handful of
-      contiguous ranges; within a group matrices come first, in registration order, so the query/key/value weights of
-      a block stay adjacent (one fused wgrad GEMM writes all three).
+      contiguous ranges; within a group the large matrices come first, in registration order, so the query/key/value
+      weights of a block stay adjacent (one fused wgrad GEMM writes all three), then the small parameters.
     Parameters that no task uses are left out (their .grad stays None, as under the reference's
     DDP(find_unused_parameters=True), P/utils/misc.py:52-65).
     Call `zero()` instead of `optimizer.zero_grad(set_to_none=True)`; if some code does set a .grad to None, the
     Functions notice (the sink is no longer bound) and fall back to returning ordinary gradients."""
 
     ALIGN = 64          # elements (256 B): slices stay 16-B aligned for the GEMM epilogue and vector fills
+    SMALL = 100000      # parameters below this size (biases, LayerNorm, 1-column heads) sit together at the end of their
+                        # group and are cleared by ONE fill per group in zero(); the large matrices are cleared / overwritten
+                        # by their first writer (cache-warm for the split-K atomics)
 
     def __init__(self, params, usage=None, bucket_bytes=128 << 20):
         params = [p for p in params if p.requires_grad]
@@ -172,7 +175,13 @@ class GradArena:
         off = 0
         for k in sorted(groups):
             plist = groups[k]
-            for p in [q for q in plist if q.dim() >= 2] + [q for q in plist if q.dim() < 2]:
+            big = [q for q in plist if q.numel() >= self.SMALL]
+            small = [q for q in plist if q.numel() < self.SMALL]
+            for p in big + small:
+                if p.numel() < self.SMALL:
+                    p.__dict__['_goat_prezero'] = True     # cleared by zero(): the kernels only ever accumulate into it
+                else:
+                    p.__dict__.pop('_goat_prezero', None)
                 self.params.append(p)
                 self.offsets[id(p)] = off
                 self.tasks_of[id(p)] = frozenset(k) if usage is not None else None
@@ -238,7 +247,8 @@ class GradArena:
         key = task.split('_')[0] if task is not None else None
         if self._cur is not None:                       # close the previous step: remember what its Functions wrote
             prev, epoch = self._cur
-            self._owned[prev] = {id(p) for p in self.params if p.__dict__.get('_goat_epoch') == epoch}
+            self._owned[prev] = {id(p) for p in self.params
+                                 if p.__dict__.get('_goat_epoch') == epoch and not p.__dict__.get('_goat_prezero')}
         hipops.ARENA_EPOCH[0] += 1
         self._cur = (key, hipops.ARENA_EPOCH[0])
         owned = self._owned.get(key)

@@ -386,9 +386,13 @@ ARENA_EPOCH = [0]       # bumped by dp.GradArena.zero(): a sink's first use in a
 
 def _first_touch(*params):
     """True if none of `params` has been written through its sink yet in this step (marks them written).
-    Mixed states (some written, some not) cannot be served by one kernel launch: the unwritten slices are cleared
-    here and the call is treated as an accumulation."""
+    Small parameters (`_goat_prezero`: biases, LayerNorm, ...) are cleared by GradArena.zero() at the start of the step:
+    they never count as a first touch — writers just accumulate.  Mixed states among the others (some written, some
+    not) cannot be served by one kernel launch: the unwritten slices are cleared here and the call is an accumulation."""
     cur = ARENA_EPOCH[0]
+    params = [p for p in params if not p.__dict__.get('_goat_prezero')]
+    if not params:
+        return False
     seen = [p.__dict__.get('_goat_epoch') == cur for p in params]
     for p, was in zip(params, seen):
         p.__dict__['_goat_epoch'] = cur
@@ -406,7 +410,7 @@ def _prep_fallback(*params):
             t.zero_()
 
 
-def _wgrad_impl(dy, x, want_bias, w_sink=None, b_sink=None, first=False):
+def _wgrad_impl(dy, x, want_bias, w_sink=None, b_sink=None, first=False, b_first=False):
     M, N = dy.shape
     K = x.shape[1]
     # default (bm 64, split) from scripts/wgrad_sweep.py; the autotuner may pick another split (output is zero-filled)
@@ -424,7 +428,7 @@ def _wgrad_impl(dy, x, want_bias, w_sink=None, b_sink=None, first=False):
         db = b_sink
         if want_bias and db is None:
             db = torch.zeros(N, dtype=torch.float32, device=dy.device)
-        elif want_bias and first:
+        elif want_bias and b_first:
             db.zero_()
         gemm(dy, x, w_sink, ta=True, tb=True, split_k=split, colsum_out=db if want_bias else None,
              split_opts=(1, 2, 3, 4, 6, 8) if tunable else None, accumulate=not first, zero_first=first)
@@ -442,17 +446,17 @@ def _wgrad_impl(dy, x, want_bias, w_sink=None, b_sink=None, first=False):
     return dw, db
 
 
-def wgrad(dy, x, want_bias, w_sink=None, b_sink=None, first=False):
+def wgrad(dy, x, want_bias, w_sink=None, b_sink=None, first=False, b_first=False):
     """dW[N,K] (f32) = dy[M,N]^T @ x[M,K] ; db[N] (f32) = colsum(dy), fused into the same kernel.
     One zero-fill covers both outputs (split-K partial tiles and the bias sums are accumulated atomically).
     With sinks (gradient-arena slices) the results are accumulated in place and (None, None) is returned."""
     side = WgradOverlap.stream
     if side is None:
-        return _wgrad_impl(dy, x, want_bias, w_sink, b_sink, first)
+        return _wgrad_impl(dy, x, want_bias, w_sink, b_sink, first, b_first)
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)                       # dy / x are ready on the main stream
     with torch.cuda.stream(side):
-        out = _wgrad_impl(dy, x, want_bias, w_sink, b_sink, first)
+        out = _wgrad_impl(dy, x, want_bias, w_sink, b_sink, first, b_first)
     dy.record_stream(side)                      # keep the operands alive until the side-stream GEMM has read them
     x.record_stream(side)
     return out
@@ -511,9 +515,10 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             w_sink = None if ctx.pad else _sink(weight)
             b_sink = _sink(ctx.bias) if w_sink is not None else None
-            first = w_sink is not None and _first_touch(*([weight] + ([ctx.bias] if b_sink is not None else [])))
+            first = w_sink is not None and _first_touch(weight)
+            b_first = b_sink is not None and _first_touch(ctx.bias)
             _prep_fallback(*(([] if w_sink is not None else [weight]) + ([] if b_sink is not None else [ctx.bias])))
-            dw, db = wgrad(dy2, x2, ctx.has_bias, w_sink, b_sink, first)
+            dw, db = wgrad(dy2, x2, ctx.has_bias, w_sink, b_sink, first, b_first)
             if ctx.pad:
                 dw = dw[:, :x2.shape[1] - ctx.pad].contiguous()
         return dx, dw, db, None, None
@@ -579,17 +584,19 @@ class _FfnFn(torch.autograd.Function):
             gemm(dy2, W2, du, tb=True, epi=_ACT_DEPI[ctx.act], aux=u)
         s2 = _sink(ctx.w2)
         sb2 = _sink(ctx.b2) if s2 is not None else None
-        f2 = s2 is not None and _first_touch(*([ctx.w2] + ([ctx.b2] if sb2 is not None else [])))
+        f2 = s2 is not None and _first_touch(ctx.w2)
+        bf2 = sb2 is not None and _first_touch(ctx.b2)
         _prep_fallback(*(([] if s2 is not None else [ctx.w2]) + ([] if sb2 is not None else [ctx.b2])))
-        dw2, db2 = wgrad(dy2, h, True, s2, sb2, f2)
+        dw2, db2 = wgrad(dy2, h, True, s2, sb2, f2, bf2)
         W1 = _shadow(ctx.w1, x2.dtype)  # [F, H]
         dx = torch.empty_like(x2)
         gemm(du, W1, dx, tb=True)
         s1 = _sink(ctx.w1)
         sb1 = _sink(ctx.b1) if s1 is not None else None
-        f1 = s1 is not None and _first_touch(*([ctx.w1] + ([ctx.b1] if sb1 is not None else [])))
+        f1 = s1 is not None and _first_touch(ctx.w1)
+        bf1 = sb1 is not None and _first_touch(ctx.b1)
         _prep_fallback(*(([] if s1 is not None else [ctx.w1]) + ([] if sb1 is not None else [ctx.b1])))
-        dw1, db1 = wgrad(du, x2, True, s1, sb1, f1)
+        dw1, db1 = wgrad(du, x2, True, s1, sb1, f1, bf1)
         return dx.view(ctx.xshape), dw1, db1, dw2, db2, None, None
 
 
@@ -663,10 +670,11 @@ class _DecoderCeFn(torch.autograd.Function):
         w_sink = _sink(weight)
         if w_sink is not None:      # the tied word-embedding table: accumulate next to the embedding scatter-add
             b_sink = _sink(ctx.bias)
-            first = _first_touch(*([weight] + ([ctx.bias] if b_sink is not None else [])))
+            first = _first_touch(weight)
+            b_first = b_sink is not None and _first_touch(ctx.bias)
             if b_sink is None:
                 _prep_fallback(ctx.bias)
-            dw, db = wgrad(dl[:, :N], h2, True, w_sink, b_sink, first)
+            dw, db = wgrad(dl[:, :N], h2, True, w_sink, b_sink, first, b_first)
             return dh.view(ctx.hshape), None, db, None
         _prep_fallback(weight, ctx.bias)
         dw, db = wgrad(dl, h2, True)
@@ -713,9 +721,10 @@ class _MultiLinearFn(torch.autograd.Function):
             dx = dx.view(ctx.xshape)
         w_sink = _sink_cat(ws)
         b_sink = _sink_cat(ctx.bs) if w_sink is not None else None
-        first = w_sink is not None and _first_touch(*(list(ws) + (list(ctx.bs) if b_sink is not None else [])))
+        first = w_sink is not None and _first_touch(*ws)
+        b_first = b_sink is not None and _first_touch(*ctx.bs)
         _prep_fallback(*(([] if w_sink is not None else list(ws)) + ([] if b_sink is not None else list(ctx.bs))))
-        dw, db = wgrad(dy2, x2, True, w_sink, b_sink, first)
+        dw, db = wgrad(dy2, x2, True, w_sink, b_sink, first, b_first)
         sizes = [w.shape[0] for w in ws]
         none = (None,) * len(ws)
         return (dx,) + (tuple(torch.split(dw, sizes, 0)) if dw is not None else none) \
