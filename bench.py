@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-TASKS = ('mlm', 'sap', 'cfp')
+TASKS = tuple(os.environ.get('GOAT_BENCH_TASKS', 'mlm,sap,cfp').split(','))   # (diagnostics: time one task alone)
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # dense peaks, MI355X_MICROARCH.md
 # algorithmic FLOPs per trajectory-step, fwd+bwd, 1:1:1 task mix at L=80,T=5,V=36,G=22
 ALGO_GFLOP_PER_TRAJ_STEP = {'mlm': 12.98, 'sap': 9.83, 'cfp': 7.6}
