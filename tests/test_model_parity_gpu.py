@@ -275,7 +275,8 @@ def test_full_size_sample_independence_and_linearity(dtype):
             if p.grad is None:
                 continue
             d = float((p.grad.double() - 3.0 * g1[n].double()).norm())
-            assert d <= rel * max(3.0 * float(g1[n].norm()), floor * gmax), (n, d)
+            # (mathematically zero gradients — e.g. the bias behind a softmax — are rounding noise of atomically ordered sums)
+            assert d <= max(rel * max(3.0 * float(g1[n].norm()), floor * gmax), 1e-6 * gmax), (n, d)
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
 
