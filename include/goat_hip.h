@@ -197,6 +197,33 @@ int goat_embed_fwd(void* stream, int dtype, const float* word, const int64_t* id
 int goat_embed_bwd(void* stream, int dtype, const void* dout, const int64_t* ids, const int64_t* type_ids, int L,
                    float* dword, float* dtype_tab, float* dpos, int rows, int H, int vocab, int word_pad, int pos_pad);
 
+/* ---- causal-learning heads (csrc/causal.hip) -------------------------------------------------------------------
+ * tanh-attention pooling of the CFP heads: a = softmax_l(tanh(x[b,l,:])·w) over ALL L <= 256 slots (no padding mask,
+ * as the reference), out[b,:] = tanh(sum_l a_l x[b,l,:])   (P/model/pretrain_goat.py:502-515,
+ * M/models/vilmodel_GOAT.py:909-922).  x [B,L,H] in `dtype`; w float32 [H]; out float32 [B,H]; attn float32 [B,L] (saved). */
+int goat_attn_pool_fwd(void* stream, int dtype, const void* x, const float* w, float* out, float* attn, int B, int L, int H);
+/* backward: dx [B,L,H] (dtype) overwritten; dw float32 [H] accumulated (atomics; caller zero-fills). */
+int goat_attn_pool_bwd(void* stream, int dtype, const void* x, const float* w, const float* attn, const float* out,
+                       const float* dout, void* dx, float* dw, int B, int L, int H);
+
+/* "door" gate of BACL type_2 / FACL: s = sigmoid(aug·wa + ba + ori·wo + bo) per row, out = s*aug + (1-s)*ori
+ * (P/model/vilmodel_goat.py:137-143; M/models/vilmodel_GOAT.py:147-153, 548-552: two nn.Linear(H,1) + nn.Sigmoid).
+ * aug/ori/out [rows,H] in `dtype`; wa/wo float32 [H]; ba/bo float32 device scalars; gate float32 [rows] (saved). */
+int goat_door_gate_fwd(void* stream, int dtype, const void* aug, const void* ori, const float* wa, const float* wo,
+                       const float* ba, const float* bo, void* out, float* gate, int rows, int H);
+/* backward: daug/dori overwritten; dwa/dwo float32 [H] and dbias float32 [1] accumulated (caller zero-fills);
+ * dbias is the gradient of BOTH biases.  H <= 1024. */
+int goat_door_gate_bwd(void* stream, int dtype, const void* aug, const void* ori, const float* wa, const float* wo,
+                       const float* gate, const void* dout, void* daug, void* dori, float* dwa, float* dwo, float* dbias,
+                       int rows, int H);
+
+/* probability-weighted dictionary sum of BACL type_1: out[b,:] = sum_k p[b,k] z[b,k,:]
+ * (P/model/vilmodel_goat.py:115-118; M/models/vilmodel_GOAT.py:246-249).  z float32 [B,K,H], p float32 [B,K];
+ * out in dtype_out.  backward: dz = p (x) dout, dp = z·dout; either may be NULL. */
+int goat_dict_wsum_fwd(void* stream, int dtype_out, const float* z, const float* p, void* out, int B, int K, int H);
+int goat_dict_wsum_bwd(void* stream, int dtype_dout, const void* dout, const float* z, const float* p, float* dz, float* dp,
+                       int B, int K, int H);
+
 /* Debug/probe helper used by tests: fills out[64*4] with the element indices returned by
  * ds_read_b64_tr_b16 when lane l points at elements 4l..4l+3 of an LDS array holding 0,1,2,... */
 int goat_probe_tr16(void* stream, uint16_t* out);

@@ -449,3 +449,66 @@ def test_decoder_cross_entropy_fused(ops, dtype, M, N):
     _close(h.grad, hr.grad, dtype, 'ce dh')
     _close(w.grad, wr.grad, dtype, 'ce dW')
     _close(b.grad, br.grad, dtype, 'ce db')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('L', [22, 80, 200])
+def test_attn_pool(ops, dtype, L):
+    """tanh-attention pooling of the CFP heads (all slots, no mask) against the reference formula."""
+    B, H = 5, 768
+    g = torch.Generator().manual_seed(41)
+    x = (torch.randn(B, L, H, generator=g) * 0.7).to(DEV, dtype).requires_grad_(True)
+    w = torch.nn.Parameter((torch.rand(H, 1, generator=g) * 0.2 - 0.1).to(DEV))
+    out = ops.attn_pool(x, w)
+    dout = torch.randn(B, H, generator=g).to(DEV)
+    out.backward(dout)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().clone().requires_grad_(True)
+    a = torch.softmax(torch.matmul(torch.tanh(xr), wr), 1)
+    ref = torch.tanh(torch.sum(xr * a, 1))
+    ref.backward(dout)
+    assert out.dtype == torch.float32
+    _close(out, ref, dtype, 'attn_pool')
+    _close(x.grad, xr.grad, dtype, 'attn_pool dx')
+    _close(w.grad, wr.grad, dtype, 'attn_pool dw')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_door_gate(ops, dtype):
+    rows, H = 333, 768
+    g = torch.Generator().manual_seed(42)
+    aug = torch.randn(3, 111, H, generator=g).to(DEV, dtype).requires_grad_(True)
+    ori = torch.randn(3, 111, H, generator=g).to(DEV, dtype).requires_grad_(True)
+    la, lo = torch.nn.Linear(H, 1).to(DEV), torch.nn.Linear(H, 1).to(DEV)
+    out = ops.door_gate(la, lo, aug, ori)
+    dout = torch.randn(3, 111, H, generator=g).to(DEV, dtype)
+    out.backward(dout)
+    got = [aug.grad, ori.grad, la.weight.grad.clone(), la.bias.grad.clone(), lo.weight.grad.clone(), lo.bias.grad.clone()]
+    ar, orr = aug.detach().float().requires_grad_(True), ori.detach().float().requires_grad_(True)
+    for m in (la, lo):
+        m.zero_grad()
+    s = torch.sigmoid(la(ar) + lo(orr))
+    ref = s * ar + (1 - s) * orr
+    ref.backward(dout.float())
+    _close(out, ref, dtype, 'door')
+    for a, b, n in zip(got, [ar.grad, orr.grad, la.weight.grad, la.bias.grad, lo.weight.grad, lo.bias.grad],
+                       ['daug', 'dori', 'dwa', 'dba', 'dwo', 'dbo']):
+        _close(a, b, dtype, 'door ' + n)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dict_weighted_sum(ops, dtype):
+    B, K, H = 4, 39, 768
+    g = torch.Generator().manual_seed(43)
+    z = torch.rand(B, K, H, generator=g).to(DEV).requires_grad_(True)
+    p = torch.rand(B, K, 1, generator=g).to(DEV).requires_grad_(True)
+    out = ops.dict_weighted_sum(z, p, dtype)
+    dout = torch.randn(B, 1, H, generator=g).to(DEV, dtype)
+    out.backward(dout)
+    zr, pr = z.detach().clone().requires_grad_(True), p.detach().clone().requires_grad_(True)
+    ref = torch.sum(zr * pr, 1, keepdim=True)
+    ref.backward(dout.float())
+    assert out.shape == (B, 1, H) and out.dtype == dtype
+    _close(out, ref, dtype, 'dict_wsum')
+    _close(z.grad, zr.grad, dtype, 'dict_wsum dz')
+    _close(p.grad, pr.grad, dtype, 'dict_wsum dp')

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libgoat_hip.so')
-SOURCES = ['gemm.hip', 'gemm2.hip', 'attention.hip', 'rowops.hip']
+SOURCES = ['gemm.hip', 'gemm2.hip', 'attention.hip', 'rowops.hip', 'causal.hip']
 
 GOAT_F32, GOAT_BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ACCUM = 0, 1, 2, 3, 4, 5
@@ -49,6 +49,12 @@ SIGNATURES = {
     'goat_gather_segmean_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
     'goat_embed_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],
     'goat_embed_bwd': [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],
+    'goat_attn_pool_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
+    'goat_attn_pool_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
+    'goat_door_gate_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
+    'goat_door_gate_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
+    'goat_dict_wsum_fwd': [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32],
+    'goat_dict_wsum_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_probe_tr16': [_vp, _vp],
 }
 

@@ -1,0 +1,305 @@
+// Small row kernels of GOAT's causal-learning heads (HBM/latency-bound, a few MB per call):
+//   * tanh-attention pooling of the CFP heads                (P/model/pretrain_goat.py:502-515, M/models/vilmodel_GOAT.py:909-922)
+//   * the "door" gate of BACL type_2 / FACL                  (P/model/vilmodel_goat.py:137-143, M/models/vilmodel_GOAT.py:147-153,548-552)
+//   * probability-weighted dictionary sums of BACL type_1    (P/model/vilmodel_goat.py:115-118, M/models/vilmodel_GOAT.py:246-249)
+// One wave64 per row / one block per sample; f32 arithmetic; parameter gradients by block partials + one atomic per column.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threads
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ------------------------------------------------------------------------------------ tanh-attention pooling
+// a = softmax_l(tanh(x_l)·w) over ALL L slots (no padding mask, as the reference); out = tanh(sum_l a_l x_l)
+constexpr int POOL_MAXL = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ out, float* __restrict__ attn, int L,
+                                                            int H) {
+  __shared__ float sc[POOL_MAXL];
+  __shared__ float red[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* xb = x + (int64_t)b * L * H;
+  for (int l = wave; l < L; l += 4) {
+    float s = 0.f;
+    for (int i = lane; i < H; i += 64) s += tanhf(to_f(xb[(int64_t)l * H + i])) * w[i];
+    s = wave_sum(s);
+    if (lane == 0) sc[l] = s;
+  }
+  __syncthreads();
+  const float v = threadIdx.x < L ? sc[threadIdx.x] : -INFINITY;
+  const float m = block_max(v, red);
+  const float e = threadIdx.x < L ? __expf(v - m) : 0.f;
+  const float tot = block_sum(e, red);
+  if (threadIdx.x < L) {
+    sc[threadIdx.x] = e / tot;
+    attn[(int64_t)b * L + threadIdx.x] = e / tot;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H; i += 256) {
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += sc[l] * to_f(xb[(int64_t)l * H + i]);
+    out[(int64_t)b * H + i] = tanhf(s);
+  }
+}
+
+// du = dout (1 - out^2) ; da_l = x_l·du ; ds = a (da - a·da) ; dx_l = a_l du + ds_l w (1 - tanh^2 x_l) ; dw += sum_l ds_l tanh x_l
+template <typename T>
+__global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ attn, const float* __restrict__ out,
+                                                            const float* __restrict__ dout, T* __restrict__ dx,
+                                                            float* __restrict__ dw, int L, int H) {
+  extern __shared__ float sm[];   // du[H] | da[POOL_MAXL] | ds[POOL_MAXL]
+  __shared__ float red[4];
+  float* du = sm;
+  float* da = sm + H;
+  float* ds = da + POOL_MAXL;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* xb = x + (int64_t)b * L * H;
+  for (int i = threadIdx.x; i < H; i += 256) {
+    const float o = out[(int64_t)b * H + i];
+    du[i] = dout[(int64_t)b * H + i] * (1.f - o * o);
+  }
+  __syncthreads();
+  for (int l = wave; l < L; l += 4) {
+    float s = 0.f;
+    for (int i = lane; i < H; i += 64) s += to_f(xb[(int64_t)l * H + i]) * du[i];
+    s = wave_sum(s);
+    if (lane == 0) da[l] = s;
+  }
+  __syncthreads();
+  const float a = threadIdx.x < L ? attn[(int64_t)b * L + threadIdx.x] : 0.f;
+  const float dot = block_sum(threadIdx.x < L ? a * da[threadIdx.x] : 0.f, red);
+  if (threadIdx.x < L) ds[threadIdx.x] = a * (da[threadIdx.x] - dot);
+  __syncthreads();
+  for (int i = threadIdx.x; i < H; i += 256) {
+    const float wi = w[i], dui = du[i];
+    float dwi = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const float t = tanhf(to_f(xb[(int64_t)l * H + i]));
+      const float al = attn[(int64_t)b * L + l];
+      dx[((int64_t)b * L + l) * H + i] = from_f<T>(al * dui + ds[l] * wi * (1.f - t * t));
+      dwi += ds[l] * t;
+    }
+    atomicAdd(dw + i, dwi);
+  }
+}
+
+// ------------------------------------------------------------------------------------ door gate
+// s = sigmoid(aug·wa + ba + ori·wo + bo) ; out = s*aug + (1-s)*ori       (one wave per row)
+template <typename T>
+__global__ __launch_bounds__(256) void door_fwd_kernel(const T* __restrict__ aug, const T* __restrict__ ori,
+                                                       const float* __restrict__ wa, const float* __restrict__ wo,
+                                                       const float* __restrict__ ba, const float* __restrict__ bo,
+                                                       T* __restrict__ out, float* __restrict__ gate, int rows, int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* a = aug + (int64_t)row * H;
+  const T* o = ori + (int64_t)row * H;
+  float g = 0.f;
+  for (int i = lane; i < H; i += 64) g += to_f(a[i]) * wa[i] + to_f(o[i]) * wo[i];
+  g = wave_sum(g) + ba[0] + bo[0];
+  const float s = 1.f / (1.f + __expf(-g));
+  if (lane == 0) gate[row] = s;
+  for (int i = lane; i < H; i += 64) out[(int64_t)row * H + i] = from_f<T>(s * to_f(a[i]) + (1.f - s) * to_f(o[i]));
+}
+
+// dgate = dout·(aug-ori) ; dpre = dgate s (1-s) ; daug = s dout + dpre wa ; dori = (1-s) dout + dpre wo ;
+// dwa += sum_rows dpre aug ; dwo += sum_rows dpre ori ; dbias += sum_rows dpre   (the two biases share it)
+constexpr int DOOR_MAXC = 16;   // columns per lane kept in registers: H <= 64*16
+template <typename T>
+__global__ __launch_bounds__(256) void door_bwd_kernel(const T* __restrict__ aug, const T* __restrict__ ori,
+                                                       const float* __restrict__ wa, const float* __restrict__ wo,
+                                                       const float* __restrict__ gate, const T* __restrict__ dout,
+                                                       T* __restrict__ daug, T* __restrict__ dori, float* __restrict__ dwa,
+                                                       float* __restrict__ dwo, float* __restrict__ dbias, int rows, int H) {
+  extern __shared__ float sm[];   // [4 waves][2][H]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float pa[DOOR_MAXC], po[DOOR_MAXC], pb = 0.f;
+#pragma unroll
+  for (int j = 0; j < DOOR_MAXC; ++j) { pa[j] = 0.f; po[j] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const T* a = aug + (int64_t)row * H;
+    const T* o = ori + (int64_t)row * H;
+    const T* d = dout + (int64_t)row * H;
+    const float s = gate[row];
+    float dg = 0.f;
+    for (int i = lane; i < H; i += 64) dg += to_f(d[i]) * (to_f(a[i]) - to_f(o[i]));
+    dg = wave_sum(dg);
+    const float dpre = dg * s * (1.f - s);
+    pb += dpre;
+#pragma unroll
+    for (int j = 0; j < DOOR_MAXC; ++j) {
+      const int i = lane + 64 * j;
+      if (i < H) {
+        const float dv = to_f(d[i]), av = to_f(a[i]), ov = to_f(o[i]);
+        daug[(int64_t)row * H + i] = from_f<T>(s * dv + dpre * wa[i]);
+        dori[(int64_t)row * H + i] = from_f<T>((1.f - s) * dv + dpre * wo[i]);
+        pa[j] += dpre * av;
+        po[j] += dpre * ov;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < DOOR_MAXC; ++j) {
+    const int i = lane + 64 * j;
+    if (i < H) { sm[(wave * 2 + 0) * H + i] = pa[j]; sm[(wave * 2 + 1) * H + i] = po[j]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * H; i += 256) {
+    const int which = i / H, col = i % H;
+    const float v = sm[(0 * 2 + which) * H + col] + sm[(1 * 2 + which) * H + col] + sm[(2 * 2 + which) * H + col] +
+                    sm[(3 * 2 + which) * H + col];
+    atomicAdd((which ? dwo : dwa) + col, v);
+  }
+  if (lane == 0) atomicAdd(dbias, pb);   // (each wave's rows; lanes hold the same value after wave_sum)
+}
+
+// ------------------------------------------------------------------------------------ weighted dictionary sum
+// out[b,:] = sum_k p[b,k] z[b,k,:]
+template <typename T>
+__global__ __launch_bounds__(256) void dict_wsum_fwd_kernel(const float* __restrict__ z, const float* __restrict__ p,
+                                                            T* __restrict__ out, int K, int H) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < H; i += 256) {
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += p[(int64_t)b * K + k] * z[((int64_t)b * K + k) * H + i];
+    out[(int64_t)b * H + i] = from_f<T>(s);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dict_wsum_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ z,
+                                                            const float* __restrict__ p, float* __restrict__ dz,
+                                                            float* __restrict__ dp, int K, int H) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* d = dout + (int64_t)b * H;
+  if (dz)
+    for (int k = 0; k < K; ++k) {
+      const float pk = p[(int64_t)b * K + k];
+      for (int i = threadIdx.x; i < H; i += 256) dz[((int64_t)b * K + k) * H + i] = pk * to_f(d[i]);
+    }
+  if (dp)
+    for (int k = wave; k < K; k += 4) {
+      float s = 0.f;
+      for (int i = lane; i < H; i += 64) s += z[((int64_t)b * K + k) * H + i] * to_f(d[i]);
+      s = wave_sum(s);
+      if (lane == 0) dp[(int64_t)b * K + k] = s;
+    }
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int goat_attn_pool_fwd(void* stream, int dtype, const void* x, const float* w, float* out, float* attn, int B,
+                                  int L, int H) {
+  if (!x || !w || !out || !attn) return GOAT_E_ARG;
+  if (B <= 0 || L <= 0 || L > POOL_MAXL || H <= 0) return GOAT_E_SHAPE;
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(attn_pool_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, ST(stream), (const bf16_t*)x, w, out, attn, L, H);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(attn_pool_fwd_kernel<float>, dim3(B), dim3(256), 0, ST(stream), (const float*)x, w, out, attn, L, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_attn_pool_bwd(void* stream, int dtype, const void* x, const float* w, const float* attn,
+                                  const float* out, const float* dout, void* dx, float* dw, int B, int L, int H) {
+  if (!x || !w || !attn || !out || !dout || !dx || !dw) return GOAT_E_ARG;
+  if (B <= 0 || L <= 0 || L > POOL_MAXL || H <= 0 || H > 8192) return GOAT_E_SHAPE;
+  const size_t sm = (size_t)(H + 2 * POOL_MAXL) * sizeof(float);
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(attn_pool_bwd_kernel<bf16_t>, dim3(B), dim3(256), sm, ST(stream), (const bf16_t*)x, w, attn, out, dout,
+                       (bf16_t*)dx, dw, L, H);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(attn_pool_bwd_kernel<float>, dim3(B), dim3(256), sm, ST(stream), (const float*)x, w, attn, out, dout,
+                       (float*)dx, dw, L, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_door_gate_fwd(void* stream, int dtype, const void* aug, const void* ori, const float* wa,
+                                  const float* wo, const float* ba, const float* bo, void* out, float* gate, int rows, int H) {
+  if (!aug || !ori || !wa || !wo || !ba || !bo || !out || !gate) return GOAT_E_ARG;
+  if (rows <= 0 || H <= 0) return GOAT_E_SHAPE;
+  const int blocks = (rows + 3) / 4;
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(door_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST(stream), (const bf16_t*)aug, (const bf16_t*)ori,
+                       wa, wo, ba, bo, (bf16_t*)out, gate, rows, H);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(door_fwd_kernel<float>, dim3(blocks), dim3(256), 0, ST(stream), (const float*)aug, (const float*)ori,
+                       wa, wo, ba, bo, (float*)out, gate, rows, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_door_gate_bwd(void* stream, int dtype, const void* aug, const void* ori, const float* wa,
+                                  const float* wo, const float* gate, const void* dout, void* daug, void* dori, float* dwa,
+                                  float* dwo, float* dbias, int rows, int H) {
+  if (!aug || !ori || !wa || !wo || !gate || !dout || !daug || !dori || !dwa || !dwo || !dbias) return GOAT_E_ARG;
+  if (rows <= 0 || H <= 0 || H > 64 * DOOR_MAXC) return GOAT_E_SHAPE;
+  int blocks = (rows + 3) / 4;
+  if (blocks > 256) blocks = 256;
+  const size_t sm = (size_t)8 * H * sizeof(float);
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(door_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), sm, ST(stream), (const bf16_t*)aug, (const bf16_t*)ori,
+                       wa, wo, gate, (const bf16_t*)dout, (bf16_t*)daug, (bf16_t*)dori, dwa, dwo, dbias, rows, H);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(door_bwd_kernel<float>, dim3(blocks), dim3(256), sm, ST(stream), (const float*)aug, (const float*)ori,
+                       wa, wo, gate, (const float*)dout, (float*)daug, (float*)dori, dwa, dwo, dbias, rows, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_dict_wsum_fwd(void* stream, int dtype_out, const float* z, const float* p, void* out, int B, int K,
+                                  int H) {
+  if (!z || !p || !out) return GOAT_E_ARG;
+  if (B <= 0 || K <= 0 || H <= 0) return GOAT_E_SHAPE;
+  if (dtype_out == GOAT_BF16)
+    hipLaunchKernelGGL(dict_wsum_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, ST(stream), z, p, (bf16_t*)out, K, H);
+  else if (dtype_out == GOAT_F32)
+    hipLaunchKernelGGL(dict_wsum_fwd_kernel<float>, dim3(B), dim3(256), 0, ST(stream), z, p, (float*)out, K, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_dict_wsum_bwd(void* stream, int dtype_dout, const void* dout, const float* z, const float* p,
+                                  float* dz, float* dp, int B, int K, int H) {
+  if (!dout || !z || !p) return GOAT_E_ARG;
+  if (B <= 0 || K <= 0 || H <= 0) return GOAT_E_SHAPE;
+  if (!dz && !dp) return 0;
+  if (dtype_dout == GOAT_BF16)
+    hipLaunchKernelGGL(dict_wsum_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, ST(stream), (const bf16_t*)dout, z, p, dz, dp, K, H);
+  else if (dtype_dout == GOAT_F32)
+    hipLaunchKernelGGL(dict_wsum_bwd_kernel<float>, dim3(B), dim3(256), 0, ST(stream), (const float*)dout, z, p, dz, dp, K, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}

@@ -1097,4 +1097,117 @@ def embedding(ids, word, type_tab=None, type_ids=None, pos_tab=None, out_dtype=N
     return _EmbedFn.apply(ids, word, type_tab, type_ids, pos_tab, out_dtype or word.dtype, word_pad, pos_pad)
 
 
+# ----------------------------------------------------------------------------- causal-learning heads
+class _AttnPoolFn(torch.autograd.Function):
+    """out = tanh(sum_l softmax_l(tanh(x_l)·w) x_l), all slots, no padding mask (P/model/pretrain_goat.py:502-515)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _need_gpu(x)
+        x = x if x.is_contiguous() else x.contiguous()
+        B, L, H = x.shape
+        wv = w.detach().reshape(-1).float().contiguous()
+        out = torch.empty((B, H), dtype=torch.float32, device=x.device)
+        attn = torch.empty((B, L), dtype=torch.float32, device=x.device)
+        st = _lib.lib().goat_attn_pool_fwd(_stream(), _dt(x), _ptr(x), _ptr(wv), _ptr(out), _ptr(attn), B, L, H)
+        _lib.check(st, 'goat_attn_pool_fwd')
+        ctx.save_for_backward(x, wv, attn, out)
+        ctx.wshape = w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wv, attn, out = ctx.saved_tensors
+        B, L, H = x.shape
+        dout = dout.float().contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.zeros(H, dtype=torch.float32, device=x.device)
+        st = _lib.lib().goat_attn_pool_bwd(_stream(), _dt(x), _ptr(x), _ptr(wv), _ptr(attn), _ptr(out), _ptr(dout), _ptr(dx),
+                                           _ptr(dw), B, L, H)
+        _lib.check(st, 'goat_attn_pool_bwd')
+        return dx, dw.view(ctx.wshape)
+
+
+def attn_pool(x, w):
+    return _AttnPoolFn.apply(x, w)
+
+
+class _DoorGateFn(torch.autograd.Function):
+    """s = sigmoid(Linear_a(aug) + Linear_o(ori)) per token; out = s*aug + (1-s)*ori (P/model/vilmodel_goat.py:137-143)."""
+
+    @staticmethod
+    def forward(ctx, aug, ori, wa, ba, wo, bo):
+        _need_gpu(aug)
+        H = aug.shape[-1]
+        a2 = aug.reshape(-1, H)
+        o2 = ori.reshape(-1, H).to(a2.dtype)
+        a2 = a2 if a2.is_contiguous() else a2.contiguous()
+        o2 = o2 if o2.is_contiguous() else o2.contiguous()
+        wav, wov = wa.detach().reshape(-1).contiguous(), wo.detach().reshape(-1).contiguous()
+        rows = a2.shape[0]
+        out = torch.empty_like(a2)
+        gate = torch.empty(rows, dtype=torch.float32, device=a2.device)
+        st = _lib.lib().goat_door_gate_fwd(_stream(), _dt(a2), _ptr(a2), _ptr(o2), _ptr(wav), _ptr(wov), _ptr(ba.detach()),
+                                           _ptr(bo.detach()), _ptr(out), _ptr(gate), rows, H)
+        _lib.check(st, 'goat_door_gate_fwd')
+        ctx.save_for_backward(a2, o2, wav, wov, gate)
+        ctx.shapes = (aug.shape, ori.shape, ori.dtype, wa.shape, wo.shape)
+        return out.view(aug.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a2, o2, wav, wov, gate = ctx.saved_tensors
+        ashape, oshape, odtype, washape, woshape = ctx.shapes
+        rows, H = a2.shape
+        d2 = dout.reshape(rows, H).to(a2.dtype)
+        d2 = d2 if d2.is_contiguous() else d2.contiguous()
+        daug, dori = torch.empty_like(a2), torch.empty_like(a2)
+        buf = torch.zeros(2 * H + 1, dtype=torch.float32, device=a2.device)
+        st = _lib.lib().goat_door_gate_bwd(_stream(), _dt(a2), _ptr(a2), _ptr(o2), _ptr(wav), _ptr(wov), _ptr(gate), _ptr(d2),
+                                           _ptr(daug), _ptr(dori), _ptr(buf), _ptr(buf, H), _ptr(buf, 2 * H), rows, H)
+        _lib.check(st, 'goat_door_gate_bwd')
+        db = buf[2 * H:]          # both biases receive the same gradient (distinct tensors: autograd may keep them as .grad)
+        return daug.view(ashape), dori.view(oshape).to(odtype), buf[:H].view(washape), db, buf[H:2 * H].view(woshape), db.clone()
+
+
+def door_gate(aug_lin, ori_lin, aug, ori):
+    """aug_lin / ori_lin: the two Linear(H,1) modules of the gate (their weights [1,H] and biases [1])."""
+    return _DoorGateFn.apply(aug, ori, aug_lin.weight, aug_lin.bias, ori_lin.weight, ori_lin.bias)
+
+
+class _DictWsumFn(torch.autograd.Function):
+    """out[b,1,:] = sum_k p[b,k] z[b,k,:] (BACL type_1 confounder expectation, P/model/vilmodel_goat.py:115-118)."""
+
+    @staticmethod
+    def forward(ctx, z, p, out_dtype):
+        _need_gpu(z)
+        zf = z.float().contiguous()
+        pf = p.float().reshape(p.shape[0], p.shape[1]).contiguous()
+        B, K, H = zf.shape
+        out = torch.empty((B, 1, H), dtype=out_dtype, device=z.device)
+        st = _lib.lib().goat_dict_wsum_fwd(_stream(), _dt(out), _ptr(zf), _ptr(pf), _ptr(out), B, K, H)
+        _lib.check(st, 'goat_dict_wsum_fwd')
+        ctx.save_for_backward(zf, pf)
+        ctx.meta = (z.dtype, p.shape, p.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        zf, pf = ctx.saved_tensors
+        zdtype, pshape, pdtype = ctx.meta
+        B, K, H = zf.shape
+        d2 = dout.reshape(B, H)
+        d2 = d2 if d2.is_contiguous() else d2.contiguous()
+        dz = torch.empty_like(zf) if ctx.needs_input_grad[0] else None
+        dp = torch.empty_like(pf) if ctx.needs_input_grad[1] else None
+        st = _lib.lib().goat_dict_wsum_bwd(_stream(), _dt(d2), _ptr(d2), _ptr(zf), _ptr(pf), _ptr(dz) if dz is not None else None,
+                                           _ptr(dp) if dp is not None else None, B, K, H)
+        _lib.check(st, 'goat_dict_wsum_bwd')
+        return (dz.to(zdtype) if dz is not None else None, dp.view(pshape).to(pdtype) if dp is not None else None, None)
+
+
+def dict_weighted_sum(z, p, out_dtype):
+    return _DictWsumFn.apply(z, p, out_dtype)
+
+
 load_tuned()

@@ -24,8 +24,7 @@ from .pretrain_model import GoatPreTrainedModel, attn_pool
 def _door(aug_lin, ori_lin, aug, ori):
     """door gate: w = sigmoid(Linear_a(aug) + Linear_o(ori)); out = w*aug + (1-w)*ori
     (M/models/vilmodel_GOAT.py:147-153, 548-552)."""
-    w = torch.sigmoid(aug_lin(aug).float() + ori_lin(ori).float()).to(aug.dtype)
-    return w * aug + (1 - w) * ori
+    return hipops.door_gate(aug_lin, ori_lin, aug, ori)
 
 
 class LanguageEncoder(nn.Module):
@@ -91,8 +90,8 @@ class LanguageEncoderDo(nn.Module):
         z_front = None
         if cfg.do_back_txt_type == 'type_1':
             if cfg.do_back_txt:
-                sd = torch.sum(z_direc.float() * z_direc_pzs.float(), 1, keepdim=True).to(dt)
-                sl = torch.sum(z_landm.float() * z_landm_pzs.float(), 1, keepdim=True).to(dt)
+                sd = hipops.dict_weighted_sum(z_direc, z_direc_pzs, dt)
+                sl = hipops.dict_weighted_sum(z_landm, z_landm_pzs, dt)
                 txt_embeds = self.z_txt_linear(txt_embeds) + self.z_direct_linear(sd) + self.z_landm_linear(sl)
             if cfg.do_front_txt and front_txt is not None:
                 zf = self.z_front_cross_attn(txt_embeds, None, front_txt.to(dt), None)
@@ -175,7 +174,7 @@ class CausalImageEmbeddings(nn.Module):
         dt = x.dtype
         z = self.do_img_layer_norm(self.do_img_before_linear(z_img_features.to(dt)))
         if cfg.do_back_img_type == 'type_1':
-            s = torch.sum(z.float() * z_img_pzs.float(), 1, keepdim=True).to(dt)
+            s = hipops.dict_weighted_sum(z, z_img_pzs, dt)
             x = self.img_after_linear(x) + self.do_img_after_linear(s)
         else:
             z = self.do_img_attn(x, None, z, None)

@@ -88,8 +88,7 @@ class LanguageEncoder(nn.Module):
 
 def _door(aug_lin, ori_lin, aug, ori):
     """door gate: w = sigmoid(Linear_a(aug) + Linear_o(ori)); out = w*aug + (1-w)*ori (P/model/vilmodel_goat.py:137-143)."""
-    w = torch.sigmoid(aug_lin(aug).float() + ori_lin(ori).float()).to(aug.dtype)
-    return w * aug + (1 - w) * ori
+    return hipops.door_gate(aug_lin, ori_lin, aug, ori)
 
 
 class LanguageEncoderDo(nn.Module):
@@ -147,8 +146,8 @@ class LanguageEncoderDo(nn.Module):
             if cfg.z_cross_attn:       # dictionary entries attend to the (key-masked) text
                 z_direc = self.z_direc_cross_attn(z_direc, None, txt_embeds, txt_kmask)
                 z_landm = self.z_landm_cross_attn(z_landm, None, txt_embeds, txt_kmask)
-            sd = torch.sum(z_direc.float() * z_direc_pzs.float(), 1, keepdim=True).to(dt)
-            sl = torch.sum(z_landm.float() * z_landm_pzs.float(), 1, keepdim=True).to(dt)
+            sd = hipops.dict_weighted_sum(z_direc, z_direc_pzs, dt)
+            sl = hipops.dict_weighted_sum(z_landm, z_landm_pzs, dt)
             txt_embeds = self.z_txt_linear(txt_embeds) + self.z_direct_linear(sd) + self.z_landm_linear(sl)
             return self.z_concat_layernorm(txt_embeds)
         # type_2: the text attends to each dictionary (no key mask on dictionary entries)
@@ -378,10 +377,8 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
 
 
 def attn_pool(x, w):
-    """tanh-attention pooling over ALL slots, no padding mask (P/model/pretrain_goat.py:502-515)."""
-    xf = x.float()
-    a = torch.softmax(torch.matmul(torch.tanh(xf), w), 1)
-    return torch.tanh(torch.sum(xf * a, 1))
+    """tanh-attention pooling over ALL slots, no padding mask (P/model/pretrain_goat.py:502-515); float32 [B,H]."""
+    return hipops.attn_pool(x, w)
 
 
 def cfp_losses(gmap_o, vp_o, fused_o, txt_o, temperature, gather=None):
