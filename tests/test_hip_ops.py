@@ -512,3 +512,33 @@ def test_dict_weighted_sum(ops, dtype):
     _close(out, ref, dtype, 'dict_wsum')
     _close(z.grad, zr.grad, dtype, 'dict_wsum dz')
     _close(p.grad, pr.grad, dtype, 'dict_wsum dp')
+
+
+@pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize('bm,ns', [(64, 2), (64, 3), (64, 4), (128, 2), (128, 3), (128, 4)])
+def test_gemm_bf16_every_tile_configuration(ops, ta, tb, bm, ns):
+    """Every (tile height, ring depth) the autotuner may pick, on a ragged shape, incl. GELU / C += A·B / split-K epilogues."""
+    from vln_goat_amd._lib import EPI_ACCUM, EPI_GELU, EPI_NONE
+    M, N, Kc = 1000, 392, 320 if not (ta and tb) else 328
+    g = torch.Generator().manual_seed(bm * 7 + ns)
+    A = torch.randn(M, Kc, generator=g)
+    B = torch.randn(N, Kc, generator=g) * 0.1
+    a = (A.T.contiguous() if ta else A).to(DEV, torch.bfloat16)
+    b = (B.T.contiguous() if tb else B).to(DEV, torch.bfloat16)
+    ref = (a.float().T if ta else a.float()) @ (b.float() if tb else b.float().T)
+    bias = torch.randn(N, generator=g).to(DEV)
+
+    def run(out, epi=EPI_NONE, aux=None, split=1, bias_=None):
+        ops._launch_gemm_bf16(a, b, out, ta, tb, M, N, Kc, bias_, epi, aux, split, bm, ns, None)
+        return out
+    out = run(torch.empty(M, N, device=DEV, dtype=torch.bfloat16), bias_=bias)
+    _close(out, ref + bias, torch.bfloat16, 'plain')
+    if not (bm == 128 and ns == 4):      # (the activation epilogues of the 128-row tile are built for 2-3 ring slots)
+        aux = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        out = run(torch.empty(M, N, device=DEV, dtype=torch.bfloat16), EPI_GELU, aux, bias_=bias)
+        _close(aux, ref + bias, torch.bfloat16, 'gelu pre-activation')
+        _close(out, torch.nn.functional.gelu(ref + bias), torch.bfloat16, 'gelu')
+    acc = run(torch.full((M, N), 2.0, device=DEV), EPI_ACCUM)
+    _close(acc - 2.0, ref, torch.bfloat16, 'accumulate')
+    acc = run(torch.full((M, N), -1.0, device=DEV), split=3)
+    _close(acc + 1.0, ref, torch.bfloat16, 'split-K')
