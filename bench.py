@@ -192,7 +192,7 @@ def cpu_baseline(args, cfg):
                       '(mlm/sap/cfp cycled) after 1 warm-up step, %d torch threads' % (B, len(times), ncores)}
 
 
-def gemm_roofline(args, model, gb):
+def gemm_roofline(args, model, gb, arena=None):
     """MFMA roofline of the dominant kernel family (goat_gemm_bf16 / goat_gemm_nt).
 
     One eager mlm+sap+cfp cycle records every GEMM launch (shape, pointers; the operand tensors are kept alive).
@@ -203,8 +203,11 @@ def gemm_roofline(args, model, gb):
     from vln_goat_amd import hipops, _lib
     hipops.PROFILE = []
     for task in TASKS:
-        for p in model.parameters():
-            p.grad = None
+        if arena is not None:
+            arena.zero(task)                 # same launch set as the timed steps (grouped weight gradients included)
+        else:
+            for p in model.parameters():
+                p.grad = None
         loss = model(gb, task, compute_loss=True)
         loss.mean().backward()
     hipops.WgradOverlap.join()
@@ -254,13 +257,16 @@ def gemm_roofline(args, model, gb):
         traffic, tsrc = round(tj['traffic_bytes_per_launch']), 'profiles/round1_pmc_gemm_traffic.json'
     algo_bytes = 0.0
     for r in recs:
+        if r[3][0] == 'grouped wgrad':
+            algo_bytes += r[3][2]
+            continue
         M_, N_, K_, epi_, split_ = r[3][:5]
         f32out = r[4][1][2] == 0 if r[4][0] == 'goat_gemm_bf16' else False
         algo_bytes += (M_ * K_ + N_ * K_) * 2 + M_ * N_ * (4 if f32out else 2) * (2 if epi_ in (1, 2) else 1) \
             + (M_ * N_ * 2 if epi_ in (3, 4) else 0)
     return {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'traffic': traffic, 'traffic_unit': 'bytes/launch (L2-miss reads x2-corrected + writes; rocprofv3 --pmc)',
-            'traffic_source': tsrc, 'algorithmic_bytes_per_launch': round(algo_bytes / max(n, 1)), 'kernel': 'gemm2_kernel (goat_gemm_bf16) + gemm_nt_kernel', 'launches_per_cycle': n,
+            'traffic_source': tsrc, 'algorithmic_bytes_per_launch': round(algo_bytes / max(n, 1)), 'kernel': 'gemm2_kernel / gemm2_group_kernel (goat_gemm_bf16, goat_wgrad_grouped) + gemm_nt_kernel', 'launches_per_cycle': n,
             'avg_launch_us': round(tot_ms * 1e3 / max(n, 1), 2),
             'algorithmic_gflop_per_launch': round(tot_fl / max(n, 1) / 1e9, 3),
             'gemm_ms_per_cycle': round(tot_ms, 3),
@@ -318,7 +324,7 @@ def main():
             'step_mfma_frac': round(value / world * algo * 1e9 / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4),
         }
         if world == 1 and not args.no_roofline:
-            out['roofline'] = gemm_roofline(args, model, gb)
+            out['roofline'] = gemm_roofline(args, model, gb, wrapper.arena)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, cfg)
         if os.environ.get('GOAT_SAVE_TUNED'):      # persist the autotuned GEMM table (copied to vln-goat_amd/tuned_gfx950.json)

@@ -181,6 +181,22 @@ int goat_gather_segmean_bwd(void* stream, int dtype, const void* dout,
                             const int32_t* idx, const int32_t* start, const float* scale,
                             float* dsrc32, int n_out, int H);
 
+/* Grouped weight gradients: n <= 16 independent problems dW_i[n_out,n_in] (float32) = dY_i[rows,n_out]^T · X_i[rows,n_in]
+ * (bf16 operands, any row count — the contraction tail is zero-filled) in ONE launch of the goat_gemm_bf16 tile
+ * kernel, unsplit.  The autograd of the several nn.Linear of a transformer block (P/model/Bert_backbone.py:170-172,302,
+ * 348,362) produces weight gradients of 36-144 tiles each; together they fill the 256 CUs without the split-K atomics
+ * and zero fills a single small problem needs.  accumulate != 0: dW += ...; dbias (may be NULL): float32 [n_out],
+ * += column sums of dY (atomic; the caller clears it).  ld_* in elements; ld_dy, ld_x multiples of 8, bases 16-B aligned. */
+typedef struct goat_wgrad_problem {
+  const void* dy; int64_t ld_dy;
+  const void* x; int64_t ld_x;
+  float* dw; int64_t ld_dw;
+  float* dbias;
+  int rows, n_out, n_in;
+  int accumulate;
+} goat_wgrad_problem;
+int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs, int n, int bm, int nstage);
+
 /* Embedding tables (float32 masters):  out[r,:] = word[ids[r],:] + type[type_ids ? type_ids[r] : 0,:] + pos[r % L,:]
  * cast to `dtype` — the three nn.Embedding lookups and two adds of BertEmbeddings.forward
  * (P/model/Bert_backbone.py:98-113; the reference's position ids are arange(L) for every sample), and with

@@ -26,7 +26,7 @@ def fam_avg(d, counter):
     n = s = 0
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            if ('gemm2_kernel' in r['Kernel_Name'] or 'gemm_nt_kernel' in r['Kernel_Name']) and r['Counter_Name'] == counter:
+            if ('gemm2_' in r['Kernel_Name'] or 'gemm_nt_kernel' in r['Kernel_Name']) and r['Counter_Name'] == counter:
                 n += 1; s += float(r['Counter_Value'])
     return n, (s / n if n else None)
 nf, f = fam_avg(out + '/pmc_FETCH_SIZE', 'FETCH_SIZE')

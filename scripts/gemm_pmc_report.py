@@ -3,7 +3,7 @@ import csv, glob, json, sys
 order = json.load(open(sys.argv[1]))
 def series(d, counter):
     f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if 'gemm2_kernel' in r['Kernel_Name'] and r['Counter_Name'] == counter]
+    rows = [r for r in csv.DictReader(open(f)) if 'gemm2_' in r['Kernel_Name'] and r['Counter_Name'] == counter]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     return [float(r['Counter_Value']) for r in rows]
 fs, ws = series(sys.argv[2], 'FETCH_SIZE'), series(sys.argv[3], 'WRITE_SIZE')

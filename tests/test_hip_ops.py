@@ -542,3 +542,40 @@ def test_gemm_bf16_every_tile_configuration(ops, ta, tb, bm, ns):
     _close(acc - 2.0, ref, torch.bfloat16, 'accumulate')
     acc = run(torch.full((M, N), -1.0, device=DEV), split=3)
     _close(acc + 1.0, ref, torch.bfloat16, 'split-K')
+
+
+def test_wgrad_grouped(ops):
+    """goat_wgrad_grouped: several dW_i = dY_i^T · X_i problems of different shapes (ragged rows, row-strided dY) in one
+    launch, with bias column sums; both tile heights."""
+    import ctypes
+    from vln_goat_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    shapes = [(3840, 768, 768), (1000, 2304, 768), (333, 768, 3072), (3840, 3072, 768), (37, 8, 768), (576, 1001, 768)]
+    for bm, ns in ((64, 3), (128, 2)):
+        arr = (_lib.WgradProblem * len(shapes))()
+        keep, refs = [], []
+        for i, (rows, n_out, n_in) in enumerate(shapes):
+            ld = (n_out + 7) // 8 * 8 + 8                                   # row-strided dY (a column slice of a wider buffer)
+            dyb = (torch.randn(rows, ld, generator=g) * 0.5).to(DEV, torch.bfloat16)
+            dy = dyb[:, :n_out]
+            x = torch.randn(rows, n_in, generator=g).to(DEV, torch.bfloat16)
+            dw = torch.full((n_out, n_in), 7.0, device=DEV)                  # stale contents: the launch overwrites
+            db = torch.zeros(n_out, device=DEV)
+            q = arr[i]
+            q.dy, q.ld_dy, q.x, q.ld_x, q.dw, q.ld_dw, q.dbias = dy.data_ptr(), ld, x.data_ptr(), n_in, dw.data_ptr(), n_in, db.data_ptr()
+            q.rows, q.n_out, q.n_in, q.accumulate = rows, n_out, n_in, 0
+            keep.append((dyb, x, dw, db))
+            refs.append((dy.float().T @ x.float(), dy.float().sum(0)))
+        st = _lib.lib().goat_wgrad_grouped(torch.cuda.current_stream().cuda_stream, ctypes.addressof(arr), len(shapes), bm, ns)
+        assert st == 0
+        for (_, _, dw, db), (rw, rb) in zip(keep, refs):
+            _close(dw, rw, torch.bfloat16, 'grouped dW')
+            _close(db, rb, torch.bfloat16, 'grouped dbias')
+        # accumulate flag: second launch adds on top
+        for i in range(len(shapes)):
+            arr[i].accumulate = 1
+            arr[i].dbias = None
+        st = _lib.lib().goat_wgrad_grouped(torch.cuda.current_stream().cuda_stream, ctypes.addressof(arr), len(shapes), bm, ns)
+        assert st == 0
+        for (_, _, dw, _), (rw, _) in zip(keep, refs):
+            _close(dw, 2 * rw, torch.bfloat16, 'grouped dW accumulate')

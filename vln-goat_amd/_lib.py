@@ -55,8 +55,16 @@ SIGNATURES = {
     'goat_door_gate_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
     'goat_dict_wsum_fwd': [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_dict_wsum_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
+    'goat_wgrad_grouped': [_vp, _vp, _i32, _i32, _i32],
     'goat_probe_tr16': [_vp, _vp],
 }
+
+
+class WgradProblem(ctypes.Structure):
+    """struct goat_wgrad_problem (include/goat_hip.h)."""
+    _fields_ = [('dy', ctypes.c_void_p), ('ld_dy', ctypes.c_int64), ('x', ctypes.c_void_p), ('ld_x', ctypes.c_int64),
+                ('dw', ctypes.c_void_p), ('ld_dw', ctypes.c_int64), ('dbias', ctypes.c_void_p),
+                ('rows', ctypes.c_int), ('n_out', ctypes.c_int), ('n_in', ctypes.c_int), ('accumulate', ctypes.c_int)]
 
 
 def build(force=False, verbose=False):

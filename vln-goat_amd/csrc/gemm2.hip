@@ -100,9 +100,16 @@ __device__ __forceinline__ uint32_t frag_addr_t(uint32_t tile_base, int kr, int 
   return tile_base + kr * RB + ((((c64 << 2) | (slot & 3))) << 4) + (byte & 15);
 }
 
+// blockIdx.x -> position in an order that gives every XCD (8 private L2s, workgroups dealt round-robin) ONE contiguous chunk
+__device__ __forceinline__ int xcd_chunk_position(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// One output tile of one GEMM problem.  `bid` = position of the tile in the problem's tile order, `split` = K-split index.
 template <bool TA, bool TB, typename OutT, int EPI, bool SPLITK, int BM, int NSTAGE>
-__global__ __launch_bounds__(NT) void gemm2_kernel(G2Args p) {
-#if defined(__HIP_DEVICE_COMPILE__)  // (host pass: the gfx950-only builtins below would silently drop the kernel stub)
+__device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (host pass: the gfx950-only builtins below would silently drop the kernel stubs)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Tile<TA, BM> TLA;
   typedef Tile<TB, BN> TLB;
@@ -114,12 +121,7 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(G2Args p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int hi = lane >> 5, l31 = lane & 31;
 
-  int nwg = gridDim.x, bid = blockIdx.x;
-  {
-    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  // `bid` now walks a contiguous chunk per XCD (each XCD has its own L2).  Inside the chunk tiles are visited
+  // `bid` walks a contiguous chunk per XCD (each XCD has its own L2).  Inside the chunk tiles are visited
   // column-major within groups of group_m tile rows, so the ~64 workgroups an XCD runs at a time cover a compact
   // group_m x (64/group_m) block: its A and B panels are fetched into that L2 once, and the 8 XCD chunks form a 2-D
   // partition of C instead of 8 full-width stripes (measured: L2-miss traffic 8.3x -> see profiles/ of the algorithmic bytes).
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(G2Args p) {
 
   int kt_begin = 0, kt_end = (p.Kc + BK - 1) / BK;
   if (SPLITK) {
-    kt_begin = blockIdx.y * p.k_tiles_per_split;
+    kt_begin = split * p.k_tiles_per_split;
     kt_end = min(kt_end, kt_begin + p.k_tiles_per_split);
     if (kt_begin >= kt_end) return;
   }
@@ -392,6 +394,31 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(G2Args p) {
 }
 
 template <bool TA, bool TB, typename OutT, int EPI, bool SPLITK, int BM, int NSTAGE>
+__global__ __launch_bounds__(NT) void gemm2_kernel(G2Args p) {
+  gemm2_tile<TA, TB, OutT, EPI, SPLITK, BM, NSTAGE>(p, xcd_chunk_position(blockIdx.x, gridDim.x), blockIdx.y);
+}
+
+// Grouped weight-gradient launch: up to GROUP_MAX (16) independent TN problems (dW_i = dY_i^T · X_i, float32 out, unsplit)
+// share one grid, so the many small weight gradients of a layer fill the chip together instead of each being split
+// along the contraction (atomics + a zero fill) to do so.  Problem i owns tiles [tile_start[i], tile_start[i+1]).
+constexpr int GROUP_MAX = 16;
+struct GroupArgs {
+  G2Args prob[GROUP_MAX];
+  int tile_start[GROUP_MAX + 1];
+  int n;
+};
+template <int BM, int NSTAGE>
+__global__ __launch_bounds__(NT) void gemm2_group_kernel(GroupArgs g) {
+  const int pos = xcd_chunk_position(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i)
+    if (i < g.n && pos >= g.tile_start[i]) pi = i;
+  const G2Args p = g.prob[pi];
+  gemm2_tile<true, true, float, GOAT_EPI_NONE, false, BM, NSTAGE>(p, pos - g.tile_start[pi], 0);
+}
+
+template <bool TA, bool TB, typename OutT, int EPI, bool SPLITK, int BM, int NSTAGE>
 int launch2s(hipStream_t st, const G2Args& a, int split) {
   constexpr int SMEM = NSTAGE * (Tile<TA, BM>::BYTES + Tile<TB, BN>::BYTES);
   auto kern = gemm2_kernel<TA, TB, OutT, EPI, SPLITK, BM, NSTAGE>;
@@ -527,4 +554,59 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   if (!trans_a && trans_b) return GOAT_G2(false, true);
   return GOAT_G2(true, true);
 #undef GOAT_G2
+}
+
+template <int BM, int NSTAGE>
+static int launch_group(hipStream_t st, const GroupArgs& g) {
+  constexpr int SMEM = NSTAGE * (Tile<true, BM>::BYTES + Tile<true, BN>::BYTES);
+  auto kern = gemm2_group_kernel<BM, NSTAGE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(g.tile_start[g.n]), dim3(NT), SMEM, st, g);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs, int n, int bm, int nstage) {
+  if (!probs || n < 1 || n > GROUP_MAX) return GOAT_E_ARG;
+  if ((bm != 64 && bm != 128) || nstage < 2 || nstage > 4) return GOAT_E_ARG;
+  GroupArgs g;
+  g.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const goat_wgrad_problem& q = probs[i];
+    if (!q.dy || !q.x || !q.dw) return GOAT_E_ARG;
+    if (q.rows <= 0 || q.n_out <= 0 || q.n_in <= 0) return GOAT_E_SHAPE;
+    if ((q.ld_dy % 8) || (q.ld_x % 8)) return GOAT_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(q.dy) & 15) || (reinterpret_cast<uintptr_t>(q.x) & 15)) return GOAT_E_SHAPE;
+    const int64_t a_bytes = (int64_t)q.rows * q.ld_dy * 2, b_bytes = (int64_t)q.rows * q.ld_x * 2;
+    if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) return GOAT_E_SHAPE;
+    G2Args& a = g.prob[i];
+    a.A = q.dy; a.B = q.x; a.C = q.dw; a.bias = nullptr; a.aux = nullptr;
+    a.lda = q.ld_dy; a.ldb = q.ld_x; a.ldc = q.ld_dw; a.ldaux = 0;
+    a.M = q.n_out; a.N = q.n_in; a.Kc = q.rows;
+    a.tiles_m = (q.n_out + bm - 1) / bm;
+    a.tiles_n = (q.n_in + BN - 1) / BN;
+    a.k_tiles_per_split = (q.rows + BK - 1) / BK;
+    a.a_bytes = (uint32_t)a_bytes; a.b_bytes = (uint32_t)b_bytes;
+    a.colsum = q.dbias;
+    a.accum = q.accumulate ? 1 : 0;
+    a.group_m = pick_group_m(a.tiles_m, a.tiles_n, bm);
+    g.tile_start[i] = tiles;
+    tiles += a.tiles_m * a.tiles_n;
+  }
+  for (int i = n; i <= GROUP_MAX; ++i) g.tile_start[i] = tiles;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (bm == 128) {
+    if (nstage == 2) return launch_group<128, 2>(st, g);
+    if (nstage == 3) return launch_group<128, 3>(st, g);
+    return launch_group<128, 4>(st, g);
+  }
+  if (nstage == 2) return launch_group<64, 2>(st, g);
+  if (nstage == 3) return launch_group<64, 3>(st, g);
+  return launch_group<64, 4>(st, g);
 }

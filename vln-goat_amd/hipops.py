@@ -9,6 +9,7 @@ Compute dtype: float32 (exact-f32 MFMA, the 1e-3 parity mode) or bfloat16 (bf16 
 accumulate).  Parameters stay float32 masters; bf16 / transposed "shadows" of the weights are cached on
 the Parameter object and refreshed when its version counter moves (i.e. once per optimizer step).
 """
+import ctypes
 import json
 import math
 import os
@@ -357,6 +358,61 @@ class WgradOverlap:
             torch.cuda.current_stream().wait_stream(cls.stream)
 
 
+class WgradQueue:
+    """Deferred weight gradients.  With a gradient arena attached the weight gradient of a Linear is not needed until the
+    backward pass ends, so instead of launching each small dW = dY^T·X on its own (36-144 tiles: split along the
+    contraction, atomics and a zero fill to occupy 256 CUs) the problems are queued and executed eight at a time by
+    goat_wgrad_grouped: one unsplit launch that fills the chip.  Flushed when full, when a queued parameter is about
+    to be written again (ordering), and by an autograd-engine callback at the end of the backward pass.
+    The first write of a slice in a step overwrites it; a later write (shared weights, BPTT) is queued as an accumulation —
+    never in the same group as an earlier write of that slice (hipops._sink flushes first)."""
+    enabled = os.environ.get('GOAT_WGRAD_GROUP', '1') != '0'
+    cfg = tuple(int(v) for v in os.environ.get('GOAT_WGRAD_GROUP_CFG', '128,2').split(','))   # (tile height, ring stages)
+    MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '8'))
+    pending = []            # (dy, x, w_sink, b_sink, accumulate)  — tensors are kept alive until the launch
+    pending_ids = set()
+    _callback_armed = False
+
+    @classmethod
+    def push(cls, dy, x, w_sink, b_sink, param_ids, accumulate):
+        cls.pending.append((dy, x, w_sink, b_sink, int(bool(accumulate))))
+        cls.pending_ids.update(param_ids)
+        if not cls._callback_armed:
+            cls._callback_armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_backward)
+        if len(cls.pending) >= cls.MAX:
+            cls.flush()
+
+    @classmethod
+    def _end_of_backward(cls):
+        cls._callback_armed = False
+        cls.flush()
+
+    @classmethod
+    def flush(cls):
+        if not cls.pending:
+            return
+        n = len(cls.pending)
+        arr = (_lib.WgradProblem * n)()
+        for i, (dy, x, w, b, acc) in enumerate(cls.pending):
+            q = arr[i]
+            q.dy, q.ld_dy, q.x, q.ld_x = _ptr(dy), dy.stride(0), _ptr(x), x.stride(0)
+            q.dw, q.ld_dw, q.dbias = _ptr(w), w.stride(0), (_ptr(b) if b is not None else None)
+            q.rows, q.n_out, q.n_in, q.accumulate = dy.shape[0], dy.shape[1], x.shape[1], acc
+        if PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        st = _lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), n, cls.cfg[0], cls.cfg[1])
+        if PROFILE is not None:
+            e1.record()
+            fl = sum(2.0 * t[0].shape[0] * t[0].shape[1] * t[1].shape[1] for t in cls.pending)
+            by = sum((t[0].shape[0] * t[0].shape[1] + t[1].shape[0] * t[1].shape[1]) * 2 + t[0].shape[1] * t[1].shape[1] * 4 for t in cls.pending)
+            PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 bm%d s%d' % cls.cfg),
+                            ('goat_wgrad_grouped', (ctypes.addressof(arr), n, cls.cfg[0], cls.cfg[1]), (arr, list(cls.pending)))))
+        cls.pending, cls.pending_ids = [], set()
+        _lib.check(st, 'goat_wgrad_grouped(n=%d)' % n)
+
+
 def _sink(param):
     """Gradient-arena slice bound to `param` (dp.GradArena.attach), or None.  When it is bound — i.e. still the
     object behind param.grad — backward passes accumulate the parameter's gradient straight into it and return
@@ -364,6 +420,8 @@ def _sink(param):
     other tensor) silently restores the ordinary autograd path."""
     if param is None:
         return None
+    if WgradQueue.pending_ids and id(param) in WgradQueue.pending_ids:
+        WgradQueue.flush()              # a queued first write of this slice must land before anything else touches it
     s = param.__dict__.get('_goat_sink')
     return s if (s is not None and param.grad is s) else None
 
@@ -410,7 +468,7 @@ def _prep_fallback(*params):
             t.zero_()
 
 
-def _wgrad_impl(dy, x, want_bias, w_sink=None, b_sink=None, first=False, b_first=False):
+def _wgrad_impl(dy, x, want_bias, w_sink=None, b_sink=None, first=False, b_first=False, defer_ids=None):
     M, N = dy.shape
     K = x.shape[1]
     # default (bm 64, split) from scripts/wgrad_sweep.py; the autotuner may pick another split (output is zero-filled)
@@ -430,6 +488,12 @@ def _wgrad_impl(dy, x, want_bias, w_sink=None, b_sink=None, first=False, b_first
             db = torch.zeros(N, dtype=torch.float32, device=dy.device)
         elif want_bias and b_first:
             db.zero_()
+        if (defer_ids is not None and WgradQueue.enabled and dy.dtype == torch.bfloat16 and (b_sink is not None or not want_bias)
+                and dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+                and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and w_sink.is_contiguous()
+                and not torch.is_grad_enabled()):
+            WgradQueue.push(dy, x, w_sink, db if want_bias else None, defer_ids, accumulate=not first)
+            return None, None
         gemm(dy, x, w_sink, ta=True, tb=True, split_k=split, colsum_out=db if want_bias else None,
              split_opts=(1, 2, 3, 4, 6, 8) if tunable else None, accumulate=not first, zero_first=first)
         return None, (db if (want_bias and b_sink is None) else None)
@@ -446,13 +510,13 @@ def _wgrad_impl(dy, x, want_bias, w_sink=None, b_sink=None, first=False, b_first
     return dw, db
 
 
-def wgrad(dy, x, want_bias, w_sink=None, b_sink=None, first=False, b_first=False):
+def wgrad(dy, x, want_bias, w_sink=None, b_sink=None, first=False, b_first=False, defer_ids=None):
     """dW[N,K] (f32) = dy[M,N]^T @ x[M,K] ; db[N] (f32) = colsum(dy), fused into the same kernel.
     One zero-fill covers both outputs (split-K partial tiles and the bias sums are accumulated atomically).
     With sinks (gradient-arena slices) the results are accumulated in place and (None, None) is returned."""
     side = WgradOverlap.stream
     if side is None:
-        return _wgrad_impl(dy, x, want_bias, w_sink, b_sink, first, b_first)
+        return _wgrad_impl(dy, x, want_bias, w_sink, b_sink, first, b_first, defer_ids)
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)                       # dy / x are ready on the main stream
     with torch.cuda.stream(side):
@@ -518,7 +582,8 @@ class _LinearFn(torch.autograd.Function):
             first = w_sink is not None and _first_touch(weight)
             b_first = b_sink is not None and _first_touch(ctx.bias)
             _prep_fallback(*(([] if w_sink is not None else [weight]) + ([] if b_sink is not None else [ctx.bias])))
-            dw, db = wgrad(dy2, x2, ctx.has_bias, w_sink, b_sink, first, b_first)
+            ids = [id(weight)] + ([id(ctx.bias)] if b_sink is not None else [])
+            dw, db = wgrad(dy2, x2, ctx.has_bias, w_sink, b_sink, first, b_first, ids if w_sink is not None else None)
             if ctx.pad:
                 dw = dw[:, :x2.shape[1] - ctx.pad].contiguous()
         return dx, dw, db, None, None
@@ -587,7 +652,7 @@ class _FfnFn(torch.autograd.Function):
         f2 = s2 is not None and _first_touch(ctx.w2)
         bf2 = sb2 is not None and _first_touch(ctx.b2)
         _prep_fallback(*(([] if s2 is not None else [ctx.w2]) + ([] if sb2 is not None else [ctx.b2])))
-        dw2, db2 = wgrad(dy2, h, True, s2, sb2, f2, bf2)
+        dw2, db2 = wgrad(dy2, h, True, s2, sb2, f2, bf2, [id(ctx.w2), id(ctx.b2)] if s2 is not None else None)
         W1 = _shadow(ctx.w1, x2.dtype)  # [F, H]
         dx = torch.empty_like(x2)
         gemm(du, W1, dx, tb=True)
@@ -596,7 +661,7 @@ class _FfnFn(torch.autograd.Function):
         f1 = s1 is not None and _first_touch(ctx.w1)
         bf1 = sb1 is not None and _first_touch(ctx.b1)
         _prep_fallback(*(([] if s1 is not None else [ctx.w1]) + ([] if sb1 is not None else [ctx.b1])))
-        dw1, db1 = wgrad(du, x2, True, s1, sb1, f1, bf1)
+        dw1, db1 = wgrad(du, x2, True, s1, sb1, f1, bf1, [id(ctx.w1), id(ctx.b1)] if s1 is not None else None)
         return dx.view(ctx.xshape), dw1, db1, dw2, db2, None, None
 
 
@@ -674,7 +739,7 @@ class _DecoderCeFn(torch.autograd.Function):
             b_first = b_sink is not None and _first_touch(ctx.bias)
             if b_sink is None:
                 _prep_fallback(ctx.bias)
-            dw, db = wgrad(dl[:, :N], h2, True, w_sink, b_sink, first, b_first)
+            dw, db = wgrad(dl[:, :N], h2, True, w_sink, b_sink, first, b_first, [id(weight), id(ctx.bias)])
             return dh.view(ctx.hshape), None, db, None
         _prep_fallback(weight, ctx.bias)
         dw, db = wgrad(dl, h2, True)
@@ -724,7 +789,8 @@ class _MultiLinearFn(torch.autograd.Function):
         first = w_sink is not None and _first_touch(*ws)
         b_first = b_sink is not None and _first_touch(*ctx.bs)
         _prep_fallback(*(([] if w_sink is not None else list(ws)) + ([] if b_sink is not None else list(ctx.bs))))
-        dw, db = wgrad(dy2, x2, True, w_sink, b_sink, first, b_first)
+        ids = [id(t) for t in ws] + [id(t) for t in ctx.bs]
+        dw, db = wgrad(dy2, x2, True, w_sink, b_sink, first, b_first, ids if w_sink is not None else None)
         sizes = [w.shape[0] for w in ws]
         none = (None,) * len(ws)
         return (dx,) + (tuple(torch.split(dw, sizes, 0)) if dw is not None else none) \
