@@ -217,10 +217,12 @@ int goat_embed_bwd(void* stream, int dtype, const void* dout, const int64_t* ids
  * tanh-attention pooling of the CFP heads: a = softmax_l(tanh(x[b,l,:])·w) over ALL L <= 256 slots (no padding mask,
  * as the reference), out[b,:] = tanh(sum_l a_l x[b,l,:])   (P/model/pretrain_goat.py:502-515,
  * M/models/vilmodel_GOAT.py:909-922).  x [B,L,H] in `dtype`; w float32 [H]; out float32 [B,H]; attn float32 [B,L] (saved). */
-int goat_attn_pool_fwd(void* stream, int dtype, const void* x, const float* w, float* out, float* attn, int B, int L, int H);
-/* backward: dx [B,L,H] (dtype) overwritten; dw float32 [H] accumulated (atomics; caller zero-fills). */
+int goat_attn_pool_fwd(void* stream, int dtype, const void* x, const float* w, float* out, float* attn, float* ws, int B,
+                       int L, int H);   /* ws: float32 scratch of B*L elements */
+/* backward: dx [B,L,H] (dtype) overwritten; dw float32 [H] accumulated (atomics; caller zero-fills); ws: float32 scratch
+ * of B*L elements.  H % 4 == 0. */
 int goat_attn_pool_bwd(void* stream, int dtype, const void* x, const float* w, const float* attn, const float* out,
-                       const float* dout, void* dx, float* dw, int B, int L, int H);
+                       const float* dout, void* dx, float* dw, float* ws, int B, int L, int H);
 
 /* "door" gate of BACL type_2 / FACL: s = sigmoid(aug·wa + ba + ori·wo + bo) per row, out = s*aug + (1-s)*ori
  * (P/model/vilmodel_goat.py:137-143; M/models/vilmodel_GOAT.py:147-153, 548-552: two nn.Linear(H,1) + nn.Sigmoid).

@@ -26,78 +26,113 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // ------------------------------------------------------------------------------------ tanh-attention pooling
 // a = softmax_l(tanh(x_l)·w) over ALL L slots (no padding mask, as the reference); out = tanh(sum_l a_l x_l)
+// Two launches per direction so that B*L rows / B*H/256 column slabs (not just B samples) are in flight:
+//   fwd  (1) score[b,l] = tanh(x_l)·w            one wave per row
+//        (2) per (b, 256-column slab): softmax over the L scores, out[cols] = tanh(sum_l a_l x[l,cols])
+//   bwd  (1) da[b,l] = x_l·du,  du = dout (1 - out^2)   one wave per row
+//        (2) per (b, slab): ds = a (da - a·da); dx[l,cols] = a_l du + ds_l w (1 - tanh^2 x); dw[cols] += sum_l ds_l tanh x
 constexpr int POOL_MAXL = 256;
 template <typename T>
-__global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
-                                                            float* __restrict__ out, float* __restrict__ attn, int L,
-                                                            int H) {
-  __shared__ float sc[POOL_MAXL];
-  __shared__ float red[4];
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const T* xb = x + (int64_t)b * L * H;
-  for (int l = wave; l < L; l += 4) {
-    float s = 0.f;
-    for (int i = lane; i < H; i += 64) s += tanhf(to_f(xb[(int64_t)l * H + i])) * w[i];
-    s = wave_sum(s);
-    if (lane == 0) sc[l] = s;
+__global__ __launch_bounds__(256) void pool_score_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ out, const float* __restrict__ dout,
+                                                         float* __restrict__ score, int rows, int L, int H) {
+  // forward (out == nullptr): score = tanh(x)·w ; backward: score = x·(dout (1 - out^2))
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * H;
+  const int b = row / L;
+  float s = 0.f;
+  if (out == nullptr) {
+    for (int i = lane; i < H; i += 64) s += tanhf(to_f(xr[i])) * w[i];
+  } else {
+    for (int i = lane; i < H; i += 64) {
+      const float o = out[(int64_t)b * H + i];
+      s += to_f(xr[i]) * dout[(int64_t)b * H + i] * (1.f - o * o);
+    }
   }
-  __syncthreads();
-  const float v = threadIdx.x < L ? sc[threadIdx.x] : -INFINITY;
+  s = wave_sum(s);
+  if (lane == 0) score[row] = s;
+}
+
+// block = 256 threads = 64 column quads x 4 row lanes; grid = (B, ceil(H/256))
+template <typename T>
+__global__ __launch_bounds__(256) void pool_out_kernel(const T* __restrict__ x, const float* __restrict__ score,
+                                                       float* __restrict__ out, float* __restrict__ attn, int L, int H) {
+  __shared__ float a[POOL_MAXL];
+  __shared__ float red[4];
+  __shared__ float part[4][4][64];
+  typedef T quad __attribute__((ext_vector_type(4)));
+  const int b = blockIdx.x, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float v = threadIdx.x < L ? score[(int64_t)b * L + threadIdx.x] : -INFINITY;
   const float m = block_max(v, red);
   const float e = threadIdx.x < L ? __expf(v - m) : 0.f;
   const float tot = block_sum(e, red);
   if (threadIdx.x < L) {
-    sc[threadIdx.x] = e / tot;
-    attn[(int64_t)b * L + threadIdx.x] = e / tot;
+    a[threadIdx.x] = e / tot;
+    if (blockIdx.y == 0) attn[(int64_t)b * L + threadIdx.x] = e / tot;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < H; i += 256) {
-    float s = 0.f;
-    for (int l = 0; l < L; ++l) s += sc[l] * to_f(xb[(int64_t)l * H + i]);
-    out[(int64_t)b * H + i] = tanhf(s);
-  }
+  const int c = blockIdx.y * 256 + tx * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < H)
+    for (int l = ty; l < L; l += 4) {
+      const quad q = *reinterpret_cast<const quad*>(x + ((int64_t)b * L + l) * H + c);
+      const float al = a[l];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += al * to_f(q[k]);
+    }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) part[ty][k][tx] = acc[k];
+  __syncthreads();
+  // thread (ty, tx) finishes column c + ty of quad tx
+  const float sum = part[0][ty][tx] + part[1][ty][tx] + part[2][ty][tx] + part[3][ty][tx];
+  if (c < H) out[(int64_t)b * H + c + ty] = tanhf(sum);
 }
 
-// du = dout (1 - out^2) ; da_l = x_l·du ; ds = a (da - a·da) ; dx_l = a_l du + ds_l w (1 - tanh^2 x_l) ; dw += sum_l ds_l tanh x_l
 template <typename T>
-__global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ attn, const float* __restrict__ out,
-                                                            const float* __restrict__ dout, T* __restrict__ dx,
-                                                            float* __restrict__ dw, int L, int H) {
-  extern __shared__ float sm[];   // du[H] | da[POOL_MAXL] | ds[POOL_MAXL]
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ attn, const float* __restrict__ out,
+                                                       const float* __restrict__ dout, const float* __restrict__ da,
+                                                       T* __restrict__ dx, float* __restrict__ dw, int L, int H) {
+  __shared__ float al[POOL_MAXL], ds[POOL_MAXL];
   __shared__ float red[4];
-  float* du = sm;
-  float* da = sm + H;
-  float* ds = da + POOL_MAXL;
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const T* xb = x + (int64_t)b * L * H;
-  for (int i = threadIdx.x; i < H; i += 256) {
-    const float o = out[(int64_t)b * H + i];
-    du[i] = dout[(int64_t)b * H + i] * (1.f - o * o);
-  }
-  __syncthreads();
-  for (int l = wave; l < L; l += 4) {
-    float s = 0.f;
-    for (int i = lane; i < H; i += 64) s += to_f(xb[(int64_t)l * H + i]) * du[i];
-    s = wave_sum(s);
-    if (lane == 0) da[l] = s;
-  }
-  __syncthreads();
+  __shared__ float part[4][4][64];
+  typedef T quad __attribute__((ext_vector_type(4)));
+  const int b = blockIdx.x, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const float a = threadIdx.x < L ? attn[(int64_t)b * L + threadIdx.x] : 0.f;
-  const float dot = block_sum(threadIdx.x < L ? a * da[threadIdx.x] : 0.f, red);
-  if (threadIdx.x < L) ds[threadIdx.x] = a * (da[threadIdx.x] - dot);
+  const float d = threadIdx.x < L ? da[(int64_t)b * L + threadIdx.x] : 0.f;
+  const float dot = block_sum(a * d, red);
+  if (threadIdx.x < L) { al[threadIdx.x] = a; ds[threadIdx.x] = a * (d - dot); }
   __syncthreads();
-  for (int i = threadIdx.x; i < H; i += 256) {
-    const float wi = w[i], dui = du[i];
-    float dwi = 0.f;
-    for (int l = 0; l < L; ++l) {
-      const float t = tanhf(to_f(xb[(int64_t)l * H + i]));
-      const float al = attn[(int64_t)b * L + l];
-      dx[((int64_t)b * L + l) * H + i] = from_f<T>(al * dui + ds[l] * wi * (1.f - t * t));
-      dwi += ds[l] * t;
+  const int c = blockIdx.y * 256 + tx * 4;
+  float dwp[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < H) {
+    float du[4], wv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float o = out[(int64_t)b * H + c + k];
+      du[k] = dout[(int64_t)b * H + c + k] * (1.f - o * o);
+      wv[k] = w[c + k];
     }
-    atomicAdd(dw + i, dwi);
+    for (int l = ty; l < L; l += 4) {
+      const int64_t base = ((int64_t)b * L + l) * H + c;
+      const quad q = *reinterpret_cast<const quad*>(x + base);
+      quad o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float t = tanhf(to_f(q[k]));
+        o[k] = from_f<T>(al[l] * du[k] + ds[l] * wv[k] * (1.f - t * t));
+        dwp[k] += ds[l] * t;
+      }
+      *reinterpret_cast<quad*>(dx + base) = o;
+    }
   }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) part[ty][k][tx] = dwp[k];
+  __syncthreads();
+  const float sum = part[0][ty][tx] + part[1][ty][tx] + part[2][ty][tx] + part[3][ty][tx];
+  if (c < H) atomicAdd(dw + c + ty, sum);
 }
 
 // ------------------------------------------------------------------------------------ door gate
@@ -207,33 +242,40 @@ __global__ __launch_bounds__(256) void dict_wsum_bwd_kernel(const T* __restrict_
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
-extern "C" int goat_attn_pool_fwd(void* stream, int dtype, const void* x, const float* w, float* out, float* attn, int B,
-                                  int L, int H) {
-  if (!x || !w || !out || !attn) return GOAT_E_ARG;
-  if (B <= 0 || L <= 0 || L > POOL_MAXL || H <= 0) return GOAT_E_SHAPE;
-  if (dtype == GOAT_BF16)
-    hipLaunchKernelGGL(attn_pool_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, ST(stream), (const bf16_t*)x, w, out, attn, L, H);
-  else if (dtype == GOAT_F32)
-    hipLaunchKernelGGL(attn_pool_fwd_kernel<float>, dim3(B), dim3(256), 0, ST(stream), (const float*)x, w, out, attn, L, H);
-  else
+extern "C" int goat_attn_pool_fwd(void* stream, int dtype, const void* x, const float* w, float* out, float* attn,
+                                  float* ws, int B, int L, int H) {
+  if (!x || !w || !out || !attn || !ws) return GOAT_E_ARG;
+  if (B <= 0 || L <= 0 || L > POOL_MAXL || H <= 0 || (H % 4)) return GOAT_E_SHAPE;
+  const int rows = B * L;
+  dim3 g1((rows + 3) / 4), g2(B, (H + 255) / 256);
+  if (dtype == GOAT_BF16) {
+    hipLaunchKernelGGL(pool_score_kernel<bf16_t>, g1, dim3(256), 0, ST(stream), (const bf16_t*)x, w, nullptr, nullptr, ws, rows, L, H);
+    hipLaunchKernelGGL(pool_out_kernel<bf16_t>, g2, dim3(256), 0, ST(stream), (const bf16_t*)x, ws, out, attn, L, H);
+  } else if (dtype == GOAT_F32) {
+    hipLaunchKernelGGL(pool_score_kernel<float>, g1, dim3(256), 0, ST(stream), (const float*)x, w, nullptr, nullptr, ws, rows, L, H);
+    hipLaunchKernelGGL(pool_out_kernel<float>, g2, dim3(256), 0, ST(stream), (const float*)x, ws, out, attn, L, H);
+  } else {
     return GOAT_E_ARG;
+  }
   GOAT_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int goat_attn_pool_bwd(void* stream, int dtype, const void* x, const float* w, const float* attn,
-                                  const float* out, const float* dout, void* dx, float* dw, int B, int L, int H) {
-  if (!x || !w || !attn || !out || !dout || !dx || !dw) return GOAT_E_ARG;
-  if (B <= 0 || L <= 0 || L > POOL_MAXL || H <= 0 || H > 8192) return GOAT_E_SHAPE;
-  const size_t sm = (size_t)(H + 2 * POOL_MAXL) * sizeof(float);
-  if (dtype == GOAT_BF16)
-    hipLaunchKernelGGL(attn_pool_bwd_kernel<bf16_t>, dim3(B), dim3(256), sm, ST(stream), (const bf16_t*)x, w, attn, out, dout,
-                       (bf16_t*)dx, dw, L, H);
-  else if (dtype == GOAT_F32)
-    hipLaunchKernelGGL(attn_pool_bwd_kernel<float>, dim3(B), dim3(256), sm, ST(stream), (const float*)x, w, attn, out, dout,
-                       (float*)dx, dw, L, H);
-  else
+                                  const float* out, const float* dout, void* dx, float* dw, float* ws, int B, int L, int H) {
+  if (!x || !w || !attn || !out || !dout || !dx || !dw || !ws) return GOAT_E_ARG;
+  if (B <= 0 || L <= 0 || L > POOL_MAXL || H <= 0 || (H % 4)) return GOAT_E_SHAPE;
+  const int rows = B * L;
+  dim3 g1((rows + 3) / 4), g2(B, (H + 255) / 256);
+  if (dtype == GOAT_BF16) {
+    hipLaunchKernelGGL(pool_score_kernel<bf16_t>, g1, dim3(256), 0, ST(stream), (const bf16_t*)x, w, out, dout, ws, rows, L, H);
+    hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, g2, dim3(256), 0, ST(stream), (const bf16_t*)x, w, attn, out, dout, ws, (bf16_t*)dx, dw, L, H);
+  } else if (dtype == GOAT_F32) {
+    hipLaunchKernelGGL(pool_score_kernel<float>, g1, dim3(256), 0, ST(stream), (const float*)x, w, out, dout, ws, rows, L, H);
+    hipLaunchKernelGGL(pool_bwd_kernel<float>, g2, dim3(256), 0, ST(stream), (const float*)x, w, attn, out, dout, ws, (float*)dx, dw, L, H);
+  } else {
     return GOAT_E_ARG;
+  }
   GOAT_LAUNCH_CHECK();
   return 0;
 }

@@ -1175,7 +1175,8 @@ class _AttnPoolFn(torch.autograd.Function):
         wv = w.detach().reshape(-1).float().contiguous()
         out = torch.empty((B, H), dtype=torch.float32, device=x.device)
         attn = torch.empty((B, L), dtype=torch.float32, device=x.device)
-        st = _lib.lib().goat_attn_pool_fwd(_stream(), _dt(x), _ptr(x), _ptr(wv), _ptr(out), _ptr(attn), B, L, H)
+        ws = torch.empty(B * L, dtype=torch.float32, device=x.device)
+        st = _lib.lib().goat_attn_pool_fwd(_stream(), _dt(x), _ptr(x), _ptr(wv), _ptr(out), _ptr(attn), _ptr(ws), B, L, H)
         _lib.check(st, 'goat_attn_pool_fwd')
         ctx.save_for_backward(x, wv, attn, out)
         ctx.wshape = w.shape
@@ -1188,8 +1189,9 @@ class _AttnPoolFn(torch.autograd.Function):
         dout = dout.float().contiguous()
         dx = torch.empty_like(x)
         dw = torch.zeros(H, dtype=torch.float32, device=x.device)
+        ws = torch.empty(B * L, dtype=torch.float32, device=x.device)
         st = _lib.lib().goat_attn_pool_bwd(_stream(), _dt(x), _ptr(x), _ptr(wv), _ptr(attn), _ptr(out), _ptr(dout), _ptr(dx),
-                                           _ptr(dw), B, L, H)
+                                           _ptr(dw), _ptr(ws), B, L, H)
         _lib.check(st, 'goat_attn_pool_bwd')
         return dx, dw.view(ctx.wshape)
 
