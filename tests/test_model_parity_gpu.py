@@ -312,3 +312,50 @@ def test_full_size_cfp_is_permutation_equivariant():
         assert float((a - b.flip(0)).abs().max()) <= 2e-2 * max(1.0, float(a.abs().max()))
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# edge cases of the input contract: one sample, longest instructions (REVERIE max_txt_len 200), long
+# trajectories / large maps, no masked token at all
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('bkw', [dict(B=1, T=1, L=5, seed=31), dict(B=2, T=[7, 6], L=[200, 163], seed=32, style='rich', n_cand=6),
+                                 dict(B=3, T=[1, 1, 2], L=[9, 200, 40], seed=33, ragged_views=True)])
+def test_edge_shapes_match_oracle(bkw, dtype):
+    import vln_goat_amd
+    from vln_goat_amd import config as gcfg, pretrain_model, synth
+    cfg = gcfg.make_config(num_l_layers=1, num_top_layer=1, num_pano_layers=1, vocab_size=600)
+    model = pretrain_model.GlocalTextPathCMTPreTraining(cfg)
+    model.load_state_dict(synth.seeded_state_dict(model, seed=3))
+    model.tie_weights()
+    batch = synth.make_pretrain_batch(vocab_size=600, **bkw)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    tol = 1e-3 if dtype == torch.float32 else 2e-2
+    vln_goat_amd.set_compute_dtype(dtype)
+    try:
+        model = model.cuda().eval()
+        gb = synth.batch_to(batch, 'cuda')
+        for task in ('mlm', 'sap', 'cfp'):
+            ref, _ = oracle_run(cfg, sd, batch, task)
+            for p in model.parameters():
+                p.grad = None
+            loss = model(gb, task, compute_loss=True)
+            loss.mean().backward()
+            assert loss.shape == ref.shape
+            assert float((loss.detach().float().cpu() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max())), (task, bkw)
+            assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+def test_mlm_without_masked_tokens_returns_empty():
+    import vln_goat_amd
+    from vln_goat_amd import config as gcfg, pretrain_model, synth
+    cfg = gcfg.make_config(num_l_layers=1, num_top_layer=1, num_pano_layers=1, vocab_size=600)
+    model = pretrain_model.GlocalTextPathCMTPreTraining(cfg).cuda().eval()
+    batch = synth.make_pretrain_batch(B=2, T=2, L=12, seed=34, vocab_size=600)
+    batch['txt_labels'].fill_(-1)
+    gb = synth.batch_to(batch, 'cuda')
+    loss = model(gb, 'mlm', compute_loss=True)
+    assert loss.shape == (0,)
+    loss.sum().backward()                       # a no-op backward must not fail either
+    assert model(gb, 'mlm', compute_loss=False).shape == (0, 600)

@@ -473,6 +473,9 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
         if 'mlm_idx' not in cache:
             cache['mlm_idx'] = (labels.reshape(-1) != -1).nonzero().squeeze(1)
             cache['mlm_tgt'] = labels.reshape(-1)[cache['mlm_idx']]
+        if cache['mlm_idx'].numel() == 0:            # no masked token in the batch: empty loss / score tensor, as the reference
+            empty = txt.reshape(-1, txt.shape[-1])[:0].float()
+            return empty.sum(1) if compute_loss else empty.new_zeros((0, self.config.vocab_size))
         masked = txt.reshape(-1, txt.shape[-1]).index_select(0, cache['mlm_idx'])
         if compute_loss:
             return self.mlm_head.predictions.loss(masked, cache['mlm_tgt'])
