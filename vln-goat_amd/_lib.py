@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libgoat_hip.so')
+LIB_PATH = os.environ.get('GOAT_HIP_LIB') or os.path.join(CSRC, 'libgoat_hip.so')     # (override: kernel A/B experiments)
 SOURCES = ['gemm.hip', 'gemm2.hip', 'attention.hip', 'rowops.hip', 'causal.hip']
 
 GOAT_F32, GOAT_BF16 = 0, 1

@@ -1,6 +1,7 @@
 // HBM-bound row kernels: residual+dropout+LayerNorm (fwd/bwd), dropout, transpose(+column sums),
 // adaptive panorama fusion, gather / segment-mean.  One wave64 per 768-wide row, 16-byte vector loads,
 // wavefront shuffles for the reductions, statistics in f32.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // ------------------------------------------------------------------------------------ LayerNorm bwd
 // grid = NPART blocks of 4 waves; wave w of block b walks rows (b*4+w), +4*NPART, ...
 // partial dgamma/dbeta per block -> ws[block][2][H]; ln_bwd_reduce sums them.
-template <typename T, int MAXC>
+template <typename T, int MAXC, int RIF>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float p, uint64_t seed,
@@ -100,15 +101,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       const int c = lane + 64 * i;
       g[i][e] = (c < nchunk) ? gamma[c * EPC + e] : 0.f;
     }
-  // two rows per wave in flight: the loads of both rows are issued before the first reduction (this kernel is
+  // RIF rows per wave in flight: the loads of both rows are issued before the first reduction (this kernel is
   // latency-bound on its 16-B loads, not on the shuffles)
   const int rstride = gridDim.x * 4;
-  for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += 2 * rstride) {
-    Chunk<T> vdy[2][MAXC], vz[2][MAXC];
-    float mu[2], rs[2], c1[2] = {0.f, 0.f}, c2[2] = {0.f, 0.f};
-    bool live[2];
+  for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += RIF * rstride) {
+    Chunk<T> vdy[RIF][MAXC], vz[RIF][MAXC];
+    float mu[RIF], rs[RIF], c1[RIF], c2[RIF];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RIF; ++u) { c1[u] = 0.f; c2[u] = 0.f; }
+    bool live[RIF];
+#pragma unroll
+    for (int u = 0; u < RIF; ++u) {
       const int row = row0 + u * rstride;
       live[u] = row < M;
       mu[u] = live[u] ? mean[row] : 0.f;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RIF; ++u) {
 #pragma unroll
       for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
@@ -145,12 +148,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RIF; ++u) {
       c1[u] = wave_sum(c1[u]) / H;
       c2[u] = wave_sum(c2[u]) / H;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RIF; ++u) {
       const int row = row0 + u * rstride;
 #pragma unroll
       for (int i = 0; i < MAXC; ++i) {
@@ -692,6 +695,9 @@ extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* r
 }
 
 #define GOAT_LN_BWD_PARTS 512
+#ifndef GOAT_LN_RIF
+#define GOAT_LN_RIF 2      // rows in flight per wave (bf16); measured: 4 rows / fewer partial blocks are slower (8.52-8.80 vs 8.45 ms/step)
+#endif
 
 extern "C" int goat_ln_bwd_ws_floats(int H) { return GOAT_LN_BWD_PARTS * 2 * H; }
 
@@ -701,18 +707,18 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
                            int M, int H, int accumulate) {
   if (!dy || !z || !gamma || !mean || !rstd || !dgamma || !dbeta || !ws) return GOAT_E_ARG;
   if (M <= 0) return GOAT_E_SHAPE;
-  int nparts = (M + 7) / 8;   // 4 waves x 2 rows in flight per block
+  int nparts = (M + 4 * GOAT_LN_RIF - 1) / (4 * GOAT_LN_RIF);   // 4 waves x RIF rows in flight per block
   if (nparts > GOAT_LN_BWD_PARTS) nparts = GOAT_LN_BWD_PARTS;
   const size_t sm = (size_t)8 * H * sizeof(float);
   if (sm > 64 * 1024) return GOAT_E_SHAPE;
   if (dtype == GOAT_BF16) {
     if (int e = ln_check<bf16_t>(H)) return e;
-    GOAT_LN_DISPATCH(bf16_t, H, hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, MC>), dim3(nparts), dim3(256), sm, ST(stream),
+    GOAT_LN_DISPATCH(bf16_t, H, hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, MC, GOAT_LN_RIF>), dim3(nparts), dim3(256), sm, ST(stream),
                                                     (const bf16_t*)dy, (const bf16_t*)z, gamma, mean, rstd, p, seed, offset,
                                                     rng_dev, (bf16_t*)dx, (bf16_t*)d_res, ws, M, H));
   } else if (dtype == GOAT_F32) {
     if (int e = ln_check<float>(H)) return e;
-    GOAT_LN_DISPATCH(float, H, hipLaunchKernelGGL((ln_bwd_kernel<float, MC>), dim3(nparts), dim3(256), sm, ST(stream),
+    GOAT_LN_DISPATCH(float, H, hipLaunchKernelGGL((ln_bwd_kernel<float, MC, 2>), dim3(nparts), dim3(256), sm, ST(stream),
                                                    (const float*)dy, (const float*)z, gamma, mean, rstd, p, seed, offset,
                                                    rng_dev, (float*)dx, (float*)d_res, ws, M, H));
   } else {

@@ -249,6 +249,7 @@ class GradArena:
             prev, epoch = self._cur
             self._owned[prev] = {id(p) for p in self.params
                                  if p.__dict__.get('_goat_epoch') == epoch and not p.__dict__.get('_goat_prezero')}
+        hipops.WgradQueue.reset()
         hipops.ARENA_EPOCH[0] += 1
         self._cur = (key, hipops.ARENA_EPOCH[0])
         owned = self._owned.get(key)

@@ -389,6 +389,12 @@ class WgradQueue:
         cls.flush()
 
     @classmethod
+    def reset(cls):
+        """Drop queued problems (GradArena.zero() calls this: anything still queued at the start of a step belongs to a
+        backward pass that was aborted by an exception — its tensors must not be written into the new step)."""
+        cls.pending, cls.pending_ids, cls._callback_armed = [], set(), False
+
+    @classmethod
     def flush(cls):
         if not cls.pending:
             return
