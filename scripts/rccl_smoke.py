@@ -34,8 +34,9 @@ for a, b in arena.ranges('sap'):
 arena.comm_stream.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(arena.comm_stream):
     for c in chunks:
-        dist.all_reduce(c)
+        arena._reduce_mean(c, 1)          # ReduceOp.AVG on RCCL (probed once), sum + divide elsewhere
 torch.cuda.current_stream().wait_stream(arena.comm_stream)
+print('ReduceOp.AVG accepted by this RCCL:', dp.GradArena._avg_ok)
 torch.cuda.synchronize()
 assert all(torch.equal(p.grad, r) for p, r in zip(m.parameters(), ref))
 packed = torch.randn(4, 8, 768, device='cuda', requires_grad=True)

@@ -275,6 +275,25 @@ class GradArena:
             self.flat[a:b].zero_()
 
     # -- communication ---------------------------------------------------------------------------
+    _avg_ok = None      # RCCL averages in the collective (ReduceOp.AVG); gloo and old stacks: sum, then one divide pass
+
+    def _reduce_mean(self, c, W):
+        cls = type(self)
+        if cls._avg_ok is None:
+            cls._avg_ok = False
+            if c.is_cuda and dist.get_backend() == 'nccl':
+                try:
+                    probe = torch.ones(8, dtype=torch.float32, device=c.device)
+                    dist.all_reduce(probe, op=dist.ReduceOp.AVG)
+                    cls._avg_ok = True
+                except (RuntimeError, ValueError):
+                    cls._avg_ok = False
+        if cls._avg_ok:
+            dist.all_reduce(c, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(c)
+            c.div_(W)
+
     def all_reduce_mean(self, task=None):
         """Average the task's gradient ranges over ranks, in place, on the communication stream."""
         W = _world()
@@ -290,13 +309,11 @@ class GradArena:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 for c in chunks:
-                    dist.all_reduce(c)
-                    c.div_(W)
+                    self._reduce_mean(c, W)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
             for c in chunks:
-                dist.all_reduce(c)
-                c.div_(W)
+                self._reduce_mean(c, W)
 
 
 class GoatDataParallel(torch.nn.Module):
