@@ -7,9 +7,13 @@ the communication:
   * a static per-task participation list (parameters that receive a gradient for that task, discovered
     on the task's first step — identical on all ranks because the task is), replacing the per-iteration
     unused-parameter bitmap all-reduce;
-  * gradients are packed bucket by bucket (reverse registration order ~ reverse autograd order) into flat
-    buffers and all-reduced on a dedicated communication stream, so the pack of bucket i+1 overlaps the
-    all-reduce of bucket i; optional bf16 wire format halves the bytes on the 7 x ~153 GB/s xGMI links;
+  * GradArena: `.grad` of every used parameter is a view into ONE float32 HBM buffer ordered by task usage; the HIP
+    backward kernels accumulate into it directly (hipops._sink), weight gradients are deferred and run as grouped
+    launches (hipops.WgradQueue), and the all-reduce (mean) runs in place on the task's 1-3 contiguous ranges in
+    128 MB chunks on a dedicated communication stream — no pack/unpack copies, ReduceOp.AVG inside RCCL;
+  * GradBuckets (legacy path, used when no arena is attached): gradients packed bucket by bucket (reverse registration
+    order ~ reverse autograd order) into flat buffers and all-reduced on the communication stream, so the pack of
+    bucket i+1 overlaps the all-reduce of bucket i; optional bf16 wire format;
   * CfpGather: the CFP contrastive negatives are shared across ranks with ONE all-gather of the packed
     [4,B,H] pooled vectors; its backward is the matching reduce-scatter (sum) so the result equals the
     single-process loss on the concatenated batch (the reference computes CFP per rank only,
