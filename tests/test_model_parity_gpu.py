@@ -359,3 +359,58 @@ def test_mlm_without_masked_tokens_returns_empty():
     assert loss.shape == (0,)
     loss.sum().backward()                       # a no-op backward must not fail either
     assert model(gb, 'mlm', compute_loss=False).shape == (0, 600)
+
+
+@pytest.mark.parametrize('task', ['mlm', 'sap', 'cfp'])
+def test_captured_step_with_branches_and_grouped_wgrads_equals_eager(task):
+    """What bench.py runs: arena clear + forward + backward captured into ONE hipGraph with parallel branches (text ∥ panorama,
+    global ∥ local encoder) and deferred grouped weight gradients.  Replays must reproduce the gradients of the plain eager,
+    single-stream, arena-less step (same kernels, so only the order of float32 atomic sums differs)."""
+    import vln_goat_amd
+    from vln_goat_amd import dp, hipops, synth
+    cfg, model, batch = build_case('pretrain_small_ragged')
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    old_mode = hipops.Branch.mode
+    try:
+        model = model.cuda().eval()
+        gb = synth.batch_to(batch, 'cuda')
+        hipops.Branch.mode = '0'
+        model(gb, task, compute_loss=True).mean().backward()
+        ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        ref_loss = model(gb, task, compute_loss=True).detach().clone()
+        wrapper = dp.GoatDataParallel(model)
+        wrapper.record_usage(task)
+        for p in model.parameters():
+            p.grad = None
+        arena = wrapper.build_arena()
+        hipops.Branch.mode = 'capture'
+
+        def step():
+            arena.zero(task)
+            loss = model(gb, task, compute_loss=True)
+            loss.mean().backward()
+            return loss
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()                      # eager arena steps: learn which slices the kernels own
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = step()
+        gmax = max(float(v.norm()) for v in ref.values())
+        for rep in range(3):
+            arena.flat.fill_(float('nan')) if rep == 1 else None      # a replay must rewrite every slice it owns
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.allclose(loss.detach().float(), ref_loss.float(), rtol=2e-3, atol=2e-3)
+            for n, p in model.named_parameters():
+                if n not in ref:
+                    continue
+                d = float((arena.views[id(p)].double() - ref[n].double()).norm())
+                assert d <= 2e-3 * max(float(ref[n].norm()), 1e-2 * gmax), (task, rep, n, d, float(ref[n].norm()))
+    finally:
+        hipops.Branch.mode = old_mode
+        vln_goat_amd.set_compute_dtype(torch.float32)

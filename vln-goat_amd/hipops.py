@@ -358,6 +358,81 @@ class WgradOverlap:
             torch.cuda.current_stream().wait_stream(cls.stream)
 
 
+class Branch:
+    """Run a block of ops as a parallel branch: `with Branch('pano') as br: ...; br.join(t1, t2)`.
+
+    GOAT's step has independent sub-graphs (text encoder vs panorama encoder; global-map vs local cross-modal encoder)
+    whose kernels are too small to fill 256 CUs on their own (66-720 workgroups).  Issued on a side HIP stream they
+    become a parallel branch of the captured hipGraph (or run concurrently in eager mode); autograd replays each
+    backward op on the stream of its forward op, so the backward passes of the branches overlap as well.
+    Fork: the side stream first waits for everything issued so far on the caller's stream.  join(): the caller's stream
+    waits for the branch; tensors handed over are registered with the caching allocator (record_stream)."""
+    mode = os.environ.get('GOAT_BRANCH_STREAMS', 'capture')      # 'capture' (default): only while a hipGraph is being captured
+    _streams = {}                                                 # (eager launches are host-bound: no gain, more syncs); 'always'; '0'
+    used = set()            # side streams with work since the last join_all()
+
+    def __init__(self, name):
+        self.name = name
+        self.side = None
+
+    def __enter__(self):
+        if Branch.mode == '0' or not torch.cuda.is_available():
+            return self
+        if Branch.mode != 'always' and not torch.cuda.is_current_stream_capturing():
+            return self
+        dev = torch.cuda.current_device()
+        self.side = Branch._streams.get((dev, self.name))
+        if self.side is None:
+            self.side = Branch._streams[(dev, self.name)] = torch.cuda.Stream(device=dev)
+        self.main = torch.cuda.current_stream()
+        self.side.wait_stream(self.main)
+        Branch.used.add(self.side)
+        self._ctx = torch.cuda.stream(self.side)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.side is None:
+            return
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self.side)
+        hooked = False
+        for t in tensors:
+            if torch.is_tensor(t):
+                t.record_stream(cur)
+                if not hooked and t.requires_grad and torch.is_grad_enabled():
+                    t.register_hook(Branch._arm)      # backward will run part of its ops on the side stream again
+                    hooked = True
+
+    _armed = False
+
+    @staticmethod
+    def _arm(grad):
+        if not Branch._armed:
+            Branch._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(Branch._end_of_backward)
+        return None
+
+    @staticmethod
+    def _end_of_backward():
+        Branch._armed = False
+        WgradQueue.flush()
+        Branch.join_all()
+
+    @classmethod
+    def join_all(cls):
+        """current stream waits for every side stream used since the last call (end of backward)."""
+        cur = torch.cuda.current_stream()
+        for s in cls.used:
+            cur.wait_stream(s)
+        cls.used = set()
+
+
 class WgradQueue:
     """Deferred weight gradients.  With a gradient arena attached the weight gradient of a Linear is not needed until the
     backward pass ends, so instead of launching each small dW = dY^T·X on its own (36-144 tiles: split along the
@@ -369,53 +444,79 @@ class WgradQueue:
     enabled = os.environ.get('GOAT_WGRAD_GROUP', '1') != '0'
     cfg = tuple(int(v) for v in os.environ.get('GOAT_WGRAD_GROUP_CFG', '128,2').split(','))   # (tile height, ring stages)
     MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '8'))
-    pending = []            # (dy, x, w_sink, b_sink, accumulate)  — tensors are kept alive until the launch
-    pending_ids = set()
+    queues = {}             # HIP stream handle -> (torch stream, [(dy, x, w_sink, b_sink, accumulate)]): tensors are kept alive until
+    pending_ids = {}        # the launch, which happens on the stream the problems were produced on;  id(param) -> stream handle
     _callback_armed = False
 
     @classmethod
     def push(cls, dy, x, w_sink, b_sink, param_ids, accumulate):
-        cls.pending.append((dy, x, w_sink, b_sink, int(bool(accumulate))))
-        cls.pending_ids.update(param_ids)
+        st = torch.cuda.current_stream()
+        q = cls.queues.setdefault(st.cuda_stream, (st, []))[1]
+        q.append((dy, x, w_sink, b_sink, int(bool(accumulate))))
+        for i in param_ids:
+            cls.pending_ids[i] = st.cuda_stream
         if not cls._callback_armed:
             cls._callback_armed = True
             torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_backward)
-        if len(cls.pending) >= cls.MAX:
-            cls.flush()
+        if len(q) >= cls.MAX:
+            cls.flush(st.cuda_stream)
 
     @classmethod
     def _end_of_backward(cls):
         cls._callback_armed = False
         cls.flush()
+        Branch.join_all()           # grouped launches on side streams must land before the caller's stream goes on
 
     @classmethod
     def reset(cls):
         """Drop queued problems (GradArena.zero() calls this: anything still queued at the start of a step belongs to a
         backward pass that was aborted by an exception — its tensors must not be written into the new step)."""
-        cls.pending, cls.pending_ids, cls._callback_armed = [], set(), False
+        cls.queues, cls.pending_ids, cls._callback_armed = {}, {}, False
 
     @classmethod
-    def flush(cls):
-        if not cls.pending:
-            return
-        n = len(cls.pending)
+    def flush_param(cls, param_id):
+        """A queued write of this parameter's slice must land before the caller touches the slice on ITS stream."""
+        h = cls.pending_ids.get(param_id)
+        if h is not None:
+            st = cls.queues[h][0]
+            cls.flush(h)
+            cur = torch.cuda.current_stream()
+            if cur.cuda_stream != h:
+                cur.wait_stream(st)
+
+    @classmethod
+    def flush(cls, handle=None):
+        """Launch the queued problems of one stream (or of every stream), each group on its own stream."""
+        for h in ([handle] if handle is not None else list(cls.queues)):
+            ent = cls.queues.get(h)
+            if not ent or not ent[1]:
+                continue
+            st, q = ent
+            cls.queues[h] = (st, [])
+            for pid in [k for k, v in cls.pending_ids.items() if v == h]:
+                del cls.pending_ids[pid]
+            with torch.cuda.stream(st):
+                cls._launch(q)
+
+    @classmethod
+    def _launch(cls, q):
+        n = len(q)
         arr = (_lib.WgradProblem * n)()
-        for i, (dy, x, w, b, acc) in enumerate(cls.pending):
-            q = arr[i]
-            q.dy, q.ld_dy, q.x, q.ld_x = _ptr(dy), dy.stride(0), _ptr(x), x.stride(0)
-            q.dw, q.ld_dw, q.dbias = _ptr(w), w.stride(0), (_ptr(b) if b is not None else None)
-            q.rows, q.n_out, q.n_in, q.accumulate = dy.shape[0], dy.shape[1], x.shape[1], acc
+        for i, (dy, x, w, b, acc) in enumerate(q):
+            p = arr[i]
+            p.dy, p.ld_dy, p.x, p.ld_x = _ptr(dy), dy.stride(0), _ptr(x), x.stride(0)
+            p.dw, p.ld_dw, p.dbias = _ptr(w), w.stride(0), (_ptr(b) if b is not None else None)
+            p.rows, p.n_out, p.n_in, p.accumulate = dy.shape[0], dy.shape[1], x.shape[1], acc
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         st = _lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), n, cls.cfg[0], cls.cfg[1])
         if PROFILE is not None:
             e1.record()
-            fl = sum(2.0 * t[0].shape[0] * t[0].shape[1] * t[1].shape[1] for t in cls.pending)
-            by = sum((t[0].shape[0] * t[0].shape[1] + t[1].shape[0] * t[1].shape[1]) * 2 + t[0].shape[1] * t[1].shape[1] * 4 for t in cls.pending)
+            fl = sum(2.0 * t[0].shape[0] * t[0].shape[1] * t[1].shape[1] for t in q)
+            by = sum((t[0].shape[0] * t[0].shape[1] + t[1].shape[0] * t[1].shape[1]) * 2 + t[0].shape[1] * t[1].shape[1] * 4 for t in q)
             PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 bm%d s%d' % cls.cfg),
-                            ('goat_wgrad_grouped', (ctypes.addressof(arr), n, cls.cfg[0], cls.cfg[1]), (arr, list(cls.pending)))))
-        cls.pending, cls.pending_ids = [], set()
+                            ('goat_wgrad_grouped', (ctypes.addressof(arr), n, cls.cfg[0], cls.cfg[1]), (arr, list(q)))))
         _lib.check(st, 'goat_wgrad_grouped(n=%d)' % n)
 
 
@@ -427,7 +528,7 @@ def _sink(param):
     if param is None:
         return None
     if WgradQueue.pending_ids and id(param) in WgradQueue.pending_ids:
-        WgradQueue.flush()              # a queued first write of this slice must land before anything else touches it
+        WgradQueue.flush_param(id(param))      # a queued write of this slice must land before anything else touches it
     s = param.__dict__.get('_goat_sink')
     return s if (s is not None and param.grad is s) else None
 

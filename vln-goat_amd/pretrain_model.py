@@ -340,35 +340,48 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
 
     # -- the three reference entry points ---------------------------------------------------------
     def forward(self, batch, return_gmap_embeds=True):
-        """GlocalTextPathCMT.forward (P/model/vilmodel_goat.py:546-594) -> (gmap_embeds, vp_embeds, txt_embeds)."""
+        """GlocalTextPathCMT.forward (P/model/vilmodel_goat.py:546-594) -> (gmap_embeds, vp_embeds, txt_embeds).
+        The panorama stem runs as a parallel branch of the text encoder, the global-map encoder as a parallel branch of
+        the local one (hipops.Branch): independent sub-graphs whose kernels are too small to fill the chip alone."""
         cache = self._indices(batch)
+        with hipops.Branch('pano') as br:
+            x, src = self._pano(batch)
         txt, txt_kmask = self._text(batch)
-        x, src = self._pano(batch)
+        br.join(x, src)
         gmap = None
         if return_gmap_embeds:
-            g, gm = self._gmap_in(batch, src, cache)
-            bias = self.global_encoder.sprels(batch['gmap_pair_dists']) if self.global_encoder.sprel_linear is not None else None
-            gmap = self.global_encoder.encoder(g, neg_mask(gm), txt, txt_kmask, bias)
+            with hipops.Branch('global') as bg:
+                g, gm = self._gmap_in(batch, src, cache)
+                bias = self.global_encoder.sprels(batch['gmap_pair_dists']) if self.global_encoder.sprel_linear is not None else None
+                gmap = self.global_encoder.encoder(g, neg_mask(gm), txt, txt_kmask, bias)
         v, vm = self._vp_in(batch, x, cache)
         vp = self.local_encoder.encoder(v, neg_mask(vm), txt, txt_kmask)
+        if return_gmap_embeds:
+            bg.join(gmap)
         return gmap, vp, txt
 
     def forward_mlm(self, batch):
         # P/model/vilmodel_goat.py:597-648: text queries attend to map / local tokens, outputs summed
         cache = self._indices(batch)
+        with hipops.Branch('pano') as br:
+            x, src = self._pano(batch)
         txt, txt_kmask = self._text(batch)
-        x, src = self._pano(batch)
-        g, gm = self._gmap_in(batch, src, cache)
-        gt = self.global_encoder.encoder(txt, txt_kmask, g, neg_mask(gm))
+        br.join(x, src)
+        with hipops.Branch('global') as bg:
+            g, gm = self._gmap_in(batch, src, cache)
+            gt = self.global_encoder.encoder(txt, txt_kmask, g, neg_mask(gm))
         v, vm = self._vp_in(batch, x, cache)
         vt = self.local_encoder.encoder(txt, txt_kmask, v, neg_mask(vm))
+        bg.join(gt)
         return gt + vt
 
     def forward_cfp(self, batch):
         # P/model/vilmodel_goat.py:650-696: single self-attention blocks, no cross-modal encoders
         cache = self._indices(batch)
+        with hipops.Branch('pano') as br:
+            x, src = self._pano(batch)
         txt, _ = self._text(batch)
-        x, src = self._pano(batch)
+        br.join(x, src)
         g, gm = self._gmap_in(batch, src, cache)
         gmap = self.global_encoder.tim_self_encoder(g, neg_mask(gm))
         v, vm = self._vp_in(batch, x, cache)
