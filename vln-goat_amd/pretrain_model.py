@@ -382,10 +382,12 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
             x, src = self._pano(batch)
         txt, _ = self._text(batch)
         br.join(x, src)
-        g, gm = self._gmap_in(batch, src, cache)
-        gmap = self.global_encoder.tim_self_encoder(g, neg_mask(gm))
+        with hipops.Branch('global') as bg:
+            g, gm = self._gmap_in(batch, src, cache)
+            gmap = self.global_encoder.tim_self_encoder(g, neg_mask(gm))
         v, vm = self._vp_in(batch, x, cache)
         vp = self.local_encoder.tim_self_encoder(v, neg_mask(vm))
+        bg.join(gmap)
         return gmap, vp, txt
 
 
@@ -603,14 +605,20 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
     # -- CFP ---------------------------------------------------------------------------------------
     def forward_cfp(self, batch, compute_loss):
         gmap, vp, txt = self.bert.forward_cfp(batch)
+        with hipops.Branch('global') as bg:          # the three heads are independent: map / text on side streams
+            if batch['extra_heads']:
+                gmap = self.tim_global_head(gmap)
+            go = attn_pool(gmap, self.tim_global_attn)
+        with hipops.Branch('pano') as bt:
+            if batch['extra_heads']:
+                txt = self.tim_txt_head(txt)
+            to = attn_pool(txt, self.tim_txt_attn)
         if batch['extra_heads']:
-            gmap = self.tim_global_head(gmap)
             vp = self.tim_local_head(vp)
-            txt = self.tim_txt_head(txt)
-        fw = self._fuse_weights(gmap, vp)
-        go = attn_pool(gmap, self.tim_global_attn)
         vo = attn_pool(vp, self.tim_local_attn)
-        to = attn_pool(txt, self.tim_txt_attn)
+        bg.join(gmap, go)
+        bt.join(txt, to)
+        fw = self._fuse_weights(gmap, vp)
         fo = go * fw + vo * (1 - fw)
         if compute_loss:
             return cfp_losses(go, vo, fo, to, self.temperature, self.cfp_gather)
