@@ -232,215 +232,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
 }
 
 // ======================================================================================== backward
-// One workgroup per (b, h); wave w owns key tile w and loops over the query tiles.
-template <typename T, int NKT>
-__global__ __launch_bounds__(NKT * 64) void attn_bwd_kernel(AttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef typename AT<T>::Frag Frag;
-  constexpr int KSTEPS = AT<T>::KSTEPS, LSTR = AT<T>::LSTR, TSTEPS = AT<T>::TSTEPS, PSTR = AT<T>::PSTR;
-  constexpr int NE = AT<T>::NE;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
-  const int nthreads = NKT * 64;
-
-  // LDS carve-up
-  T* kl = reinterpret_cast<T*>(smem);                 // [NKT*32][LSTR]   all keys
-  T* ql = kl + NKT * 32 * LSTR;                       // [32][LSTR]       Q_i
-  T* dol = ql + 32 * LSTR;                            // [32][LSTR]       dO_i
-  T* pt = dol + 32 * LSTR + wave * 32 * PSTR;         // per-wave [32 keys][PSTR] tile (P then dS)
-  float* dql = reinterpret_cast<float*>(dol + 32 * LSTR + NKT * 32 * PSTR);  // [32][HD] f32
-  float* rowd = dql + 32 * HD;                        // [32] D_i
-  float* rowl = rowd + 32;                            // [32] lse_i
-
-  const T* Qb = reinterpret_cast<const T*>(p.Q) + b * p.q_bs + h * HD;
-  const T* Kb = reinterpret_cast<const T*>(p.K) + b * p.k_bs + h * HD;
-  const T* Vb = reinterpret_cast<const T*>(p.V) + b * p.v_bs + h * HD;
-  const T* Ob = reinterpret_cast<const T*>(p.O) + b * p.o_bs + h * HD;
-  const T* dOb = reinterpret_cast<const T*>(p.dO) + b * p.do_bs + h * HD;
-  T* dQb = reinterpret_cast<T*>(p.dQ) + b * p.dq_bs + h * HD;
-  T* dKb = reinterpret_cast<T*>(p.dK) + b * p.dk_bs + h * HD;
-  T* dVb = reinterpret_cast<T*>(p.dV) + b * p.dv_bs + h * HD;
-
-  stage_rows<T>(kl, Kb, p.k_rs, 0, p.Lk, NKT * 32, tid, nthreads);
-
-  const int key_l = wave * 32 + l31;  // this lane's key when keys are across lanes (A operand rows)
-  const bool kvl = key_l < p.Lk;
-  Frag kf[KSTEPS], vf[KSTEPS];
-#pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) {
-    kf[ks] = gfrag<T>(Kb + (int64_t)key_l * p.k_rs, kvl, ks, hi);
-    vf[ks] = gfrag<T>(Vb + (int64_t)key_l * p.v_rs, kvl, ks, hi);
-  }
-  float kmv[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int key = wave * 32 + c_row(r, lane);
-    kmv[r] = (key < p.Lk) ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + key] : 0.f) : -INFINITY;
-  }
-
-  f32x16 dk[2], dv[2];
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-
-  const bool drop = p.p > 0.f;
-  const uint32_t thr = goat_thr24(p.p);
-  const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
-  const uint64_t seed = p.seed + (p.rng_dev ? *p.rng_dev : 0ull);
-
-  const int nqt = (p.Lq + 31) / 32;
-  for (int it = 0; it < nqt; ++it) {
-    const int q0 = it * 32;
-    __syncthreads();  // previous iteration's consumers done
-    stage_rows<T>(ql, Qb, p.q_rs, q0, p.Lq, 32, tid, nthreads);
-    stage_rows<T>(dol, dOb, p.do_rs, q0, p.Lq, 32, tid, nthreads);
-    for (int i = tid; i < 32 * HD; i += nthreads) dql[i] = 0.f;
-    if (wave == 0) {  // D_q = sum_d dO*O ; lse
-      const int qq = q0 + l31;
-      float dsum = 0.f;
-      if (qq < p.Lq) {
-        const T* orow = Ob + (int64_t)qq * p.o_rs + hi * 32;
-        const T* drow = dOb + (int64_t)qq * p.do_rs + hi * 32;
-#pragma unroll
-        for (int c = 0; c < 32 / NE; ++c) {
-          Chunk<T> a, d2;
-          a.load(orow + c * NE);
-          d2.load(drow + c * NE);
-#pragma unroll
-          for (int e = 0; e < NE; ++e) dsum += a.v[e] * d2.v[e];
-        }
-      }
-      dsum += __shfl_xor(dsum, 32, 64);
-      if (hi == 0) {
-        rowd[l31] = dsum;
-        rowl[l31] = (qq < p.Lq) ? p.lse[((int64_t)b * p.nh + h) * p.Lq + qq] : 0.f;
-      }
-    }
-    __syncthreads();
-
-    const int q = q0 + l31;
-    const bool qv = q < p.Lq;
-    // S^T (keys x q) and dPd^T (keys x q)
-    f32x16 s, dp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      Frag qf = *reinterpret_cast<const Frag*>(ql + l31 * LSTR + (ks * 2 + hi) * NE);
-      Frag df = *reinterpret_cast<const Frag*>(dol + l31 * LSTR + (ks * 2 + hi) * NE);
-      mma32(s, kf[ks], qf);
-      mma32(dp, vf[ks], df);
-    }
-    const float lse_q = rowl[l31];
-    const float d_q = rowd[l31];
-    const bool lse_ok = (lse_q != -INFINITY);
-    const uint64_t ctr0 = p.offset + (((uint64_t)b * p.nh + h) * p.Lq + q) * (uint64_t)p.Lk;
-    f32x16 pd, ds;  // dropped probs ; dS (unscaled)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = wave * 32 + c_row(r, lane);
-      float pr = 0.f;
-      if (qv && key < p.Lk && lse_ok) {
-        float v = s[r] * p.scale + kmv[r];
-        if (p.bias) v += p.bias[((int64_t)b * p.Lq + q) * p.Lk + key];
-        pr = __expf(v - lse_q);
-      }
-      float keep = 1.f;
-      if (drop) keep = goat_keep(seed, ctr0 + key, thr) ? keep_scale : 0.f;
-      pd[r] = pr * keep;
-      ds[r] = pr * (dp[r] * keep - d_q);
-    }
-    if (p.dbias) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = wave * 32 + c_row(r, lane);
-        if (qv && key < p.Lk) atomicAdd(p.dbias + ((int64_t)b * p.Lq + q) * p.Lk + key, ds[r]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ds[r] *= p.scale;
-
-    // dQ_i partial (q x d) += dS (q x keys_w) · K_w (keys x d)   [A from accumulator regs, B gathered]
-    {
-      f32x16 dq[2];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-#pragma unroll
-      for (int st = 0; st < TSTEPS; ++st) {
-        Frag a = acc_frag<T>(ds, st);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          Frag kb = gather_crow<T>(kl, LSTR, wave * 32, st, dt * 32 + l31, lane);
-          mma32(dq[dt], a, kb);
-        }
-      }
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(&dql[c_row(r, lane) * HD + dt * 32 + l31], dq[dt][r]);
-    }
-
-    // dV_w (keys x d) += Pd^T (keys x q) · dO_i (q x d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pt[c_row(r, lane) * PSTR + l31] = from_f<T>(pd[r]);
-    __syncthreads();
-#pragma unroll
-    for (int st = 0; st < TSTEPS; ++st) {
-      Frag a = *reinterpret_cast<const Frag*>(pt + l31 * PSTR + (2 * st + hi) * NE);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        Frag bb = gather_lin<T>(dol, LSTR, st, hi, dt * 32 + l31);
-        mma32(dv[dt], a, bb);
-      }
-    }
-    __syncthreads();
-    // dK_w (keys x d) += dS^T (keys x q) · Q_i (q x d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pt[c_row(r, lane) * PSTR + l31] = from_f<T>(ds[r]);
-    __syncthreads();
-#pragma unroll
-    for (int st = 0; st < TSTEPS; ++st) {
-      Frag a = *reinterpret_cast<const Frag*>(pt + l31 * PSTR + (2 * st + hi) * NE);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        Frag bb = gather_lin<T>(ql, LSTR, st, hi, dt * 32 + l31);
-        mma32(dk[dt], a, bb);
-      }
-    }
-    // write dQ_i (all waves' atomics are complete after this barrier)
-    __syncthreads();
-    for (int c = tid; c < 32 * (HD / NE); c += nthreads) {
-      int r = c / (HD / NE), cc = c % (HD / NE);
-      if (q0 + r < p.Lq) {
-        Chunk<T> ch;
-#pragma unroll
-        for (int e = 0; e < NE; ++e) ch.v[e] = dql[r * HD + cc * NE + e];
-        ch.store(dQb + (int64_t)(q0 + r) * p.dq_rs + cc * NE);
-      }
-    }
-  }
-
-  // dK_w, dV_w -> global (C layout: col = d (lanes), rows = keys)
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = wave * 32 + c_row(r, lane);
-      if (key < p.Lk) {
-        dKb[(int64_t)key * p.dk_rs + dt * 32 + l31] = from_f<T>(dk[dt][r]);
-        dVb[(int64_t)key * p.dv_rs + dt * 32 + l31] = from_f<T>(dv[dt][r]);
-      }
-    }
-}
-
-// ======================================================================================== backward v2
-// Two barrier-free single-wave roles per (b, h); S and dP are recomputed in each (cheap next to the removed
-// cross-wave reductions, LDS transposes and barriers of attn_bwd_kernel above, which is kept for reference):
+// Two barrier-free single-wave roles per (b, h); S and dP are recomputed in each (cheaper than the cross-wave
+// reductions, LDS transposes and barriers of a one-workgroup-per-head kernel: 17 % -> 8 % of the step):
 //   dQ role  (b, h, q-tile):  lane = query;  S^T = K·Q^T, dP^T = V·dO^T per key tile; dQ += dS·K
 //   dKV role (b, h, key-tile): lane = key;   S = Q·K^T, dP = dO·V^T per query tile; dV += Pd^T·dO, dK += dS^T·Q
 // "Transposed" B operands (K, dO, Q with the contraction index as the LDS row) come from bfrag_crow.
@@ -674,11 +467,6 @@ int launch_bwd2(hipStream_t st, const AttnArgs& a) {
 
 template <typename T>
 size_t fwd_smem(int nkt) { return (size_t)nkt * 32 * AT<T>::LSTR * sizeof(T); }
-template <typename T>
-size_t bwd_smem(int nkt) {
-  return ((size_t)nkt * 32 * AT<T>::LSTR + 2 * 32 * AT<T>::LSTR + (size_t)nkt * 32 * AT<T>::PSTR) * sizeof(T) +
-         (32 * HD + 64) * sizeof(float);
-}
 
 template <typename K>
 int set_smem(K kern, size_t bytes) {
@@ -702,22 +490,11 @@ int launch_fwd(hipStream_t st, const AttnArgs& a) {
   GOAT_LAUNCH_CHECK();
   return 0;
 }
-template <typename T, int NKT>
-int launch_bwd(hipStream_t st, const AttnArgs& a) {
-  size_t sm = bwd_smem<T>(NKT);
-  if (sm > 160 * 1024) return GOAT_E_SHAPE;
-  int e = set_smem(attn_bwd_kernel<T, NKT>, sm);
-  if (e) return e;
-  hipLaunchKernelGGL((attn_bwd_kernel<T, NKT>), dim3(a.B * a.nh), dim3(64 * NKT), sm, st, a);
-  GOAT_LAUNCH_CHECK();
-  return 0;
-}
-
 template <typename T>
-int dispatch(hipStream_t st, const AttnArgs& a, bool bwd) {
+int dispatch_fwd(hipStream_t st, const AttnArgs& a) {
   const int nkt = (a.Lk + 31) / 32;
 #define GOAT_ATTN_CASE(N) \
-  case N: return bwd ? launch_bwd<T, N>(st, a) : launch_fwd<T, N>(st, a);
+  case N: return launch_fwd<T, N>(st, a);
   switch (nkt) {
     GOAT_ATTN_CASE(1) GOAT_ATTN_CASE(2) GOAT_ATTN_CASE(3) GOAT_ATTN_CASE(4)
     GOAT_ATTN_CASE(5) GOAT_ATTN_CASE(6) GOAT_ATTN_CASE(7) GOAT_ATTN_CASE(8)
@@ -749,7 +526,7 @@ extern "C" int goat_attn_fwd(void* stream, int dtype, const void* Q, int64_t q_r
   a.kmask = kmask; a.bias = bias; a.lse = lse;
   a.B = B; a.nh = nh; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.p = p; a.seed = seed; a.offset = offset; a.rng_dev = rng_dev;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  return dtype == GOAT_BF16 ? dispatch<bf16_t>(st, a, false) : dispatch<float>(st, a, false);
+  return dtype == GOAT_BF16 ? dispatch_fwd<bf16_t>(st, a) : dispatch_fwd<float>(st, a);
 }
 
 extern "C" int goat_attn_bwd(void* stream, int dtype, const void* Q, int64_t q_rs, int64_t q_bs, const void* K,
