@@ -84,32 +84,69 @@ def build(args, rank):
     return cfg, model, batch, gb
 
 
+LATE_PREFIXES = ('bert.embeddings.', 'bert.lang_encoder.')     # backward phase 1: text encoder + embeddings (finish last)
+
+
 def make_steps(args, model, gb, world, wrapper):
-    """Returns {task: callable running one fwd+bwd step} (and, without the arena, per-task gradient lists)."""
+    """Returns {task: callable running one fwd+bwd(+all-reduce) step}.
+
+    N = 1: one hipGraph per task (arena clear + forward + backward).
+    N > 1: the backward pass is split at the text-encoder output into two graphs (dp.backward_phase_a / _b); the
+    all-reduce of the phase-0 gradients (heads, cross-modal and panorama encoders) is launched between the two replays and
+    overlaps the text-encoder backward; the phase-1 all-reduce follows.  cfp (it contains the all-gather of the
+    contrastive negatives) runs the same two phases eagerly."""
     from vln_goat_amd import hipops
     hipops.manual_seed(1234)
     hipops.AUTOTUNE = not args.no_autotune     # first sight of a GEMM shape times (tile, LDS stages, split-K) candidates
     hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')
     params = list(model.parameters())
     arena = [None]
+    two_phase = world > 1 or bool(os.environ.get('GOAT_BENCH_TWO_PHASE'))
+    boundary = {}
+    if two_phase:
+        def mark_boundary(mod, inp, out):
+            # the boundary is an identity VIEW of the text-encoder output: autograd runs the grad_fn of a tensor listed in
+            # `inputs=` when it captures its gradient — for the view that is a no-op, for the LayerNorm Function behind it
+            # it would be a second (accumulating) write of its parameter gradients
+            v = out.view_as(out)
+            boundary['txt'] = v
+            return v
+        model.bert.lang_encoder.register_forward_hook(mark_boundary)
 
     if args.overlap:
         hipops.WgradOverlap.enable()            # weight-gradient GEMMs on a side stream (joined after backward)
 
-    def step_body(task):
+    def forward(task):
         if arena[0] is not None:
-            arena[0].zero(task)                 # one fill per contiguous range of the task's gradient slices
+            arena[0].zero(task)                 # one fill per contiguous range of the task's non-kernel-owned slices
         else:
             for p in params:
                 p.grad = None
         hipops.RngState.dev.add_(0x9E3779B1)
-        loss = model(gb, task, compute_loss=True)
+        return model(gb, task, compute_loss=True)
+
+    def step_body(task):                        # single-phase step (N = 1, warm-up)
+        loss = forward(task)
         loss.mean().backward()
         hipops.WgradOverlap.join()
         return loss
 
-    use_graph = not args.no_graph
-    steps, grads, losses = {}, {}, {}
+    def phase_a(task):
+        loss = forward(task)
+        wrapper.backward_phase_a(loss.mean(), boundary['txt'])
+        return loss
+
+    def phase_b():
+        wrapper.backward_phase_b(boundary['txt'])
+
+    def eager_two_phase(task):
+        phase_a(task)
+        wrapper.reduce_gradients(task, phase=0, wait=False)
+        phase_b()
+        wrapper.reduce_gradients(task, phase=1)
+
+    use_graph = not args.no_graph and not (args.no_arena and world > 1)     # (graphs at N > 1 need the arena's static gradient storage)
+    steps = {}
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -119,39 +156,50 @@ def make_steps(args, model, gb, world, wrapper):
         if not args.no_arena:
             for p in params:
                 p.grad = None
-            arena[0] = wrapper.build_arena()     # .grad of every used parameter = view into one flat HBM buffer
+            arena[0] = wrapper.build_arena(late_prefixes=LATE_PREFIXES)    # .grad = views into one flat HBM buffer
         for task in TASKS:
-            step_body(task)
+            eager_two_phase(task) if (two_phase and arena[0] is not None) else step_body(task)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    if not use_graph:
-        for task in TASKS:
-            steps[task] = (lambda t=task: step_body(t))
-        return steps, None
+    two_phase = two_phase and arena[0] is not None
+
+    def reduce_all(task):
+        if world > 1:
+            wrapper.reduce_gradients(task)
+
     for task in TASKS:
-        if (world > 1 or os.environ.get('GOAT_BENCH_EAGER_CFP')) and task == 'cfp':
-            # the CFP step contains a collective (all-gather of the contrastive negatives): launched eagerly
-            steps[task] = (lambda t=task: step_body(t))
-            grads[task] = None
+        eager = (lambda t=task: eager_two_phase(t)) if two_phase else (lambda t=task: (step_body(t), reduce_all(t)))
+        if not use_graph or ((world > 1 or os.environ.get('GOAT_BENCH_EAGER_CFP')) and task == 'cfp'):
+            steps[task] = eager                  # (cfp at N > 1 contains a collective: launched eagerly)
             continue
         try:
             if world > 1:
                 torch.cuda.synchronize()
                 dist.barrier()
-            g = torch.cuda.CUDAGraph()
-            # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
-            with torch.cuda.graph(g, capture_error_mode='thread_local' if world > 1 else 'global'):
-                loss = step_body(task)
-            grads[task] = [p.grad for p in params] if arena[0] is None else None
-            losses[task] = loss.detach()     # (not the autograd graph: stale AccumulateGrad nodes would pin the capture stream)
-            del loss
-            steps[task] = g.replay
+            mode = 'thread_local' if world > 1 else 'global'   # thread_local: the RCCL watchdog thread may touch the HIP runtime
+            ga = torch.cuda.CUDAGraph()
+            if two_phase:
+                with torch.cuda.graph(ga, capture_error_mode=mode):
+                    phase_a(task)
+                gb_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb_, pool=ga.pool(), capture_error_mode=mode):
+                    phase_b()
+
+                def run(t=task, ga=ga, gb_=gb_):
+                    ga.replay()
+                    wrapper.reduce_gradients(t, phase=0, wait=False)     # overlaps the text-encoder backward below
+                    gb_.replay()
+                    wrapper.reduce_gradients(t, phase=1)                 # (waits for both all-reduces)
+                steps[task] = run
+            else:
+                with torch.cuda.graph(ga, capture_error_mode=mode):
+                    step_body(task)
+                steps[task] = (lambda t=task, ga=ga: (ga.replay(), reduce_all(t)))
         except Exception as e:       # never lose the run to a capture problem: fall back to eager launches for this task
             print('[bench] hipGraph capture of %s failed (%s: %s); running it eagerly' % (task, type(e).__name__, e), file=sys.stderr)
             torch.cuda.synchronize()
-            steps[task] = (lambda t=task: step_body(t))
-            grads[task] = None
-    return steps, grads
+            steps[task] = eager
+    return steps
 
 
 def cpu_baseline(args, cfg):
@@ -279,14 +327,11 @@ def main():
     cfg, model, batch, gb = build(args, rank)
     from vln_goat_amd import dp, synth
     wrapper = dp.GoatDataParallel(model, share_cfp_negatives=True)
-    steps, grads = make_steps(args, model, gb, world, wrapper)
+    steps = make_steps(args, model, gb, world, wrapper)
     n_traj = synth.n_traj_steps(batch)
 
     def run(i):
-        task = TASKS[i % len(TASKS)]
-        steps[task]()
-        if world > 1:
-            wrapper.reduce_gradients(task, grads[task] if grads is not None else None)
+        steps[TASKS[i % len(TASKS)]]()          # fwd + bwd (+ gradient all-reduce at N > 1)
 
     for i in range(args.warmup):
         run(i)
@@ -319,7 +364,7 @@ def main():
                                    'vocab 50265, per-rank batch %d, T=5, 36x768 views, L=80, tasks mlm/sap/cfp 1:1:1, dropout 0.1, '
                                    'fwd+bwd%s, random-init' % (args.layers, args.batch, ' + grad all-reduce' if world > 1 else ''),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                       'launch': 'eager' if args.no_graph else ('hipGraph replay' if world == 1 else 'hipGraph replay (mlm, sap) + eager cfp; grad all-reduce after each step')},
+                       'launch': 'eager' if args.no_graph else ('hipGraph replay' if world == 1 else 'hipGraph replay in two backward phases (mlm, sap) + eager cfp; phase-0 gradient all-reduce overlaps the text-encoder backward')},
             'samples_per_s': round(value / 5.0, 1),
             'step_mfma_frac': round(value / world * algo * 1e9 / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4),
         }

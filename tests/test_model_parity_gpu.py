@@ -414,3 +414,69 @@ def test_captured_step_with_branches_and_grouped_wgrads_equals_eager(task):
     finally:
         hipops.Branch.mode = old_mode
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('task', ['mlm', 'sap', 'cfp'])
+def test_two_phase_backward_equals_single_backward(task):
+    """dp.backward_phase_a/_b (the N>1 bench path: all-reduce of the early gradients overlaps the text-encoder backward),
+    eagerly and captured as two hipGraphs sharing a pool, against one ordinary backward."""
+    import vln_goat_amd
+    from vln_goat_amd import dp, hipops, synth
+    cfg, model, batch = build_case('pretrain_small_ragged')
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        model = model.cuda().eval()
+        gb = synth.batch_to(batch, 'cuda')
+        model(gb, task, compute_loss=True).mean().backward()
+        ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        wrapper = dp.GoatDataParallel(model)
+        wrapper.record_usage(task)
+        for p in model.parameters():
+            p.grad = None
+        arena = wrapper.build_arena(late_prefixes=('bert.embeddings.', 'bert.lang_encoder.'))
+        assert arena.ranges(task, 0) and arena.ranges(task, 1)
+        assert sorted(arena.ranges(task, 0) + arena.ranges(task, 1)) == sorted(
+            r for ph in (0, 1) for r in arena.ranges(task, ph))         # the two phases partition the task's slices
+        box = {}
+        def mark(m, i, o):
+            v = o.view_as(o)            # identity view: see dp.GoatDataParallel.backward_phase_a
+            box['txt'] = v
+            return v
+        h = model.bert.lang_encoder.register_forward_hook(mark)
+
+        def a():
+            arena.zero(task)
+            loss = model(gb, task, compute_loss=True)
+            wrapper.backward_phase_a(loss.mean(), box['txt'])
+
+        def b():
+            wrapper.backward_phase_b(box['txt'])
+        gmax = max(float(v.norm()) for v in ref.values())
+
+        def check(what):
+            torch.cuda.synchronize()
+            for n, p in model.named_parameters():
+                if n in ref:
+                    d = float((arena.views[id(p)].double() - ref[n].double()).norm())
+                    assert d <= 2e-3 * max(float(ref[n].norm()), 1e-2 * gmax), (what, n, d)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                a(); b()
+        torch.cuda.current_stream().wait_stream(side)
+        check('eager two-phase')
+        ga, gb2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            a()
+        with torch.cuda.graph(gb2, pool=ga.pool()):
+            b()
+        for rep in range(3):
+            if rep == 1:
+                arena.flat.fill_(float('nan'))
+            ga.replay()
+            gb2.replay()
+            check('captured two-phase, replay %d' % rep)
+        h.remove()
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)

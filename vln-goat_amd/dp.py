@@ -159,8 +159,13 @@ class GradArena:
                         # group and are cleared by ONE fill per group in zero(); the large matrices are cleared / overwritten
                         # by their first writer (cache-warm for the split-K atomics)
 
-    def __init__(self, params, usage=None, bucket_bytes=128 << 20):
+    def __init__(self, params, usage=None, bucket_bytes=128 << 20, phase_of=None):
+        """phase_of: optional {id(param): 0 | 1} — backward phase in which the parameter's gradient becomes final (0: the part of
+        the backward pass that runs first, e.g. heads / cross-modal / panorama encoders; 1: the rest, e.g. text encoder and
+        embeddings).  Phases are kept contiguous inside every usage group so that the phase-0 ranges can be all-reduced
+        while phase 1 is still computing (GoatDataParallel.backward_phase_a / _b)."""
         params = [p for p in params if p.requires_grad]
+        phase_of = phase_of or {}
         seen, uniq = set(), []
         for p in params:
             if id(p) not in seen:
@@ -174,14 +179,16 @@ class GradArena:
         groups = {}
         for p in uniq:
             groups.setdefault(key(p), []).append(p)
-        self.params, self.offsets, self.tasks_of = [], {}, {}
+        self.params, self.offsets, self.tasks_of, self.phase = [], {}, {}, {}
         self.bucket_elems = max(1, bucket_bytes // 4)
         off = 0
         for k in sorted(groups):
             plist = groups[k]
-            big = [q for q in plist if q.numel() >= self.SMALL]
-            small = [q for q in plist if q.numel() < self.SMALL]
-            for p in big + small:
+            ordered = []
+            for ph in sorted({phase_of.get(id(q), 0) for q in plist}):
+                sub = [q for q in plist if phase_of.get(id(q), 0) == ph]
+                ordered += [q for q in sub if q.numel() >= self.SMALL] + [q for q in sub if q.numel() < self.SMALL]
+            for p in ordered:
                 if p.numel() < self.SMALL:
                     p.__dict__['_goat_prezero'] = True     # cleared by zero(): the kernels only ever accumulate into it
                 else:
@@ -189,6 +196,7 @@ class GradArena:
                 self.params.append(p)
                 self.offsets[id(p)] = off
                 self.tasks_of[id(p)] = frozenset(k) if usage is not None else None
+                self.phase[id(p)] = phase_of.get(id(p), 0)
                 off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.numel = off
         dev = self.params[0].device if self.params else torch.device('cpu')
@@ -223,14 +231,16 @@ class GradArena:
                 p.__dict__['_goat_sink'] = self.views[id(p)]
 
     # -- ranges ----------------------------------------------------------------------------------
-    def ranges(self, task=None):
+    def ranges(self, task=None, phase=None):
         key = task.split('_')[0] if task is not None else None
-        r = self._ranges.get(key)
+        r = self._ranges.get((key, phase))
         if r is None:
             r = []
             for p in self.params:
                 t = self.tasks_of[id(p)]
                 if key is not None and t is not None and key not in t:
+                    continue
+                if phase is not None and self.phase[id(p)] != phase:
                     continue
                 a = self.offsets[id(p)]
                 b = a + (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
@@ -238,7 +248,7 @@ class GradArena:
                     r[-1][1] = b
                 else:
                     r.append([a, b])
-            r = self._ranges[key] = [tuple(x) for x in r]
+            r = self._ranges[(key, phase)] = [tuple(x) for x in r]
         return r
 
     def zero(self, task=None):
@@ -298,13 +308,15 @@ class GradArena:
             dist.all_reduce(c)
             c.div_(W)
 
-    def all_reduce_mean(self, task=None):
-        """Average the task's gradient ranges over ranks, in place, on the communication stream."""
+    def all_reduce_mean(self, task=None, phase=None, wait=True):
+        """Average the task's gradient ranges (of one backward phase, or all) over ranks, in place, on the communication
+        stream.  wait=False: return without making the caller's stream wait (call wait_comm() before the gradients are
+        read) — this is how the phase-0 all-reduce overlaps the phase-1 backward computation."""
         W = _world()
         if W == 1:
             return
         chunks = []
-        for a, b in self.ranges(task):
+        for a, b in self.ranges(task, phase):
             while a < b:
                 e = min(b, a + self.bucket_elems)
                 chunks.append(self.flat[a:e])
@@ -314,10 +326,15 @@ class GradArena:
             with torch.cuda.stream(self.comm_stream):
                 for c in chunks:
                     self._reduce_mean(c, W)
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            if wait:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
             for c in chunks:
                 self._reduce_mean(c, W)
+
+    def wait_comm(self):
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
 
 
 class GoatDataParallel(torch.nn.Module):
@@ -347,14 +364,35 @@ class GoatDataParallel(torch.nn.Module):
             if p.grad is not None:
                 self._usage.setdefault(id(p), set()).add(key)
 
-    def build_arena(self, bucket_bytes=128 << 20):
-        """Flat gradient arena over the parameters seen by record_usage (all parameters if it was never called)."""
-        self.arena = GradArena(self.module.parameters(), self._usage or None, bucket_bytes).attach()
+    def build_arena(self, bucket_bytes=128 << 20, late_prefixes=()):
+        """Flat gradient arena over the parameters seen by record_usage (all parameters if it was never called).
+        late_prefixes: parameter-name prefixes whose gradients are produced LAST in the backward pass (backward phase 1,
+        e.g. ('bert.embeddings.', 'bert.lang_encoder.')); everything else is phase 0.  See backward_phase_a/_b."""
+        phase_of = {id(p): int(any(n.startswith(pre) for pre in late_prefixes)) for n, p in self.module.named_parameters()}
+        self._late = [p for p in self.module.parameters() if phase_of[id(p)] == 1 and p.requires_grad]
+        self._early = [p for p in self.module.parameters() if phase_of[id(p)] == 0 and p.requires_grad]
+        self.arena = GradArena(self.module.parameters(), self._usage or None, bucket_bytes, phase_of).attach()
         return self.arena
 
-    def reduce_gradients(self, task, grads=None):
+    # Two-phase backward: the gradient all-reduce of the parameters that finish first (phase 0) runs on the communication
+    # stream while the rest of the backward pass (phase 1: text encoder, embeddings) is still computing.
+    #     loss = model(batch, task, True).mean(); boundary = <an identity view (t.view_as(t), substituted for t in the forward
+    #     pass by a forward hook) of the output of the phase-1 sub-network, e.g. the text encoder: autograd executes the
+    #     grad_fn of a tensor listed in `inputs=`, which must therefore be a side-effect-free node>
+    #     w.backward_phase_a(loss, boundary); w.reduce_gradients(task, phase=0, wait=False)
+    #     w.backward_phase_b(boundary);        w.reduce_gradients(task, phase=1)          # waits for both
+    def backward_phase_a(self, loss, boundary):
+        """Back-propagate `loss` down to `boundary` (its .grad is filled) and into every phase-0 parameter."""
+        boundary.grad = None
+        # retain_graph: the engine would otherwise release the saved tensors of the boundary's producer, which phase B needs
+        torch.autograd.backward(loss, inputs=self._early + [boundary], retain_graph=True)
+
+    def backward_phase_b(self, boundary):
+        torch.autograd.backward(boundary, grad_tensors=boundary.grad, inputs=self._late)
+
+    def reduce_gradients(self, task, grads=None, phase=None, wait=True):
         if self.arena is not None and grads is None:
-            return self.arena.all_reduce_mean(task)
+            return self.arena.all_reduce_mean(task, phase, wait)
         key = task.split('_')[0]
         gb = self._buckets.get(key)
         if gb is None:
