@@ -123,6 +123,7 @@ def make_steps(args, model, gb, world, wrapper):
             for p in params:
                 p.grad = None
         hipops.RngState.dev.add_(0x9E3779B1)
+        wrapper.begin_step(task)                # (N > 1: the word-embedding gradient of sap / cfp steps is exchanged sparsely)
         return model(gb, task, compute_loss=True)
 
     def step_body(task):                        # single-phase step (N = 1, warm-up)
@@ -157,6 +158,8 @@ def make_steps(args, model, gb, world, wrapper):
             for p in params:
                 p.grad = None
             arena[0] = wrapper.build_arena(late_prefixes=LATE_PREFIXES)    # .grad = views into one flat HBM buffer
+            if not os.environ.get('GOAT_BENCH_DENSE_EMBED'):
+                wrapper.enable_sparse_embedding(model.bert.embeddings.word_embeddings.weight, [t for t in TASKS if t != 'mlm'])
         for task in TASKS:
             eager_two_phase(task) if (two_phase and arena[0] is not None) else step_body(task)
     torch.cuda.current_stream().wait_stream(side)

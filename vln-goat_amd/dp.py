@@ -203,6 +203,7 @@ class GradArena:
         self.flat = torch.zeros(max(off, 1), dtype=torch.float32, device=dev)
         self.views = {id(p): self.flat[self.offsets[id(p)]:self.offsets[id(p)] + p.numel()].view_as(p) for p in self.params}
         self._ranges, self._owned, self._fills, self._cur = {}, {}, {}, None
+        self.no_zero = {}       # task -> ids of parameters whose slice zero() leaves alone (written wholesale elsewhere)
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
 
     # -- binding ---------------------------------------------------------------------------------
@@ -231,16 +232,16 @@ class GradArena:
                 p.__dict__['_goat_sink'] = self.views[id(p)]
 
     # -- ranges ----------------------------------------------------------------------------------
-    def ranges(self, task=None, phase=None):
+    def ranges(self, task=None, phase=None, exclude=frozenset()):
         key = task.split('_')[0] if task is not None else None
-        r = self._ranges.get((key, phase))
+        r = self._ranges.get((key, phase, exclude))
         if r is None:
             r = []
             for p in self.params:
                 t = self.tasks_of[id(p)]
                 if key is not None and t is not None and key not in t:
                     continue
-                if phase is not None and self.phase[id(p)] != phase:
+                if (phase is not None and self.phase[id(p)] != phase) or id(p) in exclude:
                     continue
                 a = self.offsets[id(p)]
                 b = a + (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
@@ -248,7 +249,7 @@ class GradArena:
                     r[-1][1] = b
                 else:
                     r.append([a, b])
-            r = self._ranges[(key, phase)] = [tuple(x) for x in r]
+            r = self._ranges[(key, phase, exclude)] = [tuple(x) for x in r]
         return r
 
     def zero(self, task=None):
@@ -268,7 +269,7 @@ class GradArena:
         self._cur = (key, hipops.ARENA_EPOCH[0])
         owned = self._owned.get(key)
         if owned is None:
-            for a, b in self.ranges(task):
+            for a, b in self.ranges(task, None, frozenset(self.no_zero.get(key, ()))):
                 self.flat[a:b].zero_()
             return
         fills = self._fills.get(key)
@@ -276,7 +277,7 @@ class GradArena:
             r = []
             for p in self.params:
                 t = self.tasks_of[id(p)]
-                if (key is not None and t is not None and key not in t) or id(p) in owned:
+                if (key is not None and t is not None and key not in t) or id(p) in owned or id(p) in self.no_zero.get(key, ()):
                     continue
                 a = self.offsets[id(p)]
                 b = a + (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
@@ -308,7 +309,7 @@ class GradArena:
             dist.all_reduce(c)
             c.div_(W)
 
-    def all_reduce_mean(self, task=None, phase=None, wait=True):
+    def all_reduce_mean(self, task=None, phase=None, wait=True, exclude=frozenset()):
         """Average the task's gradient ranges (of one backward phase, or all) over ranks, in place, on the communication
         stream.  wait=False: return without making the caller's stream wait (call wait_comm() before the gradients are
         read) — this is how the phase-0 all-reduce overlaps the phase-1 backward computation."""
@@ -316,7 +317,7 @@ class GradArena:
         if W == 1:
             return
         chunks = []
-        for a, b in self.ranges(task, phase):
+        for a, b in self.ranges(task, phase, exclude):
             while a < b:
                 e = min(b, a + self.bucket_elems)
                 chunks.append(self.flat[a:e])
@@ -390,8 +391,63 @@ class GoatDataParallel(torch.nn.Module):
     def backward_phase_b(self, boundary):
         torch.autograd.backward(boundary, grad_tensors=boundary.grad, inputs=self._late)
 
+    # -- sparse exchange of the word-embedding gradient -----------------------------------------------------------
+    def enable_sparse_embedding(self, table, tasks):
+        """`table`: the word-embedding Parameter; `tasks`: the tasks in which its gradient comes from lookups only
+        (not mlm: the tied decoder makes it dense).  Call after build_arena(); then begin_step(task) before each forward."""
+        from . import hipops
+        if _world() == 1 or self.arena is None or id(table) not in self.arena.views:
+            return
+        hipops.SparseEmbedGrad.params.add(id(table))
+        self._sparse = (table, {t.split('_')[0] for t in tasks})
+        for t in self._sparse[1]:
+            self.arena.no_zero.setdefault(t, set()).add(id(table))
+        self._stash = {}
+
+    def begin_step(self, task):
+        from . import hipops
+        key = task.split('_')[0]
+        sp = getattr(self, '_sparse', None)
+        if sp is not None and key in sp[1]:
+            lst = self._stash[key] = []
+            hipops.SparseEmbedGrad.sink_list = lst
+        else:
+            hipops.SparseEmbedGrad.sink_list = None
+
+    def _reduce_sparse(self, key):
+        """all-gather (rows, ids) of every rank and rebuild the averaged table gradient locally."""
+        from . import hipops
+        table = self._sparse[0]
+        view = self.arena.views[id(table)]
+        W = _world()
+        view.zero_()
+        for rows, ids, _tab, pad in self._stash.get(key, ()):
+            ids = ids.reshape(-1).contiguous()
+            if dist.get_backend() == 'gloo' and rows.is_cuda:        # (single-GPU self-tests: gloo has no GPU all-gather)
+                all_rows = torch.zeros((W,) + tuple(rows.shape), dtype=torch.float32, device=rows.device)
+                all_ids = torch.zeros((W,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+                all_rows[_rank()] = rows.float()
+                all_ids[_rank()] = ids
+                dist.all_reduce(all_rows)
+                dist.all_reduce(all_ids)
+                all_rows = all_rows.to(rows.dtype)
+            else:
+                all_rows = torch.empty((W * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)
+                all_ids = torch.empty(W * ids.shape[0], dtype=ids.dtype, device=ids.device)
+                dist.all_gather_into_tensor(all_rows, rows.contiguous())
+                dist.all_gather_into_tensor(all_ids, ids)
+            all_rows = all_rows.reshape(-1, rows.shape[1])
+            hipops.embedding_scatter_add(view, all_rows * (1.0 / W), all_ids.reshape(-1), pad)
+
     def reduce_gradients(self, task, grads=None, phase=None, wait=True):
         if self.arena is not None and grads is None:
+            key = task.split('_')[0]
+            sp = getattr(self, '_sparse', None)
+            if sp is not None and key in sp[1] and _world() > 1:
+                tid = id(sp[0])
+                if phase is None or phase == self.arena.phase[tid]:
+                    self._reduce_sparse(key)            # small all-gather + local scatter on the caller's stream
+                return self.arena.all_reduce_mean(task, phase, wait, frozenset((tid,)))
             return self.arena.all_reduce_mean(task, phase, wait)
         key = task.split('_')[0]
         gb = self._buckets.get(key)

@@ -1196,6 +1196,17 @@ def check_embed_errors():
             raise IndexError('embedding id out of range on %s' % (dev,))
 
 
+class SparseEmbedGrad:
+    """Data-parallel hook for the word-embedding table.  In a step whose only gradient of the table comes from the lookups
+    (sap, cfp: at most B*L of its 50 265 rows are touched) all-reducing the dense 154 MB table gradient is waste: with
+    `sink_list` set (dp.GoatDataParallel.begin_step), _EmbedFn.backward does not scatter into a table listed in `params`
+    but hands (d_out rows, ids, table, padding index) over; dp all-gathers rows + ids (5.9 MB per rank) and scatter-adds
+    every rank's rows locally (GoatDataParallel.reduce_gradients).  Inactive at world size 1 and in mlm steps (the tied
+    decoder makes the table gradient dense)."""
+    params = set()          # id(parameter) of the tables handled this way
+    sink_list = None        # list to append to during this step's backward, or None
+
+
 class _EmbedFn(torch.autograd.Function):
     """out = word[ids] (+ type[type_ids or 0]) (+ pos[arange(L)]) in one pass; backward scatters into f32 table
     gradients (P/model/Bert_backbone.py:98-113).  Replaces three F.embedding calls and torch's sort-based
@@ -1237,6 +1248,9 @@ class _EmbedFn(torch.autograd.Function):
             P is not None and ctx.needs_input_grad[4]
         dev = dout.device
         sw, st_, sp = (_sink(t) for t in ctx.tabs)
+        if need_w and sw is not None and SparseEmbedGrad.sink_list is not None and id(ctx.tabs[0]) in SparseEmbedGrad.params:
+            SparseEmbedGrad.sink_list.append((d2, ids, ctx.tabs[0], word_pad))      # exchanged and scattered by dp after backward
+            need_w = False
         for t, sk, need in zip(ctx.tabs, (sw, st_, sp), (need_w, need_t, need_p)):
             if sk is not None and need and _first_touch(t):
                 sk.zero_()              # first writer of this slice in the step: clear it (scatter-adds follow)
@@ -1262,8 +1276,17 @@ class _EmbedFn(torch.autograd.Function):
                 colsum(flat, out=of[:L * H])
         if need_t and type_ids is None:
             colsum(d2, out=dtab[0])            # every token has type 0: one column sum instead of `rows` atomics per column
-        return (None, None if dword is sw else dword, None if dtab is st_ else dtab, None, None if dpos is sp else dpos,
-                None, None, None)
+        return (None, None if (dword is sw or dword is None) else dword, None if dtab is st_ else dtab, None,
+                None if dpos is sp else dpos, None, None, None)
+
+
+def embedding_scatter_add(dword, rows, ids, word_pad=-1):
+    """dword[ids[r], :] += rows[r, :] (float32 table gradient, atomics) — goat_embed_bwd on the word table only."""
+    rows = rows if rows.is_contiguous() else rows.contiguous()
+    ids = ids.reshape(-1).contiguous()
+    st = _lib.lib().goat_embed_bwd(_stream(), _dt(rows), _ptr(rows), _ptr(ids), None, 1, _ptr(dword), None, None,
+                                   rows.shape[0], rows.shape[1], dword.shape[0], -1 if word_pad is None else int(word_pad), -1)
+    _lib.check(st, 'goat_embed_bwd')
 
 
 def embedding(ids, word, type_tab=None, type_ids=None, pos_tab=None, out_dtype=None, word_pad=None, pos_pad=None):
