@@ -94,7 +94,7 @@ def make_steps(args, model, gb, world, wrapper):
     N > 1: the backward pass is split at the text-encoder output into two graphs (dp.backward_phase_a / _b); the
     all-reduce of the phase-0 gradients (heads, cross-modal and panorama encoders) is launched between the two replays and
     overlaps the text-encoder backward; the phase-1 all-reduce follows.  cfp (it contains the all-gather of the
-    contrastive negatives) runs the same two phases eagerly."""
+    contrastive negatives) is captured as three graphs around the eager gather + loss (capture_cfp_around_gather)."""
     from vln_goat_amd import hipops
     hipops.manual_seed(1234)
     hipops.AUTOTUNE = not args.no_autotune     # first sight of a GEMM shape times (tile, LDS stages, split-K) candidates
@@ -170,10 +170,54 @@ def make_steps(args, model, gb, world, wrapper):
         if world > 1:
             wrapper.reduce_gradients(task)
 
+    def capture_cfp_around_gather(mode):
+        """cfp at N > 1: the all-gather of the contrastive negatives (and its reduce-scatter backward) cannot live in a graph
+        here, so the step is three graphs around a short eager middle:
+        G1 forward to the four pooled vectors | eager: gather, InfoNCE losses, their backward | G2 backward phase A | G3 phase B."""
+        from vln_goat_amd.pretrain_model import cfp_losses
+        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, capture_error_mode=mode):
+            if arena[0] is not None:
+                arena[0].zero('cfp')
+            hipops.RngState.dev.add_(0x9E3779B1)
+            wrapper.begin_step('cfp')
+            packed = torch.stack(model(gb, 'cfp', compute_loss=False), 0)            # [4, B, H] float32, autograd graph alive
+        dpacked = torch.zeros_like(packed)
+
+        def middle():
+            pd = packed.detach().requires_grad_(True)
+            cfp_losses(pd[0], pd[1], pd[2], pd[3], model.temperature, model.cfp_gather).mean().backward()
+            dpacked.copy_(pd.grad)
+        middle()
+        with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=mode):
+            wrapper.backward_phase_a(packed, boundary['txt'], grad_tensors=dpacked)
+        with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode=mode):
+            phase_b()
+
+        def run():
+            g1.replay()
+            middle()
+            g2.replay()
+            wrapper.reduce_gradients('cfp', phase=0, wait=False)
+            g3.replay()
+            wrapper.reduce_gradients('cfp', phase=1)
+        return run
+
     for task in TASKS:
         eager = (lambda t=task: eager_two_phase(t)) if two_phase else (lambda t=task: (step_body(t), reduce_all(t)))
-        if not use_graph or ((world > 1 or os.environ.get('GOAT_BENCH_EAGER_CFP')) and task == 'cfp'):
-            steps[task] = eager                  # (cfp at N > 1 contains a collective: launched eagerly)
+        if not use_graph or (os.environ.get('GOAT_BENCH_EAGER_CFP') and task == 'cfp'):
+            steps[task] = eager
+            continue
+        if task == 'cfp' and two_phase:
+            try:
+                if world > 1:
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                steps[task] = capture_cfp_around_gather('thread_local' if world > 1 else 'global')
+            except Exception as e:
+                print('[bench] hipGraph capture of cfp failed (%s: %s); running it eagerly' % (type(e).__name__, e), file=sys.stderr)
+                torch.cuda.synchronize()
+                steps[task] = eager
             continue
         try:
             if world > 1:
@@ -367,7 +411,7 @@ def main():
                                    'vocab 50265, per-rank batch %d, T=5, 36x768 views, L=80, tasks mlm/sap/cfp 1:1:1, dropout 0.1, '
                                    'fwd+bwd%s, random-init' % (args.layers, args.batch, ' + grad all-reduce' if world > 1 else ''),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                       'launch': 'eager' if args.no_graph else ('hipGraph replay' if world == 1 else 'hipGraph replay in two backward phases (mlm, sap) + eager cfp; phase-0 gradient all-reduce overlaps the text-encoder backward')},
+                       'launch': 'eager' if args.no_graph else ('hipGraph replay' if world == 1 else 'hipGraph replay in two backward phases (cfp: three graphs around the eager all-gather + loss); phase-0 gradient all-reduce overlaps the text-encoder backward')},
             'samples_per_s': round(value / 5.0, 1),
             'step_mfma_frac': round(value / world * algo * 1e9 / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4),
         }

@@ -480,3 +480,46 @@ def test_two_phase_backward_equals_single_backward(task):
         h.remove()
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+def test_cfp_backward_through_pooled_vectors_equals_loss_backward():
+    """The N>1 bench path of cfp: forward to the four pooled vectors, the InfoNCE losses and their backward as a separate
+    (eager) piece, then the two backward phases started from d(pooled) — must equal loss.mean().backward()."""
+    import vln_goat_amd
+    from vln_goat_amd import dp, synth
+    from vln_goat_amd.pretrain_model import cfp_losses
+    cfg, model, batch = build_case('pretrain_small_ragged')
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        model = model.cuda().eval()
+        gb = synth.batch_to(batch, 'cuda')
+        model(gb, 'cfp', compute_loss=True).mean().backward()
+        ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        wrapper = dp.GoatDataParallel(model)
+        wrapper.record_usage('cfp')
+        for p in model.parameters():
+            p.grad = None
+        arena = wrapper.build_arena(late_prefixes=('bert.embeddings.', 'bert.lang_encoder.'))
+        box = {}
+
+        def mark(m, i, o):
+            v = o.view_as(o)
+            box['txt'] = v
+            return v
+        h = model.bert.lang_encoder.register_forward_hook(mark)
+        for _ in range(2):
+            arena.zero('cfp')
+            packed = torch.stack(model(gb, 'cfp', compute_loss=False), 0)
+            pd = packed.detach().requires_grad_(True)
+            cfp_losses(pd[0], pd[1], pd[2], pd[3], model.temperature, model.cfp_gather).mean().backward()
+            wrapper.backward_phase_a(packed, box['txt'], grad_tensors=pd.grad)
+            wrapper.backward_phase_b(box['txt'])
+        h.remove()
+        torch.cuda.synchronize()
+        gmax = max(float(v.norm()) for v in ref.values())
+        for n, p in model.named_parameters():
+            if n in ref:
+                d = float((arena.views[id(p)].double() - ref[n].double()).norm())
+                assert d <= 2e-3 * max(float(ref[n].norm()), 1e-2 * gmax), (n, d)
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)

@@ -382,11 +382,12 @@ class GoatDataParallel(torch.nn.Module):
     #     grad_fn of a tensor listed in `inputs=`, which must therefore be a side-effect-free node>
     #     w.backward_phase_a(loss, boundary); w.reduce_gradients(task, phase=0, wait=False)
     #     w.backward_phase_b(boundary);        w.reduce_gradients(task, phase=1)          # waits for both
-    def backward_phase_a(self, loss, boundary):
-        """Back-propagate `loss` down to `boundary` (its .grad is filled) and into every phase-0 parameter."""
+    def backward_phase_a(self, loss, boundary, grad_tensors=None):
+        """Back-propagate `loss` (a scalar, or any tensor together with `grad_tensors`) down to `boundary` (its .grad is
+        filled) and into every phase-0 parameter."""
         boundary.grad = None
         # retain_graph: the engine would otherwise release the saved tensors of the boundary's producer, which phase B needs
-        torch.autograd.backward(loss, inputs=self._early + [boundary], retain_graph=True)
+        torch.autograd.backward(loss, grad_tensors=grad_tensors, inputs=self._early + [boundary], retain_graph=True)
 
     def backward_phase_b(self, boundary):
         torch.autograd.backward(boundary, grad_tensors=boundary.grad, inputs=self._late)
