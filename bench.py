@@ -84,39 +84,85 @@ def build(args, rank):
     return cfg, model, batch, gb
 
 
-LATE_PREFIXES = ('bert.embeddings.', 'bert.lang_encoder.')     # backward phase 1: text encoder + embeddings (finish last)
+class PhasePlan:
+    """How the GOAT backward pass is cut for communication overlap at N > 1 (dp.GoatDataParallel.backward_phase):
+        phase 0  heads + global / local cross-modal encoders            (their gradients are final first)
+        phase 1  panorama stem  ||  upper half of the text encoder      (parallel branches again)
+        phase 2  lower half of the text encoder + embeddings
+    Forward hooks substitute identity views for the boundary tensors: the text-encoder output, the panorama stem's outputs
+    and the output of the last text layer of phase 2."""
+
+    def __init__(self, model, n_text_layers):
+        split = max(1, n_text_layers // 2)
+        self.prefixes = [
+            ('bert.img_embeddings.',) + tuple('bert.lang_encoder.layer.%d.' % i for i in range(split, n_text_layers)),
+            ('bert.embeddings.',) + tuple('bert.lang_encoder.layer.%d.' % i for i in range(split)),
+        ]
+        if split >= n_text_layers:           # a one-layer text encoder: two phases only
+            self.prefixes = [('bert.img_embeddings.', 'bert.embeddings.', 'bert.lang_encoder.')]
+        self.b = {}
+
+        def view(t):
+            return t.view_as(t) if torch.is_tensor(t) else t
+
+        def txt_hook(mod, inp, out):
+            self.b['txt'] = view(out)
+            return self.b['txt']
+
+        def pano_hook(mod, inp, out):
+            self.b['pano'] = tuple(view(t) for t in out)
+            return self.b['pano']
+
+        def mid_hook(mod, inp, out):
+            self.b['mid'] = view(out)
+            return self.b['mid']
+        model.bert.lang_encoder.register_forward_hook(txt_hook)
+        model.bert.img_embeddings.register_forward_hook(pano_hook)
+        self.three = len(self.prefixes) == 2
+        if self.three:
+            model.bert.lang_encoder.layer[split - 1].register_forward_hook(mid_hook)
+
+    def first(self):        # boundaries of phase 0
+        return [self.b['txt']] + [t for t in self.b['pano'] if torch.is_tensor(t)]
+
+    def phases(self, wrapper, loss, grad_tensors=None):
+        """generator: runs one backward phase per step, yielding its index (the caller launches the all-reduce in between)."""
+        if not self.three:
+            wrapper.backward_phase(0, [loss], None if grad_tensors is None else [grad_tensors], [self.b['txt']])
+            yield 0
+            wrapper.backward_phase(1, [self.b['txt']], 'grad', [])
+            yield 1
+            return
+        first = self.first()
+        wrapper.backward_phase(0, [loss], None if grad_tensors is None else [grad_tensors], first)
+        yield 0
+        wrapper.backward_phase(1, first, 'grad', [self.b['mid']])
+        yield 1
+        wrapper.backward_phase(2, [self.b['mid']], 'grad', [])
+        yield 2
 
 
 def make_steps(args, model, gb, world, wrapper):
     """Returns {task: callable running one fwd+bwd(+all-reduce) step}.
 
     N = 1: one hipGraph per task (arena clear + forward + backward).
-    N > 1: the backward pass is split at the text-encoder output into two graphs (dp.backward_phase_a / _b); the
-    all-reduce of the phase-0 gradients (heads, cross-modal and panorama encoders) is launched between the two replays and
-    overlaps the text-encoder backward; the phase-1 all-reduce follows.  cfp (it contains the all-gather of the
-    contrastive negatives) is captured as three graphs around the eager gather + loss (capture_cfp_around_gather)."""
+    N > 1: the backward pass is cut into phases (PhasePlan), each captured as its own hipGraph (one shared memory pool); the
+    all-reduce of a phase's gradients is launched right after its replay and overlaps the later phases.  cfp (it contains
+    the all-gather of the contrastive negatives) gets one more cut around the eager gather + InfoNCE piece."""
     from vln_goat_amd import hipops
+    from vln_goat_amd.pretrain_model import cfp_losses
     hipops.manual_seed(1234)
     hipops.AUTOTUNE = not args.no_autotune     # first sight of a GEMM shape times (tile, LDS stages, split-K) candidates
     hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')
     params = list(model.parameters())
     arena = [None]
-    two_phase = world > 1 or bool(os.environ.get('GOAT_BENCH_TWO_PHASE'))
-    boundary = {}
-    if two_phase:
-        def mark_boundary(mod, inp, out):
-            # the boundary is an identity VIEW of the text-encoder output: autograd runs the grad_fn of a tensor listed in
-            # `inputs=` when it captures its gradient — for the view that is a no-op, for the LayerNorm Function behind it
-            # it would be a second (accumulating) write of its parameter gradients
-            v = out.view_as(out)
-            boundary['txt'] = v
-            return v
-        model.bert.lang_encoder.register_forward_hook(mark_boundary)
+    phased = world > 1 or bool(os.environ.get('GOAT_BENCH_PHASED'))
+    plan = PhasePlan(model, int(args.layers.split(',')[0])) if phased else None
 
     if args.overlap:
         hipops.WgradOverlap.enable()            # weight-gradient GEMMs on a side stream (joined after backward)
 
-    def forward(task):
+    def prologue(task):
         if arena[0] is not None:
             arena[0].zero(task)                 # one fill per contiguous range of the task's non-kernel-owned slices
         else:
@@ -124,27 +170,20 @@ def make_steps(args, model, gb, world, wrapper):
                 p.grad = None
         hipops.RngState.dev.add_(0x9E3779B1)
         wrapper.begin_step(task)                # (N > 1: the word-embedding gradient of sap / cfp steps is exchanged sparsely)
-        return model(gb, task, compute_loss=True)
 
-    def step_body(task):                        # single-phase step (N = 1, warm-up)
-        loss = forward(task)
+    def step_body(task):                        # single-graph step (N = 1, warm-up)
+        prologue(task)
+        loss = model(gb, task, compute_loss=True)
         loss.mean().backward()
         hipops.WgradOverlap.join()
         return loss
 
-    def phase_a(task):
-        loss = forward(task)
-        wrapper.backward_phase_a(loss.mean(), boundary['txt'])
-        return loss
-
-    def phase_b():
-        wrapper.backward_phase_b(boundary['txt'])
-
-    def eager_two_phase(task):
-        phase_a(task)
-        wrapper.reduce_gradients(task, phase=0, wait=False)
-        phase_b()
-        wrapper.reduce_gradients(task, phase=1)
+    def eager_phased(task):
+        prologue(task)
+        loss = model(gb, task, compute_loss=True).mean()
+        last = wrapper.n_phases - 1
+        for k in plan.phases(wrapper, loss):
+            wrapper.reduce_gradients(task, phase=k, wait=(k == last))
 
     use_graph = not args.no_graph and not (args.no_arena and world > 1)     # (graphs at N > 1 need the arena's static gradient storage)
     steps = {}
@@ -157,88 +196,81 @@ def make_steps(args, model, gb, world, wrapper):
         if not args.no_arena:
             for p in params:
                 p.grad = None
-            arena[0] = wrapper.build_arena(late_prefixes=LATE_PREFIXES)    # .grad = views into one flat HBM buffer
+            arena[0] = wrapper.build_arena(phase_prefixes=plan.prefixes if phased else None)   # .grad = views into one HBM buffer
             if not os.environ.get('GOAT_BENCH_DENSE_EMBED'):
                 wrapper.enable_sparse_embedding(model.bert.embeddings.word_embeddings.weight, [t for t in TASKS if t != 'mlm'])
+        phased = phased and arena[0] is not None
         for task in TASKS:
-            eager_two_phase(task) if (two_phase and arena[0] is not None) else step_body(task)
+            eager_phased(task) if phased else step_body(task)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    two_phase = two_phase and arena[0] is not None
 
     def reduce_all(task):
         if world > 1:
             wrapper.reduce_gradients(task)
 
-    def capture_cfp_around_gather(mode):
-        """cfp at N > 1: the all-gather of the contrastive negatives (and its reduce-scatter backward) cannot live in a graph
-        here, so the step is three graphs around a short eager middle:
-        G1 forward to the four pooled vectors | eager: gather, InfoNCE losses, their backward | G2 backward phase A | G3 phase B."""
-        from vln_goat_amd.pretrain_model import cfp_losses
-        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, capture_error_mode=mode):
-            if arena[0] is not None:
-                arena[0].zero('cfp')
-            hipops.RngState.dev.add_(0x9E3779B1)
-            wrapper.begin_step('cfp')
-            packed = torch.stack(model(gb, 'cfp', compute_loss=False), 0)            # [4, B, H] float32, autograd graph alive
-        dpacked = torch.zeros_like(packed)
+    def capture_phased(task, mode):
+        """One graph per cut.  cfp: the forward stops at the four pooled vectors; the all-gather, the InfoNCE losses and their
+        backward run eagerly between the first two graphs."""
+        graphs, pool = [], None
 
-        def middle():
-            pd = packed.detach().requires_grad_(True)
-            cfp_losses(pd[0], pd[1], pd[2], pd[3], model.temperature, model.cfp_gather).mean().backward()
-            dpacked.copy_(pd.grad)
-        middle()
-        with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=mode):
-            wrapper.backward_phase_a(packed, boundary['txt'], grad_tensors=dpacked)
-        with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode=mode):
-            phase_b()
+        def cap(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+                out = fn()
+            graphs.append(g)
+            return g.pool(), out
+        middle = None
+        if task == 'cfp':
+            def fwd():
+                prologue(task)
+                return torch.stack(model(gb, 'cfp', compute_loss=False), 0)          # [4, B, H] float32, autograd graph alive
+            pool, packed = cap(fwd)
+            dpacked = torch.zeros_like(packed)
+
+            def middle():
+                pd = packed.detach().requires_grad_(True)
+                cfp_losses(pd[0], pd[1], pd[2], pd[3], model.temperature, model.cfp_gather).mean().backward()
+                dpacked.copy_(pd.grad)
+            middle()
+            gen = plan.phases(wrapper, packed, dpacked)
+        else:
+            holder = {}
+
+            def fwd():
+                prologue(task)
+                holder['loss'] = model(gb, task, compute_loss=True).mean()
+            pool, _ = cap(fwd)
+            gen = plan.phases(wrapper, holder['loss'])
+        n_fwd = len(graphs)
+        for _ in range(wrapper.n_phases):
+            pool, _ = cap(lambda: next(gen))
+        last = wrapper.n_phases - 1
 
         def run():
-            g1.replay()
-            middle()
-            g2.replay()
-            wrapper.reduce_gradients('cfp', phase=0, wait=False)
-            g3.replay()
-            wrapper.reduce_gradients('cfp', phase=1)
+            for g in graphs[:n_fwd]:
+                g.replay()
+            if middle is not None:
+                middle()
+            for k, g in enumerate(graphs[n_fwd:]):
+                g.replay()
+                wrapper.reduce_gradients(task, phase=k, wait=(k == last))      # overlaps the replays that follow
         return run
 
     for task in TASKS:
-        eager = (lambda t=task: eager_two_phase(t)) if two_phase else (lambda t=task: (step_body(t), reduce_all(t)))
+        eager = (lambda t=task: eager_phased(t)) if phased else (lambda t=task: (step_body(t), reduce_all(t)))
         if not use_graph or (os.environ.get('GOAT_BENCH_EAGER_CFP') and task == 'cfp'):
             steps[task] = eager
-            continue
-        if task == 'cfp' and two_phase:
-            try:
-                if world > 1:
-                    torch.cuda.synchronize()
-                    dist.barrier()
-                steps[task] = capture_cfp_around_gather('thread_local' if world > 1 else 'global')
-            except Exception as e:
-                print('[bench] hipGraph capture of cfp failed (%s: %s); running it eagerly' % (type(e).__name__, e), file=sys.stderr)
-                torch.cuda.synchronize()
-                steps[task] = eager
             continue
         try:
             if world > 1:
                 torch.cuda.synchronize()
                 dist.barrier()
             mode = 'thread_local' if world > 1 else 'global'   # thread_local: the RCCL watchdog thread may touch the HIP runtime
-            ga = torch.cuda.CUDAGraph()
-            if two_phase:
-                with torch.cuda.graph(ga, capture_error_mode=mode):
-                    phase_a(task)
-                gb_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb_, pool=ga.pool(), capture_error_mode=mode):
-                    phase_b()
-
-                def run(t=task, ga=ga, gb_=gb_):
-                    ga.replay()
-                    wrapper.reduce_gradients(t, phase=0, wait=False)     # overlaps the text-encoder backward below
-                    gb_.replay()
-                    wrapper.reduce_gradients(t, phase=1)                 # (waits for both all-reduces)
-                steps[task] = run
+            if phased:
+                steps[task] = capture_phased(task, mode)
             else:
+                ga = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga, capture_error_mode=mode):
                     step_body(task)
                 steps[task] = (lambda t=task, ga=ga: (ga.replay(), reduce_all(t)))
@@ -411,7 +443,7 @@ def main():
                                    'vocab 50265, per-rank batch %d, T=5, 36x768 views, L=80, tasks mlm/sap/cfp 1:1:1, dropout 0.1, '
                                    'fwd+bwd%s, random-init' % (args.layers, args.batch, ' + grad all-reduce' if world > 1 else ''),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                       'launch': 'eager' if args.no_graph else ('hipGraph replay' if world == 1 else 'hipGraph replay in two backward phases (cfp: three graphs around the eager all-gather + loss); phase-0 gradient all-reduce overlaps the text-encoder backward')},
+                       'launch': 'eager' if args.no_graph else ('hipGraph replay' if world == 1 else 'hipGraph replay, backward cut into 3 phases whose gradient all-reduces overlap the later phases (cfp: one more cut around the eager all-gather + loss)')},
             'samples_per_s': round(value / 5.0, 1),
             'step_mfma_frac': round(value / world * algo * 1e9 / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4),
         }

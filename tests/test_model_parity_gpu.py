@@ -523,3 +523,67 @@ def test_cfp_backward_through_pooled_vectors_equals_loss_backward():
                 assert d <= 2e-3 * max(float(ref[n].norm()), 1e-2 * gmax), (n, d)
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('task', ['mlm', 'sap', 'cfp'])
+def test_three_phase_backward_plan_equals_single_backward(task):
+    """bench.PhasePlan (N>1): backward cut into heads+cross-modal | panorama || upper text layers | lower text layers +
+    embeddings, each phase its own hipGraph in one shared pool — against one ordinary backward."""
+    import bench
+    import vln_goat_amd
+    from vln_goat_amd import dp, synth
+    cfg, model, batch = build_case('pretrain_small_ragged')
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        model = model.cuda().eval()
+        gb = synth.batch_to(batch, 'cuda')
+        model(gb, task, compute_loss=True).mean().backward()
+        ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        wrapper = dp.GoatDataParallel(model)
+        wrapper.record_usage(task)
+        for p in model.parameters():
+            p.grad = None
+        plan = bench.PhasePlan(model, cfg.num_l_layers)
+        arena = wrapper.build_arena(phase_prefixes=plan.prefixes)
+        assert wrapper.n_phases == 3 and all(arena.ranges(task, k) for k in range(3))
+        gmax = max(float(v.norm()) for v in ref.values())
+
+        def check(what):
+            torch.cuda.synchronize()
+            for n, p in model.named_parameters():
+                if n in ref:
+                    d = float((arena.views[id(p)].double() - ref[n].double()).norm())
+                    assert d <= 2e-3 * max(float(ref[n].norm()), 1e-2 * gmax), (what, n, d)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                arena.zero(task)
+                for _k in plan.phases(wrapper, model(gb, task, compute_loss=True).mean()):
+                    pass
+        torch.cuda.current_stream().wait_stream(side)
+        check('eager three-phase')
+        graphs, pool, box = [], None, {}
+
+        def cap(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            graphs.append(g)
+            return g.pool()
+
+        def fwd():
+            arena.zero(task)
+            box['loss'] = model(gb, task, compute_loss=True).mean()
+        pool = cap(fwd)
+        gen = plan.phases(wrapper, box['loss'])
+        for _ in range(3):
+            pool = cap(lambda: next(gen))
+        for rep in range(3):
+            if rep == 1:
+                arena.flat.fill_(float('nan'))
+            for g in graphs:
+                g.replay()
+            check('captured three-phase, replay %d' % rep)
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)

@@ -163,7 +163,7 @@ class GradArena:
         """phase_of: optional {id(param): 0 | 1} — backward phase in which the parameter's gradient becomes final (0: the part of
         the backward pass that runs first, e.g. heads / cross-modal / panorama encoders; 1: the rest, e.g. text encoder and
         embeddings).  Phases are kept contiguous inside every usage group so that the phase-0 ranges can be all-reduced
-        while phase 1 is still computing (GoatDataParallel.backward_phase_a / _b)."""
+        while the later phases are still computing (GoatDataParallel.backward_phase)."""
         params = [p for p in params if p.requires_grad]
         phase_of = phase_of or {}
         seen, uniq = set(), []
@@ -365,32 +365,55 @@ class GoatDataParallel(torch.nn.Module):
             if p.grad is not None:
                 self._usage.setdefault(id(p), set()).add(key)
 
-    def build_arena(self, bucket_bytes=128 << 20, late_prefixes=()):
+    def build_arena(self, bucket_bytes=128 << 20, late_prefixes=(), phase_prefixes=None):
         """Flat gradient arena over the parameters seen by record_usage (all parameters if it was never called).
-        late_prefixes: parameter-name prefixes whose gradients are produced LAST in the backward pass (backward phase 1,
-        e.g. ('bert.embeddings.', 'bert.lang_encoder.')); everything else is phase 0.  See backward_phase_a/_b."""
-        phase_of = {id(p): int(any(n.startswith(pre) for pre in late_prefixes)) for n, p in self.module.named_parameters()}
-        self._late = [p for p in self.module.parameters() if phase_of[id(p)] == 1 and p.requires_grad]
-        self._early = [p for p in self.module.parameters() if phase_of[id(p)] == 0 and p.requires_grad]
+        phase_prefixes: [prefixes of phase 1, prefixes of phase 2, ...] — parameter-name prefixes grouped by the backward
+        phase in which their gradients become final (phase 0 = everything else = the part of the backward pass that runs
+        first).  late_prefixes=(...) is shorthand for one late phase.  See backward_phase()."""
+        if phase_prefixes is None:
+            phase_prefixes = [tuple(late_prefixes)] if late_prefixes else []
+
+        def phase(name):
+            for k, pres in enumerate(phase_prefixes):
+                if any(name.startswith(pre) for pre in pres):
+                    return k + 1
+            return 0
+        phase_of = {id(p): phase(n) for n, p in self.module.named_parameters()}
+        self.n_phases = len(phase_prefixes) + 1
+        self._phase_params = [[p for p in self.module.parameters() if phase_of[id(p)] == k and p.requires_grad]
+                              for k in range(self.n_phases)]
         self.arena = GradArena(self.module.parameters(), self._usage or None, bucket_bytes, phase_of).attach()
         return self.arena
 
-    # Two-phase backward: the gradient all-reduce of the parameters that finish first (phase 0) runs on the communication
-    # stream while the rest of the backward pass (phase 1: text encoder, embeddings) is still computing.
-    #     loss = model(batch, task, True).mean(); boundary = <an identity view (t.view_as(t), substituted for t in the forward
-    #     pass by a forward hook) of the output of the phase-1 sub-network, e.g. the text encoder: autograd executes the
-    #     grad_fn of a tensor listed in `inputs=`, which must therefore be a side-effect-free node>
-    #     w.backward_phase_a(loss, boundary); w.reduce_gradients(task, phase=0, wait=False)
-    #     w.backward_phase_b(boundary);        w.reduce_gradients(task, phase=1)          # waits for both
+    # Phased backward: the gradient all-reduce of the parameters that finish first runs on the communication stream while the
+    # rest of the backward pass is still computing.  The model's forward is cut at `boundaries`: identity views (t.view_as(t),
+    # substituted for t in the forward pass by a forward hook) of the outputs of the sub-networks that belong to later phases
+    # — autograd executes the grad_fn of a tensor listed in `inputs=`, which must therefore be a side-effect-free node.
+    #     w.backward_phase(0, [loss], None, [txt, pano]);          w.reduce_gradients(task, phase=0, wait=False)
+    #     w.backward_phase(1, [txt, pano], 'grad', [mid]);         w.reduce_gradients(task, phase=1, wait=False)
+    #     w.backward_phase(2, [mid], 'grad', []);                  w.reduce_gradients(task, phase=2)      # waits for all
+    def backward_phase(self, k, roots, grads, boundaries):
+        """Back-propagate from `roots` (with `grads`: None for a scalar loss, 'grad' = each root's .grad filled by the previous
+        phase, or explicit tensors) into the phase-k parameters and the .grad of `boundaries`."""
+        from . import hipops
+        if grads == 'grad':
+            pairs = [(r, r.grad) for r in roots if r is not None and r.grad is not None]
+            roots, grads = [r for r, _ in pairs], [g for _, g in pairs]
+        boundaries = [b for b in boundaries if b is not None]
+        for b in boundaries:
+            b.grad = None
+        # retain_graph (all but the last phase): the engine would otherwise release saved tensors the later phases need
+        torch.autograd.backward(roots, grad_tensors=grads, inputs=self._phase_params[k] + boundaries,
+                                retain_graph=k + 1 < self.n_phases)
+        hipops.WgradQueue.flush()
+        hipops.Branch.join_all()
+
     def backward_phase_a(self, loss, boundary, grad_tensors=None):
-        """Back-propagate `loss` (a scalar, or any tensor together with `grad_tensors`) down to `boundary` (its .grad is
-        filled) and into every phase-0 parameter."""
-        boundary.grad = None
-        # retain_graph: the engine would otherwise release the saved tensors of the boundary's producer, which phase B needs
-        torch.autograd.backward(loss, grad_tensors=grad_tensors, inputs=self._early + [boundary], retain_graph=True)
+        """two-phase shorthand: loss -> boundary + phase-0 parameters."""
+        self.backward_phase(0, [loss], None if grad_tensors is None else [grad_tensors], [boundary])
 
     def backward_phase_b(self, boundary):
-        torch.autograd.backward(boundary, grad_tensors=boundary.grad, inputs=self._late)
+        self.backward_phase(1, [boundary], 'grad', [])
 
     # -- sparse exchange of the word-embedding gradient -----------------------------------------------------------
     def enable_sparse_embedding(self, table, tasks):

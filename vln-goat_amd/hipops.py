@@ -386,6 +386,8 @@ class Branch:
             self.side = Branch._streams[(dev, self.name)] = torch.cuda.Stream(device=dev)
         self.main = torch.cuda.current_stream()
         self.side.wait_stream(self.main)
+        if Branch._stale:               # first fork of a new step: forget the streams of the previous one
+            Branch.used, Branch._stale = set(), False
         Branch.used.add(self.side)
         self._ctx = torch.cuda.stream(self.side)
         self._ctx.__enter__()
@@ -424,13 +426,16 @@ class Branch:
         WgradQueue.flush()
         Branch.join_all()
 
+    _stale = False
+
     @classmethod
     def join_all(cls):
-        """current stream waits for every side stream used since the last call (end of backward)."""
+        """current stream waits for every side stream forked in this step (called at the end of every backward phase: autograd
+        replays backward ops on the stream of their forward op)."""
         cur = torch.cuda.current_stream()
         for s in cls.used:
             cur.wait_stream(s)
-        cls.used = set()
+        cls._stale = True
 
 
 class WgradQueue:
