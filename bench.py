@@ -47,7 +47,6 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-autotune', action='store_true', help='use the static GEMM tile/stage heuristics')
-    ap.add_argument('--overlap', action='store_true', help='weight-gradient GEMMs on a side stream (measured: no gain)')
     ap.add_argument('--no-arena', action='store_true', help='per-parameter gradient tensors instead of the flat gradient arena')
     ap.add_argument('--cpu-batch', type=int, default=4)
     ap.add_argument('--layers', default='6,3,2', help='num_l_layers,num_top_layer,num_pano_layers')
@@ -159,9 +158,6 @@ def make_steps(args, model, gb, world, wrapper):
     phased = world > 1 or bool(os.environ.get('GOAT_BENCH_PHASED'))
     plan = PhasePlan(model, int(args.layers.split(',')[0])) if phased else None
 
-    if args.overlap:
-        hipops.WgradOverlap.enable()            # weight-gradient GEMMs on a side stream (joined after backward)
-
     def prologue(task):
         if arena[0] is not None:
             arena[0].zero(task)                 # one fill per contiguous range of the task's non-kernel-owned slices
@@ -175,7 +171,6 @@ def make_steps(args, model, gb, world, wrapper):
         prologue(task)
         loss = model(gb, task, compute_loss=True)
         loss.mean().backward()
-        hipops.WgradOverlap.join()
         return loss
 
     def eager_phased(task):
@@ -337,7 +332,6 @@ def gemm_roofline(args, model, gb, arena=None):
                 p.grad = None
         loss = model(gb, task, compute_loss=True)
         loss.mean().backward()
-    hipops.WgradOverlap.join()
     torch.cuda.synchronize()
     recs = hipops.PROFILE
     hipops.PROFILE = None

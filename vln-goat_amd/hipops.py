@@ -333,31 +333,6 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
     return out
 
 
-class WgradOverlap:
-    """Optional: run every weight-gradient GEMM on a side HIP stream so it overlaps the data-gradient chain
-    (dgrad -> LayerNorm-bwd -> attention-bwd ...) that autograd keeps issuing on the main stream.  GOAT's
-    GEMMs are small (180-360 workgroups on 256 CUs), so two independent GEMM streams fill the chip better than
-    one.  Weight gradients are only consumed after backward, so one join at the end suffices:
-        hipops.WgradOverlap.enable();  loss.backward();  hipops.WgradOverlap.join()
-    Works eagerly and inside torch.cuda.graph capture (fork/join inside the captured region).  Off by default
-    (torch DDP's reducer reads .grad as soon as autograd hooks fire)."""
-    stream = None
-
-    @classmethod
-    def enable(cls):
-        if cls.stream is None:
-            cls.stream = torch.cuda.Stream()
-
-    @classmethod
-    def disable(cls):
-        cls.stream = None
-
-    @classmethod
-    def join(cls):
-        if cls.stream is not None:
-            torch.cuda.current_stream().wait_stream(cls.stream)
-
-
 class Branch:
     """Run a block of ops as a parallel branch: `with Branch('pano') as br: ...; br.join(t1, t2)`.
 
@@ -625,17 +600,10 @@ def _wgrad_impl(dy, x, want_bias, w_sink=None, b_sink=None, first=False, b_first
 def wgrad(dy, x, want_bias, w_sink=None, b_sink=None, first=False, b_first=False, defer_ids=None):
     """dW[N,K] (f32) = dy[M,N]^T @ x[M,K] ; db[N] (f32) = colsum(dy), fused into the same kernel.
     One zero-fill covers both outputs (split-K partial tiles and the bias sums are accumulated atomically).
-    With sinks (gradient-arena slices) the results are accumulated in place and (None, None) is returned."""
-    side = WgradOverlap.stream
-    if side is None:
-        return _wgrad_impl(dy, x, want_bias, w_sink, b_sink, first, b_first, defer_ids)
-    cur = torch.cuda.current_stream()
-    side.wait_stream(cur)                       # dy / x are ready on the main stream
-    with torch.cuda.stream(side):
-        out = _wgrad_impl(dy, x, want_bias, w_sink, b_sink, first, b_first)
-    dy.record_stream(side)                      # keep the operands alive until the side-stream GEMM has read them
-    x.record_stream(side)
-    return out
+    With sinks (gradient-arena slices) the results are accumulated in place — deferred into a grouped launch when
+    possible (WgradQueue) — and (None, None) is returned.  (Measured and dropped: running each weight-gradient GEMM on a
+    second stream next to the dgrad chain was slower, 9.9 vs 9.3 ms per step.)"""
+    return _wgrad_impl(dy, x, want_bias, w_sink, b_sink, first, b_first, defer_ids)
 
 
 # ----------------------------------------------------------------------------- Linear
