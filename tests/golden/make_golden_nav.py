@@ -83,5 +83,40 @@ def main(only=None):
         print('wrote', path, os.path.getsize(path) // 1024, 'KiB', 'loss', float(loss))
 
 
+def extract_case():
+    """mode='extract_cfp_features' (M/models/vilmodel_GOAT.py:884-927: the pass that builds the FACL dictionaries) and
+    'instr_zdict_update' on an R2R batch; no interventions (the mode is run on a pre-trained model before fine-tuning)."""
+    vg = ref_shim.import_nav()
+    from vln_goat_amd import nav_model, synth
+    args = SimpleNamespace(num_l_layers=2, num_x_layers=2, num_pano_layers=2, dropout=0.5, feat_dropout=0.4,
+                           do_back_img=False, do_back_txt=False, do_front_img=False, do_front_his=False, do_front_txt=False,
+                           vocab_size=VOCAB, mode='extract_cfp_features')
+    cfg = nav_model.nav_config_from_args(args)
+    torch.manual_seed(0)
+    ref = vg.GlocalTextPathNavCMT(cfg)
+    ours = nav_model.GlocalTextPathNavCMT(cfg)
+    sd = synth.seeded_state_dict(ours, seed=WEIGHT_SEED)
+    rk, ok = set(ref.state_dict().keys()), set(sd.keys())
+    assert rk == ok, (sorted(rk - ok)[:8], sorted(ok - rk)[:8])
+    ref.load_state_dict(sd)
+    ref.eval()
+    batch = synth.make_pretrain_batch(B=3, T=[2, 4, 1], L=[30, 21, 12], seed=13, vocab_size=VOCAB, style='rich', ragged_views=True)
+    batch['txt_masks'] = torch.arange(batch['txt_ids'].shape[1])[None, :] < batch['txt_lens'][:, None]
+    from collections import defaultdict
+    with torch.no_grad():
+        out = ref('extract_cfp_features', defaultdict(lambda: None, batch))
+        z = ref('instr_zdict_update', defaultdict(lambda: None, {'z_txt': batch['txt_ids'], 'z_txt_mask': batch['txt_masks']}))
+    store = {k: v.numpy() for k, v in out.items()}
+    store['zdict_txt'] = z[:, :, :32].numpy()
+    path = os.path.join(HERE, 'nav_extract_cfp.npz')
+    np.savez_compressed(path, **store)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
-    main(sys.argv[1:] or None)
+    if sys.argv[1:] == ['nav_extract_cfp']:
+        extract_case()
+    else:
+        main(sys.argv[1:] or None)
+        if not sys.argv[1:]:
+            extract_case()

@@ -107,3 +107,36 @@ def test_vlnbert_wrapper_and_critic_run():
         assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_extract_cfp_features_and_zdict_update_match_reference_golden(dtype):
+    """mode='extract_cfp_features' (the pass that builds the FACL dictionaries, M/models/vilmodel_GOAT.py:884-927) and
+    mode='instr_zdict_update' against the imported reference (tests/golden/make_golden_nav.py: extract_case)."""
+    from collections import defaultdict
+    import vln_goat_amd
+    from vln_goat_amd import nav_model, synth
+    gold = load_golden('nav_extract_cfp')
+    args = SimpleNamespace(num_l_layers=2, num_x_layers=2, num_pano_layers=2, dropout=0.5, feat_dropout=0.4,
+                           do_back_img=False, do_back_txt=False, do_front_img=False, do_front_his=False, do_front_txt=False,
+                           vocab_size=1200, mode='extract_cfp_features')
+    model = nav_model.GlocalTextPathNavCMT(nav_model.nav_config_from_args(args))
+    model.load_state_dict(synth.seeded_state_dict(model, seed=11))
+    batch = synth.make_pretrain_batch(B=3, T=[2, 4, 1], L=[30, 21, 12], seed=13, vocab_size=1200, style='rich', ragged_views=True)
+    batch['txt_masks'] = torch.arange(batch['txt_ids'].shape[1])[None, :] < batch['txt_lens'][:, None]
+    tol = 1e-3 if dtype == torch.float32 else 2e-2
+    vln_goat_amd.set_compute_dtype(dtype)
+    try:
+        model = model.cuda().eval()
+        gb = synth.batch_to(batch, 'cuda')
+        with torch.no_grad():
+            out = model('extract_cfp_features', defaultdict(lambda: None, gb))
+            z = model('instr_zdict_update', defaultdict(lambda: None, {'z_txt': gb['txt_ids'], 'z_txt_mask': gb['txt_masks']}))
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)
+    for k in ('txt_outputs', 'vp_outputs', 'gmap_outputs'):
+        got, ref = out[k].float().cpu().numpy(), gold[k]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() / max(1.0, np.abs(ref).max()) < tol, k
+    got, ref = z.float().cpu().numpy()[:, :, :32], gold['zdict_txt']
+    assert np.abs(got - ref).max() / max(1.0, np.abs(ref).max()) < tol

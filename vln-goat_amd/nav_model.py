@@ -387,6 +387,9 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
 
     # ---- CFP feature extraction (builds the FACL dictionaries) -------------------------------------------------
     def extract_cfp_features(self, batch):
+        if self.img_embeddings.reverie:
+            # upstream binds traj_reverie_obj_locs to the z_img_features argument in this mode (M:889-893) — unusable as shipped
+            raise NotImplementedError('extract_cfp_features on REVERIE/SOON is broken in the reference (argument mismatch)')
         txt = self.forward_text(batch['txt_ids'], batch['txt_masks'])
         x, _, fused = self.img_embeddings.encode(batch['traj_view_img_fts'], batch['traj_loc_fts'], batch['traj_vp_view_lens'],
                                                  loc_before=True)
