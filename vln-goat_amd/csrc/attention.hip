@@ -187,10 +187,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
   if (qv && hi == 0) p.lse[((int64_t)b * p.nh + h) * p.Lq + q] = (l > 0.f) ? (msafe + __logf(l)) : -INFINITY;
 
   const bool drop = p.p > 0.f;
-  const uint32_t thr = goat_thr24(p.p);
+  const uint32_t thr = goat_thr16(p.p);
   const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
   const uint64_t ctr0 = p.offset + (((uint64_t)b * p.nh + h) * p.Lq + q) * (uint64_t)p.Lk;
-  const uint64_t seed = p.seed + (p.rng_dev ? *p.rng_dev : 0ull);
+  const GoatRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull));
 #pragma unroll
   for (int jt = 0; jt < NKT; ++jt)
 #pragma unroll
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
       float pv = s[jt][r] * inv;
       if (drop) {
         const int key = jt * 32 + c_row(r, lane);
-        pv = goat_keep(seed, ctr0 + key, thr) ? pv * keep_scale : 0.f;
+        pv = rng.keep(ctr0 + key, thr) ? pv * keep_scale : 0.f;
       }
       s[jt][r] = pv;
     }
@@ -270,9 +270,9 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnArgs p) {
   const float lse_q = qv ? p.lse[((int64_t)b * p.nh + h) * p.Lq + q] : 0.f;
   const bool lse_ok = (lse_q != -INFINITY);
   const bool drop = p.p > 0.f;
-  const uint32_t thr = goat_thr24(p.p);
+  const uint32_t thr = goat_thr16(p.p);
   const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
-  const uint64_t seed = p.seed + (p.rng_dev ? *p.rng_dev : 0ull);
+  const GoatRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull));
   const uint64_t ctr0 = p.offset + (((uint64_t)b * p.nh + h) * p.Lq + q) * (uint64_t)p.Lk;
   __syncthreads();
 
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnArgs p) {
         pr = __expf(v - lse_q);
       }
       float keep = 1.f;
-      if (drop) keep = goat_keep(seed, ctr0 + key, thr) ? keep_scale : 0.f;
+      if (drop) keep = rng.keep(ctr0 + key, thr) ? keep_scale : 0.f;
       const float d = pr * (dp[r] * keep - dsum);
       if (p.dbias && qv && key < p.Lk) atomicAdd(p.dbias + ((int64_t)b * p.Lq + q) * p.Lk + key, d);
       ds[r] = d * p.scale;
@@ -357,9 +357,9 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnArgs p) {
   }
   const float kmv = kv ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + key] : 0.f) : -INFINITY;
   const bool drop = p.p > 0.f;
-  const uint32_t thr = goat_thr24(p.p);
+  const uint32_t thr = goat_thr16(p.p);
   const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
-  const uint64_t seed = p.seed + (p.rng_dev ? *p.rng_dev : 0ull);
+  const GoatRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull));
 
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnArgs p) {
         pr = __expf(v - lse_q);
       }
       float keep = 1.f;
-      if (drop) keep = goat_keep(seed, p.offset + (((uint64_t)b * p.nh + h) * p.Lq + q) * (uint64_t)p.Lk + key, thr) ? keep_scale : 0.f;
+      if (drop) keep = rng.keep(p.offset + (((uint64_t)b * p.nh + h) * p.Lq + q) * (uint64_t)p.Lk + key, thr) ? keep_scale : 0.f;
       pd[r] = pr * keep;
       ds[r] = pr * (dp[r] * keep - rowd[qr]) * p.scale;
     }

@@ -61,20 +61,55 @@ template <> struct Chunk<bf16_t> {
 };
 
 // ---- counter-based dropout RNG -----------------------------------------------------------------
-// keep(i) for flat element index i under (seed, offset): two rounds of a multiply-xorshift hash of the
-// 64-bit counter; 24-bit uniform compared with p.  Stateless, so the backward pass regenerates the mask.
-__device__ __forceinline__ uint32_t goat_hash(uint64_t seed, uint64_t ctr) {
-  uint64_t x = ctr + seed * 0x9E3779B97F4A7C15ull;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  return (uint32_t)x;
-}
-__device__ __forceinline__ bool goat_keep(uint64_t seed, uint64_t ctr, uint32_t thr24) {
-  return (goat_hash(seed, ctr) >> 8) >= thr24;
-}
-__host__ __device__ __forceinline__ uint32_t goat_thr24(float p) {
-  return (uint32_t)(p * 16777216.0f);
+// keep(i) for flat element index i under (seed, offset).  Stateless, so the backward pass regenerates the mask.
+// The 64-bit seed is hashed ONCE per thread into two 32-bit keys; per element the work is a keyed 32-bit
+// multiply-xorshift bijection of the PAIR index i>>1 (two quarter-rate v_mul_lo_u32 + full-rate ops) whose two 16-bit
+// halves decide elements 2q and 2q+1 (drop if half < p*65536).  The first version hashed every element with two 64-bit
+// multiplies (~8 quarter-rate ops): LayerNorm / dropout / attention kernels were VALU-bound on the mask, not on HBM.
+struct GoatRng {
+  uint32_t k0, k1;
+  __device__ __forceinline__ explicit GoatRng(uint64_t seed) {
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    k0 = (uint32_t)x; k1 = (uint32_t)(x >> 32);
+  }
+  // 32 random bits for the counter pair {2q, 2q+1}
+  __device__ __forceinline__ uint32_t pair_bits(uint64_t q) const {
+    uint32_t x = ((uint32_t)q ^ k0) + __umul24((uint32_t)(q >> 32), 0x9E3779u);
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x += k1;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+  }
+  __device__ __forceinline__ bool keep(uint64_t ctr, uint32_t thr16) const {
+    const uint32_t h = pair_bits(ctr >> 1);
+    return ((ctr & 1) ? (h >> 16) : (h & 0xFFFFu)) >= thr16;
+  }
+  // bit e of the result = keep(ctr0 + e), e < N (N even): N/2 hashes when ctr0 is even (offsets are handed out in
+  // multiples of 8 and rows are multiples of the chunk width, so that is the path taken)
+  template <int N>
+  __device__ __forceinline__ uint32_t keep_bits(uint64_t ctr0, uint32_t thr16) const {
+    uint32_t m = 0;
+    if ((ctr0 & 1) == 0) {
+      const uint64_t q0 = ctr0 >> 1;
+#pragma unroll
+      for (int j = 0; j < N / 2; ++j) {
+        const uint32_t h = pair_bits(q0 + j);
+        m |= ((h & 0xFFFFu) >= thr16 ? 1u : 0u) << (2 * j);
+        m |= ((h >> 16) >= thr16 ? 1u : 0u) << (2 * j + 1);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < N; ++e) m |= (keep(ctr0 + e, thr16) ? 1u : 0u) << e;
+    }
+    return m;
+  }
+};
+__host__ __device__ __forceinline__ uint32_t goat_thr16(float p) {
+  return (uint32_t)(p * 65536.0f + 0.5f);
 }
 
 // ---- wave64 reductions ---------------------------------------------------------------------------

@@ -20,9 +20,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   if (rng_dev) seed += *rng_dev;
+  const GoatRng rng(seed);
   const int nchunk = H / EPC;
   const bool drop = p > 0.f;
-  const uint32_t thr = goat_thr24(p);
+  const uint32_t thr = goat_thr16(p);
   const float ks = drop ? 1.f / (1.f - p) : 1.f;
   Chunk<T> v[MAXC];
   float sum = 0.f;
@@ -33,8 +34,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       const int64_t base = (int64_t)row * H + c * EPC;
       v[i].load(x + base);
       if (drop) {
+        const uint32_t km = rng.keep_bits<EPC>(offset + base, thr);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[i].v[e] = goat_keep(seed, offset + base + e, thr) ? v[i].v[e] * ks : 0.f;
+        for (int e = 0; e < EPC; ++e) v[i].v[e] = ((km >> e) & 1u) ? v[i].v[e] * ks : 0.f;
       }
       if (res) {
         Chunk<T> r;
@@ -88,9 +90,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   extern __shared__ float lsum[];  // [4][2][H]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (rng_dev) seed += *rng_dev;
+  const GoatRng rng(seed);
   const int nchunk = H / EPC;
   const bool drop = p > 0.f;
-  const uint32_t thr = goat_thr24(p);
+  const uint32_t thr = goat_thr16(p);
   const float ks = drop ? 1.f / (1.f - p) : 1.f;
   float dg[MAXC][EPC], db[MAXC][EPC], g[MAXC][EPC];
 #pragma unroll
@@ -165,8 +168,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
           for (int e = 0; e < EPC; ++e) o.v[e] = (vdy[u][i].v[e] - c1[u] - vz[u][i].v[e] * c2[u]) * rs[u];
           if (dres) o.store(dres + base);
           if (drop) {
+            const uint32_t km = rng.keep_bits<EPC>(offset + base, thr);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) o.v[e] = goat_keep(seed, offset + base + e, thr) ? o.v[e] * ks : 0.f;
+            for (int e = 0; e < EPC; ++e) o.v[e] = ((km >> e) & 1u) ? o.v[e] * ks : 0.f;
           }
           if (dx) o.store(dx + base);
         }
@@ -230,7 +234,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, c
                                                       const uint64_t* __restrict__ rng_dev) {
   constexpr int EPC = DT<T>::EPC;
   if (rng_dev) seed += *rng_dev;
-  const uint32_t thr = goat_thr24(p);
+  const GoatRng rng(seed);
+  const uint32_t thr = goat_thr16(p);
   const bool drop = p > 0.f;
   const float ks = drop ? 1.f / (1.f - p) : 1.f;
   const int64_t nchunk = n / EPC;
@@ -238,8 +243,9 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, c
     Chunk<T> v;
     v.load(x + c * EPC);
     if (drop) {
+      const uint32_t km = rng.keep_bits<EPC>(offset + c * EPC, thr);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) v.v[e] = goat_keep(seed, offset + c * EPC + e, thr) ? v.v[e] * ks : 0.f;
+      for (int e = 0; e < EPC; ++e) v.v[e] = ((km >> e) & 1u) ? v.v[e] * ks : 0.f;
     }
     if (!BWD && res) {
       Chunk<T> r;
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, c
   if (blockIdx.x == 0 && threadIdx.x < (n - nchunk * EPC)) {
     const int64_t i = nchunk * EPC + threadIdx.x;
     float v = to_f(x[i]);
-    if (drop) v = goat_keep(seed, offset + i, thr) ? v * ks : 0.f;
+    if (drop) v = rng.keep(offset + i, thr) ? v * ks : 0.f;
     if (!BWD && res) v += to_f(res[i]);
     y[i] = from_f<T>(v);
   }
@@ -268,7 +274,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, 
                                                       const uint64_t* __restrict__ rng_dev) {
   constexpr int EPC = DT<T>::EPC;
   if (rng_dev) seed += *rng_dev;
-  const uint32_t thr = goat_thr24(p);
+  const GoatRng rng(seed);
+  const uint32_t thr = goat_thr16(p);
   const bool drop = p > 0.f;
   const float ks = drop ? 1.f / (1.f - p) : 1.f;
   const int64_t nchunk = n / EPC;
@@ -276,10 +283,11 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, 
     Chunk<T> d, uu;
     d.load(dy + c * EPC);
     uu.load(u + c * EPC);
+    const uint32_t km = drop ? rng.keep_bits<EPC>(offset + c * EPC, thr) : 0xFFFFFFFFu;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float g = d.v[e];
-      if (drop) g = goat_keep(seed, offset + c * EPC + e, thr) ? g * ks : 0.f;
+      if (drop) g = ((km >> e) & 1u) ? g * ks : 0.f;
       g *= (act == 1) ? dgelu_f(uu.v[e]) : (uu.v[e] > 0.f ? 1.f : 0.f);
       d.v[e] = g;
     }
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, 
     const int64_t i = nchunk * EPC + threadIdx.x;
     float g = to_f(dy[i]);
     const float uv = to_f(u[i]);
-    if (drop) g = goat_keep(seed, offset + i, thr) ? g * ks : 0.f;
+    if (drop) g = rng.keep(offset + i, thr) ? g * ks : 0.f;
     g *= (act == 1) ? dgelu_f(uv) : (uv > 0.f ? 1.f : 0.f);
     dx[i] = from_f<T>(g);
   }

@@ -59,7 +59,7 @@ class RngState:
     @classmethod
     def next(cls, numel):
         off = cls.counter
-        cls.counter += int(numel)
+        cls.counter += (int(numel) + 7) & ~7      # multiples of 8: row kernels draw masks per even-aligned counter pair
         return cls.seed, off, (cls.dev.data_ptr() if cls.dev is not None else None)
 
 
