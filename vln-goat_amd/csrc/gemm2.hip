@@ -25,6 +25,12 @@ namespace {
 
 constexpr int BN = 128, BK = 64;
 constexpr int NT = 256;
+#ifndef GOAT_GEMM_INTERLEAVE
+#define GOAT_GEMM_INTERLEAVE 1
+#endif
+#ifndef GOAT_GEMM_FRAG_DEPTH
+#define GOAT_GEMM_FRAG_DEPTH 2
+#endif
 
 struct G2Args {
   const void* A; const void* B; void* C; const float* bias; void* aux;
@@ -52,6 +58,10 @@ __device__ __forceinline__ uint2 lds_read_tr16(uint32_t addr) {
 }
 __device__ __forceinline__ void wait_lgkm0() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int N_> __device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_) : "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
 template <int N_> __device__ __forceinline__ void wait_vm() {
@@ -116,6 +126,14 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   constexpr int STAGE = TLA::BYTES + TLB::BYTES;
   constexpr int MI = BM / 64;  // 32-row MFMA tiles per wave in M
   constexpr int LOADS = TLA::IPW + TLB::IPW;
+  // k-steps a K-tile's DMA instructions are spread over: a 2-stage ring waits for them at the very next barrier, so they
+  // go behind the first two k-steps only; deeper rings have a whole K-tile of slack
+  constexpr int SPREAD = BK / 16;
+  constexpr bool INTERLEAVE = GOAT_GEMM_INTERLEAVE && NSTAGE >= 3;
+  // fragment prefetch distance in k-steps (each k-step's fragments have their own registers); bounded by the 4-bit lgkmcnt
+  constexpr int KSTEPS = BK / 16;
+  constexpr int RD = MI * (TA ? 2 : 1) + 2 * (TB ? 2 : 1);            // ds_read instructions per k-step
+  constexpr int FD = (GOAT_GEMM_FRAG_DEPTH * RD <= 15) ? GOAT_GEMM_FRAG_DEPTH : (15 / RD >= 1 ? 15 / RD : 1);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -161,6 +179,19 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
     _Pragma("unroll") for (int j = 0; j < TLB::IPW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
         rb, (lds_void*)(st_ + TLA::BYTES + (wave * TLB::IPW + j) * 1024), 16, offb[j], sb_, 0, 0);                  \
   } while (0)
+  // one DMA wave-instruction (number j_ of this wave's LOADS) of K-tile t_: the steady-state loop spreads a tile's
+  // instructions over the four k-steps, behind their MFMAs, instead of issuing all of them between the barrier and the
+  // first MFMA (each costs the wave ~60-100 issue cycles)
+#define GOAT_ISSUE_ONE(t_, j_)                                                                                      \
+  do {                                                                                                              \
+    char* st_ = smem + ((t_) % NSTAGE) * STAGE;                                                                     \
+    if ((j_) < TLA::IPW)                                                                                            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(st_ + (wave * TLA::IPW + (j_)) * 1024), 16,          \
+                                               offa[(j_) < TLA::IPW ? (j_) : 0], (uint32_t)(t_) * ka, 0, 0);        \
+    else                                                                                                            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(st_ + TLA::BYTES + (wave * TLB::IPW + (j_) - TLA::IPW) * 1024), 16, \
+                                               offb[(j_) >= TLA::IPW ? (j_) - TLA::IPW : 0], (uint32_t)(t_) * kb, 0, 0); \
+  } while (0)
 
   f32x16 acc[MI][2];
 #pragma unroll
@@ -183,12 +214,16 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   for (int t = 0; t < nkt; ++t) {
     wait_vm<(NSTAGE - 2) * LOADS>();
     __builtin_amdgcn_s_barrier();
-    GOAT_ISSUE(t + NSTAGE - 1);  // beyond the end: harmless (bounds-checked, lands in a stage nobody reads)
+    // tile t+NSTAGE-1 (beyond the end: harmless, bounds-checked, lands in a stage nobody reads).  A 2-stage ring waits for it
+    // at the very next barrier, so it is issued here, as early as possible; deeper rings have a whole K-tile of slack and
+    // spread the instructions behind the MFMAs of the four k-steps (measured: -13...-18 % on the 3-stage shapes, +4...+17 %
+    // on the 2-stage ones if done there too)
+    if (!INTERLEAVE) GOAT_ISSUE(t + NSTAGE - 1);
     const uint32_t sa = smem_base + (t % NSTAGE) * STAGE;
     const uint32_t sb = sa + TLA::BYTES;
     // fragment reads are software-pipelined one k-step ahead of the MFMAs (a wave is alone on its SIMD,
     // so nothing else hides the LDS latency)
-    bf16x8 fa[2][MI], fb[2][2];
+    bf16x8 fa[KSTEPS][MI], fb[KSTEPS][2];
 #define GOAT_LOAD_FRAGS(ks_, buf_)                                                                                   \
   do {                                                                                                              \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                                \
@@ -218,24 +253,36 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
       }                                                                                                             \
     }                                                                                                               \
   } while (0)
-    GOAT_LOAD_FRAGS(0, 0);
+#define GOAT_KSTEP(ks_)                                                                                            \
+  do {                                                                                                              \
+    constexpr int left_ = (KSTEPS - (ks_) < FD ? KSTEPS - (ks_) : FD) - 1; /* later k-steps whose reads may stay in flight */ \
+    wait_lgkm<left_ * RD>();                                                                                        \
+    if ((ks_) + FD < KSTEPS) GOAT_LOAD_FRAGS((ks_) + FD < KSTEPS ? (ks_) + FD : 0, (ks_) + FD < KSTEPS ? (ks_) + FD : 0); \
+    if (TA && do_colsum) {                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[ks_][i][e];                              \
+    }                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                  \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) mma32(acc[i][j], fa[ks_][i], fb[ks_][j]);                       \
+    if (INTERLEAVE) {                                                                                               \
+      /* the target stage was last read in iteration t-1, which every wave left before this iteration's barrier */  \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      _Pragma("unroll") for (int j = 0; j < LOADS; ++j)                                                             \
+        if (j * SPREAD / LOADS == (ks_)) GOAT_ISSUE_ONE(t + NSTAGE - 1, j);                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }                                                                                                               \
+  } while (0)
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      wait_lgkm0();
-      if (ks + 1 < BK / 16) {
-        if ((ks & 1) == 0) GOAT_LOAD_FRAGS(ks + 1, 1); else GOAT_LOAD_FRAGS(ks + 1, 0);
-      }
-      if (TA && do_colsum) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[ks & 1][i][e];
-      }
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) mma32(acc[i][j], fa[ks & 1][i], fb[ks & 1][j]);
+    for (int d = 0; d < FD; ++d) {
+      if (d == 0) GOAT_LOAD_FRAGS(0, 0);
+      if (d == 1) GOAT_LOAD_FRAGS(1, 1);
+      if (d == 2) GOAT_LOAD_FRAGS(2, 2);
     }
+    static_assert(KSTEPS == 4 && FD >= 1 && FD <= 3, "k-step unrolling below is written for BK = 64");
+    GOAT_KSTEP(0);
+    GOAT_KSTEP(1);
+    GOAT_KSTEP(2);
+    GOAT_KSTEP(3);
   }
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();

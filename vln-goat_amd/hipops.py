@@ -1381,4 +1381,5 @@ def dict_weighted_sum(z, p, out_dtype):
     return _DictWsumFn.apply(z, p, out_dtype)
 
 
-load_tuned()
+if not os.environ.get('GOAT_RETUNE'):       # (GOAT_RETUNE=1: start from an empty table and time every shape again)
+    load_tuned()
