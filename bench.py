@@ -193,7 +193,8 @@ def make_steps(args, model, gb, world, wrapper):
                 p.grad = None
             arena[0] = wrapper.build_arena(phase_prefixes=plan.prefixes if phased else None)   # .grad = views into one HBM buffer
             if not os.environ.get('GOAT_BENCH_DENSE_EMBED'):
-                wrapper.enable_sparse_embedding(model.bert.embeddings.word_embeddings.weight, [t for t in TASKS if t != 'mlm'])
+                wrapper.enable_sparse_embedding(model.bert.embeddings.word_embeddings.weight, [t for t in TASKS if t != 'mlm'],
+                                                mixed_tasks=['mlm'] if phased and 'mlm' in TASKS else ())    # (no-ops at N = 1)
         phased = phased and arena[0] is not None
         for task in TASKS:
             eager_phased(task) if phased else step_body(task)

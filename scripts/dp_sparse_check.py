@@ -39,8 +39,9 @@ def dense(task):
     torch.cuda.synchronize()
     return arena.flat.clone()
 ref = {t: dense(t) for t in tasks}
-w.enable_sparse_embedding(model.bert.embeddings.word_embeddings.weight, ['sap', 'cfp'])
+w.enable_sparse_embedding(model.bert.embeddings.word_embeddings.weight, ['sap', 'cfp'], mixed_tasks=['mlm'])   # mlm: dense decoder part early, lookups sparse
 ok = True
+assert w._sparse[2] == {'mlm'}, 'mlm must take the mixed dense + sparse path in this check'
 for t in tasks * 2:
     arena.zero(t)
     w.begin_step(t)
@@ -50,6 +51,7 @@ for t in tasks * 2:
     w.backward_phase_b(box['txt'])
     w.reduce_gradients(t, phase=1)
     torch.cuda.synchronize()
+    assert len(w._stash[t]) == 1, 'the lookup gradient of the word table must have gone through the sparse exchange'
     got = arena.flat
     worst = 0.0
     for p in arena.params:

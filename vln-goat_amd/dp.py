@@ -309,7 +309,7 @@ class GradArena:
             dist.all_reduce(c)
             c.div_(W)
 
-    def all_reduce_mean(self, task=None, phase=None, wait=True, exclude=frozenset()):
+    def all_reduce_mean(self, task=None, phase=None, wait=True, exclude=frozenset(), extra=()):
         """Average the task's gradient ranges (of one backward phase, or all) over ranks, in place, on the communication
         stream.  wait=False: return without making the caller's stream wait (call wait_comm() before the gradients are
         read) — this is how the phase-0 all-reduce overlaps the phase-1 backward computation."""
@@ -317,7 +317,7 @@ class GradArena:
         if W == 1:
             return
         chunks = []
-        for a, b in self.ranges(task, phase, exclude):
+        for a, b in tuple(self.ranges(task, phase, exclude)) + tuple(extra):        # extra: explicit (begin, end) element ranges
             while a < b:
                 e = min(b, a + self.bucket_elems)
                 chunks.append(self.flat[a:e])
@@ -416,14 +416,20 @@ class GoatDataParallel(torch.nn.Module):
         self.backward_phase(1, [boundary], 'grad', [])
 
     # -- sparse exchange of the word-embedding gradient -----------------------------------------------------------
-    def enable_sparse_embedding(self, table, tasks):
+    def enable_sparse_embedding(self, table, tasks, mixed_tasks=(), dense_phase=0):
         """`table`: the word-embedding Parameter; `tasks`: the tasks in which its gradient comes from lookups only
-        (not mlm: the tied decoder makes it dense).  Call after build_arena(); then begin_step(task) before each forward."""
+        (not mlm: the tied decoder makes it dense).  `mixed_tasks` (phased backward only): tasks in which the table gets a
+        DENSE contribution early (mlm: the tied decoder's weight gradient, produced in backward phase `dense_phase`) and the
+        lookup contribution in its own, last phase.  There the dense part is all-reduced with phase `dense_phase` (overlapping
+        the rest of the backward pass) and the lookup part is exchanged sparsely and added afterwards, instead of one
+        154 MB all-reduce after the last phase with nothing left to overlap it.
+        Call after build_arena(); then begin_step(task) before each forward."""
         from . import hipops
         if _world() == 1 or self.arena is None or id(table) not in self.arena.views:
             return
         hipops.SparseEmbedGrad.params.add(id(table))
-        self._sparse = (table, {t.split('_')[0] for t in tasks})
+        mixed = {t.split('_')[0] for t in mixed_tasks} if self.arena.phase[id(table)] != dense_phase else set()
+        self._sparse = (table, {t.split('_')[0] for t in tasks}, mixed, dense_phase)
         for t in self._sparse[1]:
             self.arena.no_zero.setdefault(t, set()).add(id(table))
         self._stash = {}
@@ -432,19 +438,21 @@ class GoatDataParallel(torch.nn.Module):
         from . import hipops
         key = task.split('_')[0]
         sp = getattr(self, '_sparse', None)
-        if sp is not None and key in sp[1]:
+        if sp is not None and (key in sp[1] or key in sp[2]):
             lst = self._stash[key] = []
             hipops.SparseEmbedGrad.sink_list = lst
         else:
             hipops.SparseEmbedGrad.sink_list = None
 
-    def _reduce_sparse(self, key):
-        """all-gather (rows, ids) of every rank and rebuild the averaged table gradient locally."""
+    def _reduce_sparse(self, key, add=False):
+        """all-gather (rows, ids) of every rank and rebuild the averaged table gradient locally (add=True: on top of the
+        already averaged dense part)."""
         from . import hipops
         table = self._sparse[0]
         view = self.arena.views[id(table)]
         W = _world()
-        view.zero_()
+        if not add:
+            view.zero_()
         for rows, ids, _tab, pad in self._stash.get(key, ()):
             ids = ids.reshape(-1).contiguous()
             if dist.get_backend() == 'gloo' and rows.is_cuda:        # (single-GPU self-tests: gloo has no GPU all-gather)
@@ -471,6 +479,17 @@ class GoatDataParallel(torch.nn.Module):
                 tid = id(sp[0])
                 if phase is None or phase == self.arena.phase[tid]:
                     self._reduce_sparse(key)            # small all-gather + local scatter on the caller's stream
+                return self.arena.all_reduce_mean(task, phase, wait, frozenset((tid,)))
+            if sp is not None and key in sp[2] and _world() > 1:
+                if phase is None:
+                    raise RuntimeError('mixed dense/sparse exchange of the embedding table needs the phased backward pass')
+                tid = id(sp[0])
+                if phase == sp[3]:                      # dense (tied decoder) part: travels with this phase's ranges
+                    a = self.arena.offsets[tid]
+                    return self.arena.all_reduce_mean(task, phase, wait, extra=((a, a + sp[0].numel()),))
+                if phase == self.arena.phase[tid]:      # lookup part: after every dense all-reduce has landed
+                    self.arena.all_reduce_mean(task, phase, True, frozenset((tid,)))
+                    return self._reduce_sparse(key, add=True)
                 return self.arena.all_reduce_mean(task, phase, wait, frozenset((tid,)))
             return self.arena.all_reduce_mean(task, phase, wait)
         key = task.split('_')[0]
