@@ -102,6 +102,8 @@ class PhasePlan:
         self.b = {}
 
         def view(t):
+            if isinstance(t, tuple):          # layers._pair: two autograd handles on one buffer, both are boundaries
+                return tuple(view(u) for u in t)
             return t.view_as(t) if torch.is_tensor(t) else t
 
         def txt_hook(mod, inp, out):
@@ -135,9 +137,10 @@ class PhasePlan:
         first = self.first()
         wrapper.backward_phase(0, [loss], None if grad_tensors is None else [grad_tensors], first)
         yield 0
-        wrapper.backward_phase(1, first, 'grad', [self.b['mid']])
+        mid = list(self.b['mid']) if isinstance(self.b['mid'], tuple) else [self.b['mid']]
+        wrapper.backward_phase(1, first, 'grad', mid)
         yield 1
-        wrapper.backward_phase(2, [self.b['mid']], 'grad', [])
+        wrapper.backward_phase(2, mid, 'grad', [])
         yield 2
 
 

@@ -94,11 +94,14 @@ int goat_ln_fwd(void* stream, int dtype, const void* x, const void* residual,
                 float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev,
                 void* y, void* z_out, float* mean, float* rstd, int M, int H);
 
-/* backward of goat_ln_fwd.  dz = LN-backward(dy) ; d_res<-dz (if non-NULL) ; dx<-dz*mask/(1-p) (if non-NULL).
+/* backward of goat_ln_fwd.  dz = LN-backward(dy + dy2) ; d_res<-dz (if non-NULL) ; dx<-dz*mask/(1-p) (if non-NULL).
+ * dy2 (may be NULL): a second upstream gradient of y, summed on load.  In the post-LN blocks y feeds both the next
+ * sub-layer's first Linear and the next LayerNorm's residual input; the two gradients arrive separately
+ * (hipops.layer_norm(fork=True)) and autograd's add kernel between them is not needed.
  * dgamma/dbeta: float32[H], overwritten (accumulate=0) or added to (accumulate=1: gradient-arena slices).  ws: float32 scratch of goat_ln_bwd_ws_floats(H) elements
  * (per-block column partials; a second tiny kernel reduces them — no atomics, deterministic). */
 int goat_ln_bwd_ws_floats(int H);
-int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* z,
+int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* dy2, const void* z,
                 const float* gamma, const float* mean, const float* rstd,
                 float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev,
                 void* dx, void* d_res, float* dgamma, float* dbeta, float* ws, int M, int H, int accumulate);

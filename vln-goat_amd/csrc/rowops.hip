@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // grid = NPART blocks of 4 waves; wave w of block b walks rows (b*4+w), +4*NPART, ...
 // partial dgamma/dbeta per block -> ws[block][2][H]; ln_bwd_reduce sums them.
 template <typename T, int MAXC, int RIF>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ z,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float p, uint64_t seed,
                                                      uint64_t offset, const uint64_t* __restrict__ rng_dev,
@@ -126,6 +126,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
           const int64_t base = (int64_t)row * H + c * EPC;
           vdy[u][i].load(dy + base);
           vz[u][i].load(z + base);
+          if (dy2) {   // second upstream gradient of the same tensor (its other consumer): summed here instead of by an add kernel
+            Chunk<T> t;
+            t.load(dy2 + base);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) vdy[u][i].v[e] += t.v[e];
+          }
         }
       }
     }
@@ -709,7 +715,7 @@ extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* r
 
 extern "C" int goat_ln_bwd_ws_floats(int H) { return GOAT_LN_BWD_PARTS * 2 * H; }
 
-extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* z, const float* gamma,
+extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* dy2, const void* z, const float* gamma,
                            const float* mean, const float* rstd, float p, uint64_t seed, uint64_t offset,
                            const uint64_t* rng_dev, void* dx, void* d_res, float* dgamma, float* dbeta, float* ws,
                            int M, int H, int accumulate) {
@@ -722,12 +728,12 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
   if (dtype == GOAT_BF16) {
     if (int e = ln_check<bf16_t>(H)) return e;
     GOAT_LN_DISPATCH(bf16_t, H, hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, MC, GOAT_LN_RIF>), dim3(nparts), dim3(256), sm, ST(stream),
-                                                    (const bf16_t*)dy, (const bf16_t*)z, gamma, mean, rstd, p, seed, offset,
+                                                    (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, gamma, mean, rstd, p, seed, offset,
                                                     rng_dev, (bf16_t*)dx, (bf16_t*)d_res, ws, M, H));
   } else if (dtype == GOAT_F32) {
     if (int e = ln_check<float>(H)) return e;
     GOAT_LN_DISPATCH(float, H, hipLaunchKernelGGL((ln_bwd_kernel<float, MC, 2>), dim3(nparts), dim3(256), sm, ST(stream),
-                                                   (const float*)dy, (const float*)z, gamma, mean, rstd, p, seed, offset,
+                                                   (const float*)dy, (const float*)dy2, (const float*)z, gamma, mean, rstd, p, seed, offset,
                                                    rng_dev, (float*)dx, (float*)d_res, ws, M, H));
   } else {
     return GOAT_E_ARG;

@@ -883,11 +883,15 @@ def multi_linear(x, weights, biases):
 
 # ----------------------------------------------------------------------------- LayerNorm / dropout
 class _LnFn(torch.autograd.Function):
-    """y = LayerNorm(residual + dropout_p(x)) (P/model/Bert_backbone.py:306-310)."""
+    """y = LayerNorm(residual + dropout_p(x)) (P/model/Bert_backbone.py:306-310).
+    fork=True returns y twice (two autograd outputs over one buffer): one for the next sub-layer's first Linear, one for
+    the next LayerNorm's residual input.  Their gradients then reach backward() separately and the kernel sums them on
+    load (goat_ln_bwd's dy2), which replaces the elementwise add autograd would otherwise launch for the shared tensor."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, p):
+    def forward(ctx, x, residual, gamma, beta, eps, p, fork=False):
         _need_gpu(x)
+        ctx.set_materialize_grads(False)
         H = x.shape[-1]
         x2 = x.reshape(-1, H)
         if not x2.is_contiguous():
@@ -913,16 +917,25 @@ class _LnFn(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.gb = (gamma, beta)
         ctx.shape = x.shape
-        return y.view(x.shape)
+        yv = y.view(x.shape)
+        return (yv, yv.view_as(yv)) if fork else yv
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dyb=None):
+        if dy is None:
+            dy, dyb = dyb, None
         z, gamma, mean, rstd = ctx.saved_tensors
         p, seed, off, dev = ctx.rng
         H = z.shape[-1]
         dy2 = dy.reshape(-1, H)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
+        if dyb is not None:
+            dyb = dyb.reshape(-1, H)
+            if dyb.dtype != dy2.dtype:
+                dyb = dyb.to(dy2.dtype)
+            if not dyb.is_contiguous():
+                dyb = dyb.contiguous()
         M = z.shape[0]
         L = _lib.lib()
         dx = torch.empty_like(z)
@@ -934,7 +947,7 @@ class _LnFn(torch.autograd.Function):
         dg = sg if sunk else torch.empty(H, dtype=torch.float32, device=z.device)
         db = sb if sunk else torch.empty(H, dtype=torch.float32, device=z.device)
         ws = torch.empty(L.goat_ln_bwd_ws_floats(H), dtype=torch.float32, device=z.device)
-        st = L.goat_ln_bwd(_stream(), _dt(z), _ptr(dy2), _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd),
+        st = L.goat_ln_bwd(_stream(), _dt(z), _ptr(dy2), _ptr(dyb) if dyb is not None else None, _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd),
                            p, seed, off, dev, _ptr(dx), _ptr(dres) if dres is not None else None,
                            _ptr(dg), _ptr(db), _ptr(ws), M, H, int(sunk and not _first_touch(*ctx.gb)))
         _lib.check(st, 'goat_ln_bwd')
@@ -945,11 +958,11 @@ class _LnFn(torch.autograd.Function):
             dr = dres.view(ctx.shape) if dres is not None else dxv
         else:
             dr = None
-        return dxv, dr, dg, db, None, None
+        return dxv, dr, dg, db, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps, residual=None, p=0.0):
-    return _LnFn.apply(x, residual, gamma, beta, float(eps), float(p))
+def layer_norm(x, gamma, beta, eps, residual=None, p=0.0, fork=False):
+    return _LnFn.apply(x, residual, gamma, beta, float(eps), float(p), bool(fork))
 
 
 class _DropAddFn(torch.autograd.Function):

@@ -13,6 +13,8 @@ kernels through `hipops`.  Reference classes mirrored here (P/ = pretrain_src/, 
   BertPredictionHeadTransform / BertLMPredictionHead / BertOnlyMLMHead   :797-838
   TransformerEncoder(Layer)  P/model/transformer.py:62-89,133-191 (pre-LN, nn.MultiheadAttention)
 """
+import os
+
 import torch
 from torch import nn
 
@@ -59,9 +61,18 @@ class Linear(nn.Linear):
         return hipops.linear(x, self.weight, self.bias, act)
 
 
+_NO_FORK = bool(os.environ.get('GOAT_NO_LN_FORK'))      # (diagnostics: A/B of the forked LayerNorm outputs)
+
+
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x, residual=None, p=0.0):
-        return hipops.layer_norm(x, self.weight, self.bias, self.eps, residual, p)
+    def forward(self, x, residual=None, p=0.0, fork=False):
+        return hipops.layer_norm(x, self.weight, self.bias, self.eps, residual, p, fork and not _NO_FORK)
+
+
+def _pair(h):
+    """A hidden state travels between post-LN sub-layers as (for the next Linear, for the next residual add): two autograd
+    handles on one buffer (hipops.layer_norm(fork=True)), so their gradients are summed inside the LayerNorm backward."""
+    return h if isinstance(h, tuple) else (h, h)
 
 
 BertLayerNorm = LayerNorm
@@ -132,8 +143,8 @@ class BertSelfOutput(nn.Module):
         self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
-    def forward(self, hidden, input_tensor):
-        return self.LayerNorm(self.dense(hidden), residual=input_tensor, p=_p(self.dropout))
+    def forward(self, hidden, input_tensor, fork=False):
+        return self.LayerNorm(self.dense(hidden), residual=input_tensor, p=_p(self.dropout), fork=fork)
 
 
 class BertAttention(nn.Module):
@@ -142,8 +153,9 @@ class BertAttention(nn.Module):
         self.self = BertSelfAttention(config)
         self.output = BertSelfOutput(config)
 
-    def forward(self, hidden, kmask=None, enc_hidden=None, enc_kmask=None, bias=None):
-        return self.output(self.self(hidden, kmask, enc_hidden, enc_kmask, bias), hidden)
+    def forward(self, hidden, kmask=None, enc_hidden=None, enc_kmask=None, bias=None, fork=False):
+        h, h_res = _pair(hidden)
+        return self.output(self.self(h, kmask, enc_hidden, enc_kmask, bias), h_res, fork)
 
 
 RobertaAttention = BertAttention
@@ -167,10 +179,11 @@ class BertOutput(nn.Module):
 RobertaIntermediate, RobertaOutput = BertIntermediate, BertOutput
 
 
-def _ffn_block(inter, out, x):
+def _ffn_block(inter, out, x, fork=False):
     """BertIntermediate -> BertOutput (dense, dropout, LayerNorm(+residual))."""
+    x, x_res = _pair(x)
     y = hipops.ffn(x, inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias, 'gelu', 0.0)
-    return out.LayerNorm(y, residual=x, p=_p(out.dropout))
+    return out.LayerNorm(y, residual=x_res, p=_p(out.dropout), fork=fork)
 
 
 class RobertaLayer(nn.Module):
@@ -181,8 +194,9 @@ class RobertaLayer(nn.Module):
         self.intermediate = RobertaIntermediate(config)
         self.output = RobertaOutput(config)
 
-    def forward(self, hidden, kmask):
-        return _ffn_block(self.intermediate, self.output, self.attention(hidden, kmask))
+    def forward(self, hidden, kmask, fork=False):
+        """hidden: a tensor or a _pair; fork=True returns a _pair (for the next layer of the same stack)."""
+        return _ffn_block(self.intermediate, self.output, self.attention(hidden, kmask, fork=True), fork)
 
 
 class BertCrossLayer(nn.Module):
@@ -200,10 +214,10 @@ class BertCrossLayer(nn.Module):
             self.lang_inter = RobertaIntermediate(config)
             self.lang_output = RobertaOutput(config)
 
-    def forward(self, hidden, enc_hidden, kmask, enc_kmask, bias=None):
-        a = self.attention(hidden, kmask, bias=bias)
-        a = self.crossattention(a, None, enc_hidden, enc_kmask)
-        return _ffn_block(self.intermediate, self.output, a)
+    def forward(self, hidden, enc_hidden, kmask, enc_kmask, bias=None, fork=False):
+        a = self.attention(hidden, kmask, bias=bias, fork=True)
+        a = self.crossattention(a, None, enc_hidden, enc_kmask, fork=True)
+        return _ffn_block(self.intermediate, self.output, a, fork)
 
 
 def init_weights(module):
@@ -226,8 +240,9 @@ class CrossmodalEncoder(nn.Module):
 
     def forward(self, q_embeds, q_kmask, kv_embeds, kv_kmask, bias=None):
         """q_kmask / kv_kmask: additive float32 [B,L] key masks (already -10000-style)."""
-        for layer in self.crossattention:
-            q_embeds = layer(q_embeds, kv_embeds, q_kmask, kv_kmask, bias)
+        n = len(self.crossattention)
+        for i, layer in enumerate(self.crossattention):
+            q_embeds = layer(q_embeds, kv_embeds, q_kmask, kv_kmask, bias, fork=i + 1 < n)
         return q_embeds
 
 

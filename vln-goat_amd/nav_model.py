@@ -39,8 +39,8 @@ class LanguageEncoder(nn.Module):
 
     def forward(self, txt_embeds, txt_masks, *unused):
         km = neg_mask(txt_masks)
-        for layer in self.layer:
-            txt_embeds = layer(txt_embeds, km)
+        for i, layer in enumerate(self.layer):       # between layers the state travels as a layers._pair (fork=True)
+            txt_embeds = layer(txt_embeds, km, fork=i + 1 < len(self.layer))
         return txt_embeds if self.update_lang_bert else txt_embeds.detach()
 
 
@@ -80,8 +80,8 @@ class LanguageEncoderDo(nn.Module):
     def forward(self, txt_embeds, txt_masks, z_direc=None, z_direc_pzs=None, z_landm=None, z_landm_pzs=None, front_txt=None):
         cfg = self.config
         km = neg_mask(txt_masks)
-        for layer in self.layer:
-            txt_embeds = layer(txt_embeds, km)
+        for i, layer in enumerate(self.layer):       # between layers the state travels as a layers._pair (fork=True)
+            txt_embeds = layer(txt_embeds, km, fork=i + 1 < len(self.layer))
         if not self.update_lang_bert:
             txt_embeds = txt_embeds.detach()
         if not (cfg.do_back_txt or cfg.do_front_txt):

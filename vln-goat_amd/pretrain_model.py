@@ -79,8 +79,8 @@ class LanguageEncoder(nn.Module):
                 param.requires_grad = False
 
     def forward(self, txt_embeds, txt_kmask):
-        for layer in self.layer:
-            txt_embeds = layer(txt_embeds, txt_kmask)
+        for i, layer in enumerate(self.layer):       # between layers the state travels as a layers._pair (fork=True)
+            txt_embeds = layer(txt_embeds, txt_kmask, fork=i + 1 < len(self.layer))
         if not self.update_lang_bert:
             txt_embeds = txt_embeds.detach()
         return txt_embeds
@@ -134,8 +134,8 @@ class LanguageEncoderDo(nn.Module):
 
     def forward(self, txt_embeds, txt_kmask, z_direc=None, z_direc_pzs=None, z_landm=None, z_landm_pzs=None):
         cfg = self.config
-        for layer in self.layer:
-            txt_embeds = layer(txt_embeds, txt_kmask)
+        for i, layer in enumerate(self.layer):       # between layers the state travels as a layers._pair (fork=True)
+            txt_embeds = layer(txt_embeds, txt_kmask, fork=i + 1 < len(self.layer))
         if not self.update_lang_bert:
             txt_embeds = txt_embeds.detach()
         if z_direc is None:
