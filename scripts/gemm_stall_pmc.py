@@ -16,7 +16,7 @@ L = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
 a = torch.randn((K, M) if ta else (M, K), device='cuda').to(torch.bfloat16)
 b = (torch.randn((K, N) if tb else (N, K), device='cuda') * 0.1).to(torch.bfloat16)
-out = torch.zeros(M, N, device='cuda', dtype=torch.bfloat16)
+out = torch.zeros(M, N, device='cuda', dtype=torch.float32 if (ta and tb) else torch.bfloat16)     # wgrad layout: f32 result
 for _ in range(5):
     rc = L.goat_gemm_bf16(st, ta, tb, hipops._dt(out), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), N,
                           M, N, K, None, 0, None, 0, 1, bm, ns, None)
