@@ -184,6 +184,7 @@ def make_steps(args, model, gb, world, wrapper):
             wrapper.reduce_gradients(task, phase=k, wait=(k == last))
 
     use_graph = not args.no_graph and not (args.no_arena and world > 1)     # (graphs at N > 1 need the arena's static gradient storage)
+    force_eager = {'cfp'} if os.environ.get('GOAT_BENCH_EAGER_CFP') else set()
     steps = {}
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -199,8 +200,23 @@ def make_steps(args, model, gb, world, wrapper):
                 wrapper.enable_sparse_embedding(model.bert.embeddings.word_embeddings.weight, [t for t in TASKS if t != 'mlm'],
                                                 mixed_tasks=['mlm'] if phased and 'mlm' in TASKS else ())    # (no-ops at N = 1)
         phased = phased and arena[0] is not None
-        for task in TASKS:
-            eager_phased(task) if phased else step_body(task)
+        try:
+            for task in TASKS:
+                eager_phased(task) if phased else step_body(task)
+        except Exception as e:      # never lose an N > 1 run to the overlap machinery: fall back to backward, then one all-reduce
+            if not phased:
+                raise
+            print('[bench] phased backward failed in warm-up (%s: %s); using the plain backward + all-reduce path' % (type(e).__name__, e),
+                  file=sys.stderr)
+            torch.cuda.synchronize()
+            phased = False
+            force_eager.add('cfp')          # (its all-gather would sit inside the capture: keep the fallback path simple)
+            wrapper._sparse = None
+            hipops.SparseEmbedGrad.params.clear()
+            hipops.SparseEmbedGrad.sink_list = None
+            arena[0].no_zero.clear()
+            for task in TASKS:
+                step_body(task)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
 
@@ -258,9 +274,10 @@ def make_steps(args, model, gb, world, wrapper):
 
     for task in TASKS:
         eager = (lambda t=task: eager_phased(t)) if phased else (lambda t=task: (step_body(t), reduce_all(t)))
-        if not use_graph or (os.environ.get('GOAT_BENCH_EAGER_CFP') and task == 'cfp'):
+        if not use_graph or task in force_eager:
             steps[task] = eager
             continue
+        launch_stream = torch.cuda.current_stream()
         try:
             if world > 1:
                 torch.cuda.synchronize()
@@ -275,8 +292,12 @@ def make_steps(args, model, gb, world, wrapper):
                 steps[task] = (lambda t=task, ga=ga: (ga.replay(), reduce_all(t)))
         except Exception as e:       # never lose the run to a capture problem: fall back to eager launches for this task
             print('[bench] hipGraph capture of %s failed (%s: %s); running it eagerly' % (task, type(e).__name__, e), file=sys.stderr)
+            torch.cuda.set_stream(launch_stream)     # (a capture that dies leaves torch on its invalidated capture stream)
+            hipops.Branch.used, hipops.Branch._armed = set(), False
+            hipops.WgradQueue.reset()
             torch.cuda.synchronize()
             steps[task] = eager
+    wrapper.launch_mode = 'phased' if phased else 'plain'
     return steps
 
 
@@ -441,7 +462,9 @@ def main():
                                    'vocab 50265, per-rank batch %d, T=5, 36x768 views, L=80, tasks mlm/sap/cfp 1:1:1, dropout 0.1, '
                                    'fwd+bwd%s, random-init' % (args.layers, args.batch, ' + grad all-reduce' if world > 1 else ''),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                       'launch': 'eager' if args.no_graph else ('hipGraph replay' if world == 1 else 'hipGraph replay, backward cut into 3 phases whose gradient all-reduces overlap the later phases (cfp: one more cut around the eager all-gather + loss)')},
+                       'launch': 'eager' if args.no_graph else ('hipGraph replay' if world == 1 else
+                                                                      'hipGraph replay, backward cut into 3 phases whose gradient all-reduces overlap the later phases (cfp: one more cut around the eager all-gather + loss)'
+                                                                      if wrapper.launch_mode == 'phased' else 'hipGraph replay of forward + backward, then one gradient all-reduce (fallback path)')},
             'samples_per_s': round(value / 5.0, 1),
             'step_mfma_frac': round(value / world * algo * 1e9 / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4),
         }
