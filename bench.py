@@ -85,19 +85,30 @@ def build(args, rank):
 
 class PhasePlan:
     """How the GOAT backward pass is cut for communication overlap at N > 1 (dp.GoatDataParallel.backward_phase):
-        phase 0  heads + global / local cross-modal encoders            (their gradients are final first)
-        phase 1  panorama stem  ||  upper half of the text encoder      (parallel branches again)
-        phase 2  lower half of the text encoder + embeddings
+        phase 0      heads + global / local cross-modal encoders            (their gradients are final first)
+        phase 1      panorama stem  ||  text layers [cuts[0], n)             (parallel branches again)
+        phase 2 ...  text layers [cuts[1], cuts[0]) ...
+        last phase   text layers [0, cuts[-1]) + embeddings                  (its all-reduce is the only exposed one: kept small)
+    Default cuts for n text layers: [n // 2, 1] (n >= 4), [n // 2] (n = 2, 3), none (n = 1: two phases).
     Forward hooks substitute identity views for the boundary tensors: the text-encoder output, the panorama stem's outputs
-    and the output of the last text layer of phase 2."""
+    and the output of the text layer below each cut (a layers._pair between layers: both handles are boundaries)."""
 
-    def __init__(self, model, n_text_layers):
-        split = max(1, n_text_layers // 2)
-        self.prefixes = [
-            ('bert.img_embeddings.',) + tuple('bert.lang_encoder.layer.%d.' % i for i in range(split, n_text_layers)),
-            ('bert.embeddings.',) + tuple('bert.lang_encoder.layer.%d.' % i for i in range(split)),
-        ]
-        if split >= n_text_layers:           # a one-layer text encoder: two phases only
+    def __init__(self, model, n_text_layers, cuts=None):
+        n = n_text_layers
+        if cuts is None:
+            cuts = [n // 2, 1] if n >= 4 else ([n // 2] if n >= 2 else [])
+        self.cuts = cuts = sorted({int(c) for c in cuts if 0 < int(c) < n}, reverse=True)
+        if cuts:
+            edges = [n] + cuts + [0]
+            self.prefixes = []
+            for k in range(len(cuts) + 1):
+                pre = tuple('bert.lang_encoder.layer.%d.' % i for i in range(edges[k + 1], edges[k]))
+                if k == 0:
+                    pre = ('bert.img_embeddings.',) + pre
+                if k == len(cuts):
+                    pre = ('bert.embeddings.',) + pre
+                self.prefixes.append(pre)
+        else:                                # a one-layer text encoder: two phases only
             self.prefixes = [('bert.img_embeddings.', 'bert.embeddings.', 'bert.lang_encoder.')]
         self.b = {}
 
@@ -114,34 +125,37 @@ class PhasePlan:
             self.b['pano'] = tuple(view(t) for t in out)
             return self.b['pano']
 
-        def mid_hook(mod, inp, out):
-            self.b['mid'] = view(out)
-            return self.b['mid']
+        def mid_hook(j):
+            def hook(mod, inp, out):
+                self.b['mid', j] = view(out)
+                return self.b['mid', j]
+            return hook
         model.bert.lang_encoder.register_forward_hook(txt_hook)
         model.bert.img_embeddings.register_forward_hook(pano_hook)
-        self.three = len(self.prefixes) == 2
-        if self.three:
-            model.bert.lang_encoder.layer[split - 1].register_forward_hook(mid_hook)
+        for j, c in enumerate(cuts):
+            model.bert.lang_encoder.layer[c - 1].register_forward_hook(mid_hook(j))
 
     def first(self):        # boundaries of phase 0
         return [self.b['txt']] + [t for t in self.b['pano'] if torch.is_tensor(t)]
 
     def phases(self, wrapper, loss, grad_tensors=None):
         """generator: runs one backward phase per step, yielding its index (the caller launches the all-reduce in between)."""
-        if not self.three:
-            wrapper.backward_phase(0, [loss], None if grad_tensors is None else [grad_tensors], [self.b['txt']])
+        grads = None if grad_tensors is None else [grad_tensors]
+        if not self.cuts:
+            wrapper.backward_phase(0, [loss], grads, [self.b['txt']])
             yield 0
             wrapper.backward_phase(1, [self.b['txt']], 'grad', [])
             yield 1
             return
-        first = self.first()
-        wrapper.backward_phase(0, [loss], None if grad_tensors is None else [grad_tensors], first)
+        seq = [self.first()]
+        for j in range(len(self.cuts)):
+            m = self.b['mid', j]
+            seq.append(list(m) if isinstance(m, tuple) else [m])
+        wrapper.backward_phase(0, [loss], grads, seq[0])
         yield 0
-        mid = list(self.b['mid']) if isinstance(self.b['mid'], tuple) else [self.b['mid']]
-        wrapper.backward_phase(1, first, 'grad', mid)
-        yield 1
-        wrapper.backward_phase(2, mid, 'grad', [])
-        yield 2
+        for k in range(1, len(seq) + 1):
+            wrapper.backward_phase(k, seq[k - 1], 'grad', seq[k] if k < len(seq) else [])
+            yield k
 
 
 def make_steps(args, model, gb, world, wrapper):
@@ -463,7 +477,7 @@ def main():
                                    'fwd+bwd%s, random-init' % (args.layers, args.batch, ' + grad all-reduce' if world > 1 else ''),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'launch': 'eager' if args.no_graph else ('hipGraph replay' if world == 1 else
-                                                                      'hipGraph replay, backward cut into 3 phases whose gradient all-reduces overlap the later phases (cfp: one more cut around the eager all-gather + loss)'
+                                                                      'hipGraph replay, backward cut into %d phases whose gradient all-reduces overlap the later phases (cfp: one more cut around the eager all-gather + loss)' % wrapper.n_phases
                                                                       if wrapper.launch_mode == 'phased' else 'hipGraph replay of forward + backward, then one gradient all-reduce (fallback path)')},
             'samples_per_s': round(value / 5.0, 1),
             'step_mfma_frac': round(value / world * algo * 1e9 / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4),

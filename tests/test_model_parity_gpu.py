@@ -587,3 +587,39 @@ def test_three_phase_backward_plan_equals_single_backward(task):
             check('captured three-phase, replay %d' % rep)
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('task', ['mlm', 'sap'])
+def test_four_phase_backward_plan_equals_single_backward(task):
+    """bench.PhasePlan on a 4-layer text encoder: cuts [2, 1] -> heads+cross-modal | panorama || text layers 3,2 | layer 1 |
+    layer 0 + embeddings (the default plan of the 6-layer bench model has the same shape), eager, against one backward."""
+    import bench
+    import vln_goat_amd
+    from vln_goat_amd import config as gcfg, dp, pretrain_model, synth
+    cfg = gcfg.make_config(num_l_layers=4, num_top_layer=2, num_pano_layers=1, vocab_size=1000)
+    torch.manual_seed(1)
+    model = pretrain_model.GlocalTextPathCMTPreTraining(cfg).cuda().eval()
+    gb = synth.batch_to(synth.make_pretrain_batch(B=3, T=[2, 3, 1], L=[30, 22, 16], seed=21, vocab_size=1000, style='rich'), 'cuda')
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        model(gb, task, compute_loss=True).mean().backward()
+        ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        wrapper = dp.GoatDataParallel(model)
+        wrapper.record_usage(task)
+        for p in model.parameters():
+            p.grad = None
+        plan = bench.PhasePlan(model, cfg.num_l_layers)
+        assert plan.cuts == [2, 1]
+        arena = wrapper.build_arena(phase_prefixes=plan.prefixes)
+        assert wrapper.n_phases == 4 and all(arena.ranges(task, k) for k in range(4))
+        gmax = max(float(v.norm()) for v in ref.values())
+        for _ in range(2):
+            arena.zero(task)
+            assert [k for k in plan.phases(wrapper, model(gb, task, compute_loss=True).mean())] == [0, 1, 2, 3]
+        torch.cuda.synchronize()
+        for n, p in model.named_parameters():
+            if n in ref:
+                d = float((arena.views[id(p)].double() - ref[n].double()).norm())
+                assert d <= 2e-3 * max(float(ref[n].norm()), 1e-2 * gmax), (n, d)
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)
