@@ -65,7 +65,8 @@ int goat_gemm_nt(void* stream, int dtype_in, int dtype_out,
  * bf16 inputs; dtype_out GOAT_BF16 or GOAT_F32 (F32 only with GOAT_EPI_NONE).  K-contiguous operands need
  * Kc % 64 == 0 (transposed operands: any Kc, the tail is zero-filled by the buffer bounds check); lda/ldb
  * multiples of 8, bases 16-B aligned, each operand < 2 GiB.  split_k>1: f32 atomic accumulation into C.
- * bm: 128 or 64 (M-tile; 64 fills the chip on small-M problems).  nstage: 2..4 LDS ring stages (2 = most
+ * bm: 64, 128 (four waves) or 256 (eight waves sharing one B tile: 25 % fewer L2->LDS bytes per flop, nstage <= 3; for
+ * M >= 2048) — the M-tile; 64 fills the chip on small-M problems.  nstage: 2..4 LDS ring stages (2 = most
  * workgroups per CU, 3-4 = deeper prefetch for long/cold contractions).
  * colsum (trans_a only, may be NULL): colsum[m] += sum_k A[k,m] (float32, atomic; caller zero-fills) — the bias
  * gradient of the Linear, accumulated from the A fragments the wgrad already holds in registers. */

@@ -515,7 +515,7 @@ def test_dict_weighted_sum(ops, dtype):
 
 
 @pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, True)])
-@pytest.mark.parametrize('bm,ns', [(64, 2), (64, 3), (64, 4), (128, 2), (128, 3), (128, 4)])
+@pytest.mark.parametrize('bm,ns', [(64, 2), (64, 3), (64, 4), (128, 2), (128, 3), (128, 4), (256, 2), (256, 3)])
 def test_gemm_bf16_every_tile_configuration(ops, ta, tb, bm, ns):
     """Every (tile height, ring depth) the autotuner may pick, on a ragged shape, incl. GELU / C += A·B / split-K epilogues."""
     from vln_goat_amd._lib import EPI_ACCUM, EPI_GELU, EPI_NONE

@@ -24,7 +24,8 @@
 namespace {
 
 constexpr int BN = 128, BK = 64;
-constexpr int NT = 256;
+constexpr int NT = 256;   // threads of the 64- and 128-row tiles (4 waves); the 256-row tile runs 8 waves (nthreads<BM>())
+template <int BM> constexpr int nthreads() { return BM == 256 ? 512 : 256; }
 #ifndef GOAT_GEMM_INTERLEAVE
 #define GOAT_GEMM_INTERLEAVE 1
 #endif
@@ -75,7 +76,6 @@ struct Tile {
   static constexpr int ROWS = T ? BK : BMN;
   static constexpr int BYTES = ROWS * RB;                 // 16 KiB (BMN=128) / 8 KiB (BMN=64)
   static constexpr int NINST = BYTES / 1024;              // DMA wave-instructions per tile
-  static constexpr int IPW = NINST / 4;                   // per wave
   static constexpr int RPB = 256 / RB > 0 ? 256 / RB : 1; // LDS rows per 256-B bank row
   static constexpr int C64 = RB / 64;                     // 64-B chunks per row
 
@@ -124,8 +124,15 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   typedef Tile<TA, BM> TLA;
   typedef Tile<TB, BN> TLB;
   constexpr int STAGE = TLA::BYTES + TLB::BYTES;
-  constexpr int MI = BM / 64;  // 32-row MFMA tiles per wave in M
-  constexpr int LOADS = TLA::IPW + TLB::IPW;
+  // waves: NW/2 wave rows x 2 wave columns, each wave a (32*MI) x 64 patch.  BM 256 = eight waves of the 128-row tile's
+  // patch: the B tile is shared by twice the rows, so a K-tile moves 48 KB through the L1 path for 2x the MFMA work (the
+  // 128-row tile is balanced 1:1 against that path)
+  constexpr int NTH = nthreads<BM>(), NW = NTH / 64;
+  constexpr int MI = BM == 64 ? 1 : 2;  // 32-row MFMA tiles per wave in M
+  constexpr int WROWS = 32 * MI;        // rows of a wave patch
+  constexpr int IPWA = TLA::NINST / NW, IPWB = TLB::NINST / NW;   // DMA wave-instructions per wave and K-tile
+  static_assert(IPWA >= 1 && IPWB >= 1, "every wave issues at least one DMA instruction per operand");
+  constexpr int LOADS = IPWA + IPWB;
   // k-steps a K-tile's DMA instructions are spread over: a 2-stage ring waits for them at the very next barrier, so they
   // go behind the first two k-steps only; deeper rings have a whole K-tile of slack
   constexpr int SPREAD = BK / 16;
@@ -161,23 +168,23 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)p.b_bytes, 0x00020000);
 
   // per-lane source offsets of this wave's DMA instructions at k-tile 0 of this split
-  uint32_t offa[TLA::IPW], offb[TLB::IPW];
+  uint32_t offa[IPWA], offb[IPWB];
   const uint32_t ka = TLA::k_step(p.lda), kb = TLB::k_step(p.ldb);
 #pragma unroll
-  for (int j = 0; j < TLA::IPW; ++j)
-    offa[j] = TLA::src_off((wave * TLA::IPW + j) * 1024 + lane * 16, m0, p.lda) + (uint32_t)kt_begin * ka;
+  for (int j = 0; j < IPWA; ++j)
+    offa[j] = TLA::src_off((wave * IPWA + j) * 1024 + lane * 16, m0, p.lda) + (uint32_t)kt_begin * ka;
 #pragma unroll
-  for (int j = 0; j < TLB::IPW; ++j)
-    offb[j] = TLB::src_off((wave * TLB::IPW + j) * 1024 + lane * 16, n0, p.ldb) + (uint32_t)kt_begin * kb;
+  for (int j = 0; j < IPWB; ++j)
+    offb[j] = TLB::src_off((wave * IPWB + j) * 1024 + lane * 16, n0, p.ldb) + (uint32_t)kt_begin * kb;
 
 #define GOAT_ISSUE(t_)                                                                                              \
   do {                                                                                                              \
     char* st_ = smem + ((t_) % NSTAGE) * STAGE;                                                                     \
     const uint32_t sa_ = (uint32_t)(t_) * ka, sb_ = (uint32_t)(t_) * kb;                                            \
-    _Pragma("unroll") for (int j = 0; j < TLA::IPW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
-        ra, (lds_void*)(st_ + (wave * TLA::IPW + j) * 1024), 16, offa[j], sa_, 0, 0);                               \
-    _Pragma("unroll") for (int j = 0; j < TLB::IPW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
-        rb, (lds_void*)(st_ + TLA::BYTES + (wave * TLB::IPW + j) * 1024), 16, offb[j], sb_, 0, 0);                  \
+    _Pragma("unroll") for (int j = 0; j < IPWA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
+        ra, (lds_void*)(st_ + (wave * IPWA + j) * 1024), 16, offa[j], sa_, 0, 0);                               \
+    _Pragma("unroll") for (int j = 0; j < IPWB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
+        rb, (lds_void*)(st_ + TLA::BYTES + (wave * IPWB + j) * 1024), 16, offb[j], sb_, 0, 0);                  \
   } while (0)
   // one DMA wave-instruction (number j_ of this wave's LOADS) of K-tile t_: the steady-state loop spreads a tile's
   // instructions over the four k-steps, behind their MFMAs, instead of issuing all of them between the barrier and the
@@ -185,12 +192,12 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
 #define GOAT_ISSUE_ONE(t_, j_)                                                                                      \
   do {                                                                                                              \
     char* st_ = smem + ((t_) % NSTAGE) * STAGE;                                                                     \
-    if ((j_) < TLA::IPW)                                                                                            \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(st_ + (wave * TLA::IPW + (j_)) * 1024), 16,          \
-                                               offa[(j_) < TLA::IPW ? (j_) : 0], (uint32_t)(t_) * ka, 0, 0);        \
+    if ((j_) < IPWA)                                                                                            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(st_ + (wave * IPWA + (j_)) * 1024), 16,          \
+                                               offa[(j_) < IPWA ? (j_) : 0], (uint32_t)(t_) * ka, 0, 0);        \
     else                                                                                                            \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(st_ + TLA::BYTES + (wave * TLB::IPW + (j_) - TLA::IPW) * 1024), 16, \
-                                               offb[(j_) >= TLA::IPW ? (j_) - TLA::IPW : 0], (uint32_t)(t_) * kb, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(st_ + TLA::BYTES + (wave * IPWB + (j_) - IPWA) * 1024), 16, \
+                                               offb[(j_) >= IPWA ? (j_) - IPWA : 0], (uint32_t)(t_) * kb, 0, 0); \
   } while (0)
 
   f32x16 acc[MI][2];
@@ -228,10 +235,10 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   do {                                                                                                              \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                                \
       if (!TA) {                                                                                                    \
-        uint4 v = lds_read_b128(frag_addr_n(sa, wm * (BM / 2) + i * 32 + l31, (ks_), hi));                           \
+        uint4 v = lds_read_b128(frag_addr_n(sa, wm * WROWS + i * 32 + l31, (ks_), hi));                           \
         fa[buf_][i] = *reinterpret_cast<bf16x8*>(&v);                                                               \
       } else {                                                                                                      \
-        const int col = wm * (BM / 2) + i * 32 + (g & 1) * 16 + (t15 & 3) * 4;                                      \
+        const int col = wm * WROWS + i * 32 + (g & 1) * 16 + (t15 & 3) * 4;                                      \
         const int kr = (ks_) * 16 + 8 * (g >> 1) + (t15 >> 2);                                                      \
         uint2 v0 = lds_read_tr16(frag_addr_t<TLA::RB, TLA::RPB, TLA::C64>(sa, kr, col));                            \
         uint2 v1 = lds_read_tr16(frag_addr_t<TLA::RB, TLA::RPB, TLA::C64>(sa, kr + 4, col));                        \
@@ -291,13 +298,13 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-      const int row = m0 + wm * (BM / 2) + i * 32 + l31;
+      const int row = m0 + wm * WROWS + i * 32 + l31;
       if (hi == 0 && row < p.M) atomicAdd(p.colsum + row, v);
     }
   }
 
   // ------------------------------------------------------------------ epilogue (as gemm.hip)
-  const int wrow0 = wm * (BM / 2), wcol0 = wn * 64;
+  const int wrow0 = wm * WROWS, wcol0 = wn * 64;
   if (SPLITK) {
     float* C = reinterpret_cast<float*>(p.C);
 #pragma unroll
@@ -325,7 +332,7 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
 
   float auxv[MI][2][16];
   if (EPI == GOAT_EPI_MUL_DGELU || EPI == GOAT_EPI_MUL_DRELU) {
-    for (int c = tid; c < BM * (BN / EPC_T); c += NT) {
+    for (int c = tid; c < BM * (BN / EPC_T); c += NTH) {
       const int r = c / (BN / EPC_T), cc = c % (BN / EPC_T);
       const int row = m0 + r, col = n0 + cc * EPC_T;
       if (row < p.M) {
@@ -372,7 +379,7 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
           for (int r = 0; r < 16; ++r)
             ct_t[(wrow0 + i * 32 + c_row(r, lane)) * CT_STRIDE_T + wcol0 + j * 32 + l31] = from_f<T>(acc[i][j][r]);
       __syncthreads();
-      for (int c = tid; c < BM * (BN / EPC_T); c += NT) {
+      for (int c = tid; c < BM * (BN / EPC_T); c += NTH) {
         const int r = c / (BN / EPC_T), cc = c % (BN / EPC_T);
         const int row = m0 + r, col = n0 + cc * EPC_T;
         if (row < p.M) {
@@ -424,7 +431,7 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
         ct_o[(wrow0 + i * 32 + c_row(r, lane)) * CT_STRIDE_O + wcol0 + j * 32 + l31] = from_f<OutT>(acc[i][j][r]);
   __syncthreads();
   const bool vec_ok = (p.ldc % EPC_O) == 0 && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
-  for (int c = tid; c < BM * (BN / EPC_O); c += NT) {
+  for (int c = tid; c < BM * (BN / EPC_O); c += NTH) {
     const int r = c / (BN / EPC_O), cc = c % (BN / EPC_O);
     const int row = m0 + r, col = n0 + cc * EPC_O;
     if (row < p.M) {
@@ -441,7 +448,7 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
 }
 
 template <bool TA, bool TB, typename OutT, int EPI, bool SPLITK, int BM, int NSTAGE>
-__global__ __launch_bounds__(NT) void gemm2_kernel(G2Args p) {
+__global__ __launch_bounds__(nthreads<BM>()) void gemm2_kernel(G2Args p) {
   gemm2_tile<TA, TB, OutT, EPI, SPLITK, BM, NSTAGE>(p, xcd_chunk_position(blockIdx.x, gridDim.x), blockIdx.y);
 }
 
@@ -476,7 +483,7 @@ int launch2s(hipStream_t st, const G2Args& a, int split) {
     attr_set = true;
   }
   dim3 grid(a.tiles_m * a.tiles_n, SPLITK ? split : 1);
-  hipLaunchKernelGGL(kern, grid, dim3(NT), SMEM, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(nthreads<BM>()), SMEM, st, a);
   GOAT_LAUNCH_CHECK();
   return 0;
 }
@@ -575,7 +582,8 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   if ((epilogue == GOAT_EPI_MUL_DGELU || epilogue == GOAT_EPI_MUL_DRELU) && !aux) return GOAT_E_ARG;
   if (epilogue == GOAT_EPI_ACCUM && (dtype_out != GOAT_F32 || bias)) return GOAT_E_ARG;
   if (split_k > 1 && (dtype_out != GOAT_F32 || (epilogue != GOAT_EPI_NONE && epilogue != GOAT_EPI_ACCUM) || bias)) return GOAT_E_ARG;
-  if (bm != 64 && bm != 128) return GOAT_E_ARG;
+  if (bm != 64 && bm != 128 && bm != 256) return GOAT_E_ARG;
+  if (bm == 256 && nstage > 3) return GOAT_E_ARG;      // 48 KiB stages: 3 is the deepest ring in 160 KiB of LDS
   const int64_t a_rows = trans_a ? Kc : M, b_rows = trans_b ? Kc : N;
   const int64_t a_bytes = a_rows * lda * 2, b_bytes = b_rows * ldb * 2;
   if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) return GOAT_E_SHAPE;
@@ -596,7 +604,9 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   a.k_tiles_per_split = (kt + split_k - 1) / split_k;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define GOAT_G2(TA_, TB_) \
-  (bm == 128 ? dispatch2<TA_, TB_, 128>(st, a, dtype_out, epilogue, split_k) : dispatch2<TA_, TB_, 64>(st, a, dtype_out, epilogue, split_k))
+  (bm == 128 ? dispatch2<TA_, TB_, 128>(st, a, dtype_out, epilogue, split_k)     \
+   : bm == 256 ? dispatch2<TA_, TB_, 256>(st, a, dtype_out, epilogue, split_k)   \
+               : dispatch2<TA_, TB_, 64>(st, a, dtype_out, epilogue, split_k))
   if (!trans_a && !trans_b) return GOAT_G2(false, false);
   if (!trans_a && trans_b) return GOAT_G2(false, true);
   return GOAT_G2(true, true);

@@ -249,9 +249,11 @@ def _tune_gemm(key, a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_opts, col
     for split in split_opts:
         if split > kt:
             continue
-        for bm in (64, 128):
+        for bm in (64, 128, 256):
             for ns in (2, 3, 4):
                 if bm == 128 and ns == 4 and out.dtype == torch.bfloat16 and epi != EPI_NONE:
+                    continue
+                if bm == 256 and (ns == 4 or M < 2048):      # 8-wave 256-row tile: 48 KiB stages, large-M problems only
                     continue
                 try:
                     t = _time_cfg(lambda: _launch_gemm_bf16(a, b, scratch, ta, tb, M, N, Kc, bias, epi, aux, split, bm, ns, cs))
