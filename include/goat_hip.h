@@ -57,6 +57,8 @@ int goat_gemm_nt(void* stream, int dtype_in, int dtype_out,
                  int M, int N, int K, const float* bias, int epilogue,
                  void* aux, int64_t ldaux, int split_k);
 
+#define GOAT_GEMM_8WAVES 0x100   /* flag in goat_gemm_bf16's nstage argument: run the 128-row tile with eight waves */
+
 /* Pipelined bf16 GEMM with direct-to-LDS (LDS-DMA) operand staging, all operand layouts (csrc/gemm2.hip):
  *   C[M,N] = epilogue( op(A) · op(B)ᵀ + bias ),  contraction length Kc
  *   trans_a=0: A is [M,Kc] (Kc contiguous) ; trans_a=1: A is [Kc,M] (M contiguous)   (same for B with N)
@@ -66,7 +68,8 @@ int goat_gemm_nt(void* stream, int dtype_in, int dtype_out,
  * Kc % 64 == 0 (transposed operands: any Kc, the tail is zero-filled by the buffer bounds check); lda/ldb
  * multiples of 8, bases 16-B aligned, each operand < 2 GiB.  split_k>1: f32 atomic accumulation into C.
  * bm: 64, 128 (four waves) or 256 (eight waves sharing one B tile: 25 % fewer L2->LDS bytes per flop, nstage <= 3; for
- * M >= 2048) — the M-tile; 64 fills the chip on small-M problems.  nstage: 2..4 LDS ring stages (2 = most
+ * M >= 2048) — the M-tile; 64 fills the chip on small-M problems.  bm 128 with nstage | GOAT_GEMM_8WAVES: the 128-row tile
+ * on eight waves (32x64 wave patches; twice the waves issue the tile's LDS-DMA).  nstage: 2..4 LDS ring stages (2 = most
  * workgroups per CU, 3-4 = deeper prefetch for long/cold contractions).
  * colsum (trans_a only, may be NULL): colsum[m] += sum_k A[k,m] (float32, atomic; caller zero-fills) — the bias
  * gradient of the Linear, accumulated from the A fragments the wgrad already holds in registers. */
@@ -190,7 +193,8 @@ int goat_gather_segmean_bwd(void* stream, int dtype, const void* dout,
  * kernel, unsplit.  The autograd of the several nn.Linear of a transformer block (P/model/Bert_backbone.py:170-172,302,
  * 348,362) produces weight gradients of 36-144 tiles each; together they fill the 256 CUs without the split-K atomics
  * and zero fills a single small problem needs.  accumulate != 0: dW += ...; dbias (may be NULL): float32 [n_out],
- * += column sums of dY (atomic; the caller clears it).  ld_* in elements; ld_dy, ld_x multiples of 8, bases 16-B aligned. */
+ * += column sums of dY (atomic; the caller clears it).  ld_* in elements; ld_dy, ld_x multiples of 8, bases 16-B aligned.
+ * bm 64 | 128, nstage 2..4 (| GOAT_GEMM_8WAVES with bm 128) as in goat_gemm_bf16. */
 typedef struct goat_wgrad_problem {
   const void* dy; int64_t ld_dy;
   const void* x; int64_t ld_x;

@@ -25,7 +25,10 @@ namespace {
 
 constexpr int BN = 128, BK = 64;
 constexpr int NT = 256;   // threads of the 64- and 128-row tiles (4 waves); the 256-row tile runs 8 waves (nthreads<BM>())
-template <int BM> constexpr int nthreads() { return BM == 256 ? 512 : 256; }
+// tile ids (the BM template argument): 64, 128, 256 = rows; TILE_128X8 = the 128-row tile run by eight waves (32x64 wave patches)
+constexpr int TILE_128X8 = 129;
+template <int BM> constexpr int tile_rows() { return BM == TILE_128X8 ? 128 : BM; }
+template <int BM> constexpr int nthreads() { return (BM == 256 || BM == TILE_128X8) ? 512 : 256; }
 #ifndef GOAT_GEMM_INTERLEAVE
 #define GOAT_GEMM_INTERLEAVE 1
 #endif
@@ -117,9 +120,10 @@ __device__ __forceinline__ int xcd_chunk_position(int bid, int nwg) {
 }
 
 // One output tile of one GEMM problem.  `bid` = position of the tile in the problem's tile order, `split` = K-split index.
-template <bool TA, bool TB, typename OutT, int EPI, bool SPLITK, int BM, int NSTAGE>
+template <bool TA, bool TB, typename OutT, int EPI, bool SPLITK, int BMID, int NSTAGE>
 __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (host pass: the gfx950-only builtins below would silently drop the kernel stubs)
+  constexpr int BM = tile_rows<BMID>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Tile<TA, BM> TLA;
   typedef Tile<TB, BN> TLB;
@@ -127,9 +131,12 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   // waves: NW/2 wave rows x 2 wave columns, each wave a (32*MI) x 64 patch.  BM 256 = eight waves of the 128-row tile's
   // patch: the B tile is shared by twice the rows, so a K-tile moves 48 KB through the L1 path for 2x the MFMA work (the
   // 128-row tile is balanced 1:1 against that path)
-  constexpr int NTH = nthreads<BM>(), NW = NTH / 64;
-  constexpr int MI = BM == 64 ? 1 : 2;  // 32-row MFMA tiles per wave in M
-  constexpr int WROWS = 32 * MI;        // rows of a wave patch
+  // Eight waves on the 128-row tile (TILE_128X8): a lone workgroup per CU is limited by how fast its waves can ISSUE the
+  // LDS-DMA instructions (each stalls the issuing wave for ~100 cycles); twice the waves halve that per-wave share.
+  constexpr int NTH = nthreads<BMID>(), NW = NTH / 64;
+  constexpr int WROWS = BM / (NW / 2);  // rows of a wave patch
+  constexpr int MI = WROWS / 32;        // 32-row MFMA tiles per wave in M
+  static_assert(MI == 1 || MI == 2, "wave patch is 32 or 64 rows");
   constexpr int IPWA = TLA::NINST / NW, IPWB = TLB::NINST / NW;   // DMA wave-instructions per wave and K-tile
   static_assert(IPWA >= 1 && IPWB >= 1, "every wave issues at least one DMA instruction per operand");
   constexpr int LOADS = IPWA + IPWB;
@@ -462,7 +469,7 @@ struct GroupArgs {
   int n;
 };
 template <int BM, int NSTAGE>
-__global__ __launch_bounds__(NT) void gemm2_group_kernel(GroupArgs g) {
+__global__ __launch_bounds__(nthreads<BM>()) void gemm2_group_kernel(GroupArgs g) {
   const int pos = xcd_chunk_position(blockIdx.x, gridDim.x);
   int pi = 0;
 #pragma unroll
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(NT) void gemm2_group_kernel(GroupArgs g) {
 
 template <bool TA, bool TB, typename OutT, int EPI, bool SPLITK, int BM, int NSTAGE>
 int launch2s(hipStream_t st, const G2Args& a, int split) {
-  constexpr int SMEM = NSTAGE * (Tile<TA, BM>::BYTES + Tile<TB, BN>::BYTES);
+  constexpr int SMEM = NSTAGE * (Tile<TA, tile_rows<BM>()>::BYTES + Tile<TB, BN>::BYTES);
   auto kern = gemm2_kernel<TA, TB, OutT, EPI, SPLITK, BM, NSTAGE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -569,6 +576,8 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
                               int M, int N, int Kc, const float* bias, int epilogue,
                               void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum) {
   if (!A || !B || !C) return GOAT_E_ARG;
+  const bool eight = (nstage & GOAT_GEMM_8WAVES) != 0;
+  nstage &= ~GOAT_GEMM_8WAVES;
   if (nstage < 2 || nstage > 4) return GOAT_E_ARG;
   g_nstage = nstage;
   if (colsum && !trans_a) return GOAT_E_ARG;
@@ -583,6 +592,7 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   if (epilogue == GOAT_EPI_ACCUM && (dtype_out != GOAT_F32 || bias)) return GOAT_E_ARG;
   if (split_k > 1 && (dtype_out != GOAT_F32 || (epilogue != GOAT_EPI_NONE && epilogue != GOAT_EPI_ACCUM) || bias)) return GOAT_E_ARG;
   if (bm != 64 && bm != 128 && bm != 256) return GOAT_E_ARG;
+  if (eight && bm != 128) return GOAT_E_ARG;
   if (bm == 256 && nstage > 3) return GOAT_E_ARG;      // 48 KiB stages: 3 is the deepest ring in 160 KiB of LDS
   const int64_t a_rows = trans_a ? Kc : M, b_rows = trans_b ? Kc : N;
   const int64_t a_bytes = a_rows * lda * 2, b_bytes = b_rows * ldb * 2;
@@ -604,7 +614,8 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   a.k_tiles_per_split = (kt + split_k - 1) / split_k;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define GOAT_G2(TA_, TB_) \
-  (bm == 128 ? dispatch2<TA_, TB_, 128>(st, a, dtype_out, epilogue, split_k)     \
+  (bm == 128 ? (eight ? dispatch2<TA_, TB_, TILE_128X8>(st, a, dtype_out, epilogue, split_k)     \
+                      : dispatch2<TA_, TB_, 128>(st, a, dtype_out, epilogue, split_k))           \
    : bm == 256 ? dispatch2<TA_, TB_, 256>(st, a, dtype_out, epilogue, split_k)   \
                : dispatch2<TA_, TB_, 64>(st, a, dtype_out, epilogue, split_k))
   if (!trans_a && !trans_b) return GOAT_G2(false, false);
@@ -615,7 +626,7 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
 
 template <int BM, int NSTAGE>
 static int launch_group(hipStream_t st, const GroupArgs& g) {
-  constexpr int SMEM = NSTAGE * (Tile<true, BM>::BYTES + Tile<true, BN>::BYTES);
+  constexpr int SMEM = NSTAGE * (Tile<true, tile_rows<BM>()>::BYTES + Tile<true, BN>::BYTES);
   auto kern = gemm2_group_kernel<BM, NSTAGE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -623,14 +634,16 @@ static int launch_group(hipStream_t st, const GroupArgs& g) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(g.tile_start[g.n]), dim3(NT), SMEM, st, g);
+  hipLaunchKernelGGL(kern, dim3(g.tile_start[g.n]), dim3(nthreads<BM>()), SMEM, st, g);
   GOAT_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs, int n, int bm, int nstage) {
   if (!probs || n < 1 || n > GROUP_MAX) return GOAT_E_ARG;
-  if ((bm != 64 && bm != 128) || nstage < 2 || nstage > 4) return GOAT_E_ARG;
+  const bool eight = (nstage & GOAT_GEMM_8WAVES) != 0;       // as in goat_gemm_bf16: the 128-row tile on eight waves
+  nstage &= ~GOAT_GEMM_8WAVES;
+  if ((bm != 64 && bm != 128) || nstage < 2 || nstage > 4 || (eight && bm != 128)) return GOAT_E_ARG;
   GroupArgs g;
   g.n = n;
   int tiles = 0;
@@ -658,6 +671,11 @@ extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs,
   }
   for (int i = n; i <= GROUP_MAX; ++i) g.tile_start[i] = tiles;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (bm == 128 && eight) {
+    if (nstage == 2) return launch_group<TILE_128X8, 2>(st, g);
+    if (nstage == 3) return launch_group<TILE_128X8, 3>(st, g);
+    return launch_group<TILE_128X8, 4>(st, g);
+  }
   if (bm == 128) {
     if (nstage == 2) return launch_group<128, 2>(st, g);
     if (nstage == 3) return launch_group<128, 3>(st, g);

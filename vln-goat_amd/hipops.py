@@ -200,6 +200,9 @@ def save_tuned(path):
 
 
 
+EIGHT_WAVES = 0x100     # GOAT_GEMM_8WAVES (include/goat_hip.h): flag in the nstage argument of goat_gemm_bf16
+
+
 def _heuristic_cfg(ta, tb, M, N, Kc, split_k):
     """(bm, nstage) measured with scripts/gemm_bench.py (hot and cold operands)."""
     tiles128 = ((M + 127) // 128) * ((N + 127) // 128) * max(1, split_k)
@@ -250,8 +253,8 @@ def _tune_gemm(key, a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_opts, col
         if split > kt:
             continue
         for bm in (64, 128, 256):
-            for ns in (2, 3, 4):
-                if bm == 128 and ns == 4 and out.dtype == torch.bfloat16 and epi != EPI_NONE:
+            for ns in (2, 3, 4) + ((EIGHT_WAVES | 2, EIGHT_WAVES | 3, EIGHT_WAVES | 4) if bm == 128 else ()):
+                if bm == 128 and (ns & 0xFF) == 4 and out.dtype == torch.bfloat16 and epi != EPI_NONE:
                     continue
                 if bm == 256 and (ns == 4 or M < 2048):      # 8-wave 256-row tile: 48 KiB stages, large-M problems only
                     continue
@@ -424,7 +427,7 @@ class WgradQueue:
     The first write of a slice in a step overwrites it; a later write (shared weights, BPTT) is queued as an accumulation —
     never in the same group as an earlier write of that slice (hipops._sink flushes first)."""
     enabled = os.environ.get('GOAT_WGRAD_GROUP', '1') != '0'
-    cfg = tuple(int(v) for v in os.environ.get('GOAT_WGRAD_GROUP_CFG', '128,2').split(','))   # (tile height, ring stages)
+    cfg = tuple(int(v) for v in os.environ.get('GOAT_WGRAD_GROUP_CFG', '128,258').split(','))   # (tile height, ring stages | 0x100 = eight waves): 128,2 on eight waves measured best (7.34 vs 7.50 ms/step on four)
     MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '8'))
     queues = {}             # HIP stream handle -> (torch stream, [(dy, x, w_sink, b_sink, accumulate)]): tensors are kept alive until
     pending_ids = {}        # the launch, which happens on the stream the problems were produced on;  id(param) -> stream handle
