@@ -18,6 +18,8 @@ CASES = [  # ta, tb, M, N, K, epi, f32out, split, bm, nstage
     (0, 0, 8640, 3072, 768, 0, 0, 1, 128, 2), (0, 0, 8640, 768, 3072, 0, 0, 1, 128, 2),
     (0, 0, 8192, 8192, 8192, 0, 0, 1, 128, 2), (0, 0, 8192, 8192, 8192, 0, 0, 1, 128, 3),
 ]
+if os.environ.get('GOAT_AB_8W'):            # the tuned eight-wave configurations of the main shapes
+    CASES = [c[:9] + (c[9] | 0x100,) if c[8] == 128 and c[4] <= 3840 else c for c in CASES]
 if os.environ.get('GOAT_AB_BM256'):         # the 8-wave 256-row tile next to the configuration each case is tuned to
     CASES = [c[:8] + cfg for c in CASES if c[0] == 0 and c[3] >= 768 for cfg in ((c[8], c[9]), (256, 2), (256, 3), (128, 0x102), (128, 0x103))]
 if os.environ.get('GOAT_AB_TN'):            # weight-gradient layout (dW = dY^T X, f32 result): every tile configuration

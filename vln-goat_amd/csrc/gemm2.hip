@@ -149,7 +149,9 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   constexpr int RD = MI * (TA ? 2 : 1) + 2 * (TB ? 2 : 1);            // ds_read instructions per k-step
   constexpr int FD = (GOAT_GEMM_FRAG_DEPTH * RD <= 15) ? GOAT_GEMM_FRAG_DEPTH : (15 / RD >= 1 ? 15 / RD : 1);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // `wave` through readfirstlane: the compiler then keeps every wave-uniform quantity (the LDS addresses of this wave's DMA
+  // pieces, hence M0) in SGPRs instead of a v_add + v_readfirstlane + s_mov chain in front of every buffer_load ... lds
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int hi = lane >> 5, l31 = lane & 31;
 
