@@ -461,10 +461,11 @@ __global__ __launch_bounds__(nthreads<BM>()) void gemm2_kernel(G2Args p) {
   gemm2_tile<TA, TB, OutT, EPI, SPLITK, BM, NSTAGE>(p, xcd_chunk_position(blockIdx.x, gridDim.x), blockIdx.y);
 }
 
-// Grouped weight-gradient launch: up to GROUP_MAX (16) independent TN problems (dW_i = dY_i^T · X_i, float32 out, unsplit)
+// Grouped weight-gradient launch: up to GROUP_MAX (24) independent TN problems (dW_i = dY_i^T · X_i, float32 out, unsplit)
 // share one grid, so the many small weight gradients of a layer fill the chip together instead of each being split
 // along the contraction (atomics + a zero fill) to do so.  Problem i owns tiles [tile_start[i], tile_start[i+1]).
-constexpr int GROUP_MAX = 16;
+constexpr int GROUP_MAX = 24;   // (the argument block stays under the 4 KiB kernel-argument limit)
+static_assert(sizeof(G2Args) * GROUP_MAX + 4 * (GROUP_MAX + 2) <= 4000, "GroupArgs must fit the kernel-argument segment");
 struct GroupArgs {
   G2Args prob[GROUP_MAX];
   int tile_start[GROUP_MAX + 1];

@@ -421,14 +421,14 @@ class Branch:
 class WgradQueue:
     """Deferred weight gradients.  With a gradient arena attached the weight gradient of a Linear is not needed until the
     backward pass ends, so instead of launching each small dW = dY^T·X on its own (36-144 tiles: split along the
-    contraction, atomics and a zero fill to occupy 256 CUs) the problems are queued and executed eight at a time by
+    contraction, atomics and a zero fill to occupy 256 CUs) the problems are queued and executed up to sixteen at a time by
     goat_wgrad_grouped: one unsplit launch that fills the chip.  Flushed when full, when a queued parameter is about
     to be written again (ordering), and by an autograd-engine callback at the end of the backward pass.
     The first write of a slice in a step overwrites it; a later write (shared weights, BPTT) is queued as an accumulation —
     never in the same group as an earlier write of that slice (hipops._sink flushes first)."""
     enabled = os.environ.get('GOAT_WGRAD_GROUP', '1') != '0'
     cfg = tuple(int(v) for v in os.environ.get('GOAT_WGRAD_GROUP_CFG', '128,258').split(','))   # (tile height, ring stages | 0x100 = eight waves): 128,2 on eight waves measured best (7.34 vs 7.50 ms/step on four)
-    MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '8'))
+    MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '16'))      # problems per launch (measured 8 / 12 / 16: 7.12 / 7.09 / 7.06 ms per step)
     queues = {}             # HIP stream handle -> (torch stream, [(dy, x, w_sink, b_sink, accumulate)]): tensors are kept alive until
     pending_ids = {}        # the launch, which happens on the stream the problems were produced on;  id(param) -> stream handle
     _callback_armed = False
