@@ -53,8 +53,48 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) outside a torch.distributed launcher: start N ranks of this script under
+    torch.distributed.run on this node (one process per GPU, rendezvous on 127.0.0.1 — the reference's launch shape,
+    pretrain_src/utils/distributed.py:53-72) and pass their output through.  Under torchrun (RANK set) this is a no-op."""
+    if args.gpus <= 1 or 'RANK' in os.environ or 'WORLD_SIZE' in os.environ:
+        return None
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args):
+    """GOAT_BENCH_LAUNCH_ONLY=1: exercise only the launch path (rank spawn, rendezvous, one all-reduce) and print the rank
+    count — what tests/test_bench_launcher.py runs on CPU with the gloo backend."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    n = world
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(os.environ.get('GOAT_DIST_BACKEND', 'gloo'))
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        n = int(t.item())
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({'metric': 'launch-check', 'n_gpus': n, 'gpus_flag': args.gpus, 'launch_only': True}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def setup_dist(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != max(1, args.gpus):
+        print('[bench] --gpus %d but WORLD_SIZE=%d: the launcher decides; reporting n_gpus=%d' % (args.gpus, world, world), file=sys.stderr)
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     local = local % max(1, torch.cuda.device_count())
@@ -435,10 +475,16 @@ def gemm_roofline(args, model, gb, arena=None):
 
 def main():
     args = parse()
+    rc = spawn_ranks(args)
+    if rc is not None:
+        sys.exit(rc)
+    if os.environ.get('GOAT_BENCH_LAUNCH_ONLY'):
+        return launch_check(args)
     world, rank, local = setup_dist(args)
     cfg, model, batch, gb = build(args, rank)
     from vln_goat_amd import dp, synth
     wrapper = dp.GoatDataParallel(model, share_cfp_negatives=True)
+    wrapper.sparse_uniform_rows = True       # every rank's synthetic batch has B*L = 48*80 token rows (no count exchange / host sync)
     steps = make_steps(args, model, gb, world, wrapper)
     n_traj = synth.n_traj_steps(batch)
 

@@ -250,6 +250,35 @@ int goat_dict_wsum_fwd(void* stream, int dtype_out, const float* z, const float*
 int goat_dict_wsum_bwd(void* stream, int dtype_dout, const void* dout, const float* z, const float* p, float* dz, float* dp,
                        int B, int K, int H);
 
+/* ---- fused optimizer step on the gradient arena ------------------------------------------------------------
+ * The reference's update (P/train_r2r_goat.py:349-366): grad-norm clip 5.0 over every parameter that has a gradient
+ * (torch.nn.utils.clip_grad_norm_), then HF-style AdamW (P/optim/adamw.py:53-110): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= step_size * m / (sqrt(v) + eps) with step_size = lr * sqrt(1-b2^t) / (1-b1^t) (t = that PARAMETER's own step count);
+ * then the decoupled decay applied AFTER the update, p -= lr * weight_decay * p (weight_decay 0 for names containing
+ * "bias" / "LayerNorm.weight", P/optim/misc.py:13-23); parameters without a gradient in this step are skipped entirely.
+ * Here: gradients live in ONE float32 arena (dp.GradArena), the moments in two arenas of the same layout, the parameters
+ * stay the model's own float32 tensors.
+ *   goat_grad_sqnorm : *out_sq += sum of g^2 over the element ranges [begin, end) of `ranges` (int64 pairs, device memory)
+ *   goat_adamw_step  : one launch over `nchunks` chunks (<= 65536 elements each; chunk c = {tensor index, first element}
+ *                      int32 pairs in device memory) of the tensors described by `tensors` (device memory).  The clip
+ *                      coefficient min(1, max_norm / (sqrt(*sq_norm) + 1e-6)) is computed in the kernel from the device
+ *                      scalar goat_grad_sqnorm produced (max_norm <= 0: no clipping), so the step needs no host
+ *                      synchronisation.  shadow0 / shadow1 (optional): bf16 copies of the parameter (the operand "shadows"
+ *                      the GEMMs read) refreshed in the same pass. */
+typedef struct goat_adamw_tensor {
+  float* param;            /* float32 master weights */
+  void* shadow0;           /* bf16 copy, same element order, or NULL */
+  void* shadow1;           /* second bf16 copy (e.g. inside a row-concatenated QKV shadow), or NULL */
+  int64_t arena_off;       /* first element of this tensor in the gradient / moment arenas */
+  int64_t numel;
+  float step_size;         /* lr * sqrt(1 - b2^t) / (1 - b1^t) for this tensor's step count t (or lr without bias correction) */
+  float decay;             /* lr * weight_decay (0: no decay) */
+} goat_adamw_tensor;
+int goat_grad_sqnorm(void* stream, const float* arena, const int64_t* ranges, int n_ranges, float* out_sq);
+int goat_adamw_step(void* stream, const float* grad_arena, float* exp_avg, float* exp_avg_sq, const goat_adamw_tensor* tensors,
+                    const int32_t* chunks, int nchunks, float beta1, float beta2, float eps, float max_norm,
+                    const float* sq_norm);
+
 /* Debug/probe helper used by tests: fills out[64*4] with the element indices returned by
  * ds_read_b64_tr_b16 when lane l points at elements 4l..4l+3 of an LDS array holding 0,1,2,... */
 int goat_probe_tr16(void* stream, uint16_t* out);

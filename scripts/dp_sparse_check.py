@@ -16,7 +16,10 @@ cfg = gcfg.make_config(num_l_layers=2, num_top_layer=2, num_pano_layers=1, vocab
 torch.manual_seed(0)
 model = pretrain_model.GlocalTextPathCMTPreTraining(cfg).cuda().eval()
 vln_goat_amd.set_compute_dtype(torch.bfloat16)
-gb = synth.batch_to(synth.make_pretrain_batch(B=4, T=[2, 3, 1, 2], L=[30, 22, 16, 25], seed=50 + rank, vocab_size=1000, style='rich'), 'cuda')
+# instruction lengths differ between the ranks (the collate pads to the per-batch maximum: 30 vs 27 tokens, i.e. 120 vs 108 token
+# rows in the sparse exchange of the word-embedding gradient)
+gb = synth.batch_to(synth.make_pretrain_batch(B=4, T=[2, 3, 1, 2], L=[30, 22, 16, 25] if rank == 0 else [27, 19, 12, 21], seed=50 + rank,
+                                              vocab_size=1000, style='rich'), 'cuda')
 w = dp.GoatDataParallel(model)
 tasks = ('mlm', 'sap', 'cfp')
 for t in tasks:

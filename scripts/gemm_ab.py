@@ -10,21 +10,22 @@ import sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, ROOT)
 
-CASES = [  # ta, tb, M, N, K, epi, f32out, split, bm, nstage
-    (0, 0, 3840, 3072, 768, 1, 0, 1, 128, 2), (0, 0, 3840, 3072, 768, 0, 0, 1, 128, 2), (0, 0, 3840, 768, 3072, 0, 0, 1, 128, 3),
-    (0, 0, 3840, 768, 3072, 0, 0, 1, 128, 2), (0, 0, 3840, 2304, 768, 0, 0, 1, 128, 2), (0, 0, 3840, 768, 768, 0, 0, 1, 128, 3),
-    (0, 0, 3840, 768, 768, 0, 0, 1, 64, 2), (0, 1, 3840, 3072, 768, 3, 0, 1, 64, 2), (0, 1, 3840, 768, 3072, 0, 0, 1, 128, 3),
-    (0, 1, 3840, 768, 768, 0, 0, 1, 128, 3), (1, 1, 3072, 768, 3840, 0, 1, 1, 64, 3), (1, 1, 768, 768, 3840, 0, 1, 4, 64, 2),
-    (0, 0, 8640, 3072, 768, 0, 0, 1, 128, 2), (0, 0, 8640, 768, 3072, 0, 0, 1, 128, 2),
-    (0, 0, 8192, 8192, 8192, 0, 0, 1, 128, 2), (0, 0, 8192, 8192, 8192, 0, 0, 1, 128, 3),
+def T(bm, bn):
+    return bm | (bn << 16)
+
+
+CASES = [  # ta, tb, M, N, K, epi, f32out, split, tile (rows | cols << 16), nstage (| 0x100: eight waves on 128x128)
+    (0, 0, 3840, 3072, 768, 0, 0, 1, T(192, 256), 2), (0, 0, 3840, 3072, 768, 1, 0, 1, T(192, 256), 2), (0, 0, 3840, 3072, 768, 0, 0, 1, T(256, 256), 2),
+    (0, 0, 3840, 3072, 768, 0, 0, 1, 128, 0x102), (0, 0, 3840, 2304, 768, 0, 0, 1, T(256, 192), 2), (0, 0, 3840, 2304, 768, 0, 0, 1, 128, 0x102),
+    (0, 0, 3840, 768, 3072, 0, 0, 1, 128, 0x104), (0, 0, 3840, 768, 3072, 0, 0, 1, T(128, 256), 3), (0, 0, 3840, 768, 768, 0, 0, 1, 128, 0x104),
+    (0, 0, 3840, 768, 768, 0, 0, 1, 64, 2),
+    (0, 1, 3840, 3072, 768, 3, 0, 1, T(192, 256), 2), (0, 1, 3840, 3072, 768, 3, 0, 1, 128, 0x102), (0, 1, 3840, 768, 3072, 0, 0, 1, 128, 0x104),
+    (0, 1, 3840, 768, 3072, 0, 0, 1, T(128, 256), 3),
+    (1, 1, 3072, 768, 3840, 0, 1, 1, 128, 0x104), (1, 1, 3072, 768, 3840, 0, 1, 1, T(256, 256), 2), (1, 1, 3072, 768, 3840, 0, 1, 1, T(128, 256), 3),
+    (1, 1, 768, 768, 3840, 0, 1, 4, 128, 0x103),
+    (0, 0, 8640, 3072, 768, 0, 0, 1, T(256, 256), 2), (0, 0, 8640, 3072, 768, 0, 0, 1, 128, 0x102), (0, 0, 8640, 768, 3072, 0, 0, 1, T(128, 256), 3),
+    (0, 0, 1776, 768, 768, 0, 0, 1, 64, 4), (0, 0, 8192, 8192, 8192, 0, 0, 1, T(256, 256), 2), (0, 0, 8192, 8192, 8192, 0, 0, 1, T(128, 256), 3),
 ]
-if os.environ.get('GOAT_AB_8W'):            # the tuned eight-wave configurations of the main shapes
-    CASES = [c[:9] + (c[9] | 0x100,) if c[8] == 128 and c[4] <= 3840 else c for c in CASES]
-if os.environ.get('GOAT_AB_BM256'):         # the 8-wave 256-row tile next to the configuration each case is tuned to
-    CASES = [c[:8] + cfg for c in CASES if c[0] == 0 and c[3] >= 768 for cfg in ((c[8], c[9]), (256, 2), (256, 3), (128, 0x102), (128, 0x103))]
-if os.environ.get('GOAT_AB_TN'):            # weight-gradient layout (dW = dY^T X, f32 result): every tile configuration
-    CASES = [(1, 1, m, n, k, 0, 1, 1, bm, ns) for (m, n, k) in ((3072, 768, 3840), (768, 3072, 3840), (768, 768, 3840), (2304, 768, 3840))
-             for bm in (64, 128) for ns in (2, 3, 4)]
 
 
 def worker():

@@ -23,8 +23,13 @@ CASES = {
     # REVERIE: object tokens in every panorama + object-grounding head
     'nav_reverie_objects': dict(do_back_txt_type='type_2', do_back_img_type='type_1', do_add_method='door', dataset='reverie',
                                 obj_feat_size=768),
+    # BASELINE.json configs[3] at the size of the fine-tuning script (M/scripts/run_r2r_goat.sh: 6/3/2 layers, batch 12,
+    # max_instr_len 200, BACL + FACL on, dictionaries 35/39/50/24) with a G ~ 60 global map, full vocabulary
+    'nav_config4_full': dict(do_back_txt_type='type_2', do_back_img_type='type_1', do_add_method='door'),
 }
-EPISODE = {'nav_reverie_objects': dict(objects=5, seed=9)}
+FULL = {'nav_config4_full': dict(num_l_layers=6, num_x_layers=3, num_pano_layers=2, vocab_size=50265, dropout=0.1, feat_dropout=0.5)}
+EPISODE = {'nav_reverie_objects': dict(objects=5, seed=9),
+           'nav_config4_full': dict(B=12, L=200, n_steps=3, seed=21, vocab_size=50265, extra_nodes=51)}
 WEIGHT_SEED = 11
 VOCAB = 1200
 
@@ -44,9 +49,9 @@ def main(only=None):
     for name, over in CASES.items():
         if only and name not in only:
             continue
-        args = SimpleNamespace(num_l_layers=2, num_x_layers=2, num_pano_layers=2, dropout=0.5, feat_dropout=0.4,
-                               do_back_img=True, do_back_txt=True, do_front_img=True, do_front_his=True, do_front_txt=True,
-                               vocab_size=VOCAB, mode='train', **over)
+        args = SimpleNamespace(**{**dict(num_l_layers=2, num_x_layers=2, num_pano_layers=2, dropout=0.5, feat_dropout=0.4,
+                                         do_back_img=True, do_back_txt=True, do_front_img=True, do_front_his=True, do_front_txt=True,
+                                         vocab_size=VOCAB, mode='train'), **FULL.get(name, {}), **over})
         cfg = nav_model.nav_config_from_args(args)
         torch.manual_seed(0)
         ref = vg.GlocalTextPathNavCMT(cfg)

@@ -36,7 +36,16 @@ CASES = {
     'pretrain_bacl_type1_xattn': (dict(num_l_layers=2, num_top_layer=2, num_pano_layers=2, vocab_size=1000, do_back_txt=True,
                                        do_back_txt_type='type_1', z_cross_attn=True),
                                   dict(B=3, T=[2, 1, 3], L=[30, 24, 16], seed=9, vocab_size=1000, style='survey', zdict=(35, 39))),
+    # ---- full-size pins: BASELINE.json configs[1] / configs[4] at the sizes bench.py times them -------------
+    # config 2: full R2R model (6/3/2 layers, vocab 50 265), per-rank batch 48, T=5, 36 views, L=80
+    'pretrain_config2_full': (dict(), dict(B=48, T=5, L=80, seed=100, style='survey')),
+    # config 5 shape: REVERIE model (object tokens, OG head, name embeddings), L=160, per-rank batch 32, up to 20 objects
+    'pretrain_config5_reverie_full': (dict(name='REVERIE', obj_feat_size=768, image_prob_size=1000, obj_prob_size=1000,
+                                           obj_name_vocab_size=45, use_obj_name=True,
+                                           pretrain_tasks=['mlm', 'mrc', 'sap', 'og', 'cfp']),
+                                      dict(B=32, T=5, L=160, seed=105, style='survey', objects=20, mrc=True, prob_size=1000)),
 }
+FULL_SIZE = ('pretrain_config2_full', 'pretrain_config5_reverie_full')
 
 
 def case_tasks(name):
@@ -71,9 +80,14 @@ def fingerprint(grad):
     return np.concatenate([[float(flat.double().norm())], first.numpy()]).astype(np.float32)
 
 
-def oracle_run(cfg, sd, batch, task):
-    """Runs the oracle with autograd; returns (loss_vec, {name: grad}) for the parameter tensors in sd."""
+def oracle_run(cfg, sd, batch, task, autocast_bf16=False):
+    """Runs the oracle with autograd; returns (loss_vec, {name: grad}) for the parameter tensors in sd.
+    autocast_bf16: the same restatement under stock torch.autocast(bfloat16) on the CPU — the yardstick the GPU tests use
+    for what bf16 rounding alone does to each gradient tensor."""
     from oracle import goat_oracle
+    if autocast_bf16:
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            return oracle_run(cfg, sd, batch, task)
     leaves = {}
     for k, v in sd.items():
         if v.is_floating_point():

@@ -516,10 +516,15 @@ def test_dict_weighted_sum(ops, dtype):
 
 @pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, True)])
 @pytest.mark.parametrize('bm,ns', [(64, 2), (64, 3), (64, 4), (128, 2), (128, 3), (128, 4), (256, 2), (256, 3),
-                                   (128, 0x102), (128, 0x103), (128, 0x104)])      # 0x100: the 128-row tile on eight waves
+                                   (128, 0x102), (128, 0x103), (128, 0x104),      # 0x100: the 128-row tile on eight waves
+                                   (128 | 256 << 16, 2), (128 | 256 << 16, 3), (192 | 256 << 16, 2), (256 | 192 << 16, 2),
+                                   (256 | 256 << 16, 2)])                          # rows | columns << 16: the 8-wave wide tiles
 def test_gemm_bf16_every_tile_configuration(ops, ta, tb, bm, ns):
-    """Every (tile height, ring depth) the autotuner may pick, on a ragged shape, incl. GELU / C += A·B / split-K epilogues."""
-    from vln_goat_amd._lib import EPI_ACCUM, EPI_GELU, EPI_NONE
+    """Every (tile, ring depth) the autotuner may pick, on a ragged shape, incl. GELU / x GELU' / C += A·B / split-K epilogues."""
+    from vln_goat_amd._lib import EPI_ACCUM, EPI_GELU, EPI_MUL_DGELU, EPI_NONE
+    rows, cols = bm & 0xFFFF, (bm >> 16) or 128
+    if (ta and rows & (rows - 1)) or (tb and cols & (cols - 1)):
+        pytest.skip('a transposed operand needs a power-of-two tile width on its side')
     M, N, Kc = 1000, 392, 320 if not (ta and tb) else 328
     g = torch.Generator().manual_seed(bm * 7 + ns)
     A = torch.randn(M, Kc, generator=g)
@@ -534,11 +539,17 @@ def test_gemm_bf16_every_tile_configuration(ops, ta, tb, bm, ns):
         return out
     out = run(torch.empty(M, N, device=DEV, dtype=torch.bfloat16), bias_=bias)
     _close(out, ref + bias, torch.bfloat16, 'plain')
-    if not (bm == 128 and (ns & 0xFF) == 4):      # (the activation epilogues of the 128-row tile are built for 2-3 ring slots)
+    if not (bm == 128 and (ns & 0xFF) == 4) and not ta:      # (activation epilogues: forward / dgrad layouts; the 128-row tile has them for 2-3 ring slots)
         aux = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         out = run(torch.empty(M, N, device=DEV, dtype=torch.bfloat16), EPI_GELU, aux, bias_=bias)
         _close(aux, ref + bias, torch.bfloat16, 'gelu pre-activation')
         _close(out, torch.nn.functional.gelu(ref + bias), torch.bfloat16, 'gelu')
+        uu = aux.float().requires_grad_(True)
+        torch.nn.functional.gelu(uu).sum().backward()
+        out = run(torch.empty(M, N, device=DEV, dtype=torch.bfloat16), EPI_MUL_DGELU, aux)
+        _close(out, ref * uu.grad, torch.bfloat16, "x gelu'")
+    out32 = run(torch.empty(M, N, device=DEV), bias_=bias)
+    _close(out32, ref + bias, torch.bfloat16, 'f32 result with bias')
     acc = run(torch.full((M, N), 2.0, device=DEV), EPI_ACCUM)
     _close(acc - 2.0, ref, torch.bfloat16, 'accumulate')
     acc = run(torch.full((M, N), -1.0, device=DEV), split=3)
@@ -552,7 +563,7 @@ def test_wgrad_grouped(ops):
     from vln_goat_amd import _lib
     g = torch.Generator().manual_seed(77)
     shapes = [(3840, 768, 768), (1000, 2304, 768), (333, 768, 3072), (3840, 3072, 768), (37, 8, 768), (576, 1001, 768)]
-    for bm, ns in ((64, 3), (128, 2), (128, 0x102), (128, 0x103)):      # 0x100: eight waves on the 128-row tile
+    for bm, ns in ((64, 3), (128, 2), (128, 0x102), (128, 0x103), (256, 2), (128 | 256 << 16, 3), (256 | 256 << 16, 2)):      # 0x100: eight waves on the 128-row tile; rows | columns << 16
         arr = (_lib.WgradProblem * len(shapes))()
         keep, refs = [], []
         for i, (rows, n_out, n_in) in enumerate(shapes):

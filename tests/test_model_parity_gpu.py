@@ -51,15 +51,17 @@ def test_losses_and_grads_match_oracle(case, task, dtype):
     # gradients: every parameter tensor, relative L2 error.  Gradients that are mathematically zero
     # (e.g. key biases: softmax is shift-invariant) are checked on an absolute scale instead.
     gmax = max(float(g.norm()) for g in ref_grads.values() if g is not None)
-    # bf16 tolerances are calibrated on stock PyTorch: the CPU oracle under torch.autocast(bfloat16) differs from
-    # its own fp32 run by 6.6% (sap) / 0.8% (mlm) / 2.0% (cfp) aggregate on these cases (worst tensor 15%).
-    rtol = 1e-3 if dtype == torch.float32 else 0.35       # per tensor
-    agg_tol = 1e-4 if dtype == torch.float32 else 0.12    # sum |err| / sum |ref| over all tensors
-    # gradients far below the scale of the others (sums of cancelling terms, e.g. the scalar bias of the fusion score)
-    # sit inside the bf16 rounding noise of the big terms: those are held to an absolute bound instead
-    tiny = (1e-6 if dtype == torch.float32 else 2e-3) * gmax
-    abs_tol = (1e-4 if dtype == torch.float32 else 5e-3) * gmax
-    bad, num, den = [], 0.0, 0.0
+    if dtype == torch.float32:
+        _check_grads_f32(model, ref_grads, gmax)
+    else:
+        # bf16: the bound of every tensor is MEASURED here — the same oracle under stock torch.autocast(bfloat16) on the
+        # CPU shows what bf16 rounding of the operands does to that gradient on this very batch
+        _, ac_grads = oracle_run(cfg, sd, batch, task, autocast_bf16=True)
+        _check_grads_bf16(model, ref_grads, ac_grads, gmax)
+
+
+def _check_grads_f32(model, ref_grads, gmax):
+    tiny, abs_tol, bad, num, den = 1e-6 * gmax, 1e-4 * gmax, [], 0.0, 0.0
     for n, p in model.named_parameters():
         rg = ref_grads.get(n)
         if rg is None or float(rg.norm()) <= tiny:
@@ -71,13 +73,59 @@ def test_losses_and_grads_match_oracle(case, task, dtype):
         d = float((p.grad.double().cpu() - rg.double()).norm())
         num += d
         den += float(rg.double().norm())
-        lim = rtol
-        if dtype == torch.bfloat16 and any(k in n for k in ILL_CONDITIONED):
-            lim = 0.7
-        if d / float(rg.double().norm()) > lim:
+        if d / float(rg.double().norm()) > 1e-3:
             bad.append((n, d / float(rg.double().norm())))
     assert not bad, bad[:10]
-    assert num / den < agg_tol, num / den
+    assert num / den < 1e-4, num / den
+
+
+# how far the HIP bf16 path may sit from the fp32 gradients, in units of the error stock autocast makes on the same tensor
+# of the same batch: it rounds at more points (every activation is stored in bf16, autocast keeps LayerNorm / softmax
+# outputs in fp32), hence the factor; FLOOR for tensors autocast happens to hit exactly.  Calibration
+# (scripts/diag_bf16_grads.py on an MI355X, profiles/round2_bf16_grad_calibration.txt): aggregate e_hip / e_ac = 0.9-1.3 over
+# 7 cases x tasks, median per tensor 0.84-1.31, worst single tensor 2.9 (sap_fuse_linear.net.0.bias)
+BF16_K, BF16_FLOOR, BF16_NORM_K, BF16_NORM_FLOOR = 4.0, 0.03, 4.0, 0.025
+
+
+def _check_grads_bf16(model, ref_grads, ac_grads, gmax):
+    """per tensor:  ||g_hip - g_ref|| <= max(K ||g_autocast - g_ref||, FLOOR ||g_ref||)   (rounding noise), and
+                    | ||g_hip|| / ||g_ref|| - 1 | <= max(K' |autocast ratio - 1|, FLOOR')  (a mis-scaled kernel moves the norm
+    one-for-one, rounding noise only to second order);  aggregate over all tensors with the same rule.
+    The four door-gate parameters are sums of cancelling terms (dout orthogonal to the LayerNorm input): their relative
+    error is the group's largest autocast error, not each tensor's own."""
+    tiny, abs_tol = 2e-3 * gmax, 5e-3 * gmax
+    rows, num, den, num_ac = [], 0.0, 0.0, 0.0
+    ill_ac = 0.0
+    for n, p in model.named_parameters():
+        rg = ref_grads.get(n)
+        if rg is None or float(rg.norm()) <= tiny:
+            if p.grad is not None:
+                ref0 = rg.double() if rg is not None else 0.0
+                assert float((p.grad.double().cpu() - ref0).norm()) <= abs_tol, n
+            continue
+        assert p.grad is not None, n
+        rn = float(rg.double().norm())
+        g, ga = p.grad.double().cpu(), ac_grads[n].double()
+        e_hip, e_ac = float((g - rg.double()).norm()) / rn, float((ga - rg.double()).norm()) / rn
+        r_hip, r_ac = abs(float(g.norm()) / rn - 1.0), abs(float(ga.norm()) / rn - 1.0)
+        if any(k in n for k in ILL_CONDITIONED):
+            ill_ac = max(ill_ac, e_ac)
+        rows.append((n, e_hip, e_ac, r_hip, r_ac))
+        num += e_hip * rn
+        num_ac += e_ac * rn
+        den += rn
+    bad = []
+    for n, e_hip, e_ac, r_hip, r_ac in rows:
+        if any(k in n for k in ILL_CONDITIONED):
+            if e_hip > max(BF16_K * ill_ac, 0.25):
+                bad.append((n, 'err', e_hip, ill_ac))
+            continue
+        if e_hip > max(BF16_K * e_ac, BF16_FLOOR):
+            bad.append((n, 'err', e_hip, e_ac))
+        if r_hip > max(BF16_NORM_K * r_ac, BF16_NORM_FLOOR, 0.75 * e_hip):
+            bad.append((n, 'norm', r_hip, r_ac))
+    assert not bad, bad[:12]
+    assert num / den < max(2.0 * num_ac / den, 0.02), (num / den, num_ac / den)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -210,6 +258,83 @@ def test_og_and_mrc_outputs_match_reference_golden(case, dtype):
         assert np.array_equal(np.isinf(lg), np.isinf(ref))
         m = ~np.isinf(ref)
         assert float(np.abs(lg[m] - ref[m]).max()) / max(1.0, float(np.abs(ref[m]).max())) < tol
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Full-size pins: BASELINE.json configs[1] (R2R, 6/3/2 layers, 50 265 vocabulary, batch 48, T=5, L=80) and the
+# configs[4] shape (REVERIE model, L=160, batch 32, <= 20 objects, mlm/mrc/sap/og/cfp) against outputs of the IMPORTED
+# REFERENCE at that size (tests/golden/make_golden_pretrain.py): loss vectors, logits / pooled vectors / predictions, and the
+# L2 norm + leading elements of every parameter gradient.  fp32 <= 1e-3, bf16 <= 2e-2 on outputs.
+from helpers import FULL_SIZE, fingerprint  # noqa: E402
+FULL_CASE_TASKS = [(c, t) for c in FULL_SIZE for t in case_tasks(c)]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case,task', FULL_CASE_TASKS)
+def test_full_size_matches_reference_golden(case, task, dtype):
+    import vln_goat_amd
+    from vln_goat_amd import synth
+    cfg, model, batch = build_case(case)
+    gold = load_golden(case)
+    tol = 1e-3 if dtype == torch.float32 else 2e-2
+    vln_goat_amd.set_compute_dtype(dtype)
+    try:
+        model = model.cuda().eval()
+        gb = synth.batch_to(batch, 'cuda')
+        loss = model(gb, task, compute_loss=True)
+        loss.mean().backward()
+        with torch.no_grad():
+            outs = {}
+            if task == 'sap':
+                gl, ll, fl, _, _ = model(gb, 'sap', compute_loss=False)
+                outs = {'sap_global_logits': gl, 'sap_local_logits': ll, 'sap_fused_logits': fl}
+            elif task == 'cfp':
+                go, vo, fo, to = model(gb, 'cfp', compute_loss=False)
+                outs = {'cfp_gmap_out': go, 'cfp_vp_out': vo, 'cfp_fused_out': fo, 'cfp_txt_out': to}
+            elif task == 'og':
+                outs = {'og_logits': model(gb, 'og', compute_loss=False)}
+            elif task == 'mrc':
+                vp, _, op, _ = model(gb, 'mrc', compute_loss=False)
+                outs = {'mrc_view_pred': vp}
+                if op is not None:
+                    outs['mrc_obj_pred'] = op
+            elif task == 'mlm':
+                sc = model(gb, 'mlm', compute_loss=False).float()
+                outs = {'mlm_scores_head': sc[:, :64], 'mlm_scores_lse': torch.logsumexp(sc, 1)}
+        torch.cuda.synchronize()
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)
+    ref = gold[task + '_loss_vec']
+    got = loss.detach().float().cpu().numpy()
+    assert got.shape == ref.shape
+    assert float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max())) < tol, 'loss vector'
+    for key, t in outs.items():
+        ref, g = gold[key], t.float().cpu().numpy()
+        assert g.shape == ref.shape, key
+        assert np.array_equal(np.isinf(g), np.isinf(ref)), key
+        m = ~np.isinf(ref)
+        assert float(np.abs(g[m] - ref[m]).max()) / max(1.0, float(np.abs(ref[m]).max())) < tol, key
+    # every parameter gradient: ||g|| and g[:8] against the reference's
+    names = [str(n) for n in gold['param_names']]
+    fp = gold[task + '_grad_fp']
+    params = dict(model.named_parameters())
+    gmax = float(fp[:, 0].max())
+    rtol, tiny = (2e-3, 1e-6) if dtype == torch.float32 else (None, 2e-3)
+    bad = []
+    for i, n in enumerate(names):
+        refp, gotp = fp[i], fingerprint(params[n].grad)
+        if refp[0] <= tiny * gmax:
+            assert gotp[0] <= (1e-4 if dtype == torch.float32 else 5e-3) * gmax, n
+            continue
+        if dtype == torch.float32:
+            if np.abs(gotp - refp).max() / refp[0] > rtol:
+                bad.append((n, gotp[0], refp[0]))
+        else:
+            # bf16: the norm of every gradient tensor (rounding noise moves a norm only to second order; a mis-scaled or
+            # partly missing gradient moves it one-for-one).  Cancelling sums (the door gates) are excluded as in the small cases.
+            if not any(k in n for k in ILL_CONDITIONED) and abs(gotp[0] / refp[0] - 1.0) > 0.06:
+                bad.append((n, gotp[0], refp[0]))
+    assert not bad, bad[:12]
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -17,19 +17,27 @@ CASES = {
     # REVERIE: object tokens in every panorama + object-grounding head (must match tests/golden/make_golden_nav.py)
     'nav_reverie_objects': dict(do_back_txt_type='type_2', do_back_img_type='type_1', do_add_method='door', dataset='reverie',
                                 obj_feat_size=768),
+    # BASELINE.json configs[3] at the size of M/scripts/run_r2r_goat.sh (6/3/2 layers, batch 12, max_instr_len 200, full
+    # vocabulary, BACL + FACL on, dictionaries 35/39/50/24), G = 60 map nodes at the last step  
+    'nav_config4_full': dict(do_back_txt_type='type_2', do_back_img_type='type_1', do_add_method='door'),
 }
-EPISODE = {'nav_reverie_objects': dict(objects=5, seed=9)}
+FULL = {'nav_config4_full': dict(num_l_layers=6, num_x_layers=3, num_pano_layers=2, vocab_size=50265, dropout=0.1, feat_dropout=0.5)}
+EPISODE = {'nav_reverie_objects': dict(objects=5, seed=9),
+           'nav_config4_full': dict(B=12, L=200, n_steps=3, seed=21, vocab_size=50265, extra_nodes=51)}
 
 
-def _build(over, epkw=None):
+def _args(case, **extra):
+    return SimpleNamespace(**{**dict(num_l_layers=2, num_x_layers=2, num_pano_layers=2, dropout=0.5, feat_dropout=0.4,
+                                     do_back_img=True, do_back_txt=True, do_front_img=True, do_front_his=True, do_front_txt=True,
+                                     vocab_size=1200, mode='train'), **FULL.get(case, {}), **CASES[case], **extra})
+
+
+def _build(case):
     from vln_goat_amd import nav_model, synth
-    args = SimpleNamespace(num_l_layers=2, num_x_layers=2, num_pano_layers=2, dropout=0.5, feat_dropout=0.4,
-                           do_back_img=True, do_back_txt=True, do_front_img=True, do_front_his=True, do_front_txt=True,
-                           vocab_size=1200, mode='train', **over)
-    cfg = nav_model.nav_config_from_args(args)
+    cfg = nav_model.nav_config_from_args(_args(case))
     model = nav_model.GlocalTextPathNavCMT(cfg)
     model.load_state_dict(synth.seeded_state_dict(model, seed=11))
-    ep = synth.make_nav_episode(**{**dict(B=2, L=44, n_steps=3, seed=5, vocab_size=1200), **(epkw or {})})
+    ep = synth.make_nav_episode(**{**dict(B=2, L=44, n_steps=3, seed=5, vocab_size=1200), **EPISODE.get(case, {})})
     return model, ep
 
 
@@ -39,7 +47,7 @@ def test_nav_episode_matches_reference_golden(case, dtype):
     import vln_goat_amd
     from vln_goat_amd import synth
     gold = load_golden(case)
-    model, ep = _build(CASES[case], EPISODE.get(case))
+    model, ep = _build(case)
     vln_goat_amd.set_compute_dtype(dtype)
     try:
         model = model.cuda().eval()
@@ -107,6 +115,75 @@ def test_vlnbert_wrapper_and_critic_run():
         assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('case', ['nav_type2_door', 'nav_reverie_objects'])
+def test_vlnbert_wrapper_matches_reference_golden(case):
+    """a-16: the episode of the golden vectors driven through `VLNBert(mode, batch)` (M/models/model.py:21-38) instead of the
+    bare GlocalTextPathNavCMT.  eval(): the environment dropout is the identity, so the wrapper must reproduce the reference
+    loss, logits and [MEM] state; train(): with `already_dropout` unset the raw view features ARE dropped (p = feat_dropout,
+    survivors scaled by 1/(1-p)) before the model sees them, objects even when `already_dropout` is set."""
+    import vln_goat_amd
+    from vln_goat_amd import nav_model, synth
+    gold = load_golden(case)
+    _, ep = _build(case)
+    net = nav_model.VLNBert(_args(case, bert_ckpt_file=None))
+    net.vln_bert.load_state_dict(synth.seeded_state_dict(net.vln_bert, seed=11))
+    assert isinstance(net.drop_env, torch.nn.Dropout) and net.drop_env.p == 0.4          # used directly by the agent (M/r2r/agent.py:460)
+    net = net.cuda().eval()
+    loss, rec = synth.run_nav_episode(lambda m, b: net(m, dict(b)), ep, device='cuda')
+    assert abs(float(loss) - float(gold['loss'][0])) / max(1.0, abs(float(gold['loss'][0]))) < 1e-3
+    for t, s in enumerate(rec['steps']):
+        for k in ('fused_logits', 'cls_embeds'):
+            ref, got = gold['s%d_%s' % (t, k)], s[k].detach().float().cpu().numpy()
+            m = ~np.isinf(ref)
+            assert np.array_equal(np.isinf(got), np.isinf(ref)) and np.abs(got[m] - ref[m]).max() / max(1.0, np.abs(ref[m]).max()) < 1e-3, (t, k)
+    # training mode: what reaches the model is the dropped tensor
+    seen = {}
+    net.train()
+    orig = net.vln_bert.forward
+    net.vln_bert.forward = lambda mode, batch: seen.update({k: batch[k] for k in ('view_img_fts', 'reverie_obj_img_fts') if batch.get(k) is not None}) or (None, None, None)
+    st = ep['steps'][0]
+    x = st['view_img_fts'].cuda()
+    pin = {'view_img_fts': x, 'loc_fts': st['loc_fts'].cuda(), 'nav_types': st['nav_types'].cuda(), 'view_lens': st['view_lens'].cuda()}
+    if 'reverie_obj_img_fts' in st:
+        pin['reverie_obj_img_fts'] = st['reverie_obj_img_fts'].cuda()
+    net('panorama', dict(pin))
+    y = seen['view_img_fts'].float()
+    kept = y != 0
+    frac = float(kept.float().mean()) / float((x != 0).float().mean())
+    assert abs(frac - 0.6) < 0.02, frac                                                    # p = feat_dropout = 0.4
+    assert torch.allclose(y[kept], (x.float() / 0.6)[kept], rtol=1e-5, atol=1e-6)
+    net('panorama', dict(pin, already_dropout=True))
+    assert torch.equal(seen['view_img_fts'].float(), x.float())                           # views untouched ...
+    if 'reverie_obj_img_fts' in st:
+        o = seen['reverie_obj_img_fts'].float()
+        assert float((o == 0).float().mean()) > float((pin['reverie_obj_img_fts'] == 0).float().mean()) + 0.2      # ... objects still dropped
+    net.vln_bert.forward = orig
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_critic_matches_plain_torch(dtype):
+    """M/models/model.py:40-50: Linear(768,512) - ReLU - Dropout - Linear(512,1), squeeze."""
+    import vln_goat_amd
+    from vln_goat_amd import nav_model
+    torch.manual_seed(3)
+    critic = nav_model.Critic(SimpleNamespace(dropout=0.5)).cuda().eval()
+    x = torch.randn(12, 768, device='cuda', requires_grad=True)
+    vln_goat_amd.set_compute_dtype(dtype)
+    try:
+        v = critic(x)
+        v.sum().backward()
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)
+    w0, b0, w1, b1 = (t.detach().float() for t in (critic.state2value[0].weight, critic.state2value[0].bias, critic.state2value[3].weight, critic.state2value[3].bias))
+    xr = x.detach().clone().requires_grad_(True)
+    ref = (torch.relu(xr @ w0.T + b0) @ w1.T + b1).squeeze()
+    ref.sum().backward()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert v.shape == ref.shape == (12,)
+    assert float((v.float() - ref).abs().max()) < tol * max(1.0, float(ref.abs().max()))
+    assert float((x.grad.float() - xr.grad).norm() / xr.grad.norm()) < (1e-4 if dtype == torch.float32 else 3e-2)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

@@ -44,3 +44,253 @@ def test_pretrain_step_trains_the_hip_model(use_arena):
             assert last[name] < first[name], (name, first[name], last[name])
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+def _total_norm(fp):
+    import numpy as np
+    return float(np.sqrt((fp[:, 0].astype(np.float64) ** 2).sum()))
+
+
+@pytest.mark.parametrize('use_arena', [False, True])
+def test_pretrain_step_matches_config1_golden(use_arena):
+    """the harness driven against the reference capture it is pinned to — config 1 (2/2/2 layers, full
+    vocabulary, B=4), dropout off: per task the mean of the reference's loss vector, the clipped-gradient norm
+    (clip_grad_norm_ 5.0, P/train_r2r_goat.py:349-354) and the L2 norm + leading elements of every parameter's .grad as the
+    optimizer sees it (after clipping), fp32 <= 1e-3.  lr = 0: the weights stay at the golden state for every task."""
+    import numpy as np
+    import vln_goat_amd
+    from helpers import build_case, case_tasks, fingerprint, load_golden
+    from vln_goat_amd import dp, synth, train_step
+    case = 'pretrain_config1'
+    cfg, model, batch = build_case(case)
+    gold = load_golden(case)
+    model = model.cuda().eval()
+    gb = synth.batch_to(batch, 'cuda')
+    wrapper = dp.GoatDataParallel(model)
+    if use_arena:
+        for t in case_tasks(case):
+            for p in model.parameters():
+                p.grad = None
+            model(gb, t, True).mean().backward()
+            wrapper.record_usage(t)
+        for p in model.parameters():
+            p.grad = None
+        wrapper.build_arena()
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.0)
+    step = train_step.PretrainStep(model, opt, grad_accum=1, grad_norm=5.0, wrapper=wrapper)
+    names = [str(n) for n in gold['param_names']]
+    params = dict(model.named_parameters())
+    for rnd in range(2):                                     # twice: the second round runs on the arena's learned owner sets
+        for task in case_tasks(case):
+            info = step(task, gb)
+            torch.cuda.synchronize()
+            ref_loss = float(gold[task + '_loss_vec'].mean())
+            assert abs(info['loss'] - ref_loss) < 1e-3 * max(1.0, abs(ref_loss)), (task, info['loss'], ref_loss)
+            assert info['n_loss_units'] == gold[task + '_loss_vec'].shape[0]
+            fp = gold[task + '_grad_fp']
+            tot = _total_norm(fp)
+            assert abs(info['grad_norm'] - tot) < 2e-3 * tot, (task, info['grad_norm'], tot)
+            coef = min(1.0, 5.0 / (tot + 1e-6))
+            gmax = float(fp[:, 0].max()) * coef
+            for i, n in enumerate(names):
+                ref, g = fp[i] * coef, params[n].grad
+                if fp[i][0] == 0.0:                          # the reference left .grad at None (parameter unused by the task)
+                    assert g is None or float(g.norm()) <= 1e-5 * gmax, (task, n)
+                    continue
+                got = fingerprint(g)
+                assert np.abs(got - ref).max() <= 2e-3 * max(ref[0], 1e-4 * gmax), (task, n, got, ref)
+
+
+def test_arena_step_updates_only_the_parameters_of_the_task():
+    """with the gradient arena attached a sap / cfp step must leave the parameters only mlm uses (mlm_head.*)
+    exactly where they are — their arena slices still hold the last mlm gradient, and an optimizer that saw it would apply it
+    again (moments and weight decay included).  The arena run must match the arena-less run weight for weight."""
+    import vln_goat_amd
+    from vln_goat_amd import config as gcfg, dp, pretrain_model, synth, train_step
+    cfg = gcfg.make_config(num_l_layers=1, num_top_layer=1, num_pano_layers=1, vocab_size=500,
+                           hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    gb = synth.batch_to(synth.make_pretrain_batch(B=3, T=[2, 1, 2], L=[20, 14, 9], seed=4, vocab_size=500, style='rich'), 'cuda')
+    runs = []
+    for use_arena in (False, True):
+        torch.manual_seed(0)
+        model = pretrain_model.GlocalTextPathCMTPreTraining(cfg).cuda().train()
+        wrapper = dp.GoatDataParallel(model)
+        if use_arena:
+            for t in ('mlm', 'sap', 'cfp'):
+                for p in model.parameters():
+                    p.grad = None
+                model(gb, t, True).mean().backward()
+                wrapper.record_usage(t)
+            for p in model.parameters():
+                p.grad = None
+            wrapper.build_arena()
+        # (SGD with momentum and weight decay: linear in the gradient, so mathematically-zero gradients — rounding noise of
+        # atomically ordered sums — stay noise instead of being normalised to +-lr as Adam would)
+        opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.05, momentum=0.9, weight_decay=0.05)
+        step = train_step.PretrainStep(model, opt, grad_accum=1, grad_norm=5.0, wrapper=wrapper)
+        snaps = []
+        for name in ('mlm', 'sap', 'cfp', 'sap', 'mlm'):
+            step(name, gb)
+            torch.cuda.synchronize()
+            snaps.append({n: p.detach().clone() for n, p in model.named_parameters()})
+        runs.append(snaps)
+    plain, arena = runs
+    for k, (a, b) in enumerate(zip(plain, arena)):
+        for n in a:
+            assert torch.allclose(a[n], b[n], rtol=2e-4, atol=2e-6), (k, n, float((a[n] - b[n]).abs().max()))
+    head = [n for n in plain[0] if n.startswith('mlm_head.predictions.transform')]
+    assert head
+    for n in head:                                               # untouched by the sap and cfp steps that follow the first mlm step
+        assert torch.equal(arena[0][n], arena[1][n]) and torch.equal(arena[1][n], arena[2][n]) and torch.equal(arena[2][n], arena[3][n]), n
+        assert not torch.equal(arena[3][n], arena[4][n]), n      # and moved again by the second mlm step
+
+
+def test_fused_adamw_matches_reference_trace():
+    """N3: goat_grad_sqnorm + goat_adamw_step on the gradient arena against three steps of the REFERENCE optimizer
+    (P/optim/adamw.py:53-110 behind clip_grad_norm_(5.0); tests/golden/make_contract.py wrote the trace): a clipped step, two
+    unclipped ones, a parameter that never gets a gradient, one that skips a step (its bias correction lags), a changing
+    learning rate, weight decay on matrices only, bf16 shadows refreshed in the same pass."""
+    import numpy as np
+    from helpers import load_golden
+    from vln_goat_amd import dp, hipops, optim
+    tr = load_golden('adamw_trace')
+    names = [str(n) for n in tr['names']]
+    params = {n: torch.nn.Parameter(torch.from_numpy(tr['p0_' + n]).cuda()) for n in names}
+    usage = {id(params[n]): ({'a', 'b'} if n not in ('head.weight', 'unused.weight') else ({'a'} if n == 'head.weight' else set())) for n in names}
+    arena = dp.GradArena(list(params.values()), usage).attach()
+    assert id(params['unused.weight']) not in arena.views
+    opt = optim.FusedAdamW(params.items(), arena, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01)
+    assert sorted(opt.param_groups[1]['names']) == ['enc.LayerNorm.bias', 'enc.LayerNorm.weight', 'enc.dense.bias']
+    sh = hipops._shadow(params['enc.dense.weight'], torch.bfloat16)                  # a cached bf16 operand copy
+    for step, task in enumerate(('a', 'b', 'a')):
+        arena.bind(task)
+        arena.flat.zero_()
+        for n in names:
+            if ('g%d_%s' % (step, n)) in tr:
+                arena.views[id(params[n])].copy_(torch.from_numpy(tr['g%d_%s' % (step, n)]))
+        for g in opt.param_groups:
+            g['lr'] = float(tr['lr'][step])
+        opt.step(task, max_norm=5.0)
+        torch.cuda.synchronize()
+        assert abs(opt.last_grad_norm() - float(tr['gnorm%d' % step][0])) < 1e-4 * float(tr['gnorm%d' % step][0])
+        for n in names:
+            ref = tr['p%d_%s' % (step + 1, n)]
+            got = params[n].detach().cpu().numpy()
+            assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()) + 1e-9, (step, n, np.abs(got - ref).max())
+        assert torch.equal(sh, params['enc.dense.weight'].detach().to(torch.bfloat16))       # refreshed in the same pass
+        assert hipops._shadow(params['enc.dense.weight'], torch.bfloat16) is sh               # and still the cached object
+    for n in names:
+        if ('m_' + n) in tr:
+            stt = opt.state_of(params[n])
+            assert np.abs(stt['exp_avg'].cpu().numpy() - tr['m_' + n]).max() <= 1e-6 * max(1e-3, np.abs(tr['m_' + n]).max())
+            assert np.abs(stt['exp_avg_sq'].cpu().numpy() - tr['v_' + n]).max() <= 1e-6 * max(1e-6, np.abs(tr['v_' + n]).max())
+    assert opt.steps[id(params['head.weight'])] == 2 and opt.steps[id(params['emb.word.weight'])] == 3
+
+
+def _arena_for(model, gb, tasks=('mlm', 'sap', 'cfp')):
+    from vln_goat_amd import dp
+    wrapper = dp.GoatDataParallel(model)
+    for t in tasks:
+        for p in model.parameters():
+            p.grad = None
+        model(gb, t, True).mean().backward()
+        wrapper.record_usage(t)
+    for p in model.parameters():
+        p.grad = None
+    return wrapper, wrapper.build_arena()
+
+
+def test_fused_adamw_on_the_model_matches_torch_adamw():
+    """The fused step inside PretrainStep on the real model (fp32 path: deterministic operands) next to torch.optim.AdamW with the
+    reference's two parameter groups: same weights after two rounds of mlm / sap / cfp.  (torch applies the decoupled decay
+    before the update and the reference after it, and they place eps differently: second-order differences, far below the
+    tolerance; parameters whose gradient is rounding noise are normalised to +-lr by any Adam and are left out.)"""
+    from vln_goat_amd import config as gcfg, optim, pretrain_model, synth, train_step
+    cfg = gcfg.make_config(num_l_layers=1, num_top_layer=1, num_pano_layers=1, vocab_size=400,
+                           hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    gb = synth.batch_to(synth.make_pretrain_batch(B=3, T=[2, 1, 2], L=[20, 14, 9], seed=4, vocab_size=400, style='rich'), 'cuda')
+    finals, gnorms = [], []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        model = pretrain_model.GlocalTextPathCMTPreTraining(cfg).cuda().train()
+        wrapper, arena = _arena_for(model, gb)
+        if fused:
+            opt = optim.FusedAdamW(model.named_parameters(), arena, lr=1e-4, betas=(0.9, 0.98), eps=1e-10, weight_decay=0.01)
+        else:
+            named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+            nd = [p for n, p in named if any(k in n for k in optim.NO_DECAY)]
+            dc = [p for n, p in named if not any(k in n for k in optim.NO_DECAY)]
+            opt = torch.optim.AdamW([{'params': dc, 'weight_decay': 0.01}, {'params': nd, 'weight_decay': 0.0}], lr=1e-4, betas=(0.9, 0.98), eps=1e-10)
+        step = train_step.PretrainStep(model, opt, grad_accum=1, grad_norm=5.0, wrapper=wrapper)
+        start = {n: p.detach().clone() for n, p in model.named_parameters()}
+        noisy = set()
+        for rnd in range(2):
+            for name in ('mlm', 'sap', 'cfp'):
+                info = step(name, gb)
+                gn = info['grad_norm']
+                gnorms.append(gn() if callable(gn) else gn)
+                if not fused:
+                    gmax = max(float(p.grad.norm()) for p in model.parameters() if p.grad is not None)
+                    noisy |= {n for n, p in model.named_parameters() if p.grad is not None and float(p.grad.norm()) < 1e-5 * gmax}
+        torch.cuda.synchronize()
+        finals.append(({n: p.detach().clone() for n, p in model.named_parameters()}, start, noisy))
+    (a, start, noisy), (b, _, _) = finals
+    assert all(abs(x - y) < 1e-3 * x for x, y in zip(gnorms[:6], gnorms[6:])), gnorms
+    moved = 0
+    for n in a:
+        if n in noisy:
+            continue
+        da, db = (a[n] - start[n]).double(), (b[n] - start[n]).double()
+        if float(da.norm()) == 0.0:
+            assert float(db.norm()) == 0.0, n                     # parameters no task uses are never touched
+            continue
+        moved += 1
+        assert float((da - db).norm()) <= 2e-2 * float(da.norm()) + 1e-9, (n, float((da - db).norm()), float(da.norm()))
+    assert moved > 100
+
+
+def test_fused_adamw_keeps_the_bf16_shadows_coherent():
+    """bf16 path: the fused step refreshes the operand shadows (plain, row-concatenated QKV / KV, vocabulary-padded decoder) in
+    its own pass.  After a few steps every cached bf16 copy equals the rounded float32 master, and a forward pass on the cached
+    copies equals the forward pass after dropping every cache (copies rebuilt from the masters)."""
+    import vln_goat_amd
+    from vln_goat_amd import config as gcfg, optim, pretrain_model, synth, train_step
+    cfg = gcfg.make_config(num_l_layers=2, num_top_layer=1, num_pano_layers=1, vocab_size=1000,
+                           hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    model = pretrain_model.GlocalTextPathCMTPreTraining(cfg).cuda().train()
+    gb = synth.batch_to(synth.make_pretrain_batch(B=4, T=[2, 3, 1, 2], L=[30, 22, 16, 25], seed=5, vocab_size=1000, style='rich'), 'cuda')
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        wrapper, arena = _arena_for(model, gb)
+        opt = optim.FusedAdamW(model.named_parameters(), arena, lr=2e-4, betas=(0.9, 0.98), weight_decay=0.01)
+        step = train_step.PretrainStep(model, opt, grad_accum=1, grad_norm=5.0, wrapper=wrapper)
+        before = {n: p.detach().clone() for n, p in model.named_parameters()}
+        for it in range(2):
+            for name in ('mlm', 'sap', 'cfp'):
+                assert step(name, gb)['updated']
+        torch.cuda.synchronize()
+        assert sum(1 for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n])) > 100
+        checked = {'plain': 0, 'cat': 0, 'rowpad': 0}
+        byid = {id(q): q for q in model.parameters()}
+        for n, p in model.named_parameters():
+            for k, (ver, t) in (p.__dict__.get('_goat_shadow') or {}).items():
+                if k[0] == 'cat' and t.dtype == torch.bfloat16:
+                    assert torch.equal(t, torch.cat([byid[i].detach() for i in k[3]], 0).to(torch.bfloat16)), n
+                    checked['cat'] += 1
+                elif k[0] == 'rowpad':
+                    assert torch.equal(t[:p.shape[0]], p.detach().to(torch.bfloat16)) and not bool(t[p.shape[0]:].any()), n
+                    checked['rowpad'] += 1
+                elif k[0] == torch.bfloat16 and k[1] is False and k[2] == 0:
+                    assert torch.equal(t, p.detach().to(torch.bfloat16)), n
+                    checked['plain'] += 1
+        assert checked['plain'] > 10 and checked['cat'] > 3 and checked['rowpad'] == 1, checked
+        with torch.no_grad():
+            cached = [model(gb, t, True).float().clone() for t in ('mlm', 'sap', 'cfp')]
+            for p in model.parameters():
+                p.__dict__.pop('_goat_shadow', None)
+            fresh = [model(gb, t, True).float() for t in ('mlm', 'sap', 'cfp')]
+        for x, y in zip(cached, fresh):
+            assert torch.equal(x, y)
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('GOAT_HIP_LIB') or os.path.join(CSRC, 'libgoat_hip.so')     # (override: kernel A/B experiments)
-SOURCES = ['gemm.hip', 'gemm2.hip', 'attention.hip', 'rowops.hip', 'causal.hip']
+SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm3.hip', 'attention.hip', 'rowops.hip', 'causal.hip', 'optim.hip']
 
 GOAT_F32, GOAT_BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ACCUM = 0, 1, 2, 3, 4, 5
@@ -56,8 +56,16 @@ SIGNATURES = {
     'goat_dict_wsum_fwd': [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_dict_wsum_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_wgrad_grouped': [_vp, _vp, _i32, _i32, _i32],
+    'goat_grad_sqnorm': [_vp, _vp, _vp, _i32, _vp],
+    'goat_adamw_step': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _vp],
     'goat_probe_tr16': [_vp, _vp],
 }
+
+
+class AdamwTensor(ctypes.Structure):
+    """struct goat_adamw_tensor (include/goat_hip.h)."""
+    _fields_ = [('param', ctypes.c_void_p), ('shadow0', ctypes.c_void_p), ('shadow1', ctypes.c_void_p), ('arena_off', ctypes.c_int64),
+                ('numel', ctypes.c_int64), ('step_size', ctypes.c_float), ('decay', ctypes.c_float)]
 
 
 class WgradProblem(ctypes.Structure):
@@ -70,7 +78,7 @@ class WgradProblem(ctypes.Structure):
 def build(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into csrc/libgoat_hip.so (in-tree, travels with the repo snapshot)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, 'common.hpp'), os.path.join(_HERE, '..', 'include', 'goat_hip.h')]
+    deps = srcs + [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'gemm2_tile.hpp'), os.path.join(_HERE, '..', 'include', 'goat_hip.h')]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

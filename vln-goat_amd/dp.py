@@ -273,7 +273,7 @@ class GradArena:
                 self.flat[a:b].zero_()
             return
         fills = self._fills.get(key)
-        if fills is None or fills[0] != len(owned):
+        if fills is None or fills[0] != frozenset(owned):
             r = []
             for p in self.params:
                 t = self.tasks_of[id(p)]
@@ -285,11 +285,27 @@ class GradArena:
                     r[-1][1] = b
                 else:
                     r.append([a, b])
-            fills = self._fills[key] = (len(owned), r)
+            fills = self._fills[key] = (frozenset(owned), r)
         for a, b in fills[1]:
             self.flat[a:b].zero_()
 
     # -- communication ---------------------------------------------------------------------------
+    def close_step(self):
+        """End of an eager backward pass: zero() skipped the slices the HIP Functions wrote last time (they clear / overwrite
+        them on first touch).  If one of those Functions did NOT run this time (e.g. pretrain_model's early return when no
+        token is masked), its slice still holds the previous step's gradient: clear it now, before anything reads .grad.
+        Host-side check of ~300 dictionary entries; replayed hipGraphs have a static data flow and do not need it."""
+        if self._cur is None:
+            return 0
+        key, epoch = self._cur
+        owned = self._owned.get(key, ())
+        n = 0
+        for p in self.params:
+            if id(p) in owned and p.__dict__.get('_goat_epoch') != epoch:
+                self.views[id(p)].zero_()
+                n += 1
+        return n
+
     _avg_ok = None      # RCCL averages in the collective (ReduceOp.AVG); gloo and old stacks: sum, then one divide pass
 
     def _reduce_mean(self, c, W):
@@ -351,6 +367,11 @@ class GoatDataParallel(torch.nn.Module):
         if share_cfp_negatives and hasattr(model, 'cfp_gather'):
             model.cfp_gather = CfpGather()
         if _world() > 1:
+            from . import hipops
+            hipops.RngState.rank_salt = _rank()      # every rank draws its own dropout masks (the reference seeds seed + rank,
+            counter = hipops.RngState.counter        # P/utils/misc.py:12-16 via train_r2r_goat.py:72)
+            hipops.manual_seed(hipops.RngState.base)
+            hipops.RngState.counter = counter
             # DDP constructor semantics: rank-0 parameters/buffers broadcast to all (P/utils/misc.py:58)
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, 0)
@@ -455,6 +476,17 @@ class GoatDataParallel(torch.nn.Module):
             view.zero_()
         for rows, ids, _tab, pad in self._stash.get(key, ()):
             ids = ids.reshape(-1).contiguous()
+            # The collate pads txt_ids to the per-batch maximum length, so B*L differs between ranks in real training: the ranks
+            # first agree on the largest row count and pad with zero rows (id 0: a scatter-add of zeros changes nothing).
+            # sparse_uniform_rows = True (fixed-shape synthetic batches, bench.py) skips the exchange and its host sync.
+            if not getattr(self, 'sparse_uniform_rows', False):
+                cnt = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+                dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+                nmax = int(cnt.item())
+                if rows.shape[0] < nmax:
+                    fill = nmax - rows.shape[0]
+                    rows = torch.cat([rows, rows.new_zeros((fill, rows.shape[1]))], 0)
+                    ids = torch.cat([ids, ids.new_zeros(fill)], 0)
             if dist.get_backend() == 'gloo' and rows.is_cuda:        # (single-GPU self-tests: gloo has no GPU all-gather)
                 all_rows = torch.zeros((W,) + tuple(rows.shape), dtype=torch.float32, device=rows.device)
                 all_ids = torch.zeros((W,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)

@@ -52,19 +52,25 @@ def _ptr(t, off=0):
 class RngState:
     """Dropout counter state.  Eager: host counter.  Graph capture: `dev` (uint64 on device) is bumped
     by one in-graph add per replay so every replay draws fresh masks (see goat_hip.h)."""
-    seed = 0x5EED
+    seed = None         # None: taken from torch.initial_seed() at first use (so torch.manual_seed / the reference trainer's
+    rank_salt = 0       # set_random_seed(seed + rank) steer it); rank_salt: GoatDataParallel folds the rank in
+    base = None         # what manual_seed() was given
     counter = 0
     dev = None
 
     @classmethod
     def next(cls, numel):
+        if cls.seed is None:
+            cls.seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + 0x5EED + cls.rank_salt * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF
         off = cls.counter
         cls.counter += (int(numel) + 7) & ~7      # multiples of 8: row kernels draw masks per even-aligned counter pair
         return cls.seed, off, (cls.dev.data_ptr() if cls.dev is not None else None)
 
 
-def manual_seed(seed):
-    RngState.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
+def manual_seed(seed=None):
+    """Seed of the dropout masks of the HIP kernels.  None: re-derive from torch.initial_seed() (call after torch.manual_seed)."""
+    RngState.base = seed
+    RngState.seed = None if seed is None else (int(seed) + RngState.rank_salt * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF
     RngState.counter = 0
 
 
@@ -181,8 +187,8 @@ TUNED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_gfx
 
 def load_tuned(path=None):
     """Merge a saved table of autotuned GEMM configurations (measured on an MI355X by bench.py) into _TUNED."""
-    path = path or TUNED_FILE
-    if not os.path.exists(path):
+    path = path or os.environ.get('GOAT_TUNED_FILE') or TUNED_FILE
+    if os.environ.get('GOAT_NO_TUNED') or not os.path.exists(path):      # GOAT_NO_TUNED=1: re-tune from scratch (bench.py GOAT_SAVE_TUNED=...)
         return 0
     with open(path) as f:
         tab = json.load(f)
@@ -201,6 +207,32 @@ def save_tuned(path):
 
 
 EIGHT_WAVES = 0x100     # GOAT_GEMM_8WAVES (include/goat_hip.h): flag in the nstage argument of goat_gemm_bf16
+
+
+def tile(bm, bn=128):
+    """tile argument of goat_gemm_bf16 / goat_wgrad_grouped: rows | columns << 16 (128 columns: just the row count)."""
+    return bm if bn == 128 else (bm | (bn << 16))
+
+
+def tile_name(t):
+    return '%dx%d' % (t & 0xFFFF, (t >> 16) or 128)
+
+
+def _tile_candidates(ta, tb, M, N):
+    """(tile, ring stages) pairs the autotuner times for one GEMM shape.  The 8-wave 192/256-wide tiles (csrc/gemm3.hip) need a
+    power-of-two width on a transposed operand's side; they only pay when the problem has enough rows / columns."""
+    c = [(64, 2), (64, 3), (64, 4), (128, 2), (128, 3), (128, 4), (128, EIGHT_WAVES | 2), (128, EIGHT_WAVES | 3), (128, EIGHT_WAVES | 4)]
+    if M >= 2048:
+        c += [(256, 2), (256, 3)]
+    if N >= 256 and M >= 512:
+        c += [(tile(128, 256), 2), (tile(128, 256), 3)]
+        if M >= 1024:
+            c += [(tile(256, 256), 2)]
+            if not ta:
+                c += [(tile(192, 256), 2)]
+    if N >= 384 and M >= 1024 and not ta and not tb:
+        c += [(tile(256, 192), 2)]
+    return c
 
 
 def _heuristic_cfg(ta, tb, M, N, Kc, split_k):
@@ -252,20 +284,17 @@ def _tune_gemm(key, a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_opts, col
     for split in split_opts:
         if split > kt:
             continue
-        for bm in (64, 128, 256):
-            for ns in (2, 3, 4) + ((EIGHT_WAVES | 2, EIGHT_WAVES | 3, EIGHT_WAVES | 4) if bm == 128 else ()):
-                if bm == 128 and (ns & 0xFF) == 4 and out.dtype == torch.bfloat16 and epi != EPI_NONE:
-                    continue
-                if bm == 256 and (ns == 4 or M < 2048):      # 8-wave 256-row tile: 48 KiB stages, large-M problems only
-                    continue
-                try:
-                    t = _time_cfg(lambda: _launch_gemm_bf16(a, b, scratch, ta, tb, M, N, Kc, bias, epi, aux, split, bm, ns, cs))
-                except RuntimeError:
-                    continue
-                if split > 1:       # a split launch needs its float32 output cleared first: count that fill (ms)
-                    t += 1.5e-3 + out.numel() * 4 / 4.0e9
-                if best is None or t < best[0]:
-                    best = (t, bm, ns, split)
+        for bm, ns in _tile_candidates(ta, tb, M, N):
+            if bm == 128 and (ns & 0xFF) == 4 and out.dtype == torch.bfloat16 and epi != EPI_NONE:
+                continue
+            try:
+                t = _time_cfg(lambda: _launch_gemm_bf16(a, b, scratch, ta, tb, M, N, Kc, bias, epi, aux, split, bm, ns, cs))
+            except RuntimeError:
+                continue
+            if split > 1:       # a split launch needs its float32 output cleared first: count that fill (ms)
+                t += 1.5e-3 + out.numel() * 4 / 4.0e9
+            if best is None or t < best[0]:
+                best = (t, bm, ns, split)
     _TUNED[key] = best[1:]
     return best[1:]
 
@@ -284,6 +313,10 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
     M = a.shape[1] if ta else a.shape[0]
     N = b.shape[1] if tb else b.shape[0]
     assert (b.shape[0] if tb else b.shape[1]) == Kc and out.shape[0] == M and out.shape[1] == N
+    if M == 0 or N == 0:          # empty problem (e.g. an MRC batch without masked rows): the reference returns an empty tensor
+        return out
+    if Kc == 0:
+        return out if accumulate else out.zero_()
     fast = (a.dtype == torch.bfloat16 and not (ta and not tb) and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
             and ((ta and tb) or Kc % 64 == 0) and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
             and a.stride(1) == 1 and b.stride(1) == 1)
@@ -329,7 +362,7 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
     _launch_gemm_bf16(a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_k, bm, nstage, colsum_out)
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * Kc, (M, N, Kc, epi, split_k, 'v2 t%d%d bm%d s%d' % (ta, tb, bm, nstage)),
+        PROFILE.append((e0, e1, 2.0 * M * N * Kc, (M, N, Kc, epi, split_k, 'v2 t%d%d %s s%d' % (ta, tb, tile_name(bm), nstage)),
                         ('goat_gemm_bf16', (int(ta), int(tb), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out),
                                             out.stride(0), M, N, Kc, _ptr(bias) if bias is not None else None, epi,
                                             _ptr(aux) if aux is not None else None, aux.stride(0) if aux is not None else 0,
@@ -500,7 +533,7 @@ class WgradQueue:
             e1.record()
             fl = sum(2.0 * t[0].shape[0] * t[0].shape[1] * t[1].shape[1] for t in q)
             by = sum((t[0].shape[0] * t[0].shape[1] + t[1].shape[0] * t[1].shape[1]) * 2 + t[0].shape[1] * t[1].shape[1] * 4 for t in q)
-            PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 bm%d s%d' % cls.cfg),
+            PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 %s s%d' % (tile_name(cls.cfg[0]), cls.cfg[1])),
                             ('goat_wgrad_grouped', (ctypes.addressof(arr), n, cls.cfg[0], cls.cfg[1]), (arr, list(q)))))
         _lib.check(st, 'goat_wgrad_grouped(n=%d)' % n)
 

@@ -525,11 +525,16 @@ def nav_config_from_args(args):
 
 
 def remap_pretrain_checkpoint(ckpt_weights):
-    """Pre-train -> fine-tune key map (M/models/vlnbert_init.py:52-69)."""
+    """Pre-train -> fine-tune key map (M/models/vlnbert_init.py:52-69): strip `module.`, `vln_bert` -> `bert`, heads /
+    `sap_fuse` / `tim*` / `temperature` keys move under `bert.` (except the `*self_encoder*` ones).  The reference then loads
+    the dictionary through HF `from_pretrained` of a model whose base_model_prefix is `bert`, which strips that prefix again:
+    the keys returned here are the fine-tune model's own state_dict keys."""
     new = {}
     for k, v in ckpt_weights.items():
         if k.startswith('module'):
             k = k[7:]
+        if k.startswith('vln_bert'):
+            k = 'bert' + k[8:]
         if '_head' in k or 'sap_fuse' in k:
             new['bert.' + k] = v
         elif 'tim' in k or 'temperature' in k:
@@ -539,11 +544,42 @@ def remap_pretrain_checkpoint(ckpt_weights):
     return {(k[5:] if k.startswith('bert.') else k): v for k, v in new.items()}
 
 
+def remap_bert_checkpoint(named_params):
+    """`bert-base-uncased` initialisation (M/models/vlnbert_init.py:24-33): `bert.encoder.layer` -> `bert.lang_encoder.layer`."""
+    new = {}
+    for k, v in named_params.items():
+        k = k.replace('bert.encoder.layer', 'bert.lang_encoder.layer')
+        new[k[5:] if k.startswith('bert.') else k] = v
+    return new
+
+
+def remap_meter_checkpoint(state_dict):
+    """METER initialisation (M/models/vlnbert_init.py:34-49; P/train_r2r_goat.py:153-171): text transformer -> embeddings +
+    lang_encoder, `cross_modal_image_layers` -> the cross-attention stacks of BOTH the local and the global encoder."""
+    new = {}
+    for k, v in state_dict.items():
+        if 'text_transformer.embeddings' in k:
+            new[k.replace('text_transformer.', 'bert.')] = v
+        elif 'text_transformer.encoder' in k:
+            new[k.replace('text_transformer.encoder', 'bert.lang_encoder')] = v
+        elif 'cross_modal_image_layers' in k:
+            new[k.replace('cross_modal_image_layers', 'bert.local_encoder.encoder.crossattention')] = v
+            new[k.replace('cross_modal_image_layers', 'bert.global_encoder.encoder.crossattention')] = v
+        else:
+            new[k] = v
+    return {(k[5:] if k.startswith('bert.') else k): v for k, v in new.items()}
+
+
 def get_vlnbert_models(args, config=None):
     cfg = config if config is not None else nav_config_from_args(args)
     sd = None
     path = getattr(args, 'bert_ckpt_file', None)
-    if path:
+    if path == 'bert':
+        raise RuntimeError("bert_ckpt_file='bert' needs the hub model (no network here): pass remap_bert_checkpoint(named_parameters) as state_dict")
+    if path == 'meter':
+        raw = torch.load('datasets/pretrained/METER/meter_clip16_224_roberta_pretrain.ckpt', map_location='cpu')['state_dict']
+        sd = remap_meter_checkpoint(raw)
+    elif path:
         raw = torch.load(path, map_location='cpu')
         sd = remap_pretrain_checkpoint(raw)
     return GlocalTextPathNavCMT.from_pretrained(None, config=cfg, state_dict=sd)

@@ -53,10 +53,25 @@ class GoatPreTrainedModel(nn.Module):
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path=None, config=None, state_dict=None, **kwargs):
+        """HF `from_pretrained(None, config=, state_dict=)` as the reference calls it (P/train_r2r_goat.py:192-197,
+        M/models/vlnbert_init.py:152): non-strict load; keys the model does not have and tensors of another shape are dropped.
+        Unlike HF's logger.warning this is reported on the model (`model.load_report`) and through `warnings.warn`, and a
+        state_dict from which NOTHING could be loaded raises — a wrong key map must not silently leave random weights."""
+        import warnings
         model = cls(config)
         if state_dict:
             own = model.state_dict()
             keep = {k: v for k, v in state_dict.items() if k in own and own[k].shape == v.shape}
+            rep = {'loaded': len(keep), 'unexpected': sorted(k for k in state_dict if k not in own),
+                   'mismatched': sorted(k for k, v in state_dict.items() if k in own and own[k].shape != v.shape),
+                   'missing': sorted(k for k in own if k not in keep)}
+            model.load_report = rep
+            if not keep:
+                raise RuntimeError('from_pretrained: none of the %d checkpoint tensors matches the model (first keys: %s) — wrong key map?'
+                                   % (len(state_dict), list(state_dict)[:3]))
+            if rep['unexpected'] or rep['mismatched'] or rep['missing']:
+                warnings.warn('from_pretrained: loaded %d tensors; %d unexpected, %d shape-mismatched (dropped), %d missing (kept at init)'
+                              % (rep['loaded'], len(rep['unexpected']), len(rep['mismatched']), len(rep['missing'])))
             model.load_state_dict(keep, strict=False)
             model.tie_weights()
         return model

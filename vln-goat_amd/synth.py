@@ -244,12 +244,14 @@ def seeded_state_dict(model, seed=0, perturb=True):
 
 # ======================================================================================= fine-tune episode
 def make_nav_episode(B=2, L=44, V=36, n_steps=3, n_cand=4, seed=0, vocab_size=50265, dict_sizes=(35, 39, 50, 24),
-                     objects=0):
+                     objects=0, extra_nodes=0):
     """Synthetic stand-in for one DAgger rollout of the fine-tuning loop (M/r2r/agent.py:515-592; shapes of
     M/utils/efficiency_count.py:16-137): text once, then per step a panorama and the graph inputs.  Returns a
     dict of CPU tensors / lists; `run_nav_episode` drives any model exposing `model(mode, batch)`.
     objects > 0: REVERIE-style steps — up to `objects` object tokens after the views of every panorama (at least one
-    on the last step), nav type 2, `vp_obj_masks`, and an object-grounding target on the last step."""
+    on the last step), nav type 2, `vp_obj_masks`, and an object-grounding target on the last step.
+    extra_nodes: unvisited map nodes seen earlier in the episode that are not candidates of the current step (their image
+    embeddings are the zero padding of run_nav_episode) — pads the global map to the G ~ 60 of a long rollout."""
     rs = np.random.RandomState(seed)
     Kd, Kl, Kr, Kf = dict_sizes
     f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
@@ -282,7 +284,7 @@ def make_nav_episode(B=2, L=44, V=36, n_steps=3, n_cand=4, seed=0, vocab_size=50
         for b in range(B):
             fts[b, view_lens[b]:] = 0
             loc[b, view_lens[b]:] = 0
-        G = 2 + (t + 1) + n_cand                      # [stop], [MEM], visited nodes, current candidates
+        G = 2 + (t + 1) + n_cand + extra_nodes        # [stop], [MEM], visited nodes, current candidates (, older unvisited nodes)
         gmap_vpids, vp_cand_vpids = [], []
         gvis = np.zeros((B, G), dtype=bool)
         for b in range(B):
@@ -291,7 +293,7 @@ def make_nav_episode(B=2, L=44, V=36, n_steps=3, n_cand=4, seed=0, vocab_size=50
             if t > 0:
                 cands[1] = visited[t - 1]             # a back-edge: candidate already visited
             unv = [c for c in cands if c not in visited]
-            ids = [None, 'MEM'] + visited + unv
+            ids = [None, 'MEM'] + visited + unv + ['b%d_x%d' % (b, k) for k in range(extra_nodes)]
             ids += [None] * (G - len(ids))
             gmap_vpids.append(ids[:G])
             gvis[b, 2:2 + len(visited)] = True

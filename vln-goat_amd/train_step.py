@@ -47,7 +47,8 @@ class PretrainStep:
     `model(batch, task, compute_loss)` contract).
 
         step = PretrainStep(model, optimizer, grad_accum=1, grad_norm=5.0, wrapper=GoatDataParallel(model) or None)
-        info = step(name, batch)      # {'task', 'loss', 'n_loss_units', 'updated', 'grad_norm'}
+        info = step(name, batch)      # {'task', 'loss', 'n_loss_units', 'updated', 'grad_norm'}  (grad_norm: a float, or with the
+                                      #  fused optimizer a callable that reads the device scalar on request)
     """
 
     def __init__(self, model, optimizer=None, grad_accum=1, grad_norm=5.0, wrapper=None, lr_schedule=None):
@@ -65,7 +66,8 @@ class PretrainStep:
     def _zero(self, task):
         arena = self._arena()
         if arena is not None:
-            arena.zero(task)                      # .grad stays bound to the arena views
+            arena.bind(task)                      # .grad = arena view for the parameters `task` uses, None for the others: the
+            arena.zero(task)                      # optimizer skips them, as after the reference's zero_grad + DDP unused-parameter step
         elif self.optimizer is not None:
             self.optimizer.zero_grad()
         else:
@@ -101,6 +103,9 @@ class PretrainStep:
         info = {'task': task, 'loss': float(loss.detach()), 'n_loss_units': n_units, 'updated': False, 'grad_norm': None}
         if self.micro_step % self.grad_accum != 0:
             return info
+        arena = self._arena()
+        if arena is not None:
+            arena.close_step()                    # slices a kernel "owned" last time but did not write this time must not keep old values
         self._average(task)
         self.global_step += 1
         if self.optimizer is not None:
@@ -108,8 +113,12 @@ class PretrainStep:
                 lr = self.lr_schedule(self.global_step)
                 for g in self.optimizer.param_groups:
                     g['lr'] = lr
-            if self.grad_norm is not None and self.grad_norm != -1:
-                info['grad_norm'] = float(torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm))
-            self.optimizer.step()
+            if hasattr(self.optimizer, 'arena'):       # optim.FusedAdamW: norm, clip and update in two kernels on the arena
+                self.optimizer.step(task, max_norm=self.grad_norm if (self.grad_norm is not None and self.grad_norm != -1) else None)
+                info['grad_norm'] = self.optimizer.last_grad_norm
+            else:
+                if self.grad_norm is not None and self.grad_norm != -1:
+                    info['grad_norm'] = float(torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm))
+                self.optimizer.step()
         info['updated'] = True
         return info
