@@ -102,8 +102,11 @@ int goat_ln_fwd(void* stream, int dtype, const void* x, const void* residual,
  * dy2 (may be NULL): a second upstream gradient of y, summed on load.  In the post-LN blocks y feeds both the next
  * sub-layer's first Linear and the next LayerNorm's residual input; the two gradients arrive separately
  * (hipops.layer_norm(fork=True)) and autograd's add kernel between them is not needed.
- * dgamma/dbeta: float32[H], overwritten (accumulate=0) or added to (accumulate=1: gradient-arena slices).  ws: float32 scratch of goat_ln_bwd_ws_floats(H) elements
- * (per-block column partials; a second tiny kernel reduces them — no atomics, deterministic). */
+ * dgamma/dbeta: float32[H], overwritten (accumulate=0) or added to (accumulate=1: gradient-arena slices).
+ * ws == NULL (default): every block adds its column partials to dgamma / dbeta with float atomics — one launch, summation
+ *   order not reproducible (accumulate=0 clears the two vectors with a memset node first).
+ * ws != NULL: float32 scratch of goat_ln_bwd_ws_floats(H) elements for per-block column partials; a second tiny kernel
+ *   reduces them — no atomics, deterministic (round-1 behaviour: 43 extra launches per pre-training step). */
 int goat_ln_bwd_ws_floats(int H);
 int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* dy2, const void* z,
                 const float* gamma, const float* mean, const float* rstd,
@@ -278,6 +281,18 @@ int goat_grad_sqnorm(void* stream, const float* arena, const int64_t* ranges, in
 int goat_adamw_step(void* stream, const float* grad_arena, float* exp_avg, float* exp_avg_sq, const goat_adamw_tensor* tensors,
                     const int32_t* chunks, int nchunks, float beta1, float beta2, float eps, float max_norm,
                     const float* sq_norm);
+
+/* CFP contrastive losses (P/model/pretrain_goat.py:519-534): loss[i] = sum over x in {gmap, vp, fused} of
+ * 1/2 [CE(x_loc[i]·txt_allᵀ/τ, t_i) + CE(txt_loc[i]·x_allᵀ/τ, t_i)], t_i = target0 + i.  x_loc / x_all: arrays of 3 device
+ * pointers ([Bl,H] / [Ba,H] float32; all = loc on one rank, the all-gathered rows under data parallelism); loss [Bl]
+ * PRE-ZEROED (six contributions are added atomically); prob: [6,Bl,Ba] float32 scratch the backward reads.
+ * Backward: gradients are ADDED to the pre-zeroed dx_loc[k] / dx_all[k] / dtxt_loc / dtxt_all (any may be NULL; loc and
+ * all pointers may alias on one rank).  Replaces ~70 ATen launches of the torch formulation of a CFP step. */
+int goat_infonce_fwd(void* stream, const float* const* x_loc, const float* const* x_all, const float* txt_loc,
+                     const float* txt_all, float* loss, float* prob, int Bl, int Ba, int H, int target0, float temperature);
+int goat_infonce_bwd(void* stream, const float* const* x_loc, const float* const* x_all, const float* txt_loc,
+                     const float* txt_all, const float* dloss, const float* prob, float* const* dx_loc, float* const* dx_all,
+                     float* dtxt_loc, float* dtxt_all, int Bl, int Ba, int H, int target0, float temperature);
 
 /* Debug/probe helper used by tests: fills out[64*4] with the element indices returned by
  * ds_read_b64_tr_b16 when lane l points at elements 4l..4l+3 of an LDS array holding 0,1,2,... */

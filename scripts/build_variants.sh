@@ -10,7 +10,7 @@ for spec in "$@"; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c gemm2.hip -o ab/gemm2_$name.o &
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c gemm3.hip -o ab/gemm3_$name.o &
     wait
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/libgoat_$name.so gemm.o ab/gemm2_$name.o ab/gemm3_$name.o attention.o rowops.o causal.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/libgoat_$name.so ab/gemm2_$name.o ab/gemm3_$name.o $(ls *.o | grep -v '^gemm[23]\.o$')
     echo built ab/libgoat_$name.so
   ) &
 done

@@ -591,3 +591,62 @@ def test_wgrad_grouped(ops):
         assert st == 0
         for (_, _, dw, _), (rw, _) in zip(keep, refs):
             _close(dw, 2 * rw, torch.bfloat16, 'grouped dW accumulate')
+
+
+def test_gemm_bf16_full_size_every_tile_no_corruption(ops):
+    """Full-size FFN-up shape (3840 x 3072 x 768, GELU + saved pre-activation) on every tile the autotuner may pick, launched
+    several times: no NaN / wrong element anywhere.  (Round 2 found isolated wrong elements on the 4-wave 128x128 tile only at
+    this size: the inline-asm non-temporal store lacked the `s_nop` that covers the >64-bit store-data hazard.)"""
+    from vln_goat_amd._lib import EPI_GELU
+    M, N, K = 3840, 3072, 768
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    b = (torch.randn(N, K, generator=g) * 0.05).to(DEV, torch.bfloat16)
+    bias = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    u = a.float() @ b.float().T + bias
+    want = torch.nn.functional.gelu(u)
+    scale = float(want.abs().max())
+    for bm, ns in ops._tile_candidates(False, False, M, N):
+        out = torch.full((M, N), float('nan'), device=DEV, dtype=torch.bfloat16)
+        aux = torch.full((M, N), float('nan'), device=DEV, dtype=torch.bfloat16)
+        try:
+            for _ in range(3):
+                ops._launch_gemm_bf16(a, b, out, False, False, M, N, K, bias, EPI_GELU, aux, 1, bm, ns, None)
+        except RuntimeError:
+            continue                                   # (a configuration this build does not instantiate)
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(out.float()).any()) and not bool(torch.isnan(aux.float()).any()), (bm, ns)
+        assert float((out.float() - want).abs().max()) < 2e-2 * scale, (bm, ns)
+        assert float((aux.float() - u).abs().max()) < 2e-2 * float(u.abs().max()), (bm, ns)
+
+
+@pytest.mark.parametrize('Bl,Ba,t0', [(48, 48, 0), (5, 5, 0), (6, 18, 6)])
+def test_infonce_fused_matches_torch(ops, Bl, Ba, t0):
+    """goat_infonce_fwd / _bwd against the torch formulation of P/model/pretrain_goat.py:519-534 — one rank (loc == all: the same
+    tensors, gradients of both roles land in one buffer) and the data-parallel layout (all = gathered rows, target offset)."""
+    H, tau = 768, 0.7
+    g = torch.Generator().manual_seed(Bl * 31 + Ba)
+    full = [torch.tanh(torch.randn(Ba, H, generator=g)).to(DEV) for _ in range(4)]
+    if Ba == Bl:
+        loc = [t.clone().requires_grad_(True) for t in full]
+        alls = loc
+    else:
+        loc = [t[t0:t0 + Bl].clone().requires_grad_(True) for t in full]
+        alls = [t.clone().requires_grad_(True) for t in full]
+    loss = ops.infonce(loc[0], loc[1], loc[2], loc[3], alls[0], alls[1], alls[2], alls[3], t0, tau)
+    w = torch.rand(Bl, generator=g).to(DEV)
+    (loss * w).sum().backward()
+    rl = [t.detach().clone().requires_grad_(True) for t in loc]
+    ra = rl if Ba == Bl else [t.detach().clone().requires_grad_(True) for t in alls]
+    tgt = torch.arange(Bl, device=DEV) + t0
+    ref = 0
+    for k in range(3):
+        row = torch.nn.functional.cross_entropy((rl[k] @ ra[3].T) / tau, tgt, reduction='none')
+        col = torch.nn.functional.cross_entropy((rl[3] @ ra[k].T) / tau, tgt, reduction='none')
+        ref = ref + (row + col) / 2.0
+    (ref * w).sum().backward()
+    _close(loss, ref, torch.float32, 'infonce loss')
+    for k in range(4):
+        _close(loc[k].grad, rl[k].grad, torch.float32, 'infonce dloc %d' % k)
+        if Ba != Bl:
+            _close(alls[k].grad, ra[k].grad, torch.float32, 'infonce dall %d' % k)

@@ -158,7 +158,7 @@ def test_vlnbert_wrapper_matches_reference_golden(case):
     assert torch.equal(seen['view_img_fts'].float(), x.float())                           # views untouched ...
     if 'reverie_obj_img_fts' in st:
         o = seen['reverie_obj_img_fts'].float()
-        assert float((o == 0).float().mean()) > float((pin['reverie_obj_img_fts'] == 0).float().mean()) + 0.2      # ... objects still dropped
+        assert float((o == 0).float().mean()) > float((pin['reverie_obj_img_fts'] == 0).float().mean()) + 0.12      # ... objects still dropped
     net.vln_bert.forward = orig
 
 

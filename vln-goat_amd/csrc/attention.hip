@@ -7,25 +7,12 @@
 // in LDS and the "transposed" MFMA operands are gathered from there, exploiting that the k-order inside an
 // MFMA step is free as long as A and B agree.  Dropout on the probabilities uses the stateless counter hash
 // of common.hpp and is regenerated in the backward pass.
-#include "common.hpp"
+#include <cstdlib>
+#include "attn_args.hpp"
 
 namespace {
 
 constexpr int HD = 64;  // head dim
-
-struct AttnArgs {
-  const void *Q, *K, *V, *O, *dO;
-  void *Ow, *dQ, *dK, *dV;
-  int64_t q_rs, q_bs, k_rs, k_bs, v_rs, v_bs, o_rs, o_bs, do_rs, do_bs;
-  int64_t dq_rs, dq_bs, dk_rs, dk_bs, dv_rs, dv_bs;
-  const float *kmask, *bias;
-  float* lse;
-  float* dbias;
-  int B, nh, Lq, Lk;
-  float scale, p;
-  uint64_t seed, offset;
-  const uint64_t* rng_dev;
-};
 
 template <typename T> struct AT {
   typedef typename FragT<T>::type Frag;
@@ -503,6 +490,11 @@ int dispatch_fwd(hipStream_t st, const AttnArgs& a) {
   return GOAT_E_SHAPE;
 }
 
+bool use_v2() {       // GOAT_ATTN_V1=1: the round-1 kernels for every problem (A/B experiments)
+  static const bool v = !(getenv("GOAT_ATTN_V1") && getenv("GOAT_ATTN_V1")[0] == '1');
+  return v;
+}
+
 bool strides_ok(int dtype, int64_t rs, int64_t bs, const void* ptr) {
   const int epc = dtype == GOAT_BF16 ? 8 : 4;
   return (rs % epc) == 0 && (bs % epc) == 0 && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0;
@@ -526,6 +518,10 @@ extern "C" int goat_attn_fwd(void* stream, int dtype, const void* Q, int64_t q_r
   a.kmask = kmask; a.bias = bias; a.lse = lse;
   a.B = B; a.nh = nh; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.p = p; a.seed = seed; a.offset = offset; a.rng_dev = rng_dev;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == GOAT_BF16 && use_v2()) {          // LDS-staged kernels (attention2.hip) for Lq, Lk <= 128
+    const int rc = goat_attn2_fwd(st, a);
+    if (rc != GOAT_E_SHAPE) return rc;
+  }
   return dtype == GOAT_BF16 ? dispatch_fwd<bf16_t>(st, a) : dispatch_fwd<float>(st, a);
 }
 
@@ -550,5 +546,9 @@ extern "C" int goat_attn_bwd(void* stream, int dtype, const void* Q, int64_t q_r
   a.kmask = kmask; a.bias = bias; a.lse = const_cast<float*>(lse); a.dbias = dbias;
   a.B = B; a.nh = nh; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.p = p; a.seed = seed; a.offset = offset; a.rng_dev = rng_dev;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == GOAT_BF16 && use_v2()) {
+    const int rc = goat_attn2_bwd(st, a);
+    if (rc != GOAT_E_SHAPE) return rc;
+  }
   return dtype == GOAT_BF16 ? launch_bwd2<bf16_t>(st, a) : launch_bwd2<float>(st, a);
 }

@@ -1,0 +1,545 @@
+// goat_attn2_fwd / goat_attn2_bwd: masked multi-head attention (head_dim 64, bf16) for GOAT's short sequences (<= 128 rows on
+// either side), one workgroup per (sample, head).
+//
+// Why a second set of kernels: the round-1 kernels (attention.hip) run one wave per 32-row tile and fetch their MFMA fragments
+// straight from global memory inside the tile loops (16 B per lane from 32 different rows per instruction, K re-read by every
+// query tile, Q/dO re-staged per iteration behind a barrier, 2-byte result stores).  On the GOAT shapes they move 1 TB/s:
+// 21.7 us forward / 49.4 us backward for the 48 x 12 heads of 80 tokens (profiles/round2_attention_kernels.txt) — latency,
+// not bandwidth.  Here every operand of a (sample, head) is brought into LDS ONCE with coalesced 16-byte loads (8 lanes per
+// 128-byte row), the tile loops touch only LDS and registers, and results leave through LDS as 16-byte row segments.
+//   forward : waves = query tiles.  S^T = K·Q^T (softmax rows lane-local, as in round 1), O^T = V^T·P^T with swapped MFMA roles
+//             so that a lane holds 4 consecutive head columns of its query row (8-byte LDS writes).
+//   backward: waves = query tiles (dQ role: lane = query) + key tiles (dK/dV role: lane = key); S and dP are recomputed per
+//             role (cheaper than a cross-wave reduction); D = rowsum(dO * O) is computed while dO is staged.
+// Semantics (additive key mask, optional [B,Lq,Lk] bias with gradient, dropout on the probabilities from the stateless
+// counter hash, LSE saved) are exactly those of attention.hip; P/model/Bert_backbone.py:246-290, transformer.py:172-176.
+#include "attn_args.hpp"
+
+namespace {
+
+constexpr int HD = 64, NE = 8, LSTR = HD + NE;     // LDS row stride in elements (144 B: conflict-free 16-byte fragment reads)
+constexpr int KSTEPS = 4, TSTEPS = 2;
+constexpr int TILE = 32 * LSTR;                      // elements per 32-row tile
+#ifndef GOAT_ATTN_TIMING     // experiments only: forward kernel writes 8 s_memtime stamps of wave 0 per block behind the LSE array (the caller allocates B*nh*8 extra words)
+#define GOAT_ATTN_TIMING 0
+#endif
+#if GOAT_ATTN_TIMING
+#define GOAT_STAMP(i_) do { if (tid == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); reinterpret_cast<uint32_t*>(p.lse + (int64_t)p.B * p.nh * p.Lq)[blockIdx.x * 8 + (i_)] = (uint32_t)__builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define GOAT_STAMP(i_) do { } while (0)
+#endif
+
+__device__ __forceinline__ bf16x8 lds_frag(const bf16_t* tile, int row, int ks, int hi) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * LSTR + (ks * 2 + hi) * NE);
+}
+// B fragment "fixed column, accumulator-pattern rows" of a row-major [row][64] LDS tile: two ds_read_b64_tr_b16
+__device__ __forceinline__ bf16x8 bfrag_crow(const bf16_t* lds, int row_base, int step, int dt, int lane) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+  const int g = lane >> 4, t15 = lane & 15;
+  const int col = dt * 32 + (g & 1) * 16 + (t15 & 3) * 4;
+  const int r0 = row_base + 16 * step + 4 * (g >> 1) + (t15 >> 2);
+  bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(lds + r0 * LSTR + col));
+  bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(lds + (r0 + 8) * LSTR + col));
+  bf16x8 f;
+  f[0] = v0[0]; f[1] = v0[1]; f[2] = v0[2]; f[3] = v0[3];
+  f[4] = v1[0]; f[5] = v1[1]; f[6] = v1[2]; f[7] = v1[3];
+  return f;
+}
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int step) {
+  bf16x8 f;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) f[e] = (bf16_t)a[step * NE + e];
+  return f;
+}
+// One operand of a (sample, head): [nrows, 64] head slice in global memory (row stride rs) -> LDS [rows_pad][LSTR], zero beyond nrows
+struct StageOp {
+  const bf16_t* g;
+  bf16_t* lds;
+  int64_t rs;
+  int nrows, rows_pad;
+};
+// Cooperative copy of NOP operands.  The 16-byte chunks of all operands form one index space; every lane keeps DEPTH loads in
+// flight before the first LDS write (the per-chunk load -> wait -> write loop of the first version cost 12 dependent global
+// round trips, 6 100 of the 24 700 cycles of a forward block).
+template <int NOP, int DEPTH>
+__device__ __forceinline__ void stage_ops(const StageOp (&op)[NOP], int tid, int nthreads) {
+  int total = 0;
+#pragma unroll
+  for (int i = 0; i < NOP; ++i) total += op[i].rows_pad * 8;
+  for (int c0 = tid; c0 < total; c0 += nthreads * DEPTH) {
+    uint4 v[DEPTH];
+    bf16_t* dst[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      // operand / row / chunk of this lane's d-th chunk by selects (ONE load site per chunk: branches around per-operand loads
+      // made the compiler reuse the destination registers and wait for every load in turn)
+      const int c = c0 + d * nthreads;
+      int cl = c;
+      const bf16_t* src = op[0].g;
+      bool ld = false;
+      dst[d] = nullptr;
+#pragma unroll
+      for (int i = 0; i < NOP; ++i) {
+        const int n = op[i].rows_pad * 8;
+        const bool in = (c < total) && cl >= 0 && cl < n;
+        const int r = cl >> 3, cc = cl & 7;
+        src = in ? op[i].g + (int64_t)r * op[i].rs + cc * NE : src;
+        dst[d] = in ? op[i].lds + r * LSTR + cc * NE : dst[d];
+        ld = in ? (r < op[i].nrows) : ld;
+        cl -= n;
+      }
+      v[d] = uint4{0u, 0u, 0u, 0u};
+      if (ld) v[d] = *reinterpret_cast<const uint4*>(src);
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (dst[d] != nullptr) *reinterpret_cast<uint4*>(dst[d]) = v[d];
+  }
+}
+// Dropout bits of one (sample, head): a 32-bit key per block (from the 64-bit seed / offset / device counter of common.hpp's
+// GoatRng, mixed once), then ONE 32-bit multiply-xorshift hash per PAIR of consecutive probability indices
+// idx = q * Lk + key; its 16-bit halves decide the two elements.  The first version hashed every element through
+// GoatRng::keep with 64-bit counters: 6 700 of 24 700 cycles of a forward block.  Forward and backward regenerate the same bits.
+struct HeadRng {
+  uint32_t k;
+  __device__ __forceinline__ HeadRng(uint64_t seed, uint64_t offset, uint32_t bh) {
+    uint64_t x = (seed + 0x9E3779B97F4A7C15ull * (offset + 1)) ^ ((uint64_t)bh * 0xD6E8FEB86659FD93ull);
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    k = (uint32_t)x;
+  }
+  __device__ __forceinline__ uint32_t pair(uint32_t pair_idx) const {
+    uint32_t x = pair_idx ^ k;
+    x *= 0x7FEB352Du; x ^= x >> 15;
+    x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+  }
+  __device__ __forceinline__ bool keep(uint32_t idx, uint32_t thr16) const {
+    const uint32_t h = pair(idx >> 1);
+    return ((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thr16;
+  }
+  // bit e = keep(idx0 + e), e < 4
+  __device__ __forceinline__ uint32_t keep4(uint32_t idx0, uint32_t thr16) const {
+    uint32_t m = 0;
+    if ((idx0 & 1u) == 0) {
+      const uint32_t h0 = pair(idx0 >> 1), h1 = pair((idx0 >> 1) + 1);
+      m |= ((h0 & 0xFFFFu) >= thr16 ? 1u : 0u) | ((h0 >> 16) >= thr16 ? 2u : 0u);
+      m |= ((h1 & 0xFFFFu) >= thr16 ? 4u : 0u) | ((h1 >> 16) >= thr16 ? 8u : 0u);
+    } else {
+      const uint32_t h0 = pair(idx0 >> 1), h1 = pair((idx0 >> 1) + 1), h2 = pair((idx0 >> 1) + 2);
+      m |= ((h0 >> 16) >= thr16 ? 1u : 0u) | ((h1 & 0xFFFFu) >= thr16 ? 2u : 0u);
+      m |= ((h1 >> 16) >= thr16 ? 4u : 0u) | ((h2 & 0xFFFFu) >= thr16 ? 8u : 0u);
+    }
+    return m;
+  }
+};
+// the 16 mask values of this lane's keys in key tile jt (keys jt*32 + 4*hi + 8*g + {0..3}): four 16-byte LDS reads
+__device__ __forceinline__ void load_kmask(const float* kml, int jt, int hi, float (&km)[16]) {
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(kml + jt * 32 + 4 * hi + 8 * g4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) km[4 * g4 + e] = t[e];
+  }
+}
+// a wave's [32 x 64] result, lane = row, acc[dt][r] = column dt*32 + c_row(r, lane): 8-byte packed writes into the wave's own
+// LDS tile, then 16-byte row segments to global rows row0 .. row0+31 (< nrows)
+__device__ __forceinline__ void store_tile(bf16_t* tile, const f32x16 (&acc)[2], bf16_t* g, int64_t rs, int row0, int nrows, int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)acc[dt][4 * q4 + e];
+      *reinterpret_cast<bf16x4*>(tile + l31 * LSTR + dt * 32 + 4 * hi + 8 * q4) = o;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same-wave LDS hand-over between lanes
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int idx = c * 64 + lane, r = idx >> 3, cc = idx & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(tile + r * LSTR + cc * NE);
+    if (row0 + r < nrows) goat_store_stream(reinterpret_cast<f32x4*>(g + (int64_t)(row0 + r) * rs + cc * NE), *reinterpret_cast<const f32x4*>(&v));
+  }
+}
+
+// ======================================================================================== forward
+template <int NKT>
+__global__ __launch_bounds__(256) void attn2_fwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+  const int nqt = (p.Lq + 31) / 32;
+  bf16_t* kl = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* vl = kl + NKT * TILE;
+  bf16_t* ql = vl + NKT * TILE;
+  float* kml = reinterpret_cast<float*>(ql + nqt * TILE);      // additive key mask, -inf beyond Lk
+
+  const bf16_t* Qb = reinterpret_cast<const bf16_t*>(p.Q) + b * p.q_bs + h * HD;
+  const bf16_t* Kb = reinterpret_cast<const bf16_t*>(p.K) + b * p.k_bs + h * HD;
+  const bf16_t* Vb = reinterpret_cast<const bf16_t*>(p.V) + b * p.v_bs + h * HD;
+  bf16_t* Ob = reinterpret_cast<bf16_t*>(p.Ow) + b * p.o_bs + h * HD;
+  GOAT_STAMP(0);
+  {
+    const StageOp ops[3] = {{Kb, kl, p.k_rs, p.Lk, NKT * 32}, {Vb, vl, p.v_rs, p.Lk, NKT * 32}, {Qb, ql, p.q_rs, p.Lq, nqt * 32}};
+    stage_ops<3, 8>(ops, tid, nth);
+  }
+  for (int i = tid; i < NKT * 32; i += nth) kml[i] = i < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + i] : 0.f) : -INFINITY;
+  GOAT_STAMP(1);
+  __syncthreads();
+  GOAT_STAMP(2);
+
+  const int q0 = wave * 32, q = q0 + l31;
+  const bool qv = q < p.Lq;
+  bf16_t* qt = ql + q0 * LSTR;
+  bf16x8 qf[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = lds_frag(qt, l31, ks, hi);
+
+  // S^T tiles: rows = keys (accumulator registers), cols = queries (lanes)
+  f32x16 s[NKT];
+#pragma unroll
+  for (int jt = 0; jt < NKT; ++jt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[jt][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) mma32(s[jt], lds_frag(kl + jt * TILE, l31, ks, hi), qf[ks]);
+  }
+  GOAT_STAMP(3);
+  // scale + additive key mask (registers), optional bias (one uniform branch around independent loads), row max
+  float m = -INFINITY;
+#pragma unroll
+  for (int jt = 0; jt < NKT; ++jt) {
+    float km[16];
+    load_kmask(kml, jt, hi, km);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[jt][r] = s[jt][r] * p.scale + km[r];
+  }
+  if (p.bias != nullptr) {
+    const float* brow = p.bias + ((int64_t)b * p.Lq + (qv ? q : 0)) * p.Lk;
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = jt * 32 + c_row(r, lane);
+        s[jt][r] += (qv && key < p.Lk) ? brow[key] : 0.f;
+      }
+  }
+#pragma unroll
+  for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, s[jt][r]);
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float l = 0.f;
+  const float msafe = (m == -INFINITY) ? 0.f : m;
+#pragma unroll
+  for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(s[jt][r] - msafe);
+      s[jt][r] = e;
+      l += e;
+    }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  if (qv && hi == 0) p.lse[((int64_t)b * p.nh + h) * p.Lq + q] = (l > 0.f) ? (msafe + __logf(l)) : -INFINITY;
+
+  GOAT_STAMP(4);
+  // dropout: the keep bits of 4 consecutive keys from 2 pair hashes (3 when q * Lk is odd)
+  const bool drop = p.p > 0.f;
+  const uint32_t thr = goat_thr16(p.p);
+  const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
+  const HeadRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull), p.offset, (uint32_t)blockIdx.x);
+  const uint32_t idx0 = (uint32_t)q * (uint32_t)p.Lk;
+  if (drop) {
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const uint32_t kb = rng.keep4(idx0 + jt * 32 + 4 * hi + 8 * g4, thr);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[jt][4 * g4 + e] = ((kb >> e) & 1u) ? s[jt][4 * g4 + e] * (inv * keep_scale) : 0.f;
+      }
+  } else {
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[jt][r] *= inv;
+  }
+
+  GOAT_STAMP(5);
+  // O^T (d x q) = V^T (d x keys) · P^T (keys x q): lane = query, registers = head columns
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+    for (int st = 0; st < TSTEPS; ++st) {
+      const bf16x8 pa = acc_frag(s[jt], st);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) mma32(o[dt], bfrag_crow(vl, jt * 32, st, dt, lane), pa);
+    }
+  GOAT_STAMP(6);
+  store_tile(qt, o, Ob, p.o_rs, q0, p.Lq, lane);          // this wave's Q tile is dead: nobody else reads it
+  GOAT_STAMP(7);
+}
+
+// ======================================================================================== backward
+__global__ __launch_bounds__(512) void attn2_bwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+  const int nqt = (p.Lq + 31) / 32, nkt = (p.Lk + 31) / 32;
+  bf16_t* ql = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* dol = ql + nqt * TILE;
+  bf16_t* kl = dol + nqt * TILE;
+  bf16_t* vl = kl + nkt * TILE;
+  float* Dl = reinterpret_cast<float*>(vl + nkt * TILE);      // D_q = sum_d dO[q,d] O[q,d]
+  float* lsel = Dl + nqt * 32;
+  float* kml = lsel + nqt * 32;
+
+  const bf16_t* Qb = reinterpret_cast<const bf16_t*>(p.Q) + b * p.q_bs + h * HD;
+  const bf16_t* Kb = reinterpret_cast<const bf16_t*>(p.K) + b * p.k_bs + h * HD;
+  const bf16_t* Vb = reinterpret_cast<const bf16_t*>(p.V) + b * p.v_bs + h * HD;
+  const bf16_t* Ob = reinterpret_cast<const bf16_t*>(p.O) + b * p.o_bs + h * HD;
+  const bf16_t* dOb = reinterpret_cast<const bf16_t*>(p.dO) + b * p.do_bs + h * HD;
+  {
+    const StageOp ops[3] = {{Qb, ql, p.q_rs, p.Lq, nqt * 32}, {Kb, kl, p.k_rs, p.Lk, nkt * 32}, {Vb, vl, p.v_rs, p.Lk, nkt * 32}};
+    stage_ops<3, 8>(ops, tid, nth);
+  }
+  // dO, with D_q on the way: the 8 lanes that move a row's eight 16-byte chunks reduce their partial dot products
+  // (4 chunks of dO and of O in flight per lane; every lane of a wave runs the same number of iterations)
+  for (int c0 = tid; c0 < nqt * 32 * 8; c0 += nth * 4) {
+    uint4 dv[4], ov[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int c = c0 + d * nth, r = c >> 3, cc = c & 7;
+      dv[d] = uint4{0u, 0u, 0u, 0u};
+      ov[d] = uint4{0u, 0u, 0u, 0u};
+      if (c < nqt * 32 * 8 && r < p.Lq) {
+        dv[d] = *reinterpret_cast<const uint4*>(dOb + (int64_t)r * p.do_rs + cc * NE);
+        ov[d] = *reinterpret_cast<const uint4*>(Ob + (int64_t)r * p.o_rs + cc * NE);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int c = c0 + d * nth, r = c >> 3, cc = c & 7;
+      const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(&dv[d]), o8 = *reinterpret_cast<const bf16x8*>(&ov[d]);
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) part += (float)d8[e] * (float)o8[e];
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      part += __shfl_xor(part, 4, 64);
+      if (c < nqt * 32 * 8) {
+        *reinterpret_cast<uint4*>(dol + r * LSTR + cc * NE) = dv[d];
+        if (cc == 0) Dl[r] = part;
+      }
+    }
+  }
+  for (int i = tid; i < nqt * 32; i += nth) lsel[i] = i < p.Lq ? p.lse[((int64_t)b * p.nh + h) * p.Lq + i] : -INFINITY;
+  for (int i = tid; i < nkt * 32; i += nth) kml[i] = i < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + i] : 0.f) : -INFINITY;
+  __syncthreads();
+
+  const bool drop = p.p > 0.f;
+  const uint32_t thr = goat_thr16(p.p);
+  const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
+  const HeadRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull), p.offset, (uint32_t)blockIdx.x);
+  f32x16 ra[2], rb[2];           // results: dQ role uses ra (dQ); dK/dV role ra = dK, rb = dV
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ra[dt][r] = 0.f; rb[dt][r] = 0.f; }
+
+  if (wave < nqt) {
+    // ---- dQ role: lane = query.  S^T = K·Q^T, dP^T = V·dO^T per key tile; dQ^T += K^T·dS^T
+    const int q0 = wave * 32, q = q0 + l31;
+    const bool qv = q < p.Lq;
+    bf16x8 qf[KSTEPS], dof[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      qf[ks] = lds_frag(ql + q0 * LSTR, l31, ks, hi);
+      dof[ks] = lds_frag(dol + q0 * LSTR, l31, ks, hi);
+    }
+    const float dsum = Dl[q], lse_q = lsel[q];
+    const bool ok = qv && (lse_q != -INFINITY);
+    for (int jt = 0; jt < nkt; ++jt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        mma32(s, lds_frag(kl + jt * TILE, l31, ks, hi), qf[ks]);
+        mma32(dp, lds_frag(vl + jt * TILE, l31, ks, hi), dof[ks]);
+      }
+      // probabilities: exp(S scale + mask (+ bias) - lse); masked / padded keys carry -inf in kml, invalid queries lse = +inf
+      float km[16];
+      load_kmask(kml, jt, hi, km);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = s[r] * p.scale + km[r];
+      if (p.bias != nullptr) {
+        const float* brow = p.bias + ((int64_t)b * p.Lq + (qv ? q : 0)) * p.Lk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = jt * 32 + c_row(r, lane);
+          s[r] += (qv && key < p.Lk) ? brow[key] : 0.f;
+        }
+      }
+      f32x16 ds;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const uint32_t kb = drop ? rng.keep4((uint32_t)q * (uint32_t)p.Lk + jt * 32 + 4 * hi + 8 * g4, thr) : 0xFu;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g4 + e;
+          const float pr = ok ? __expf(s[r] - lse_q) : 0.f;
+          const float keep = ((kb >> e) & 1u) ? keep_scale : 0.f;
+          const float d = pr * (dp[r] * keep - dsum);
+          ds[r] = d * p.scale;
+          s[r] = d;
+        }
+      }
+      if (p.dbias != nullptr && qv) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = jt * 32 + c_row(r, lane);
+          if (key < p.Lk) atomicAdd(p.dbias + ((int64_t)b * p.Lq + q) * p.Lk + key, s[r]);
+        }
+      }
+#pragma unroll
+      for (int st = 0; st < TSTEPS; ++st) {
+        const bf16x8 a = acc_frag(ds, st);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) mma32(ra[dt], bfrag_crow(kl, jt * 32, st, dt, lane), a);
+      }
+    }
+  } else {
+    // ---- dK / dV role: lane = key.  S = Q·K^T, dP = dO·V^T per query tile; dV^T += dO^T·Pd, dK^T += Q^T·dS
+    const int k0 = (wave - nqt) * 32, key = k0 + l31;
+    const bool kv = key < p.Lk;
+    bf16x8 kf[KSTEPS], vf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      kf[ks] = lds_frag(kl + k0 * LSTR, l31, ks, hi);
+      vf[ks] = lds_frag(vl + k0 * LSTR, l31, ks, hi);
+    }
+    const float kmv = kml[key];
+    for (int it = 0; it < nqt; ++it) {
+      const int q0 = it * 32;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        mma32(s, lds_frag(ql + q0 * LSTR, l31, ks, hi), kf[ks]);
+        mma32(dp, lds_frag(dol + q0 * LSTR, l31, ks, hi), vf[ks]);
+      }
+      float lq[16], dq[16];                 // lse and D of this lane's 16 queries (q0 + 4*hi + 8*g + {0..3})
+      load_kmask(lsel, it, hi, lq);
+      load_kmask(Dl, it, hi, dq);
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int q = q0 + c_row(r, lane);
+          s[r] = s[r] * p.scale + ((q < p.Lq && kv) ? p.bias[((int64_t)b * p.Lq + q) * p.Lk + key] : 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] *= p.scale;
+      }
+      f32x16 pd, ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = q0 + c_row(r, lane);
+        // (padded queries: lse = -inf -> exp(+inf) would be inf: guarded; masked keys: kmv = -inf -> 0)
+        const float pr = (lq[r] != -INFINITY && kv) ? __expf(s[r] + kmv - lq[r]) : 0.f;
+        float keep = 1.f;
+        if (drop) keep = rng.keep((uint32_t)q * (uint32_t)p.Lk + key, thr) ? keep_scale : 0.f;
+        pd[r] = pr * keep;
+        ds[r] = pr * (dp[r] * keep - dq[r]) * p.scale;
+      }
+#pragma unroll
+      for (int st = 0; st < TSTEPS; ++st) {
+        const bf16x8 ap = acc_frag(pd, st), as = acc_frag(ds, st);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          mma32(rb[dt], bfrag_crow(dol, q0, st, dt, lane), ap);
+          mma32(ra[dt], bfrag_crow(ql, q0, st, dt, lane), as);
+        }
+      }
+    }
+  }
+  __syncthreads();      // every wave is done reading the staged operands: their tiles become the result staging areas
+  if (wave < nqt) {
+    bf16_t* dQb = reinterpret_cast<bf16_t*>(p.dQ) + b * p.dq_bs + h * HD;
+    store_tile(ql + wave * TILE, ra, dQb, p.dq_rs, wave * 32, p.Lq, lane);
+  } else {
+    const int kt = wave - nqt;
+    bf16_t* dKb = reinterpret_cast<bf16_t*>(p.dK) + b * p.dk_bs + h * HD;
+    bf16_t* dVb = reinterpret_cast<bf16_t*>(p.dV) + b * p.dv_bs + h * HD;
+    store_tile(kl + kt * TILE, ra, dKb, p.dk_rs, kt * 32, p.Lk, lane);
+    store_tile(vl + kt * TILE, rb, dVb, p.dv_rs, kt * 32, p.Lk, lane);
+  }
+}
+
+template <typename K>
+int set_smem(K kern, size_t bytes, size_t& cur) {
+  if (bytes > 64 * 1024 && bytes > cur) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    cur = bytes;
+  }
+  return 0;
+}
+
+template <int NKT>
+int launch_fwd(hipStream_t st, const AttnArgs& a) {
+  const int nqt = (a.Lq + 31) / 32;
+  const size_t sm = (size_t)(2 * NKT + nqt) * TILE * 2 + NKT * 32 * 4;
+  static size_t cur = 0;
+  if (int e = set_smem(attn2_fwd_kernel<NKT>, sm, cur)) return e;
+  hipLaunchKernelGGL(attn2_fwd_kernel<NKT>, dim3(a.B * a.nh), dim3(64 * nqt), sm, st, a);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+int goat_attn2_fwd(hipStream_t st, const AttnArgs& a) {
+  const int nkt = (a.Lk + 31) / 32, nqt = (a.Lq + 31) / 32;
+  if (nkt > 4 || nqt > 4) return GOAT_E_SHAPE;
+  // 16-byte row segments on every operand and on O
+  if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.q_bs | a.k_bs | a.v_bs | a.o_bs) & 7) return GOAT_E_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(a.Ow) & 15)) return GOAT_E_SHAPE;
+  switch (nkt) {
+    case 1: return launch_fwd<1>(st, a);
+    case 2: return launch_fwd<2>(st, a);
+    case 3: return launch_fwd<3>(st, a);
+    case 4: return launch_fwd<4>(st, a);
+  }
+  return GOAT_E_SHAPE;
+}
+
+int goat_attn2_bwd(hipStream_t st, const AttnArgs& a) {
+  const int nkt = (a.Lk + 31) / 32, nqt = (a.Lq + 31) / 32;
+  if (nkt > 4 || nqt > 4) return GOAT_E_SHAPE;
+  if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.do_rs | a.dq_rs | a.dk_rs | a.dv_rs | a.q_bs | a.k_bs | a.v_bs | a.o_bs | a.do_bs | a.dq_bs |
+       a.dk_bs | a.dv_bs) & 7)
+    return GOAT_E_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(a.O) & 15) || (reinterpret_cast<uintptr_t>(a.dO) & 15) || (reinterpret_cast<uintptr_t>(a.dQ) & 15) ||
+      (reinterpret_cast<uintptr_t>(a.dK) & 15) || (reinterpret_cast<uintptr_t>(a.dV) & 15))
+    return GOAT_E_SHAPE;
+  const size_t sm = (size_t)(2 * nqt + 2 * nkt) * TILE * 2 + (size_t)(2 * nqt + nkt) * 32 * 4;
+  static size_t cur = 0;
+  if (int e = set_smem(attn2_bwd_kernel, sm, cur)) return e;
+  hipLaunchKernelGGL(attn2_bwd_kernel, dim3(a.B * a.nh), dim3(64 * (nqt + nkt)), sm, st, a);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}

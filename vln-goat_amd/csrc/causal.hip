@@ -238,6 +238,84 @@ __global__ __launch_bounds__(256) void dict_wsum_bwd_kernel(const T* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------ CFP: 3 x symmetric InfoNCE
+// loss_i = sum over x in {gmap, vp, fused} of 1/2 [ CE(x_loc[i] . txt_all^T / tau, t_i) + CE(txt_loc[i] . x_all^T / tau, t_i) ],
+// t_i = target0 + i  (P/model/pretrain_goat.py:519-534; `all` = the rows of every data-parallel rank, = `loc` on one rank).
+// Six (pair, direction) similarity problems of [Bl x Ba x H]: the reference issues ~70 ATen kernels for them and their
+// gradients (18 mm, 19 div, 6 log_softmax ...: 0.7 ms of a CFP step); here one forward and one backward launch.
+//   forward : block (pd, i): S[j] = <A_pd[i], B_pd[j]> / tau for all j (one wave per j, lanes over H), softmax over j saved to
+//             prob[pd][i][:], 0.5 * (lse - S[t_i]) added to loss[i].
+//   backward: block (pd, 64-column tile): G = (prob - onehot) * dloss_i / (2 tau);  dA[:, cols] += G . B[:, cols],
+//             dB[:, cols] += G^T . A[:, cols]  (float atomics: several problems feed the same tensor).
+struct NceArgs {
+  const float* a[6];      // [Bl, H] operand whose rows are the samples of this rank
+  const float* b[6];      // [Ba, H] operand holding the candidates
+  float* da[6];
+  float* db[6];
+  float* prob;            // [6, Bl, Ba]
+  float* loss;            // [Bl] (pre-zeroed)
+  const float* dloss;     // [Bl]
+  int Bl, Ba, H, target0;
+  float inv_tau;
+};
+
+__global__ __launch_bounds__(256) void infonce_fwd_kernel(NceArgs p) {
+  extern __shared__ float sh[];           // [Ba] similarities
+  const int pd = blockIdx.x / p.Bl, i = blockIdx.x % p.Bl;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* arow = p.a[pd] + (int64_t)i * p.H;
+  for (int j = wave; j < p.Ba; j += 4) {
+    const float* brow = p.b[pd] + (int64_t)j * p.H;
+    float s = 0.f;
+    for (int k = lane * 4; k < p.H; k += 256) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(arow + k), y = *reinterpret_cast<const f32x4*>(brow + k);
+      s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    }
+    s = wave_sum(s);
+    if (lane == 0) sh[j] = s * p.inv_tau;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float m = -INFINITY;
+    for (int j = lane; j < p.Ba; j += 64) m = fmaxf(m, sh[j]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = lane; j < p.Ba; j += 64) l += __expf(sh[j] - m);
+    l = wave_sum(l);
+    const float lse = m + __logf(l);
+    float* pr = p.prob + ((int64_t)pd * p.Bl + i) * p.Ba;
+    for (int j = lane; j < p.Ba; j += 64) pr[j] = __expf(sh[j] - lse);
+    if (lane == 0) atomicAdd(p.loss + i, 0.5f * (lse - sh[p.target0 + i]));
+  }
+}
+
+__global__ __launch_bounds__(256) void infonce_bwd_kernel(NceArgs p) {
+  const int pd = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  if (c >= p.H) return;
+  const float* A = p.a[pd];
+  const float* B = p.b[pd];
+  const float* pr = p.prob + (int64_t)pd * p.Bl * p.Ba;
+  const float half_tau = 0.5f * p.inv_tau;
+  // dA[i, c] = sum_j G[i, j] B[j, c]
+  if (p.da[pd] != nullptr)
+    for (int i = grp; i < p.Bl; i += 4) {
+      const float gi = p.dloss[i] * half_tau;
+      const int t = p.target0 + i;
+      float acc = 0.f;
+      for (int j = 0; j < p.Ba; ++j) acc += (pr[(int64_t)i * p.Ba + j] - (j == t ? 1.f : 0.f)) * B[(int64_t)j * p.H + c];
+      atomicAdd(p.da[pd] + (int64_t)i * p.H + c, acc * gi);
+    }
+  // dB[j, c] = sum_i G[i, j] A[i, c]
+  if (p.db[pd] != nullptr)
+    for (int j = grp; j < p.Ba; j += 4) {
+      float acc = 0.f;
+      for (int i = 0; i < p.Bl; ++i)
+        acc += (pr[(int64_t)i * p.Ba + j] - (j == p.target0 + i ? 1.f : 0.f)) * (p.dloss[i] * half_tau) * A[(int64_t)i * p.H + c];
+      atomicAdd(p.db[pd] + (int64_t)j * p.H + c, acc);
+    }
+}
+
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -342,6 +420,50 @@ extern "C" int goat_dict_wsum_bwd(void* stream, int dtype_dout, const void* dout
     hipLaunchKernelGGL(dict_wsum_bwd_kernel<float>, dim3(B), dim3(256), 0, ST(stream), (const float*)dout, z, p, dz, dp, K, H);
   else
     return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+// x_loc / txt_loc: [Bl, H]; x_all / txt_all: [Ba, H] (order gmap, vp, fused); gradients are ADDED to d* (pre-zeroed by the
+// caller; pointers may alias when loc == all); prob: [6, Bl, Ba] scratch written by the forward and read by the backward.
+static int nce_fill(NceArgs& a, const float* const* x_loc, const float* const* x_all, const float* txt_loc, const float* txt_all,
+                    float* const* dx_loc, float* const* dx_all, float* dtxt_loc, float* dtxt_all, float* prob, int Bl, int Ba, int H,
+                    int target0, float temperature) {
+  if (!x_loc || !x_all || !txt_loc || !txt_all || !prob) return GOAT_E_ARG;
+  if (Bl <= 0 || Ba < Bl || H <= 0 || (H % 4) || target0 < 0 || target0 + Bl > Ba || !(temperature > 0.f)) return GOAT_E_SHAPE;
+  for (int k = 0; k < 3; ++k) {
+    if (!x_loc[k] || !x_all[k]) return GOAT_E_ARG;
+    a.a[2 * k] = x_loc[k]; a.b[2 * k] = txt_all;            // image -> all texts
+    a.a[2 * k + 1] = txt_loc; a.b[2 * k + 1] = x_all[k];     // text -> all images
+    a.da[2 * k] = dx_loc ? dx_loc[k] : nullptr; a.db[2 * k] = dtxt_all;
+    a.da[2 * k + 1] = dtxt_loc; a.db[2 * k + 1] = dx_all ? dx_all[k] : nullptr;
+  }
+  a.prob = prob; a.Bl = Bl; a.Ba = Ba; a.H = H; a.target0 = target0; a.inv_tau = 1.f / temperature;
+  return 0;
+}
+
+extern "C" int goat_infonce_fwd(void* stream, const float* const* x_loc, const float* const* x_all, const float* txt_loc,
+                                const float* txt_all, float* loss, float* prob, int Bl, int Ba, int H, int target0, float temperature) {
+  NceArgs a = {};
+  if (!loss) return GOAT_E_ARG;
+  if (int e = nce_fill(a, x_loc, x_all, txt_loc, txt_all, nullptr, nullptr, nullptr, nullptr, prob, Bl, Ba, H, target0, temperature)) return e;
+  if ((size_t)Ba * 4 > 64 * 1024) return GOAT_E_SHAPE;
+  a.loss = loss;
+  hipLaunchKernelGGL(infonce_fwd_kernel, dim3(6 * Bl), dim3(256), (size_t)Ba * 4, reinterpret_cast<hipStream_t>(stream), a);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_infonce_bwd(void* stream, const float* const* x_loc, const float* const* x_all, const float* txt_loc,
+                                const float* txt_all, const float* dloss, const float* prob, float* const* dx_loc, float* const* dx_all,
+                                float* dtxt_loc, float* dtxt_all, int Bl, int Ba, int H, int target0, float temperature) {
+  NceArgs a = {};
+  if (!dloss) return GOAT_E_ARG;
+  if (int e = nce_fill(a, x_loc, x_all, txt_loc, txt_all, dx_loc, dx_all, dtxt_loc, dtxt_all, const_cast<float*>(prob), Bl, Ba, H, target0,
+                       temperature))
+    return e;
+  a.dloss = dloss;
+  hipLaunchKernelGGL(infonce_bwd_kernel, dim3(6, (H + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
   GOAT_LAUNCH_CHECK();
   return 0;
 }

@@ -95,7 +95,9 @@ template <int N_> __device__ __forceinline__ void wait_lgkm() {
 template <int N_> __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
-// 16-byte result store.  GOAT_G2_STORE: 0 plain, 1 nt (non-temporal), 2 sc1 (write-through: the line leaves the XCD's L2 right
+// 16-byte result store (inline asm ends in `s_nop 1`: the compiler does not know the statement is a >64-bit VMEM store and would
+// otherwise overwrite the data registers inside the store-data hazard window — seen as isolated wrong elements).
+// GOAT_G2_STORE: 0 plain, 1 nt (non-temporal), 2 sc1 (write-through: the line leaves the XCD's L2 right
 // away instead of in the write-back burst at the end of the kernel, MI355X_MICROARCH.md "publish-large")
 #ifndef GOAT_G2_STORE
 #define GOAT_G2_STORE 1       // measured: 3840x3072x768 25.9 (plain) -> 21.5 us (nt), 8640x3072x768 64.1 -> 47.7 us
@@ -104,10 +106,10 @@ typedef uint32_t g2_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16(void* dst, const uint4& v) {
 #if GOAT_G2_STORE == 1
   const g2_u32x4 q = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(q) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(q) : "memory");
 #elif GOAT_G2_STORE == 2
   const g2_u32x4 q = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(q) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(q) : "memory");
 #else
   *reinterpret_cast<uint4*>(dst) = v;
 #endif
@@ -189,8 +191,11 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   // fragment prefetch distance in k-steps (each k-step's fragments have their own registers); bounded by the 4-bit lgkmcnt
   constexpr bool SWAP = !SPLITK && sizeof(OutT) == 2;                  // bf16 results: swapped MFMA operand roles (see the epilogue)
   constexpr int RD = MI * (TA ? 2 : 1) + NI * (TB ? 2 : 1);            // ds_read instructions per k-step
-  constexpr int FD = (GOAT_GEMM_FRAG_DEPTH * RD <= 15) ? GOAT_GEMM_FRAG_DEPTH : (15 / RD >= 1 ? 15 / RD : 1);
-  static_assert(RD <= 15, "one k-step of fragment reads must fit the lgkmcnt counter");
+  // (the counted wait in front of k-step ks allows (FD-1)*RD reads to stay in flight: THAT must fit the 4-bit lgkmcnt; with more
+  // than 15 reads issued the wave simply stalls at issue.  Round 1 required FD*RD <= 15 and ran every transposed-operand tile
+  // — all weight gradients — one k-step ahead only.)
+  constexpr int FD = ((GOAT_GEMM_FRAG_DEPTH - 1) * RD <= 15) ? GOAT_GEMM_FRAG_DEPTH : (15 / RD + 1 >= 1 ? (15 / RD + 1 < 3 ? 15 / RD + 1 : 3) : 1);
+  static_assert(RD <= 15 && (FD - 1) * RD <= 15, "the reads a counted wait leaves in flight must fit the lgkmcnt counter");
 
   // `wave` through readfirstlane: the compiler then keeps every wave-uniform quantity (the LDS addresses of this wave's DMA
   // pieces, hence M0) in SGPRs instead of a v_add + v_readfirstlane + s_mov chain in front of every buffer_load ... lds

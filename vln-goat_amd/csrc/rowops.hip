@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       // round z to the storage type so forward statistics and backward recomputation agree
 #pragma unroll
       for (int e = 0; e < EPC; ++e) v[i].v[e] = to_f(from_f<T>(v[i].v[e]));
-      if (zout) v[i].store(zout + base);
+      if (zout) v[i].store_stream(zout + base);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) sum += v[i].v[e];
     }
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       Chunk<T> o;
 #pragma unroll
       for (int e = 0; e < EPC; ++e) o.v[e] = (v[i].v[e] - mu) * rs * gamma[c * EPC + e] + beta[c * EPC + e];
-      o.store(y + (int64_t)row * H + c * EPC);
+      o.store_stream(y + (int64_t)row * H + c * EPC);
     }
   }
 }
@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ rstd, float p, uint64_t seed,
                                                      uint64_t offset, const uint64_t* __restrict__ rng_dev,
                                                      T* __restrict__ dx, T* __restrict__ dres,
-                                                     float* __restrict__ ws, int M, int H) {
+                                                     float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int M, int H) {
   constexpr int EPC = DT<T>::EPC;
   extern __shared__ float lsum[];  // [4][2][H]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -172,13 +173,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
           Chunk<T> o;
 #pragma unroll
           for (int e = 0; e < EPC; ++e) o.v[e] = (vdy[u][i].v[e] - c1[u] - vz[u][i].v[e] * c2[u]) * rs[u];
-          if (dres) o.store(dres + base);
+          if (dres) o.store_stream(dres + base);
           if (drop) {
             const uint32_t km = rng.keep_bits<EPC>(offset + base, thr);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o.v[e] = ((km >> e) & 1u) ? o.v[e] * ks : 0.f;
           }
-          if (dx) o.store(dx + base);
+          if (dx) o.store_stream(dx + base);
         }
       }
     }
@@ -201,8 +202,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) s += lsum[(w * 2 + which) * H + col];
-    ws[(int64_t)blockIdx.x * 2 * H + i] = s;
-  }
+    if (ws != nullptr) ws[(int64_t)blockIdx.x * 2 * H + i] = s;          // deterministic mode: per-block partials + ln_bwd_reduce_kernel
+    else atomicAdd((which == 0 ? dgamma : dbeta) + col, s);                // default: one float atomic per block and column into the
+  }                                                                        // (pre-zeroed) gradient; no second launch
 }
 
 // 256 threads = 16 columns x 16 part-groups; every thread sums nparts/16 partials with 4 independent chains
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, c
 #pragma unroll
       for (int e = 0; e < EPC; ++e) v.v[e] += r.v[e];
     }
-    v.store(y + c * EPC);
+    v.store_stream(y + c * EPC);
   }
   // tail
   if (blockIdx.x == 0 && threadIdx.x < (n - nchunk * EPC)) {
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, 
       g *= (act == 1) ? dgelu_f(uu.v[e]) : (uu.v[e] > 0.f ? 1.f : 0.f);
       d.v[e] = g;
     }
-    d.store(dx + c * EPC);
+    d.store_stream(dx + c * EPC);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n - nchunk * EPC)) {
     const int64_t i = nchunk * EPC + threadIdx.x;
@@ -719,29 +721,36 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
                            const float* mean, const float* rstd, float p, uint64_t seed, uint64_t offset,
                            const uint64_t* rng_dev, void* dx, void* d_res, float* dgamma, float* dbeta, float* ws,
                            int M, int H, int accumulate) {
-  if (!dy || !z || !gamma || !mean || !rstd || !dgamma || !dbeta || !ws) return GOAT_E_ARG;
+  if (!dy || !z || !gamma || !mean || !rstd || !dgamma || !dbeta) return GOAT_E_ARG;
   if (M <= 0) return GOAT_E_SHAPE;
   int nparts = (M + 4 * GOAT_LN_RIF - 1) / (4 * GOAT_LN_RIF);   // 4 waves x RIF rows in flight per block
   if (nparts > GOAT_LN_BWD_PARTS) nparts = GOAT_LN_BWD_PARTS;
   const size_t sm = (size_t)8 * H * sizeof(float);
   if (sm > 64 * 1024) return GOAT_E_SHAPE;
+  if (ws == nullptr && !accumulate) {      // atomic mode writes by accumulation: an overwrite clears the two vectors first
+    hipError_t e1 = hipMemsetAsync(dgamma, 0, (size_t)H * sizeof(float), ST(stream));
+    hipError_t e2 = hipMemsetAsync(dbeta, 0, (size_t)H * sizeof(float), ST(stream));
+    if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+  }
   if (dtype == GOAT_BF16) {
     if (int e = ln_check<bf16_t>(H)) return e;
     GOAT_LN_DISPATCH(bf16_t, H, hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, MC, GOAT_LN_RIF>), dim3(nparts), dim3(256), sm, ST(stream),
                                                     (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, gamma, mean, rstd, p, seed, offset,
-                                                    rng_dev, (bf16_t*)dx, (bf16_t*)d_res, ws, M, H));
+                                                    rng_dev, (bf16_t*)dx, (bf16_t*)d_res, ws, dgamma, dbeta, M, H));
   } else if (dtype == GOAT_F32) {
     if (int e = ln_check<float>(H)) return e;
     GOAT_LN_DISPATCH(float, H, hipLaunchKernelGGL((ln_bwd_kernel<float, MC, 2>), dim3(nparts), dim3(256), sm, ST(stream),
                                                    (const float*)dy, (const float*)dy2, (const float*)z, gamma, mean, rstd, p, seed, offset,
-                                                   rng_dev, (float*)dx, (float*)d_res, ws, M, H));
+                                                   rng_dev, (float*)dx, (float*)d_res, ws, dgamma, dbeta, M, H));
   } else {
     return GOAT_E_ARG;
   }
   GOAT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 15) / 16), dim3(256), 0, ST(stream), ws, dgamma, dbeta, nparts,
-                     H, accumulate);
-  GOAT_LAUNCH_CHECK();
+  if (ws != nullptr) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 15) / 16), dim3(256), 0, ST(stream), ws, dgamma, dbeta, nparts,
+                       H, accumulate);
+    GOAT_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -350,7 +350,12 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
             cfg = _tune_gemm(key, a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_opts or (split_k,), colsum_out)
         else:
             cfg = _heuristic_cfg(ta, tb, M, N, Kc, split_k) + (split_k,)
-    bm, nstage, split_k = cfg
+    bm, nstage, split_cfg = cfg
+    # a split launch accumulates with atomics: only allowed when the caller zero-filled `out` (split requested / split_opts
+    # given), asked for the clear (zero_first) or accumulates anyway.  A tuned entry with split > 1 must never be applied to a
+    # buffer the caller left uninitialised (found by the full-size gradient pins of round 2).
+    may_split = split_k > 1 or split_opts is not None or zero_first or accumulate
+    split_k = split_cfg if may_split else 1
     if zero_first and split_k > 1:
         out.zero_()
     if accumulate and split_k == 1:
@@ -460,7 +465,7 @@ class WgradQueue:
     The first write of a slice in a step overwrites it; a later write (shared weights, BPTT) is queued as an accumulation —
     never in the same group as an earlier write of that slice (hipops._sink flushes first)."""
     enabled = os.environ.get('GOAT_WGRAD_GROUP', '1') != '0'
-    cfg = tuple(int(v) for v in os.environ.get('GOAT_WGRAD_GROUP_CFG', '128,258').split(','))   # (tile height, ring stages | 0x100 = eight waves): 128,2 on eight waves measured best (7.34 vs 7.50 ms/step on four)
+    cfg = tuple(int(v) for v in os.environ.get('GOAT_WGRAD_GROUP_CFG', '256,3').split(','))   # (tile = rows | cols << 16, ring stages | 0x100 = eight waves on 128x128): scripts/wgrad_group_bench.py, profiles/round2_wgrad_grouped.txt
     MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '16'))      # problems per launch (measured 8 / 12 / 16: 7.12 / 7.09 / 7.06 ms per step)
     queues = {}             # HIP stream handle -> (torch stream, [(dy, x, w_sink, b_sink, accumulate)]): tensors are kept alive until
     pending_ids = {}        # the launch, which happens on the stream the problems were produced on;  id(param) -> stream handle
@@ -920,6 +925,9 @@ def multi_linear(x, weights, biases):
 
 
 # ----------------------------------------------------------------------------- LayerNorm / dropout
+LN_DETERMINISTIC = os.environ.get('GOAT_LN_DETERMINISTIC', '0') == '1'
+
+
 class _LnFn(torch.autograd.Function):
     """y = LayerNorm(residual + dropout_p(x)) (P/model/Bert_backbone.py:306-310).
     fork=True returns y twice (two autograd outputs over one buffer): one for the next sub-layer's first Linear, one for
@@ -984,10 +992,12 @@ class _LnFn(torch.autograd.Function):
             _prep_fallback(*ctx.gb)
         dg = sg if sunk else torch.empty(H, dtype=torch.float32, device=z.device)
         db = sb if sunk else torch.empty(H, dtype=torch.float32, device=z.device)
-        ws = torch.empty(L.goat_ln_bwd_ws_floats(H), dtype=torch.float32, device=z.device)
+        # LN_DETERMINISTIC: per-block partials in a workspace + a second (reduction) launch; default: the blocks add their column
+        # partials to dgamma / dbeta with float atomics (43 fewer launches per step; summation order is not reproducible)
+        ws = torch.empty(L.goat_ln_bwd_ws_floats(H), dtype=torch.float32, device=z.device) if LN_DETERMINISTIC else None
         st = L.goat_ln_bwd(_stream(), _dt(z), _ptr(dy2), _ptr(dyb) if dyb is not None else None, _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd),
                            p, seed, off, dev, _ptr(dx), _ptr(dres) if dres is not None else None,
-                           _ptr(dg), _ptr(db), _ptr(ws), M, H, int(sunk and not _first_touch(*ctx.gb)))
+                           _ptr(dg), _ptr(db), _ptr(ws) if ws is not None else None, M, H, int(sunk and not _first_touch(*ctx.gb)))
         _lib.check(st, 'goat_ln_bwd')
         if sunk:
             dg = db = None
@@ -1434,3 +1444,52 @@ def dict_weighted_sum(z, p, out_dtype):
 
 if not os.environ.get('GOAT_RETUNE'):       # (GOAT_RETUNE=1: start from an empty table and time every shape again)
     load_tuned()
+
+
+# ----------------------------------------------------------------------------- CFP contrastive losses
+class _InfoNceFn(torch.autograd.Function):
+    """loss[i] = sum_{x in gmap, vp, fused} 1/2 [CE(x_loc[i]·txt_all^T/tau, t0+i) + CE(txt_loc[i]·x_all^T/tau, t0+i)]
+    (P/model/pretrain_goat.py:519-534) in one forward and one backward launch (goat_infonce_fwd / _bwd).  `*_all` are the
+    candidates of every data-parallel rank (the same tensors as `*_loc` on one rank)."""
+
+    @staticmethod
+    def forward(ctx, g_loc, v_loc, f_loc, t_loc, g_all, v_all, f_all, t_all, target0, temperature):
+        for t in (g_loc, v_loc, f_loc, t_loc, g_all, v_all, f_all, t_all):
+            _need_gpu(t)
+        ins = [t.float().contiguous() for t in (g_loc, v_loc, f_loc, t_loc, g_all, v_all, f_all, t_all)]
+        Bl, H = ins[0].shape
+        Ba = ins[4].shape[0]
+        loss = torch.zeros(Bl, dtype=torch.float32, device=ins[0].device)
+        prob = torch.empty((6, Bl, Ba), dtype=torch.float32, device=ins[0].device)
+        xl = (ctypes.c_void_p * 3)(*[_ptr(t) for t in ins[0:3]])
+        xa = (ctypes.c_void_p * 3)(*[_ptr(t) for t in ins[4:7]])
+        st = _lib.lib().goat_infonce_fwd(_stream(), xl, xa, _ptr(ins[3]), _ptr(ins[7]), _ptr(loss), _ptr(prob), Bl, Ba, H,
+                                         int(target0), float(temperature))
+        _lib.check(st, 'goat_infonce_fwd')
+        ctx.save_for_backward(prob, *ins)
+        ctx.same = tuple(a is b for a, b in zip((g_loc, v_loc, f_loc, t_loc), (g_all, v_all, f_all, t_all)))
+        ctx.cfg = (Bl, Ba, H, int(target0), float(temperature))
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        prob, *ins = ctx.saved_tensors
+        Bl, Ba, H, target0, temperature = ctx.cfg
+        dev = prob.device
+        dloc = torch.zeros((4, Bl, H), dtype=torch.float32, device=dev)
+        need_all = [not s for s in ctx.same]
+        dall = torch.zeros((4, Ba, H), dtype=torch.float32, device=dev) if any(need_all) else None
+        gl = [dloc[k] for k in range(4)]
+        ga = [(dall[k] if need_all[k] else dloc[k]) for k in range(4)]      # same tensor passed as loc and all: one gradient buffer
+        xl = (ctypes.c_void_p * 3)(*[_ptr(t) for t in ins[0:3]])
+        xa = (ctypes.c_void_p * 3)(*[_ptr(t) for t in ins[4:7]])
+        dxl = (ctypes.c_void_p * 3)(*[_ptr(t) for t in gl[0:3]])
+        dxa = (ctypes.c_void_p * 3)(*[_ptr(t) for t in ga[0:3]])
+        st = _lib.lib().goat_infonce_bwd(_stream(), xl, xa, _ptr(ins[3]), _ptr(ins[7]), _ptr(dloss.float().contiguous()), _ptr(prob),
+                                         dxl, dxa, _ptr(gl[3]), _ptr(ga[3]), Bl, Ba, H, target0, temperature)
+        _lib.check(st, 'goat_infonce_bwd')
+        return tuple(gl) + tuple((ga[k] if need_all[k] else None) for k in range(4)) + (None, None)
+
+
+def infonce(g_loc, v_loc, f_loc, t_loc, g_all, v_all, f_all, t_all, target0, temperature):
+    return _InfoNceFn.apply(g_loc, v_loc, f_loc, t_loc, g_all, v_all, f_all, t_all, target0, temperature)
