@@ -31,6 +31,21 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 TASKS = tuple(os.environ.get('GOAT_BENCH_TASKS', 'mlm,sap,cfp').split(','))   # (diagnostics: time one task alone)
+# BASELINE.json configs -> (model-config overrides, synthetic batch shape, per-rank batch, task cycle, description)
+WORKLOADS = {
+    'config2': dict(cfg={}, batch=dict(T=5, L=80, style='survey'), per_rank=48, tasks=TASKS,
+                    text='Full R2R GOAT pretrain config (pretrain_src/run_r2r_goat.sh): %(layers)s layers text/cross/pano, vocab 50265, '
+                         'per-rank batch %(batch)d, T=5, 36x768 views, L=80, tasks mlm/sap/cfp 1:1:1, dropout 0.1'),
+    # configs[4]: REVERIE model (object tokens after the views, object-grounding head, object-name embeddings), 160-token
+    # instructions, 32 per rank (= 256 over 8), up to 20 objects per panorama, tasks of reverie_GOAT_pretrain.json
+    'config5': dict(cfg=dict(name='REVERIE', obj_feat_size=768, image_prob_size=1000, obj_prob_size=1000, obj_name_vocab_size=45,
+                             use_obj_name=True, pretrain_tasks=['mlm', 'mrc', 'sap', 'og', 'cfp']),
+                    batch=dict(T=5, L=160, style='survey', objects=20, mrc=True, prob_size=1000), per_rank=32,
+                    tasks=('mlm', 'mrc', 'sap', 'og', 'cfp'),
+                    text='REVERIE GOAT pretrain config (pretrain_src/config/reverie_GOAT_pretrain.json shapes): %(layers)s layers, '
+                         'vocab 50265, per-rank batch %(batch)d, T=5, 36 views + up to 20 objects x 768, L=160, tasks '
+                         'mlm/mrc/sap/og/cfp cycled, dropout 0.1'),
+}
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # dense peaks, MI355X_MICROARCH.md
 # algorithmic FLOPs per trajectory-step, fwd+bwd, 1:1:1 task mix at L=80,T=5,V=36,G=22
 ALGO_GFLOP_PER_TRAJ_STEP = {'mlm': 12.98, 'sap': 9.83, 'cfp': 7.6}
@@ -41,14 +56,17 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=6)
-    ap.add_argument('--batch', type=int, default=48, help='per-rank batch (train_batch_size of r2r_GOAT_pretrain.json)')
+    ap.add_argument('--batch', type=int, default=None, help='per-rank batch (default: 48 = train_batch_size of r2r_GOAT_pretrain.json; 32 for config5)')
+    ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS), help='BASELINE.json configuration timed as the headline')
+    ap.add_argument('--leg', default=None, choices=['config5', 'config4'], help='(internal) run one extra leg alone and print its JSON')
+    ap.add_argument('--no-extra-configs', action='store_true', help='skip the config 4 / config 5 / fresh-batch / optimizer legs (extra keys of the JSON line, N = 1 only)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-autotune', action='store_true', help='use the static GEMM tile/stage heuristics')
     ap.add_argument('--no-arena', action='store_true', help='per-parameter gradient tensors instead of the flat gradient arena')
-    ap.add_argument('--cpu-batch', type=int, default=4)
+    ap.add_argument('--cpu-batch', type=int, default=48, help='batch of the CPU-oracle timing (SURVEY 8d: the GPU workload, B = 48)')
     ap.add_argument('--layers', default='6,3,2', help='num_l_layers,num_top_layer,num_pano_layers')
     return ap.parse_args()
 
@@ -109,18 +127,27 @@ def setup_dist(args):
     return world, rank, local
 
 
-def build(args, rank):
+def build(args, rank, workload='config2'):
     import vln_goat_amd
     from vln_goat_amd import config as gcfg, pretrain_model, synth
+    wl = WORKLOADS[workload]
     nl, nx, npano = [int(x) for x in args.layers.split(',')]
-    cfg = gcfg.make_config(num_l_layers=nl, num_top_layer=nx, num_pano_layers=npano)
+    cfg = gcfg.make_config(num_l_layers=nl, num_top_layer=nx, num_pano_layers=npano, **wl['cfg'])
     torch.manual_seed(0)
     model = pretrain_model.GlocalTextPathCMTPreTraining(cfg)    # random init (reference init rule)
     model = model.cuda().train()
     vln_goat_amd.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
-    batch = synth.make_pretrain_batch(B=args.batch, T=5, L=80, seed=100 + rank, style='survey')
-    gb = synth.batch_to(batch, 'cuda')
-    return cfg, model, batch, gb
+    batch = synth.make_pretrain_batch(B=args.batch or wl['per_rank'], seed=100 + rank, **wl['batch'])
+    static = None
+    if workload == 'config2' and not os.environ.get('GOAT_BENCH_NO_STATIC'):
+        # the device batch lives at fixed addresses with its index tensors (train_step.StaticBatch): the captured steps can be
+        # fed a new host batch per replay (the fresh_batch leg); for the timed headline it is loaded once, like any batch
+        from vln_goat_amd import train_step
+        static = train_step.StaticBatch(cfg, batch, [t for t in wl['tasks'] if t in ('mlm', 'sap', 'cfp')])
+        gb = static.gb
+    else:
+        gb = synth.batch_to(batch, 'cuda')
+    return cfg, model, batch, gb, static
 
 
 class PhasePlan:
@@ -198,7 +225,7 @@ class PhasePlan:
             yield k
 
 
-def make_steps(args, model, gb, world, wrapper):
+def make_steps(args, model, gb, world, wrapper, tasks=None):
     """Returns {task: callable running one fwd+bwd(+all-reduce) step}.
 
     N = 1: one hipGraph per task (arena clear + forward + backward).
@@ -207,6 +234,7 @@ def make_steps(args, model, gb, world, wrapper):
     the all-gather of the contrastive negatives) gets one more cut around the eager gather + InfoNCE piece."""
     from vln_goat_amd import hipops
     from vln_goat_amd.pretrain_model import cfp_losses
+    TASKS = tuple(tasks) if tasks is not None else globals()['TASKS']
     hipops.manual_seed(1234)
     hipops.AUTOTUNE = not args.no_autotune     # first sight of a GEMM shape times (tile, LDS stages, split-K) candidates
     hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')
@@ -356,14 +384,25 @@ def make_steps(args, model, gb, world, wrapper):
 
 
 def cpu_baseline(args, cfg):
-    """The CPU oracle (a port of the reference path; validated against the imported reference in the build
-    container) timed on this box's host cores: fp32, dropout on, bounded sample (a few seconds of CPU work).
-    Threads are capped at 32: these GEMMs are small (M = B*80 rows) and oversubscribing a 256-thread host
-    makes the CPU path slower, not faster."""
+    """The CPU oracle (a port of the reference path; validated against the imported reference in the build container) timed
+    on this box's host cores as SURVEY 8d prescribes: the GPU workload itself (B = 48, T = 5, L = 80, the full model), fp32,
+    dropout on, 2 warm-up steps, then the MEDIAN of >= 5 timed steps (mlm / sap / cfp cycled; more while the sample stays
+    under ~30 s).  Threads: every core up to 64 — these GEMMs have M = B*80 = 3840 rows and stop scaling beyond that on a
+    many-socket host; the record names the host CPU, its core count and the threads used."""
     from oracle import goat_oracle
     from vln_goat_amd import pretrain_model, synth
-    ncores = min(os.cpu_count() or 1, 32)
+    avail = os.cpu_count() or 1
+    ncores = min(avail, int(os.environ.get('GOAT_CPU_THREADS', '64')))
     torch.set_num_threads(ncores)
+    cpu_model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    cpu_model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
     model = pretrain_model.GlocalTextPathCMTPreTraining(cfg)
     sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in model.state_dict().items()}
     sd['mlm_head.predictions.decoder.weight'] = sd['bert.embeddings.word_embeddings.weight']
@@ -380,17 +419,18 @@ def cpu_baseline(args, cfg):
         return time.time() - t0
 
     t_start = time.time()
-    one('sap')                                   # warm-up (allocator, thread pool)
+    warm = [one('sap'), one('mlm')]              # 2 warm-up steps (allocator, thread pool)
     times = []
-    for cyc in range(3):
-        for task in TASKS:
-            times.append(one(task))
-        if time.time() - t_start > 25:
-            break
-    per_step = sum(times) / len(times)
-    return {'value': round(B * 5 / per_step, 2), 'unit': 'trajectory-steps/s', 'cores': ncores, 'kind': 'port',
-            'sample': 'oracle/goat_oracle.py fp32 fwd+bwd, full R2R config, B=%d T=5 L=80, dropout on, %d timed steps '
-                      '(mlm/sap/cfp cycled) after 1 warm-up step, %d torch threads' % (B, len(times), ncores)}
+    i = 0
+    while len(times) < 5 or (len(times) < 12 and time.time() - t_start < 30):
+        times.append(one(TASKS[i % len(TASKS)]))
+        i += 1
+    med = sorted(times)[len(times) // 2]
+    return {'value': round(B * 5 / med, 2), 'unit': 'trajectory-steps/s', 'cores': ncores, 'kind': 'port',
+            'cpu_model': cpu_model, 'cores_available': avail, 'median_s_per_step': round(med, 3),
+            'sample': 'oracle/goat_oracle.py fp32 fwd+bwd, full R2R config, B=%d T=5 L=80, dropout on: median of %d timed steps '
+                      '(mlm/sap/cfp cycled) after 2 warm-up steps, %d torch threads on %d available cores (%s), %.0f s of CPU work'
+                      % (B, len(times), ncores, avail, cpu_model, time.time() - t_start)}
 
 
 def gemm_roofline(args, model, gb, arena=None):
@@ -473,32 +513,34 @@ def gemm_roofline(args, model, gb, arena=None):
             'method': 'HIP events around a hipGraph replay of the %d recorded GEMM launches of one mlm+sap+cfp cycle' % n}
 
 
-def main():
-    args = parse()
-    rc = spawn_ranks(args)
-    if rc is not None:
-        sys.exit(rc)
-    if os.environ.get('GOAT_BENCH_LAUNCH_ONLY'):
-        return launch_check(args)
-    world, rank, local = setup_dist(args)
-    cfg, model, batch, gb = build(args, rank)
+def measure_pretrain(args, world, rank, workload, n_steps, n_warmup):
+    """Builds the model + batch of `workload`, captures its steps and times n_steps of them (the bench contract: warm-up,
+    barrier + synchronize on both sides, max over ranks).  -> dict with the timing and the live objects."""
     from vln_goat_amd import dp, synth
+    wl = WORKLOADS[workload]
+    tasks = tuple(wl['tasks'])
+    cfg, model, batch, gb, static = build(args, rank, workload)
     wrapper = dp.GoatDataParallel(model, share_cfp_negatives=True)
-    wrapper.sparse_uniform_rows = True       # every rank's synthetic batch has B*L = 48*80 token rows (no count exchange / host sync)
-    steps = make_steps(args, model, gb, world, wrapper)
-    n_traj = synth.n_traj_steps(batch)
+    wrapper.sparse_uniform_rows = True       # every rank's synthetic batch has B*L token rows (no count exchange / host sync)
+    steps = make_steps(args, model, gb, world, wrapper, tasks)
 
     def run(i):
-        steps[TASKS[i % len(TASKS)]]()          # fwd + bwd (+ gradient all-reduce at N > 1)
+        steps[tasks[i % len(tasks)]]()          # fwd + bwd (+ gradient all-reduce at N > 1)
 
-    for i in range(args.warmup):
+    dt = timed(run, n_steps, n_warmup, world)
+    return {'dt': dt, 'n_traj': synth.n_traj_steps(batch), 'cfg': cfg, 'model': model, 'batch': batch, 'gb': gb,
+            'wrapper': wrapper, 'steps': steps, 'tasks': tasks, 'run': run, 'static': static}
+
+
+def timed(run, n_steps, n_warmup, world):
+    for i in range(n_warmup):
         run(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(n_steps):
         run(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -509,32 +551,240 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    return dt
+
+
+def leg_process(args, name):
+    """config 4 / config 5 legs run in a child process (own model, own graphs): whatever happens there, the headline line of
+    this process is printed.  -> the child's JSON object, or {'error': ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--leg', name, '--steps', str(args.steps), '--dtype', args.dtype, '--layers', args.layers]
+    cmd += ['--no-graph'] if args.no_graph else []
+    cmd += ['--no-autotune'] if args.no_autotune else []
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {'error': 'timed out after 900 s'}
+    lines = [x for x in r.stdout.splitlines() if x.startswith('{')]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write(r.stderr[-2000:])
+        return {'error': 'exit code %d: %s' % (r.returncode, r.stderr.strip().splitlines()[-1][:300] if r.stderr.strip() else '')}
+    return json.loads(lines[-1])
+
+
+def leg(name, fn):
+    """extra legs never cost the headline: a failure is reported in place of the numbers."""
+    try:
+        return fn()
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        torch.cuda.synchronize()
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+
+
+def fresh_batch_leg(args, m):
+    """The captured steps fed with a NEW host batch per step.  Inside the timed region, per
+    step: the batch's index tensors are rebuilt on the host from its viewpoint-id strings (graphmap.py), written into the
+    batch's pinned buffer, the whole batch (27 MB: features, ids, labels, map tensors, indices) goes H2D in one copy on a side
+    stream, is swapped into the fixed-address batch with one D2D copy, the masks are recomputed, and the task's hipGraph is
+    replayed.  The host batches (3, cycled) were collated into pinned buffers beforehand, as a loader's workers would leave them.
+    Second figure: RAGGED batches (T ~ U{1..7}, L ~ U{20..80}: every step another shape) through the eager path — H2D of the
+    batch, lazy index build, eager launches (static GEMM heuristics: no first-sight tuning per shape)."""
+    from vln_goat_amd import hipops, synth
+    sb, tasks, steps, wl = m['static'], m['tasks'], m['steps'], WORKLOADS['config2']
+    if sb is None:
+        return {'error': 'no static batch'}
+    B = args.batch or wl['per_rank']
+    K = 3
+    hosts = [synth.make_pretrain_batch(B=B, seed=500 + k, **wl['batch']) for k in range(K)]
+    bufs = [sb.pack(h) for h in hosts]
+    done = [None] * K
+
+    def run(i):
+        k = i % K
+        if done[k] is not None:
+            done[k].synchronize()                    # this buffer's previous H2D has been executed
+        sb.pack(hosts[k], bufs[k], tensors=False)    # host: index build from the id strings
+        done[k] = sb.stage(bufs[k])                  # side stream: H2D
+        sb.commit()                                  # compute stream: swap in + masks
+        steps[tasks[i % len(tasks)]]()
+    n = max(6, min(args.steps, 30))
+    dt = timed(run, n, 3, 1)
+    out = {'ms_per_step': round(dt / n * 1e3, 3), 'value': round(m['n_traj'] * n / dt, 1), 'unit': 'trajectory-steps/s', 'steps': n,
+           'h2d_bytes_per_step': sb.nbytes,
+           'what': 'new host batch per step (fixed shape B=%d T=5 L=80): host index build + one pinned H2D (side stream) + one D2D swap '
+                   '+ mask refresh + hipGraph replay, all inside the timed region' % B}
+    # ragged, eager
+    model, arena = m['model'], m['wrapper'].arena
+    rs = __import__('numpy').random.RandomState(7)
+    ragged = [synth.make_pretrain_batch(B=B, T=rs.randint(1, 8, B).tolist(), L=rs.randint(20, 81, B).tolist(), seed=600 + k, style='survey')
+              for k in range(6)]
+    auto, hipops.AUTOTUNE = hipops.AUTOTUNE, False
+
+    def eager(i):
+        task = tasks[i % len(tasks)]
+        gb = synth.batch_to(ragged[i % len(ragged)], 'cuda')
+        arena.zero(task)
+        hipops.RngState.dev.add_(0x9E3779B1)
+        model(gb, task, compute_loss=True).mean().backward()
+    try:
+        n2 = 12
+        dt2 = timed(eager, n2, 6, 1)
+    finally:
+        hipops.AUTOTUNE = auto
+    traj = sum(synth.n_traj_steps(ragged[i % len(ragged)]) for i in range(n2))
+    out['ragged_eager'] = {'ms_per_step': round(dt2 / n2 * 1e3, 3), 'value': round(traj / dt2, 1), 'unit': 'trajectory-steps/s',
+                           'steps': n2, 'what': 'B=%d, T ~ U{1..7}, L ~ U{20..80}, a new shape every step: pageable H2D + lazy index '
+                                                'build + eager launches (host-bound)' % B}
+    return out
+
+
+def optimizer_leg(args, m):
+    """fwd + bwd + the fused clip + AdamW update (P/train_r2r_goat.py:349-366 per update) on the headline
+    workload: the captured step, then optim.FusedAdamW.step(task) on the gradient arena (two kernels, no host sync)."""
+    from vln_goat_amd import optim
+    opt = optim.FusedAdamW(m['model'].named_parameters(), m['wrapper'].arena, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01)
+    tasks, steps = m['tasks'], m['steps']
+
+    def run(i):
+        t = tasks[i % len(tasks)]
+        steps[t]()
+        opt.step(t, max_norm=5.0)
+    n = max(6, min(args.steps, 30))
+    dt = timed(run, n, 3, 1)
+    return {'ms_per_step': round(dt / n * 1e3, 3), 'value': round(m['n_traj'] * n / dt, 1), 'unit': 'trajectory-steps/s', 'steps': n,
+            'what': 'hipGraph replay of fwd+bwd, then goat_grad_sqnorm + goat_adamw_step (clip 5.0, lr 5e-5, betas 0.9/0.98, decay 0.01; '
+                    'bf16 weight shadows refreshed by the update kernel)'}
+
+
+def config5_leg(args):
+    n = max(10, min(args.steps, 30))
+    m = measure_pretrain(args, 1, 0, 'config5', n, 5)
+    out = {'value': round(m['n_traj'] * n / m['dt'], 1), 'unit': 'trajectory-steps/s', 'ms_per_step': round(m['dt'] / n * 1e3, 3),
+           'steps': n, 'samples_per_s': round(m['n_traj'] * n / m['dt'] / 5.0, 1),
+           'workload': WORKLOADS['config5']['text'] % {'layers': args.layers, 'batch': args.batch or 32} + ', fwd+bwd, hipGraph replay'}
+    m.clear()
+    return out
+
+
+def config4_leg(args):
+    """BASELINE.json configs[3] per rank: the fine-tuning model's calls of one rollout (text once, then panorama + navigation
+    per step with the [MEM] token carried: back-propagation through time) with BACL + FACL on, at the shapes of
+    M/scripts/run_r2r_goat.sh (batch 12 per rank, max_instr_len 200, dictionaries 35/39/50/24, G = 60 map nodes): forward,
+    imitation loss, backward.  A trajectory-step = one panorama of one sample."""
+    import vln_goat_amd
+    from types import SimpleNamespace
+    from vln_goat_amd import nav_model, synth, hipops
+    a = SimpleNamespace(num_l_layers=6, num_x_layers=3, num_pano_layers=2, dropout=0.1, feat_dropout=0.5, vocab_size=50265,
+                        do_back_img=True, do_back_txt=True, do_front_img=True, do_front_his=True, do_front_txt=True,
+                        do_back_txt_type='type_2', do_back_img_type='type_1', do_add_method='door', mode='train')
+    torch.manual_seed(0)
+    model = nav_model.GlocalTextPathNavCMT(nav_model.nav_config_from_args(a)).cuda().train()
+    vln_goat_amd.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+    B, T = 12, 3
+    ep = synth.make_nav_episode(B=B, L=200, n_steps=T, seed=21, vocab_size=50265, extra_nodes=51)
+    mv = lambda x: x.cuda() if torch.is_tensor(x) else x
+    for st in ep['steps']:            # the agent's collate: logit-fusion matrix of the step from the id strings (host)
+        st['nav_fusion'] = nav_model.nav_fusion_matrix(st['vp_cand_vpids'], st['gmap_vpids'], st['gmap_visited_masks'],
+                                                       st['gmap_step_ids'].shape[1], st['vp_masks'].shape[1])
+    ep = {k: ([{kk: mv(vv) for kk, vv in st.items()} for st in v] if k == 'steps' else mv(v)) for k, v in ep.items()}
+    params = list(model.parameters())
+    hipops.manual_seed(4321)
+    hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')       # per-replay dropout counter
+
+    def episode():
+        for p in params:
+            p.grad = None
+        hipops.RngState.dev.add_(0x9E3779B1)
+        loss, _ = synth.run_nav_episode(lambda m, b: model(m, b), ep, device='cuda')
+        loss.backward()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            episode()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    run, launch = (lambda i: episode()), 'eager'
+    if not args.no_graph:
+        launch_stream = torch.cuda.current_stream()
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                episode()
+            run, launch = (lambda i: g.replay()), 'hipGraph replay'
+        except Exception as e:      # noqa: BLE001
+            print('[bench] hipGraph capture of the navigation episode failed (%s: %s); running it eagerly' % (type(e).__name__, e), file=sys.stderr)
+            torch.cuda.set_stream(launch_stream)
+            hipops.Branch.used, hipops.Branch._armed = set(), False
+            hipops.WgradQueue.reset()
+            torch.cuda.synchronize()
+    n = max(6, min(args.steps, 20))
+    dt = timed(run, n, 2, 1)
+    return {'value': round(B * T * n / dt, 1), 'unit': 'trajectory-steps/s', 'ms_per_episode': round(dt / n * 1e3, 3), 'episodes': n,
+            'launch': launch,
+            'workload': 'map_nav_src fine-tune model calls of one rollout (run_r2r_goat.sh shapes): 6,3,2 layers, batch 12, L=200, 3 steps x '
+                        '(panorama 36x768 + navigation, G=60), BACL+FACL on (type_2 / type_1 / door), dictionaries 35/39/50/24, dropout '
+                        '0.1 / feat 0.5, BPTT through the [MEM] token, fwd+bwd, synthetic per-step inputs (no simulator)'}
+
+
+def main():
+    args = parse()
+    rc = spawn_ranks(args)
+    if rc is not None:
+        sys.exit(rc)
+    if os.environ.get('GOAT_BENCH_LAUNCH_ONLY'):
+        return launch_check(args)
+    if args.leg:
+        torch.cuda.set_device(0)
+        print(json.dumps(config5_leg(args) if args.leg == 'config5' else config4_leg(args)))
+        return
+    world, rank, local = setup_dist(args)
+    wl = WORKLOADS[args.workload]
+    per_rank = args.batch or wl['per_rank']
+    m = measure_pretrain(args, world, rank, args.workload, args.steps, args.warmup)
+    dt, n_traj, wrapper = m['dt'], m['n_traj'], m['wrapper']
 
     if rank == 0:
         value = n_traj * world * args.steps / dt
         algo = sum(ALGO_GFLOP_PER_TRAJ_STEP.values()) / 3.0
         out = {
-            'metric': 'trajectory-steps/sec fwd+bwd (GOAT pretrain, 36 views x 768, 80 tok)',
+            'metric': 'trajectory-steps/sec fwd+bwd (GOAT pretrain, 36 views x 768, %d tok)' % wl['batch']['L'],
             'value': round(value, 1), 'unit': 'trajectory-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'Full R2R GOAT pretrain config (pretrain_src/run_r2r_goat.sh): %s layers text/cross/pano, '
-                                   'vocab 50265, per-rank batch %d, T=5, 36x768 views, L=80, tasks mlm/sap/cfp 1:1:1, dropout 0.1, '
-                                   'fwd+bwd%s, random-init' % (args.layers, args.batch, ' + grad all-reduce' if world > 1 else ''),
-                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+            'config': {'workload': wl['text'] % {'layers': args.layers, 'batch': per_rank}
+                                   + ', fwd+bwd%s, random-init' % (' + grad all-reduce' if world > 1 else ''),
+                       'name': 'BASELINE.json configs[%d]' % {'config2': 1, 'config5': 4}[args.workload],
+                       'global_batch': per_rank * world, 'parallelism': 'dp%d' % world,
                        'launch': 'eager' if args.no_graph else ('hipGraph replay' if world == 1 else
                                                                       'hipGraph replay, backward cut into %d phases whose gradient all-reduces overlap the later phases (cfp: one more cut around the eager all-gather + loss)' % wrapper.n_phases
                                                                       if wrapper.launch_mode == 'phased' else 'hipGraph replay of forward + backward, then one gradient all-reduce (fallback path)')},
             'samples_per_s': round(value / 5.0, 1),
-            'step_mfma_frac': round(value / world * algo * 1e9 / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4),
         }
-        if world == 1 and not args.no_roofline:
-            out['roofline'] = gemm_roofline(args, model, gb, wrapper.arena)
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args, cfg)
+        headline = args.workload == 'config2' and TASKS == ('mlm', 'sap', 'cfp')
+        if headline:
+            out['step_mfma_frac'] = round(value / world * algo * 1e9 / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4)
+        if world == 1 and headline and not args.no_roofline:
+            out['roofline'] = gemm_roofline(args, m['model'], m['gb'], wrapper.arena)
+        if world == 1 and headline and not args.no_extra_configs and not args.no_graph and not args.no_arena:
+            out['fresh_batch'] = leg('fresh_batch', lambda: fresh_batch_leg(args, m))
+            if 'ms_per_step' in out['fresh_batch']:
+                out['fresh_batch_ms_per_step'] = out['fresh_batch']['ms_per_step']
+            out['with_optimizer'] = leg('with_optimizer', lambda: optimizer_leg(args, m))
         if os.environ.get('GOAT_SAVE_TUNED'):      # persist the autotuned GEMM table (copied to vln-goat_amd/tuned_gfx950.json)
             from vln_goat_amd import hipops
             hipops.save_tuned(os.environ['GOAT_SAVE_TUNED'])
+        cfg = m['cfg']
+        if world == 1 and headline and not args.no_extra_configs:
+            m.clear()
+            out['config5_reverie'] = leg_process(args, 'config5')
+            out['config4_nav'] = leg_process(args, 'config4')
+        if world == 1 and headline and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, cfg)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -1,0 +1,51 @@
+"""Autograd nodes behind the ATen glue kernels of the backward pass: leaf aten ops with device time grouped by the enclosing
+`autograd::engine::evaluate_function: <Node>` event (torch.profiler), one eager step per task."""
+import sys, os, collections
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+import bench
+from vln_goat_amd import hipops, dp
+from torch.profiler import profile, ProfilerActivity
+
+class A: pass
+args = A(); args.batch = 48; args.dtype = 'bf16'; args.layers = '6,3,2'
+torch.cuda.set_device(0)
+cfg, model, batch, gb = bench.build(args, 0)
+hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')
+wrapper = dp.GoatDataParallel(model)
+for task in bench.TASKS:
+    for p in model.parameters():
+        p.grad = None
+    model(gb, task, compute_loss=True).mean().backward()
+    wrapper.record_usage(task)
+for p in model.parameters():
+    p.grad = None
+arena = wrapper.build_arena()
+for rep in range(2):
+    for task in bench.TASKS:
+        arena.zero(task)
+        model(gb, task, compute_loss=True).mean().backward()
+torch.cuda.synchronize()
+agg, tim = collections.Counter(), collections.Counter()
+for task in bench.TASKS:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        arena.zero(task)
+        model(gb, task, compute_loss=True).mean().backward()
+        torch.cuda.synchronize()
+    for ev in prof.events():
+        if not ev.name.startswith('aten::'):
+            continue
+        dt = getattr(ev, 'self_device_time_total', 0) or 0
+        if dt <= 0:
+            continue
+        node, par = 'forward / python', ev.cpu_parent
+        while par is not None:
+            if 'evaluate_function' in par.name:
+                node = par.name.split(':')[-1].strip()
+                break
+            par = par.cpu_parent
+        agg[(ev.name, node)] += 1
+        tim[(ev.name, node)] += dt
+print('per mlm+sap+cfp cycle: leaf aten ops with device time by autograd node')
+for k, c in sorted(agg.items(), key=lambda kv: -tim[kv[0]])[:60]:
+    print('  %4d  %8.1f us  %-26s %s' % (c, tim[k], k[0], k[1]))

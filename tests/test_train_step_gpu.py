@@ -294,3 +294,78 @@ def test_fused_adamw_keeps_the_bf16_shadows_coherent():
             assert torch.equal(x, y)
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+def test_static_batch_feeds_a_captured_step_with_new_batches():
+    """train_step.StaticBatch: the hipGraph captured on the fixed-address batch, replayed after pack / stage / commit of a
+    NEW host batch (other ids, lengths, features, map strings), returns the losses and gradients the eager model computes on
+    that batch — index tensors and memoised masks follow the new data (dropout off: deterministic)."""
+    import vln_goat_amd
+    from vln_goat_amd import config as gcfg, hipops, pretrain_model, synth, train_step
+    cfg = gcfg.make_config(num_l_layers=2, num_top_layer=2, num_pano_layers=1, vocab_size=1000,
+                           hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    model = pretrain_model.GlocalTextPathCMTPreTraining(cfg).cuda().eval()
+    mk = lambda seed: synth.make_pretrain_batch(B=4, T=3, L=30, seed=seed, vocab_size=1000, style='survey')
+    first, second = mk(5), mk(6)
+    second['txt_lens'] = torch.tensor([30, 11, 23, 17])            # other text lengths: the key masks must follow
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        sb = train_step.StaticBatch(cfg, first)
+        params = [p for p in model.parameters() if p.requires_grad]
+        out = {}
+
+        def step(task):
+            for p in params:
+                p.grad = None
+            loss = model(sb.gb, task, compute_loss=True)
+            loss.mean().backward()
+            out[task] = loss
+
+        graphs = {}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for t in ('mlm', 'sap', 'cfp'):
+                step(t)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        grads = {}
+        for t in ('mlm', 'sap', 'cfp'):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step(t)
+            graphs[t] = g
+            grads[t] = {id(p): p.grad for p in params if p.grad is not None}
+        buf = sb.pack(second)
+        ev = sb.stage(buf)
+        sb.commit()
+        assert ev is not None
+        for t in ('mlm', 'sap', 'cfp'):
+            graphs[t].replay()
+            torch.cuda.synchronize()
+            got_loss = out[t].detach().float().clone()
+            got = {k: v.detach().float().clone() for k, v in grads[t].items()}
+            gb = synth.batch_to(second, 'cuda')                   # eager on a plain device copy of the same host batch
+            for p in params:
+                p.grad = None
+            ref = model(gb, t, compute_loss=True)
+            ref.mean().backward()
+            torch.cuda.synchronize()
+            assert torch.allclose(got_loss, ref.detach().float(), rtol=1e-3, atol=1e-3), (t, got_loss, ref)
+            n = 0
+            top = max(float(p.grad.abs().max()) for p in params if p.grad is not None)
+            for p in params:
+                if p.grad is None:
+                    continue
+                a, b = got[id(p)], p.grad.float()
+                # (per tensor, with a floor: key biases have an identically zero gradient — softmax shift invariance — and
+                #  hold rounding noise only)
+                scale = max(float(b.abs().max()), 0.05 * top)
+                assert float((a - b).abs().max()) <= 2e-2 * scale, t
+                n += 1
+            assert n > 10
+        with pytest.raises(ValueError):
+            sb.pack(synth.make_pretrain_batch(B=4, T=2, L=30, seed=7, vocab_size=1000, style='survey'))
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)

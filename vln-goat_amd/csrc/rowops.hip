@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // ------------------------------------------------------------------------------------ LayerNorm bwd
 // grid = NPART blocks of 4 waves; wave w of block b walks rows (b*4+w), +4*NPART, ...
 // partial dgamma/dbeta per block -> ws[block][2][H]; ln_bwd_reduce sums them.
-template <typename T, int MAXC, int RIF>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ z,
+template <typename T, int MAXC, int RIF, int NWV>
+__global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ z,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float p, uint64_t seed,
                                                      uint64_t offset, const uint64_t* __restrict__ rng_dev,
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      int M, int H) {
   constexpr int EPC = DT<T>::EPC;
-  extern __shared__ float lsum[];  // [4][2][H]
+  extern __shared__ float lsum[];  // [NWV][2][H]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (rng_dev) seed += *rng_dev;
   const GoatRng rng(seed);
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
   // RIF rows per wave in flight: the loads of both rows are issued before the first reduction (this kernel is
   // latency-bound on its 16-B loads, not on the shuffles)
-  const int rstride = gridDim.x * 4;
-  for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += RIF * rstride) {
+  const int rstride = gridDim.x * NWV;
+  for (int row0 = blockIdx.x * NWV + wave; row0 < M; row0 += RIF * rstride) {
     Chunk<T> vdy[RIF][MAXC], vz[RIF][MAXC];
     float mu[RIF], rs[RIF], c1[RIF], c2[RIF];
 #pragma unroll
@@ -197,11 +197,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * H; i += 256) {
+  for (int i = threadIdx.x; i < 2 * H; i += 64 * NWV) {
     const int which = i / H, col = i % H;
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s += lsum[(w * 2 + which) * H + col];
+    for (int w = 0; w < NWV; ++w) s += lsum[(w * 2 + which) * H + col];
     if (ws != nullptr) ws[(int64_t)blockIdx.x * 2 * H + i] = s;          // deterministic mode: per-block partials + ln_bwd_reduce_kernel
     else atomicAdd((which == 0 ? dgamma : dbeta) + col, s);                // default: one float atomic per block and column into the
   }                                                                        // (pre-zeroed) gradient; no second launch
@@ -711,6 +711,9 @@ extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* r
 }
 
 #define GOAT_LN_BWD_PARTS 512
+#ifndef GOAT_LN_BWD_WAVES
+#define GOAT_LN_BWD_WAVES 8    // waves per block of the atomic-mode LayerNorm backward (scripts/ln_bench.py: 4 -> 20.4 us, 8 -> 15.8, 16 -> 42 at 3840 rows)
+#endif
 #ifndef GOAT_LN_RIF
 #define GOAT_LN_RIF 2      // rows in flight per wave (bf16); measured: 4 rows / fewer partial blocks are slower (8.52-8.80 vs 8.45 ms/step)
 #endif
@@ -723,28 +726,46 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
                            int M, int H, int accumulate) {
   if (!dy || !z || !gamma || !mean || !rstd || !dgamma || !dbeta) return GOAT_E_ARG;
   if (M <= 0) return GOAT_E_SHAPE;
-  int nparts = (M + 4 * GOAT_LN_RIF - 1) / (4 * GOAT_LN_RIF);   // 4 waves x RIF rows in flight per block
+  // deterministic mode (ws): 4-wave blocks, up to 512 per-block partial rows reduced by a second kernel (round 1).
+  // atomic mode: GOAT_LN_BWD_WAVES-wave blocks (default 8) so that fewer blocks contend for the 2*H gradient words —
+  // 512 four-wave blocks made the kernel 20 us instead of 12 + 5 (profiles/round2_ln_bench.txt)
+  const bool det = ws != nullptr;
+  const int nwv = det ? 4 : GOAT_LN_BWD_WAVES;
+  int nparts = (M + nwv * GOAT_LN_RIF - 1) / (nwv * GOAT_LN_RIF);   // nwv waves x RIF rows in flight per block
   if (nparts > GOAT_LN_BWD_PARTS) nparts = GOAT_LN_BWD_PARTS;
-  const size_t sm = (size_t)8 * H * sizeof(float);
-  if (sm > 64 * 1024) return GOAT_E_SHAPE;
-  if (ws == nullptr && !accumulate) {      // atomic mode writes by accumulation: an overwrite clears the two vectors first
+  const size_t sm = (size_t)nwv * 2 * H * sizeof(float);
+  if (sm > 160 * 1024) return GOAT_E_SHAPE;
+  if (!det && !accumulate) {      // atomic mode writes by accumulation: an overwrite clears the two vectors first
     hipError_t e1 = hipMemsetAsync(dgamma, 0, (size_t)H * sizeof(float), ST(stream));
     hipError_t e2 = hipMemsetAsync(dbeta, 0, (size_t)H * sizeof(float), ST(stream));
     if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
   }
+#define GOAT_LN_BWD_LAUNCH(T_, RIF_, NWV_)                                                                                    \
+  do {                                                                                                                        \
+    auto kern_ = ln_bwd_kernel<T_, MC, RIF_, NWV_>;                                                                           \
+    if (sm > 64 * 1024) {                                                                                                     \
+      static bool attr_ = false;                                                                                              \
+      if (!attr_) {                                                                                                           \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) \
+          return GOAT_E_SHAPE;                                                                                                \
+        attr_ = true;                                                                                                         \
+      }                                                                                                                       \
+    }                                                                                                                         \
+    hipLaunchKernelGGL(kern_, dim3(nparts), dim3(64 * NWV_), sm, ST(stream), (const T_*)dy, (const T_*)dy2, (const T_*)z, gamma, mean, \
+                       rstd, p, seed, offset, rng_dev, (T_*)dx, (T_*)d_res, ws, dgamma, dbeta, M, H);                         \
+  } while (0)
   if (dtype == GOAT_BF16) {
     if (int e = ln_check<bf16_t>(H)) return e;
-    GOAT_LN_DISPATCH(bf16_t, H, hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, MC, GOAT_LN_RIF>), dim3(nparts), dim3(256), sm, ST(stream),
-                                                    (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, gamma, mean, rstd, p, seed, offset,
-                                                    rng_dev, (bf16_t*)dx, (bf16_t*)d_res, ws, dgamma, dbeta, M, H));
+    if (det) { GOAT_LN_DISPATCH(bf16_t, H, GOAT_LN_BWD_LAUNCH(bf16_t, GOAT_LN_RIF, 4)); }
+    else { GOAT_LN_DISPATCH(bf16_t, H, GOAT_LN_BWD_LAUNCH(bf16_t, GOAT_LN_RIF, GOAT_LN_BWD_WAVES)); }
   } else if (dtype == GOAT_F32) {
     if (int e = ln_check<float>(H)) return e;
-    GOAT_LN_DISPATCH(float, H, hipLaunchKernelGGL((ln_bwd_kernel<float, MC, 2>), dim3(nparts), dim3(256), sm, ST(stream),
-                                                   (const float*)dy, (const float*)dy2, (const float*)z, gamma, mean, rstd, p, seed, offset,
-                                                   rng_dev, (float*)dx, (float*)d_res, ws, dgamma, dbeta, M, H));
+    if (det) { GOAT_LN_DISPATCH(float, H, GOAT_LN_BWD_LAUNCH(float, 2, 4)); }
+    else { GOAT_LN_DISPATCH(float, H, GOAT_LN_BWD_LAUNCH(float, 2, GOAT_LN_BWD_WAVES)); }
   } else {
     return GOAT_E_ARG;
   }
+#undef GOAT_LN_BWD_LAUNCH
   GOAT_LAUNCH_CHECK();
   if (ws != nullptr) {
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 15) / 16), dim3(256), 0, ST(stream), ws, dgamma, dbeta, nparts,

@@ -69,21 +69,19 @@ def build_gmap_index(traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vp
 def build_vp_index(traj_step_lens, traj_vp_view_lens, V):
     """Local-branch tokens: (b,0) = zero [stop]; (b,j>=1) = view j-1 of sample b's LAST panorama, for
     j < max_b(view_len_last)+1 — padded view slots included, as in the reference (pad_tensors_wgrad of
-    x[-1] then [:max_vp_len], P/model/vilmodel_goat.py:378-388)."""
-    step_lens = _to_list(traj_step_lens)
-    view_lens = _to_list(traj_vp_view_lens)
+    x[-1] then [:max_vp_len], P/model/vilmodel_goat.py:378-388).  Pure arithmetic: numpy, no per-token Python."""
+    step_lens = np.asarray(_to_list(traj_step_lens), dtype=np.int64)
+    view_lens = np.asarray(_to_list(traj_vp_view_lens), dtype=np.int64)
     B = len(step_lens)
     last = np.cumsum(step_lens) - 1
-    vp_lens = [view_lens[n] + 1 for n in last]
-    width = max(vp_lens)
-    idx, start = [], [0]
-    for b in range(B):
-        for j in range(width):
-            if j >= 1:
-                idx.append(int(last[b]) * V + (j - 1))
-            start.append(len(idx))
-    return (torch.tensor(idx, dtype=torch.int32), torch.tensor(start, dtype=torch.int32),
-            torch.tensor(vp_lens, dtype=torch.int64), width)
+    vp_lens = view_lens[last] + 1
+    width = int(vp_lens.max())
+    idx = (last[:, None] * V + np.arange(width - 1, dtype=np.int64)[None, :]).reshape(-1)
+    per_tok = np.ones((B, width), dtype=np.int64)
+    per_tok[:, 0] = 0                                  # the [stop] slot is an empty segment
+    start = np.concatenate([[0], np.cumsum(per_tok.reshape(-1))])
+    return (torch.from_numpy(idx.astype(np.int32)), torch.from_numpy(start.astype(np.int32)),
+            torch.from_numpy(vp_lens.astype(np.int64)), width)
 
 
 def build_sap_fusion(traj_cand_vpids, gmap_vpids, gmap_visited_masks, n_gmap, n_local):
@@ -116,17 +114,21 @@ def build_obj_concat_index(view_lens, obj_lens, V, O, W):
     (view_len <= j < view_len + obj_len) or padding — the per-row torch.cat + pad_tensors_wgrad of
     P/model/vilmodel_goat.py:331-340 as one gather.  Source rows: [0, N*V) views, [N*V, N*V + N*O) objects.
     -> (idx int32 [n_tokens], start int32 [N*W + 1]); padding slots are empty segments (zeros)."""
-    view_lens, obj_lens = _to_list(view_lens), _to_list(obj_lens)
-    N = len(view_lens)
-    idx, start = [], [0]
-    for n in range(N):
-        vl, ol = int(view_lens[n]), int(obj_lens[n])
-        if vl + ol > W:
-            raise ValueError('row %d: %d views + %d objects exceed the padded width %d' % (n, vl, ol, W))
-        for j in range(W):
-            if j < vl:
-                idx.append(n * V + j)
-            elif j < vl + ol:
-                idx.append(N * V + n * O + (j - vl))
-            start.append(len(idx))
-    return torch.tensor(idx or [-1], dtype=torch.int32), torch.tensor(start, dtype=torch.int32)
+    vl = np.asarray(_to_list(view_lens), dtype=np.int64)
+    ol = np.asarray(_to_list(obj_lens), dtype=np.int64)
+    N = len(vl)
+    over = np.nonzero(vl + ol > W)[0]
+    if over.size:
+        n = int(over[0])
+        raise ValueError('row %d: %d views + %d objects exceed the padded width %d' % (n, vl[n], ol[n], W))
+    J = np.arange(W, dtype=np.int64)[None, :]
+    rows = np.arange(N, dtype=np.int64)[:, None]
+    is_view = J < vl[:, None]
+    is_obj = (J >= vl[:, None]) & (J < (vl + ol)[:, None])
+    src = np.where(is_view, rows * V + J, N * V + rows * O + (J - vl[:, None]))
+    used = is_view | is_obj
+    idx = src[used]
+    start = np.concatenate([[0], np.cumsum(used.reshape(-1))])
+    if idx.size == 0:
+        idx = np.array([-1])
+    return torch.from_numpy(idx.astype(np.int32)), torch.from_numpy(start.astype(np.int32))

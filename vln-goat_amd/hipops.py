@@ -926,6 +926,7 @@ def multi_linear(x, weights, biases):
 
 # ----------------------------------------------------------------------------- LayerNorm / dropout
 LN_DETERMINISTIC = os.environ.get('GOAT_LN_DETERMINISTIC', '0') == '1'
+LN_ATOMIC_MAX_ROWS = int(os.environ.get('GOAT_LN_ATOMIC_MAX_ROWS', '4096'))
 
 
 class _LnFn(torch.autograd.Function):
@@ -994,7 +995,8 @@ class _LnFn(torch.autograd.Function):
         db = sb if sunk else torch.empty(H, dtype=torch.float32, device=z.device)
         # LN_DETERMINISTIC: per-block partials in a workspace + a second (reduction) launch; default: the blocks add their column
         # partials to dgamma / dbeta with float atomics (43 fewer launches per step; summation order is not reproducible)
-        ws = torch.empty(L.goat_ln_bwd_ws_floats(H), dtype=torch.float32, device=z.device) if LN_DETERMINISTIC else None
+        # (measured, scripts/ln_bench.py: atomics 15.8 vs 16.7 us at 3840 rows and one launch fewer; 26.3 vs 22.2 us at 8640 rows)
+        ws = torch.empty(L.goat_ln_bwd_ws_floats(H), dtype=torch.float32, device=z.device) if (LN_DETERMINISTIC or M > LN_ATOMIC_MAX_ROWS) else None
         st = L.goat_ln_bwd(_stream(), _dt(z), _ptr(dy2), _ptr(dyb) if dyb is not None else None, _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd),
                            p, seed, off, dev, _ptr(dx), _ptr(dres) if dres is not None else None,
                            _ptr(dg), _ptr(db), _ptr(ws) if ws is not None else None, M, H, int(sunk and not _first_touch(*ctx.gb)))

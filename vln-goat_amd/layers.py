@@ -15,6 +15,8 @@ kernels through `hipops`.  Reference classes mirrored here (P/ = pretrain_src/, 
 """
 import os
 
+import weakref
+
 import torch
 from torch import nn
 
@@ -39,21 +41,58 @@ def compute_dtype():
     return _COMPUTE_DTYPE[0]
 
 
+# Masks depend on the batch's length tensors only; the blocks of a model ask for the same mask many times per step (every
+# cross-modal layer converts the same bool mask into its additive form: 21 tiny ATen launches per pre-training step).  They are
+# memoised per INPUT TENSOR OBJECT (identity checked through a weak reference, so a recycled address cannot alias, and the
+# tensor's version counter, so an in-place edit invalidates) — results are read-only by convention.
+# A captured step reads the memoised tensors at fixed addresses: after new data has been copied into a static batch
+# (train_step.StaticBatch.commit) `refresh_masks()` recomputes the stale entries IN PLACE, sources before derived masks.
+_MASK_MEMO = {}
+
+
+def _memo(tag, t, extra, compute):
+    key = (tag, id(t), extra)
+    ent = _MASK_MEMO.get(key)
+    if ent is not None and ent[0]() is t and ent[1] == t._version:
+        return ent[2]
+    r = compute(t)
+    if len(_MASK_MEMO) > 512:
+        _MASK_MEMO.clear()
+    _MASK_MEMO[key] = [weakref.ref(t), t._version, r, compute]
+    return r
+
+
+def refresh_masks():
+    """recompute, into the same storage, every memoised mask whose source tensor was edited in place (insertion order: a mask
+    derived from another memoised mask is refreshed after it).  Entries of dead tensors are dropped."""
+    for key in list(_MASK_MEMO):
+        ent = _MASK_MEMO[key]
+        t = ent[0]()
+        if t is None:
+            del _MASK_MEMO[key]
+        elif ent[1] != t._version:
+            ent[2].copy_(ent[3](t))
+            ent[1] = t._version
+
+
 def neg_mask(masks, value=-10000.0):
     """bool [N,L] -> additive float32 key mask [N,L] (P/model/ops.py:25-34 without the broadcast dims)."""
-    return (1.0 - masks.float()) * value
+    return _memo('neg', masks, value, lambda m: (1.0 - m.float()) * value)
 
 
 def inf_mask(masks):
     """bool [N,L] (True = valid) -> 0 / -inf (nn.MultiheadAttention key_padding_mask semantics)."""
-    return torch.zeros(masks.shape, dtype=torch.float32, device=masks.device).masked_fill(~masks, float('-inf'))
+    return _memo('inf', masks, None,
+                 lambda m: torch.zeros(m.shape, dtype=torch.float32, device=m.device).masked_fill(~m, float('-inf')))
 
 
 def gen_seq_masks(seq_lens, max_len=None):
     # P/model/ops.py:36-44
     if max_len is None:
         max_len = int(seq_lens.max())
-    return torch.arange(max_len, device=seq_lens.device).unsqueeze(0) < seq_lens.unsqueeze(1)
+    max_len = int(max_len)
+    return _memo('seq', seq_lens, max_len,
+                 lambda sl: torch.arange(max_len, device=sl.device).unsqueeze(0) < sl.unsqueeze(1))
 
 
 class Linear(nn.Linear):

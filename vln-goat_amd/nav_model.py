@@ -339,7 +339,10 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
     def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
                                     gmap_pair_dists, gmap_visited_masks, gmap_vpids, vp_img_embeds, vp_pos_fts, vp_masks,
                                     vp_nav_masks, vp_obj_masks, vp_cand_vpids, front_vp_feats=None, front_gmap_feats=None,
-                                    flops_count=False):
+                                    flops_count=False, nav_fusion=None):
+        """nav_fusion: optional precomputed `nav_fusion_matrix(...)` on the device ([B, G, W] float32) — the agent knows the
+        id strings and the visited flags on the host when it collates the step, so the call itself needs no device -> host
+        read (and can be captured into a hipGraph)."""
         dt = compute_dtype()
         txt_embeds = txt_embeds.to(dt)
         txt_masks = txt_masks.bool() if txt_masks.dtype != torch.bool else txt_masks
@@ -375,7 +378,8 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
         add0[:, 0] = ll[:, 0]
         fused = fused + add0
         if not flops_count:
-            M = _nav_fusion_matrix(vp_cand_vpids, gmap_vpids, gmap_visited_masks, G, ll.shape[1]).to(gl.device)
+            M = nav_fusion if nav_fusion is not None else \
+                nav_fusion_matrix(vp_cand_vpids, gmap_vpids, gmap_visited_masks, G, ll.shape[1]).to(gl.device)
             fused = fused + torch.bmm(M, ll.masked_fill(navm, 0.0).unsqueeze(2)).squeeze(2)
         obj_logits = None
         if vp_obj_masks is not None and getattr(self.config, 'dataset', 'r2r') in ('reverie', 'soon'):
@@ -431,7 +435,8 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
                 batch['txt_embeds'], batch['txt_masks'], batch['gmap_img_embeds'], batch['gmap_step_ids'], batch['gmap_pos_fts'],
                 batch['gmap_masks'], batch['gmap_pair_dists'], batch['gmap_visited_masks'], batch['gmap_vpids'],
                 batch['vp_img_embeds'], batch['vp_pos_fts'], batch['vp_masks'], batch['vp_nav_masks'], batch['vp_obj_masks'],
-                batch['vp_cand_vpids'], batch['front_vp_feats'], batch['front_gmap_feats'], flops_count=batch['flops_count'])
+                batch['vp_cand_vpids'], batch['front_vp_feats'], batch['front_gmap_feats'], flops_count=batch['flops_count'],
+                nav_fusion=batch.get('nav_fusion'))
         if mode == 'instr_zdict_update':
             return self.forward_text(batch['z_txt'], batch['z_txt_mask'], batch['instr_z_direction_features'],
                                      batch['instr_z_direction_pzs'], batch['instr_z_landmark_features'],
@@ -441,7 +446,7 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
         raise ValueError('invalid mode %r' % mode)
 
 
-def _nav_fusion_matrix(vp_cand_vpids, gmap_vpids, gmap_visited_masks, G, W):
+def nav_fusion_matrix(vp_cand_vpids, gmap_vpids, gmap_visited_masks, G, W):
     """fused[b,g] += sum_j M[b,g,j]*local[b,j] — the host loop of M/models/vilmodel_GOAT.py:790-806
     ([stop] and [MEM] slots, j <= 1, are skipped on both sides)."""
     vis = gmap_visited_masks.detach().cpu().tolist()
@@ -464,6 +469,9 @@ def _nav_fusion_matrix(vp_cand_vpids, gmap_vpids, gmap_visited_masks, G, W):
                     for j in bw:
                         M[b, g, j] += 1.0
     return torch.from_numpy(M)
+
+
+_nav_fusion_matrix = nav_fusion_matrix
 
 
 class VLNBert(nn.Module):

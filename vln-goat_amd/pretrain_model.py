@@ -595,7 +595,8 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
                             raise ValueError('MRC mask selects a padded %s slot (sample %d, slot %d)' % (which, b, j))
                         rows.append(b * width + off + j)
             dev = batch['traj_view_img_fts'].device
-            cache[key] = (torch.tensor(rows, dtype=torch.int64, device=dev), mask.to(dev))
+            # (the soft-label rows as flat indices too: boolean-mask indexing would synchronise, and could not be captured)
+            cache[key] = (torch.tensor(rows, dtype=torch.int64, device=dev), mask.reshape(-1).nonzero().squeeze(1).to(dev))
         return cache[key]
 
     def forward_mrc(self, batch, compute_loss):
@@ -604,15 +605,17 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
         _, vp, _ = self.bert(batch, return_gmap_embeds=False)
         B, W1, H = vp.shape
         flat = vp.reshape(B * W1, H)
-        rows, vmask = self._mrc_rows(batch, 'view', W1)
+        rows, vsel = self._mrc_rows(batch, 'view', W1)
         v_pred = self.image_classifier(flat.index_select(0, rows)).float()
-        v_tgt = batch['vp_view_probs'][vmask]
+        probs = batch['vp_view_probs']
+        v_tgt = probs.reshape(-1, probs.shape[-1]).index_select(0, vsel)
         o_pred = o_tgt = None
         if batch['traj_obj_img_fts'] is not None:
-            orow, omask = self._mrc_rows(batch, 'obj', W1)
+            orow, osel = self._mrc_rows(batch, 'obj', W1)
             head = self.obj_classifier if self.obj_classifier is not None else self.image_classifier
             o_pred = head(flat.index_select(0, orow)).float()
-            o_tgt = batch['vp_obj_probs'][omask]
+            probs = batch['vp_obj_probs']
+            o_tgt = probs.reshape(-1, probs.shape[-1]).index_select(0, osel)
         if not compute_loss:
             return v_pred, v_tgt, o_pred, o_tgt
         loss = F.kl_div(F.log_softmax(v_pred, dim=-1), v_tgt.float(), reduction='none').sum(dim=1)

@@ -408,7 +408,7 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
                'gmap_vpids': st['gmap_vpids'], 'vp_img_embeds': vimg, 'vp_pos_fts': mv(st['vp_pos_fts']),
                'vp_masks': mv(st['vp_masks']), 'vp_nav_masks': mv(st['vp_nav_masks']),
                'vp_obj_masks': mv(st['vp_obj_masks']) if has_obj else None,
-               'vp_cand_vpids': st['vp_cand_vpids'], 'flops_count': False}
+               'vp_cand_vpids': st['vp_cand_vpids'], 'flops_count': False, 'nav_fusion': st.get('nav_fusion')}
         if use_facl:
             nin['front_vp_feats'], nin['front_gmap_feats'] = mv(ep['front_vp_feats']), mv(ep['front_gmap_feats'])
         out = model('navigation', dd(nin))

@@ -122,3 +122,161 @@ class PretrainStep:
                 self.optimizer.step()
         info['updated'] = True
         return info
+
+
+def collate_indices(config, batch, tasks=('mlm', 'sap', 'cfp')):
+    """Everything a pre-training step derives from the id STRINGS and label positions of a batch, built on the host from the
+    CPU batch (what pretrain_model.GlocalTextPathCMTPreTraining otherwise builds lazily on first use and caches in
+    batch['_goat_cache']): the graph-map / local-branch gather indices (graphmap.py; P/model/vilmodel_goat.py:377-391,430-468),
+    the MLM row selection (P/model/pretrain_goat.py:196-206) and the SAP fusion matrix (:329-345).  R2R batches (views only)."""
+    from . import graphmap
+    if batch.get('traj_obj_img_fts') is not None:
+        raise NotImplementedError('collate_indices: object batches (REVERIE/SOON) build their indices lazily')
+    V = batch['traj_view_img_fts'].shape[1]
+    G = batch['gmap_step_ids'].shape[1]
+    lens = batch['traj_vp_view_lens']
+    out = {}
+    out['gmap'] = graphmap.build_gmap_index(batch['traj_step_lens'], lens, batch['traj_vpids'], batch['traj_cand_vpids'],
+                                            batch['gmap_vpids'], G, V, bool(config.adaptive_pano_fusion))
+    out['vp'] = graphmap.build_vp_index(batch['traj_step_lens'], lens, V)
+    W = out['vp'][3]
+    if 'mlm' in tasks:
+        labels = batch['txt_labels'].reshape(-1)
+        idx = (labels != -1).nonzero().squeeze(1)
+        out['mlm_idx'], out['mlm_tgt'] = idx, labels[idx]
+    if 'sap' in tasks:
+        last = torch.as_tensor(batch['traj_step_lens']).cumsum(0) - 1
+        nav = batch['traj_nav_types'][last] != 1
+        nav = torch.cat([torch.zeros(nav.shape[0], 1, dtype=torch.bool), nav], 1)[:, :W]
+        out['sap'] = (nav, graphmap.build_sap_fusion(batch['traj_cand_vpids'], batch['gmap_vpids'], batch['gmap_visited_masks'], G, W))
+    return out
+
+
+class StaticBatch:
+    """A device batch at FIXED addresses behind a captured (hipGraph) step, fed with a new host batch per step.
+
+    Every tensor of the batch and every index tensor of `collate_indices` is a view into ONE device buffer; a host batch is
+    packed into a pinned buffer of the same layout (`pack`: the collate step of a loader, P/data/loader.py:78-120), moved with one
+    asynchronous H2D copy into a staging buffer on a side stream (`stage`: overlaps the running step) and swapped in with
+    one D2D copy on the compute stream (`commit`), after which the memoised masks are refreshed in place.  The shapes are
+    those of the batch the object was built from: a host batch with any other shape (ragged T / L, another map size) raises
+    ValueError — such batches go through the eager path (or a StaticBatch of their own shape bucket).
+
+        sb = StaticBatch(model.config, host_batch, tasks)       # sb.gb: the device batch to capture the step on
+        ... capture model(sb.gb, task) ...
+        buf = sb.pack(next_host_batch); sb.stage(buf); sb.commit(); graph.replay()
+    """
+    ALIGN = 256
+
+    def __init__(self, config, host_batch, tasks=('mlm', 'sap', 'cfp'), device='cuda'):
+        self.config, self.tasks, self.device = config, tuple(tasks), torch.device(device)
+        idx = collate_indices(config, host_batch, self.tasks)
+        self.layout = []                   # (key path, offset, shape, dtype)
+        off = 0
+        for path, t in self._tensors(host_batch, idx):
+            n = t.numel() * t.element_size()
+            self.layout.append((path, off, tuple(t.shape), t.dtype))
+            off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.nbytes = max(off, self.ALIGN)
+        self.flat = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
+        self.staging = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
+        self.vp_width = idx['vp'][3]
+        self.gb = self._views(self.flat, host_batch)
+        self.side = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        self._staged = torch.cuda.Event() if self.side is not None else None
+        self._consumed = torch.cuda.Event() if self.side is not None else None
+        first = self.pack(host_batch, _idx=idx)
+        self.flat.copy_(first)
+        self._pending = None
+
+    @staticmethod
+    def _tensors(batch, idx):
+        for k in sorted(batch):
+            if torch.is_tensor(batch[k]):
+                yield ('batch', k), batch[k]
+        for k in sorted(idx):
+            v = idx[k]
+            for i, t in enumerate(v if isinstance(v, tuple) else (v,)):
+                if torch.is_tensor(t):
+                    yield ('idx', k, i), t
+
+    def _views(self, flat, host_batch):
+        gb = {k: v for k, v in host_batch.items() if not torch.is_tensor(v) and k != '_goat_cache'}
+        parts = {}
+        for path, off, shape, dtype in self.layout:
+            n = 1
+            for s in shape:
+                n *= s
+            v = flat[off:off + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(shape)
+            if path[0] == 'batch':
+                gb[path[1]] = v
+            else:
+                parts.setdefault(path[1], {})[path[2]] = v
+        cache = {}
+        for k, d in parts.items():
+            if k == 'vp':
+                cache[k] = (d[0], d[1], d[2], self.vp_width)
+            elif k in ('mlm_idx', 'mlm_tgt'):
+                cache[k] = d[0]
+            else:
+                cache[k] = tuple(d[i] for i in sorted(d))
+        gb['_goat_cache'] = cache
+        return gb
+
+    def new_pinned(self):
+        t = torch.empty(self.nbytes, dtype=torch.uint8)
+        return t.pin_memory() if self.device.type == 'cuda' else t
+
+    def pack(self, host_batch, out=None, _idx=None, tensors=True):
+        """host batch -> flat (pinned) buffer in the device layout; builds the batch's index tensors on the way.
+        tensors=False: only the index tensors are (re)built and written — for a loader that collated the batch's tensors
+        straight into `out` (its previous pack)."""
+        idx = _idx if _idx is not None else collate_indices(self.config, host_batch, self.tasks)
+        if idx['vp'][3] != self.vp_width:
+            raise ValueError('StaticBatch: local-branch width %d != %d of the captured shape' % (idx['vp'][3], self.vp_width))
+        out = out if out is not None else self.new_pinned()
+        got = dict(self._tensors(host_batch, idx))
+        dst = out.numpy()
+        if len(got) != len(self.layout):
+            raise ValueError('StaticBatch: the batch has a different set of tensors than the captured one')
+        for path, off, shape, dtype in self.layout:
+            if not tensors and path[0] == 'batch':
+                continue
+            t = got.get(path)
+            if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+                raise ValueError('StaticBatch: %s is %s %s, the captured shape is %s %s'
+                                 % ('/'.join(map(str, path)), None if t is None else tuple(t.shape), None if t is None else t.dtype, shape, dtype))
+            n = t.numel() * t.element_size()
+            # (plain memcpy through numpy: torch's threaded copy_ costs more in thread wake-ups than it saves on 27 MB)
+            dst[off:off + n] = t.contiguous().view(-1).view(torch.uint8).numpy() if n else dst[off:off]
+        return out
+
+    def stage(self, packed):
+        """asynchronous H2D of a packed batch into the staging buffer (side stream; waits until the previous commit has read it).
+        -> event that completes when `packed` has been read (None on CPU): synchronise on it before rewriting the buffer."""
+        if self.side is None:
+            self._pending = packed
+            return None
+        self.side.wait_event(self._consumed)
+        with torch.cuda.stream(self.side):
+            self.staging.copy_(packed, non_blocking=True)
+            self._staged.record(self.side)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self._pending = packed
+        return done
+
+    def commit(self):
+        """compute stream: staged batch -> the static buffer (one D2D copy), then the memoised masks are recomputed in place."""
+        from . import layers
+        if self._pending is None:
+            raise RuntimeError('StaticBatch.commit without a staged batch')
+        if self.side is None:
+            self.flat.copy_(self._pending)
+        else:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self._staged)
+            self.flat.copy_(self.staging, non_blocking=True)
+            self._consumed.record(cur)
+        self._pending = None
+        layers.refresh_masks()
