@@ -106,8 +106,21 @@ int goat_ln_fwd(void* stream, int dtype, const void* x, const void* residual,
  * ws == NULL (default): every block adds its column partials to dgamma / dbeta with float atomics — one launch, summation
  *   order not reproducible (accumulate=0 clears the two vectors with a memset node first).
  * ws != NULL: float32 scratch of goat_ln_bwd_ws_floats(H) elements for per-block column partials; a second tiny kernel
- *   reduces them — no atomics, deterministic (round-1 behaviour: 43 extra launches per pre-training step). */
+ *   reduces them — no atomics, deterministic (round-1 behaviour: 43 extra launches per pre-training step).
+ * accumulate == 2 (ws required, goat_ln_bwd_nparts(M) * 2 * H floats): the per-block partials are LEFT in ws and nothing is
+ *   written to dgamma / dbeta; the caller sums the partials of many LayerNorm calls into their gradient vectors with ONE
+ *   goat_ln_reduce_batched launch when the backward pass ends (the column reduction is 40 % of this kernel's time at the GOAT
+ *   row counts; deterministic). */
+typedef struct goat_ln_partial {
+  const float* ws;         /* partials written by goat_ln_bwd(..., accumulate = 2): [nparts][2][H] float32 */
+  float* dgamma;           /* float32[H], ADDED to */
+  float* dbeta;
+  int32_t nparts;          /* goat_ln_bwd_nparts(M) of that call */
+  int32_t reserved;
+} goat_ln_partial;
 int goat_ln_bwd_ws_floats(int H);
+int goat_ln_bwd_nparts(int M);
+int goat_ln_reduce_batched(void* stream, const goat_ln_partial* entries, int n, int H);
 int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* dy2, const void* z,
                 const float* gamma, const float* mean, const float* rstd,
                 float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev,
@@ -284,10 +297,11 @@ int goat_adamw_step(void* stream, const float* grad_arena, float* exp_avg, float
 
 /* CFP contrastive losses (P/model/pretrain_goat.py:519-534): loss[i] = sum over x in {gmap, vp, fused} of
  * 1/2 [CE(x_loc[i]·txt_allᵀ/τ, t_i) + CE(txt_loc[i]·x_allᵀ/τ, t_i)], t_i = target0 + i.  x_loc / x_all: arrays of 3 device
- * pointers ([Bl,H] / [Ba,H] float32; all = loc on one rank, the all-gathered rows under data parallelism); loss [Bl]
- * PRE-ZEROED (six contributions are added atomically); prob: [6,Bl,Ba] float32 scratch the backward reads.
- * Backward: gradients are ADDED to the pre-zeroed dx_loc[k] / dx_all[k] / dtxt_loc / dtxt_all (any may be NULL; loc and
- * all pointers may alias on one rank).  Replaces ~70 ATen launches of the torch formulation of a CFP step. */
+ * pointers ([Bl,H] / [Ba,H] float32; all = loc on one rank, the all-gathered rows under data parallelism); loss [Bl] is
+ * ADDED to (one writer per sample: deterministic); prob: [6,Bl,Ba] float32 scratch the backward reads.
+ * Backward: gradients are ADDED to dx_loc[k] / dx_all[k] / dtxt_loc / dtxt_all (any may be NULL; loc and all pointers may
+ * alias on one rank).  Every output element has one writer that sums its contributions in a fixed order — no atomics, so a
+ * captured or phased step reproduces the eager one bit for bit.  Replaces ~70 ATen launches of the torch formulation. */
 int goat_infonce_fwd(void* stream, const float* const* x_loc, const float* const* x_all, const float* txt_loc,
                      const float* txt_all, float* loss, float* prob, int Bl, int Ba, int H, int target0, float temperature);
 int goat_infonce_bwd(void* stream, const float* const* x_loc, const float* const* x_all, const float* txt_loc,

@@ -148,6 +148,44 @@ def test_layer_norm_fwd_bwd(ops, dtype, with_res):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_layer_norm_deferred_column_reduction(ops, dtype):
+    """goat_ln_bwd(accumulate = 2) + goat_ln_reduce_batched: two LayerNorm calls that share gamma / beta (bound to
+    pre-zeroed gradient slices, as under the gradient arena) and a third with its own leave their column partials behind;
+    the one batched reduction at the end of the backward pass adds them up — same values as torch autograd."""
+    H = 768
+    g = torch.Generator().manual_seed(31)
+    mk = lambda *s: torch.randn(*s, generator=g)
+    params = [(1 + 0.1 * mk(H)).to(DEV).requires_grad_(True) for _ in range(2)] + [(0.1 * mk(H)).to(DEV).requires_grad_(True) for _ in range(2)]
+    g1, g2, b1, b2 = params
+    sinks = [torch.zeros(H, device=DEV) for _ in params]
+    for prm, snk in zip(params, sinks):
+        prm.grad = snk
+        prm.__dict__['_goat_sink'] = snk
+        prm.__dict__['_goat_prezero'] = True
+    xs = [mk(m, H).to(DEV, dtype).requires_grad_(True) for m in (515, 3840, 1056)]
+    dys = [mk(m, H).to(DEV, dtype) for m in (515, 3840, 1056)]
+    try:
+        assert ops.LnReduceQueue.enabled
+        ys = [ops.layer_norm(xs[0], g1, b1, 1e-12), ops.layer_norm(xs[1], g1, b1, 1e-12), ops.layer_norm(xs[2], g2, b2, 1e-12)]
+        torch.autograd.backward(ys, dys)
+        assert not ops.LnReduceQueue.items            # flushed by the end-of-backward callback
+        torch.cuda.synchronize()
+    finally:
+        for prm in params:
+            prm.__dict__.pop('_goat_sink', None)
+            prm.__dict__.pop('_goat_prezero', None)
+    xr = [x.detach().float().requires_grad_(True) for x in xs]
+    pr = [q.detach().clone().requires_grad_(True) for q in params]
+    yr = [torch.nn.functional.layer_norm(xr[0], (H,), pr[0], pr[2], 1e-12), torch.nn.functional.layer_norm(xr[1], (H,), pr[0], pr[2], 1e-12),
+          torch.nn.functional.layer_norm(xr[2], (H,), pr[1], pr[3], 1e-12)]
+    torch.autograd.backward(yr, [d.float() for d in dys])
+    for a, b in zip(xs, xr):
+        _close(a.grad, b.grad, dtype, 'ln deferred dx')
+    for snk, q, n in zip(sinks, pr, ['dgamma shared', 'dgamma own', 'dbeta shared', 'dbeta own']):
+        _close(snk, q.grad, dtype, 'ln deferred ' + n)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_dropout_mask_consistency_and_rate(ops, dtype):
     ops.manual_seed(123)
     n = 1 << 20

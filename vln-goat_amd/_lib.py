@@ -35,6 +35,8 @@ SIGNATURES = {
     'goat_transpose': [_vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _vp],
     'goat_ln_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
     'goat_ln_bwd_ws_floats': [_i32],
+    'goat_ln_bwd_nparts': [_i32],
+    'goat_ln_reduce_batched': [_vp, _vp, _i32, _i32],
     'goat_ln_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_dropout_add_fwd': [_vp, _i32, _vp, _vp, _vp, _i64, _f32, _u64, _u64, _vp],
     'goat_dropout_bwd': [_vp, _i32, _vp, _vp, _i64, _f32, _u64, _u64, _vp],
@@ -62,6 +64,12 @@ SIGNATURES = {
     'goat_infonce_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32],
     'goat_probe_tr16': [_vp, _vp],
 }
+
+
+class LnPartial(ctypes.Structure):
+    """struct goat_ln_partial (include/goat_hip.h)."""
+    _fields_ = [('ws', ctypes.c_void_p), ('dgamma', ctypes.c_void_p), ('dbeta', ctypes.c_void_p), ('nparts', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
 
 
 class AdamwTensor(ctypes.Structure):

@@ -244,76 +244,93 @@ __global__ __launch_bounds__(256) void dict_wsum_bwd_kernel(const T* __restrict_
 // t_i = target0 + i  (P/model/pretrain_goat.py:519-534; `all` = the rows of every data-parallel rank, = `loc` on one rank).
 // Six (pair, direction) similarity problems of [Bl x Ba x H]: the reference issues ~70 ATen kernels for them and their
 // gradients (18 mm, 19 div, 6 log_softmax ...: 0.7 ms of a CFP step); here one forward and one backward launch.
-//   forward : block (pd, i): S[j] = <A_pd[i], B_pd[j]> / tau for all j (one wave per j, lanes over H), softmax over j saved to
-//             prob[pd][i][:], 0.5 * (lse - S[t_i]) added to loss[i].
-//   backward: block (pd, 64-column tile): G = (prob - onehot) * dloss_i / (2 tau);  dA[:, cols] += G . B[:, cols],
-//             dB[:, cols] += G^T . A[:, cols]  (float atomics: several problems feed the same tensor).
+//   forward : block i: for each of the six problems S[j] = <A_pd[i], B_pd[j]> / tau for all j (one wave per j, lanes over H),
+//             softmax over j saved to prob[pd][i][:]; loss[i] += sum_pd 0.5 * (lse - S[t_i])  — one writer per sample.
+//   backward: every output tensor element has ONE writer that sums its contributions in a fixed order (no atomics: in a bf16
+//             chain a 1e-7 summation-order difference is amplified to ~1e-3 by the roundings downstream, and the captured /
+//             phased steps must reproduce the eager step).  G_pd = (prob_pd - onehot) * dloss_i / (2 tau);
+//             dA_pd[i] = sum_j G[i,j] B_pd[j],  dB_pd[j] = sum_i G[i,j] A_pd[i].  An output "role" is (tensor, its terms): pointers
+//             that alias (loc == all on one rank) are merged into one role on the host.
 struct NceArgs {
   const float* a[6];      // [Bl, H] operand whose rows are the samples of this rank
   const float* b[6];      // [Ba, H] operand holding the candidates
   float* da[6];
   float* db[6];
   float* prob;            // [6, Bl, Ba]
-  float* loss;            // [Bl] (pre-zeroed)
+  float* loss;            // [Bl]
   const float* dloss;     // [Bl]
   int Bl, Ba, H, target0;
   float inv_tau;
 };
 
+struct NceRole { float* out; int rows; int n; int pd[6]; int is_b[6]; };
+struct NceBwdArgs { NceArgs p; NceRole role[8]; int nroles; int row_groups; };
+
 __global__ __launch_bounds__(256) void infonce_fwd_kernel(NceArgs p) {
   extern __shared__ float sh[];           // [Ba] similarities
-  const int pd = blockIdx.x / p.Bl, i = blockIdx.x % p.Bl;
+  __shared__ float lsum;
+  const int i = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* arow = p.a[pd] + (int64_t)i * p.H;
-  for (int j = wave; j < p.Ba; j += 4) {
-    const float* brow = p.b[pd] + (int64_t)j * p.H;
-    float s = 0.f;
-    for (int k = lane * 4; k < p.H; k += 256) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(arow + k), y = *reinterpret_cast<const f32x4*>(brow + k);
-      s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+  if (threadIdx.x == 0) lsum = 0.f;
+  for (int pd = 0; pd < 6; ++pd) {
+    const float* arow = p.a[pd] + (int64_t)i * p.H;
+    __syncthreads();
+    for (int j = wave; j < p.Ba; j += 4) {
+      const float* brow = p.b[pd] + (int64_t)j * p.H;
+      float s = 0.f;
+      for (int k = lane * 4; k < p.H; k += 256) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(arow + k), y = *reinterpret_cast<const f32x4*>(brow + k);
+        s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+      }
+      s = wave_sum(s);
+      if (lane == 0) sh[j] = s * p.inv_tau;
     }
-    s = wave_sum(s);
-    if (lane == 0) sh[j] = s * p.inv_tau;
+    __syncthreads();
+    if (wave == 0) {
+      float m = -INFINITY;
+      for (int j = lane; j < p.Ba; j += 64) m = fmaxf(m, sh[j]);
+      m = wave_max(m);
+      float l = 0.f;
+      for (int j = lane; j < p.Ba; j += 64) l += __expf(sh[j] - m);
+      l = wave_sum(l);
+      const float lse = m + __logf(l);
+      float* pr = p.prob + ((int64_t)pd * p.Bl + i) * p.Ba;
+      for (int j = lane; j < p.Ba; j += 64) pr[j] = __expf(sh[j] - lse);
+      if (lane == 0) lsum += 0.5f * (lse - sh[p.target0 + i]);
+    }
   }
   __syncthreads();
-  if (wave == 0) {
-    float m = -INFINITY;
-    for (int j = lane; j < p.Ba; j += 64) m = fmaxf(m, sh[j]);
-    m = wave_max(m);
-    float l = 0.f;
-    for (int j = lane; j < p.Ba; j += 64) l += __expf(sh[j] - m);
-    l = wave_sum(l);
-    const float lse = m + __logf(l);
-    float* pr = p.prob + ((int64_t)pd * p.Bl + i) * p.Ba;
-    for (int j = lane; j < p.Ba; j += 64) pr[j] = __expf(sh[j] - lse);
-    if (lane == 0) atomicAdd(p.loss + i, 0.5f * (lse - sh[p.target0 + i]));
-  }
+  if (threadIdx.x == 0) p.loss[i] += lsum;
 }
 
-__global__ __launch_bounds__(256) void infonce_bwd_kernel(NceArgs p) {
-  const int pd = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-  if (c >= p.H) return;
-  const float* A = p.a[pd];
-  const float* B = p.b[pd];
-  const float* pr = p.prob + (int64_t)pd * p.Bl * p.Ba;
+// grid (role * row_groups + row group of 4 rows, 64-column tile); thread = (row in group, column)
+__global__ __launch_bounds__(256) void infonce_bwd_kernel(NceBwdArgs q) {
+  const NceArgs& p = q.p;
+  const int ro = blockIdx.x / q.row_groups, rg = blockIdx.x % q.row_groups;
+  const NceRole& role = q.role[ro];
+  const int r = rg * 4 + (threadIdx.x >> 6), c = blockIdx.y * 64 + (threadIdx.x & 63);
+  if (r >= role.rows || c >= p.H) return;
   const float half_tau = 0.5f * p.inv_tau;
-  // dA[i, c] = sum_j G[i, j] B[j, c]
-  if (p.da[pd] != nullptr)
-    for (int i = grp; i < p.Bl; i += 4) {
-      const float gi = p.dloss[i] * half_tau;
-      const int t = p.target0 + i;
-      float acc = 0.f;
-      for (int j = 0; j < p.Ba; ++j) acc += (pr[(int64_t)i * p.Ba + j] - (j == t ? 1.f : 0.f)) * B[(int64_t)j * p.H + c];
-      atomicAdd(p.da[pd] + (int64_t)i * p.H + c, acc * gi);
-    }
-  // dB[j, c] = sum_i G[i, j] A[i, c]
-  if (p.db[pd] != nullptr)
-    for (int j = grp; j < p.Ba; j += 4) {
-      float acc = 0.f;
+  float tot = 0.f;
+  for (int t = 0; t < role.n; ++t) {
+    const int pd = role.pd[t];
+    const float* pr = p.prob + (int64_t)pd * p.Bl * p.Ba;
+    float acc = 0.f;
+    if (!role.is_b[t]) {            // dA[r, c] = g_r * sum_j (P[r, j] - [j == t_r]) B[j, c]
+      if (r < p.Bl) {
+        const float* B = p.b[pd];
+        const int tr = p.target0 + r;
+        for (int j = 0; j < p.Ba; ++j) acc += (pr[(int64_t)r * p.Ba + j] - (j == tr ? 1.f : 0.f)) * B[(int64_t)j * p.H + c];
+        acc *= p.dloss[r] * half_tau;
+      }
+    } else if (r < p.Ba) {          // dB[r, c] = sum_i g_i (P[i, r] - [r == t_i]) A[i, c]
+      const float* A = p.a[pd];
       for (int i = 0; i < p.Bl; ++i)
-        acc += (pr[(int64_t)i * p.Ba + j] - (j == p.target0 + i ? 1.f : 0.f)) * (p.dloss[i] * half_tau) * A[(int64_t)i * p.H + c];
-      atomicAdd(p.db[pd] + (int64_t)j * p.H + c, acc);
+        acc += (pr[(int64_t)i * p.Ba + r] - (r == p.target0 + i ? 1.f : 0.f)) * (p.dloss[i] * half_tau) * A[(int64_t)i * p.H + c];
     }
+    tot += acc;
+  }
+  role.out[(int64_t)r * p.H + c] += tot;
 }
 
 }  // namespace
@@ -449,7 +466,7 @@ extern "C" int goat_infonce_fwd(void* stream, const float* const* x_loc, const f
   if (int e = nce_fill(a, x_loc, x_all, txt_loc, txt_all, nullptr, nullptr, nullptr, nullptr, prob, Bl, Ba, H, target0, temperature)) return e;
   if ((size_t)Ba * 4 > 64 * 1024) return GOAT_E_SHAPE;
   a.loss = loss;
-  hipLaunchKernelGGL(infonce_fwd_kernel, dim3(6 * Bl), dim3(256), (size_t)Ba * 4, reinterpret_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(infonce_fwd_kernel, dim3(Bl), dim3(256), (size_t)Ba * 4, reinterpret_cast<hipStream_t>(stream), a);
   GOAT_LAUNCH_CHECK();
   return 0;
 }
@@ -463,7 +480,25 @@ extern "C" int goat_infonce_bwd(void* stream, const float* const* x_loc, const f
                        temperature))
     return e;
   a.dloss = dloss;
-  hipLaunchKernelGGL(infonce_bwd_kernel, dim3(6, (H + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  NceBwdArgs q = {};
+  q.p = a;
+  // roles: one per distinct output pointer; its terms in the fixed order pd = 0..5, dA before dB
+  for (int pd = 0; pd < 6; ++pd)
+    for (int is_b = 0; is_b < 2; ++is_b) {
+      float* out = is_b ? a.db[pd] : a.da[pd];
+      if (!out) continue;
+      int ro = 0;
+      while (ro < q.nroles && q.role[ro].out != out) ++ro;
+      if (ro == q.nroles) { q.role[ro].out = out; q.role[ro].rows = 0; q.role[ro].n = 0; ++q.nroles; }
+      NceRole& role = q.role[ro];
+      role.pd[role.n] = pd; role.is_b[role.n] = is_b; ++role.n;
+      const int rows = is_b ? Ba : Bl;
+      if (rows > role.rows) role.rows = rows;
+    }
+  if (q.nroles == 0) return 0;
+  q.row_groups = (Ba + 3) / 4;
+  hipLaunchKernelGGL(infonce_bwd_kernel, dim3(q.nroles * q.row_groups, (H + 63) / 64), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), q);
   GOAT_LAUNCH_CHECK();
   return 0;
 }

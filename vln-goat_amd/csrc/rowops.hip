@@ -6,6 +6,9 @@
 
 namespace {
 
+#ifndef GOAT_LN_ABL
+#define GOAT_LN_ABL 0      // (ablation builds of scripts/ln_bench.py: 1 no column reduction, 2 no dropout hash, 4 no stores)
+#endif
 constexpr int MAXC_MAX = 8;  // 16-B chunks per lane kept in registers: H <= 64*MAXC*EPC (MAXC is a template parameter)
 
 // ------------------------------------------------------------------------------------ LayerNorm fwd
@@ -173,8 +176,16 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(const T* __restrict__ 
           Chunk<T> o;
 #pragma unroll
           for (int e = 0; e < EPC; ++e) o.v[e] = (vdy[u][i].v[e] - c1[u] - vz[u][i].v[e] * c2[u]) * rs[u];
+#if GOAT_LN_ABL & 4
+          asm volatile("" ::"v"(o.v[0]), "v"(o.v[EPC - 1]));
+          continue;
+#endif
           if (dres) o.store_stream(dres + base);
+#if GOAT_LN_ABL & 2
+          if (false) {
+#else
           if (drop) {
+#endif
             const uint32_t km = rng.keep_bits<EPC>(offset + base, thr);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o.v[e] = ((km >> e) & 1u) ? o.v[e] * ks : 0.f;
@@ -185,6 +196,11 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(const T* __restrict__ 
     }
   }
   // block reduction of the column partials
+#if GOAT_LN_ABL & 1
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) asm volatile("" ::"v"(dg[i][0]), "v"(db[i][0]), "v"(dg[i][EPC - 1]), "v"(db[i][EPC - 1]));
+  return;
+#endif
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int c = lane + 64 * i;
@@ -232,6 +248,39 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     for (int k = 0; k < 16; ++k) t += red[k][cx];
     float* dst = (i < H) ? dgamma + i : dbeta + (i - H);
     *dst = accumulate ? *dst + t : t;
+  }
+}
+
+// Deferred reduction (goat_ln_bwd with accumulate == 2 leaves per-block partials behind): ONE launch at the end of the backward pass
+// sums the partials of up to 64 LayerNorm calls into their (pre-zeroed / accumulating) gradient vectors.  blockIdx.y = entry.
+struct LnPartial { const float* ws; float* dgamma; float* dbeta; int nparts; int pad; };
+struct LnReduceArgs { LnPartial e[64]; int n; int H; };
+__global__ __launch_bounds__(256) void ln_reduce_batched_kernel(LnReduceArgs a) {
+  __shared__ float red[16][17];
+  const LnPartial& en = a.e[blockIdx.y];
+  const float* __restrict__ ws = en.ws;
+  const int nparts = en.nparts, H = a.H;
+  const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < 2 * H) {
+    int b = g;
+    for (; b + 48 < nparts; b += 64) {
+      s0 += ws[(int64_t)b * 2 * H + i];
+      s1 += ws[(int64_t)(b + 16) * 2 * H + i];
+      s2 += ws[(int64_t)(b + 32) * 2 * H + i];
+      s3 += ws[(int64_t)(b + 48) * 2 * H + i];
+    }
+    for (; b < nparts; b += 16) s0 += ws[(int64_t)b * 2 * H + i];
+  }
+  red[g][cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && i < 2 * H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cx];
+    float* dst = (i < H) ? en.dgamma + i : en.dbeta + (i - H);
+    *dst += t;
   }
 }
 
@@ -437,7 +486,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in
 // ------------------------------------------------------------------------------------ pano fusion
 // one block (4 waves) per panorama; V <= 64 slots.  score_v = tanh(x_v·a + a0); w = softmax_v(score)
 template <typename T>
-__global__ __launch_bounds__(256) void pano_fusion_fwd_kernel(const T* __restrict__ x, const float* __restrict__ a,
+__global__ __launch_bounds__(256) void pano_fusion_fwd_generic(const T* __restrict__ x, const float* __restrict__ a,
                                                               const float* __restrict__ a0, T* __restrict__ fused,
                                                               float* __restrict__ wsave, int V, int H) {
   __shared__ float sc[64];
@@ -468,7 +517,7 @@ __global__ __launch_bounds__(256) void pano_fusion_fwd_kernel(const T* __restric
 // backward: df[H] given.  g_v = x_v·df ; d(softmax in)_v = w_v (g_v - sum_u w_u g_u) ;
 // dscore_v = d(softmax in)_v * (1 - tanh^2(x_v·a + a0)) ; dx_v = w_v*df + dscore_v * a
 template <typename T>
-__global__ __launch_bounds__(256) void pano_fusion_bwd_kernel(const T* __restrict__ x, const float* __restrict__ a,
+__global__ __launch_bounds__(256) void pano_fusion_bwd_generic(const T* __restrict__ x, const float* __restrict__ a,
                                                               const float* __restrict__ a0,
                                                               const float* __restrict__ wsave, const T* __restrict__ dfused,
                                                               T* __restrict__ dx, float* __restrict__ da,
@@ -511,6 +560,201 @@ __global__ __launch_bounds__(256) void pano_fusion_bwd_kernel(const T* __restric
     float s = 0.f;
     for (int v = 0; v < V; ++v) s += dsc[v];
     atomicAdd(da0, s);
+  }
+}
+
+// Single-pass versions (H % EPC == 0, H <= 64*EPC*MAXC): one block of 8 waves per panorama, wave w keeps rows w, w+8, ... (<= 8 of
+// them) in registers as 16-byte chunks, so x is read once (the generic kernels above read it twice with 2-byte loads: 70 / 82 us
+// for 240 panoramas of 36 x 768 against ~8 us here).  Cross-wave sums (the fused vector, da) go through LDS.
+constexpr int PF_NW = 8, PF_RMAX = 8;
+template <typename T, int MAXC>
+__global__ __launch_bounds__(64 * PF_NW) void pano_fusion_fwd_kernel(const T* __restrict__ x, const float* __restrict__ a,
+                                                                     const float* __restrict__ a0, T* __restrict__ fused,
+                                                                     float* __restrict__ wsave, int V, int H) {
+  constexpr int EPC = DT<T>::EPC;
+  extern __shared__ float psm[];   // [PF_NW][H]
+  __shared__ float sc[64];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = H / EPC;
+  const T* xb = x + (int64_t)n * V * H;
+  Chunk<T> xv[PF_RMAX][MAXC];
+#pragma unroll
+  for (int r = 0; r < PF_RMAX; ++r) {
+    const int v = wave + PF_NW * r;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (v < V && c < nchunk) xv[r][i].load(xb + (int64_t)v * H + c * EPC);
+      else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) xv[r][i].v[e] = 0.f;
+      }
+    }
+  }
+  float av[MAXC][EPC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) av[i][e] = c < nchunk ? a[c * EPC + e] : 0.f;
+  }
+  const float bias = a0[0];
+#pragma unroll
+  for (int r = 0; r < PF_RMAX; ++r) {
+    const int v = wave + PF_NW * r;
+    if (v < V) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s += xv[r][i].v[e] * av[i][e];
+      s = wave_sum(s);
+      if (lane == 0) sc[v] = tanhf(s + bias);
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float v = lane < V ? sc[lane] : -INFINITY;
+    const float m = wave_max(v);
+    const float e = lane < V ? __expf(v - m) : 0.f;
+    const float l = wave_sum(e);
+    if (lane < V) { sc[lane] = e / l; wsave[(int64_t)n * V + lane] = e / l; }
+  }
+  __syncthreads();
+  float acc[MAXC][EPC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[i][e] = 0.f;
+#pragma unroll
+  for (int r = 0; r < PF_RMAX; ++r) {
+    const int v = wave + PF_NW * r;
+    if (v < V) {
+      const float w = sc[v];
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[i][e] += w * xv[r][i].v[e];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) psm[wave * H + c * EPC + e] = acc[i][e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H; i += 64 * PF_NW) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < PF_NW; ++w) s += psm[w * H + i];
+    fused[(int64_t)n * H + i] = from_f<T>(s);
+  }
+}
+
+template <typename T, int MAXC>
+__global__ __launch_bounds__(64 * PF_NW) void pano_fusion_bwd_kernel(const T* __restrict__ x, const float* __restrict__ a,
+                                                                     const float* __restrict__ a0,
+                                                                     const float* __restrict__ wsave, const T* __restrict__ dfused,
+                                                                     T* __restrict__ dx, float* __restrict__ da,
+                                                                     float* __restrict__ da0, int V, int H) {
+  constexpr int EPC = DT<T>::EPC;
+  extern __shared__ float psm[];   // [PF_NW][H]
+  __shared__ float gl[64], tl[64], dsc[64], wl[64];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = H / EPC;
+  const T* xb = x + (int64_t)n * V * H;
+  Chunk<T> xv[PF_RMAX][MAXC];
+#pragma unroll
+  for (int r = 0; r < PF_RMAX; ++r) {
+    const int v = wave + PF_NW * r;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (v < V && c < nchunk) xv[r][i].load(xb + (int64_t)v * H + c * EPC);
+      else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) xv[r][i].v[e] = 0.f;
+      }
+    }
+  }
+  float av[MAXC][EPC];
+  Chunk<T> dfv[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) dfv[i].load(dfused + (int64_t)n * H + c * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      av[i][e] = c < nchunk ? a[c * EPC + e] : 0.f;
+      if (c >= nchunk) dfv[i].v[e] = 0.f;
+    }
+  }
+  const float bias = a0[0];
+#pragma unroll
+  for (int r = 0; r < PF_RMAX; ++r) {
+    const int v = wave + PF_NW * r;
+    if (v < V) {
+      float g = 0.f, s = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { g += xv[r][i].v[e] * dfv[i].v[e]; s += xv[r][i].v[e] * av[i][e]; }
+      g = wave_sum(g);
+      s = wave_sum(s);
+      if (lane == 0) { gl[v] = g; tl[v] = tanhf(s + bias); }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float w = lane < V ? wsave[(int64_t)n * V + lane] : 0.f;
+    const float g = lane < V ? gl[lane] : 0.f;
+    const float wg = wave_sum(w * g);
+    const float d = w * (g - wg) * (1.f - tl[lane < V ? lane : 0] * tl[lane < V ? lane : 0]);
+    if (lane < V) { dsc[lane] = d; wl[lane] = w; }
+    const float tot = wave_sum(lane < V ? d : 0.f);
+    if (lane == 0) atomicAdd(da0, tot);
+  }
+  __syncthreads();
+  float acc[MAXC][EPC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[i][e] = 0.f;
+#pragma unroll
+  for (int r = 0; r < PF_RMAX; ++r) {
+    const int v = wave + PF_NW * r;
+    if (v < V) {
+      const float w = wl[v], d = dsc[v];
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          o.v[e] = w * dfv[i].v[e] + d * av[i][e];
+          acc[i][e] += d * xv[r][i].v[e];
+        }
+        if (c < nchunk) o.store_stream(dx + ((int64_t)n * V + v) * H + c * EPC);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) psm[wave * H + c * EPC + e] = acc[i][e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H; i += 64 * PF_NW) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < PF_NW; ++w) s += psm[w * H + i];
+    atomicAdd(da + i, s);
   }
 }
 
@@ -720,6 +964,28 @@ extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* r
 
 extern "C" int goat_ln_bwd_ws_floats(int H) { return GOAT_LN_BWD_PARTS * 2 * H; }
 
+extern "C" int goat_ln_bwd_nparts(int M) {       // partial rows written by goat_ln_bwd(..., accumulate = 2)
+  int nparts = (M + GOAT_LN_BWD_WAVES * GOAT_LN_RIF - 1) / (GOAT_LN_BWD_WAVES * GOAT_LN_RIF);
+  return nparts > GOAT_LN_BWD_PARTS ? GOAT_LN_BWD_PARTS : nparts;
+}
+
+extern "C" int goat_ln_reduce_batched(void* stream, const goat_ln_partial* entries, int n, int H) {
+  if (!entries || n < 0 || H <= 0) return GOAT_E_ARG;
+  for (int first = 0; first < n; first += 64) {
+    LnReduceArgs a;
+    a.n = n - first < 64 ? n - first : 64;
+    a.H = H;
+    for (int k = 0; k < a.n; ++k) {
+      const goat_ln_partial& e = entries[first + k];
+      if (!e.ws || !e.dgamma || !e.dbeta || e.nparts <= 0) return GOAT_E_ARG;
+      a.e[k].ws = e.ws; a.e[k].dgamma = e.dgamma; a.e[k].dbeta = e.dbeta; a.e[k].nparts = e.nparts; a.e[k].pad = 0;
+    }
+    hipLaunchKernelGGL(ln_reduce_batched_kernel, dim3((2 * H + 15) / 16, a.n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    GOAT_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* dy2, const void* z, const float* gamma,
                            const float* mean, const float* rstd, float p, uint64_t seed, uint64_t offset,
                            const uint64_t* rng_dev, void* dx, void* d_res, float* dgamma, float* dbeta, float* ws,
@@ -729,13 +995,17 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
   // deterministic mode (ws): 4-wave blocks, up to 512 per-block partial rows reduced by a second kernel (round 1).
   // atomic mode: GOAT_LN_BWD_WAVES-wave blocks (default 8) so that fewer blocks contend for the 2*H gradient words —
   // 512 four-wave blocks made the kernel 20 us instead of 12 + 5 (profiles/round2_ln_bench.txt)
-  const bool det = ws != nullptr;
+  // accumulate == 2: the per-block partials stay in ws (goat_ln_bwd_nparts(M) rows of 2*H floats) and the caller reduces them
+  // later with goat_ln_reduce_batched — the column reduction was 6.8 of the kernel's 15.8 us at 3840 rows (profiles/round2_ln_bench.txt)
+  const bool defer = accumulate == 2;
+  if (defer && ws == nullptr) return GOAT_E_ARG;
+  const bool det = ws != nullptr && !defer;
   const int nwv = det ? 4 : GOAT_LN_BWD_WAVES;
   int nparts = (M + nwv * GOAT_LN_RIF - 1) / (nwv * GOAT_LN_RIF);   // nwv waves x RIF rows in flight per block
   if (nparts > GOAT_LN_BWD_PARTS) nparts = GOAT_LN_BWD_PARTS;
   const size_t sm = (size_t)nwv * 2 * H * sizeof(float);
   if (sm > 160 * 1024) return GOAT_E_SHAPE;
-  if (!det && !accumulate) {      // atomic mode writes by accumulation: an overwrite clears the two vectors first
+  if (!det && !defer && !accumulate) {      // atomic mode writes by accumulation: an overwrite clears the two vectors first
     hipError_t e1 = hipMemsetAsync(dgamma, 0, (size_t)H * sizeof(float), ST(stream));
     hipError_t e2 = hipMemsetAsync(dbeta, 0, (size_t)H * sizeof(float), ST(stream));
     if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
@@ -767,7 +1037,7 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
   }
 #undef GOAT_LN_BWD_LAUNCH
   GOAT_LAUNCH_CHECK();
-  if (ws != nullptr) {
+  if (det) {
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 15) / 16), dim3(256), 0, ST(stream), ws, dgamma, dbeta, nparts,
                        H, accumulate);
     GOAT_LAUNCH_CHECK();
@@ -903,14 +1173,27 @@ extern "C" int goat_pano_fusion_fwd(void* stream, int dtype, const void* x, cons
                                     float* wsave, int N, int V, int H) {
   if (!x || !a || !a0 || !fused || !wsave) return GOAT_E_ARG;
   if (N <= 0 || V <= 0 || V > 64 || H <= 0) return GOAT_E_SHAPE;
-  if (dtype == GOAT_BF16)
-    hipLaunchKernelGGL(pano_fusion_fwd_kernel<bf16_t>, dim3(N), dim3(256), 0, ST(stream), (const bf16_t*)x, a, a0,
-                       (bf16_t*)fused, wsave, V, H);
-  else if (dtype == GOAT_F32)
-    hipLaunchKernelGGL(pano_fusion_fwd_kernel<float>, dim3(N), dim3(256), 0, ST(stream), (const float*)x, a, a0,
-                       (float*)fused, wsave, V, H);
-  else
+  size_t sm = (size_t)PF_NW * H * sizeof(float);
+#ifdef GOAT_PANO_GENERIC
+  sm = 1 << 30;
+#endif
+  if (dtype == GOAT_BF16) {
+    if (H % 8 == 0 && H <= 64 * 8 * 2 && sm <= 64 * 1024)
+      hipLaunchKernelGGL((pano_fusion_fwd_kernel<bf16_t, 2>), dim3(N), dim3(64 * PF_NW), sm, ST(stream), (const bf16_t*)x, a, a0,
+                         (bf16_t*)fused, wsave, V, H);
+    else
+      hipLaunchKernelGGL(pano_fusion_fwd_generic<bf16_t>, dim3(N), dim3(256), 0, ST(stream), (const bf16_t*)x, a, a0,
+                         (bf16_t*)fused, wsave, V, H);
+  } else if (dtype == GOAT_F32) {
+    if (H % 4 == 0 && H <= 64 * 4 * 3 && sm <= 64 * 1024)
+      hipLaunchKernelGGL((pano_fusion_fwd_kernel<float, 3>), dim3(N), dim3(64 * PF_NW), sm, ST(stream), (const float*)x, a, a0,
+                         (float*)fused, wsave, V, H);
+    else
+      hipLaunchKernelGGL(pano_fusion_fwd_generic<float>, dim3(N), dim3(256), 0, ST(stream), (const float*)x, a, a0,
+                         (float*)fused, wsave, V, H);
+  } else {
     return GOAT_E_ARG;
+  }
   GOAT_LAUNCH_CHECK();
   return 0;
 }
@@ -920,14 +1203,27 @@ extern "C" int goat_pano_fusion_bwd(void* stream, int dtype, const void* x, cons
                                     int V, int H) {
   if (!x || !a || !a0 || !wsave || !dfused || !dx || !da || !da0) return GOAT_E_ARG;
   if (N <= 0 || V <= 0 || V > 64 || H <= 0) return GOAT_E_SHAPE;
-  if (dtype == GOAT_BF16)
-    hipLaunchKernelGGL(pano_fusion_bwd_kernel<bf16_t>, dim3(N), dim3(256), 0, ST(stream), (const bf16_t*)x, a, a0,
-                       wsave, (const bf16_t*)dfused, (bf16_t*)dx, da, da0, V, H);
-  else if (dtype == GOAT_F32)
-    hipLaunchKernelGGL(pano_fusion_bwd_kernel<float>, dim3(N), dim3(256), 0, ST(stream), (const float*)x, a, a0, wsave,
-                       (const float*)dfused, (float*)dx, da, da0, V, H);
-  else
+  size_t sm = (size_t)PF_NW * H * sizeof(float);
+#ifdef GOAT_PANO_GENERIC
+  sm = 1 << 30;
+#endif
+  if (dtype == GOAT_BF16) {
+    if (H % 8 == 0 && H <= 64 * 8 * 2 && sm <= 64 * 1024)
+      hipLaunchKernelGGL((pano_fusion_bwd_kernel<bf16_t, 2>), dim3(N), dim3(64 * PF_NW), sm, ST(stream), (const bf16_t*)x, a, a0,
+                         wsave, (const bf16_t*)dfused, (bf16_t*)dx, da, da0, V, H);
+    else
+      hipLaunchKernelGGL(pano_fusion_bwd_generic<bf16_t>, dim3(N), dim3(256), 0, ST(stream), (const bf16_t*)x, a, a0,
+                         wsave, (const bf16_t*)dfused, (bf16_t*)dx, da, da0, V, H);
+  } else if (dtype == GOAT_F32) {
+    if (H % 4 == 0 && H <= 64 * 4 * 3 && sm <= 64 * 1024)
+      hipLaunchKernelGGL((pano_fusion_bwd_kernel<float, 3>), dim3(N), dim3(64 * PF_NW), sm, ST(stream), (const float*)x, a, a0, wsave,
+                         (const float*)dfused, (float*)dx, da, da0, V, H);
+    else
+      hipLaunchKernelGGL(pano_fusion_bwd_generic<float>, dim3(N), dim3(256), 0, ST(stream), (const float*)x, a, a0, wsave,
+                         (const float*)dfused, (float*)dx, da, da0, V, H);
+  } else {
     return GOAT_E_ARG;
+  }
   GOAT_LAUNCH_CHECK();
   return 0;
 }

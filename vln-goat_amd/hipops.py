@@ -478,23 +478,30 @@ class WgradQueue:
         q.append((dy, x, w_sink, b_sink, int(bool(accumulate))))
         for i in param_ids:
             cls.pending_ids[i] = st.cuda_stream
+        cls.arm()
+        if len(q) >= cls.MAX:
+            cls.flush(st.cuda_stream)
+
+    @classmethod
+    def arm(cls):
+        """(inside a backward pass) have the autograd engine call _end_of_backward when this pass ends."""
         if not cls._callback_armed:
             cls._callback_armed = True
             torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_backward)
-        if len(q) >= cls.MAX:
-            cls.flush(st.cuda_stream)
 
     @classmethod
     def _end_of_backward(cls):
         cls._callback_armed = False
         cls.flush()
         Branch.join_all()           # grouped launches on side streams must land before the caller's stream goes on
+        LnReduceQueue.flush()       # (after the join: the partials may have been produced on side streams)
 
     @classmethod
     def reset(cls):
         """Drop queued problems (GradArena.zero() calls this: anything still queued at the start of a step belongs to a
         backward pass that was aborted by an exception — its tensors must not be written into the new step)."""
         cls.queues, cls.pending_ids, cls._callback_armed = {}, {}, False
+        LnReduceQueue.items = []
 
     @classmethod
     def flush_param(cls, param_id):
@@ -541,6 +548,34 @@ class WgradQueue:
             PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 %s s%d' % (tile_name(cls.cfg[0]), cls.cfg[1])),
                             ('goat_wgrad_grouped', (ctypes.addressof(arr), n, cls.cfg[0], cls.cfg[1]), (arr, list(q)))))
         _lib.check(st, 'goat_wgrad_grouped(n=%d)' % n)
+
+
+class LnReduceQueue:
+    """Deferred dgamma / dbeta of LayerNorm backward.  With a gradient arena attached the two vectors are not needed until
+    the backward pass ends; goat_ln_bwd then only leaves its per-block column partials behind (accumulate = 2) and ONE
+    goat_ln_reduce_batched launch per backward pass adds the partials of every LayerNorm call to the arena slices — instead
+    of ~1500 contended float atomics per block, or a reduction launch per call (scripts/ln_bench.py: 15.8 -> 9-10 us per call at
+    3840 rows).  Deterministic.  Flushed by WgradQueue's end-of-backward callback."""
+    enabled = os.environ.get('GOAT_LN_DEFER', '1') != '0'
+    MIN_ROWS = 64
+    items = []              # (ws, dgamma sink, dbeta sink, nparts, H): tensors kept alive until the launch
+
+    @classmethod
+    def push(cls, ws, dg, db, nparts, H):
+        cls.items.append((ws, dg, db, nparts, H))
+        WgradQueue.arm()
+
+    @classmethod
+    def flush(cls):
+        items, cls.items = cls.items, []
+        by_h = {}
+        for it in items:
+            by_h.setdefault(it[4], []).append(it)
+        for H, group in by_h.items():
+            arr = (_lib.LnPartial * len(group))()
+            for e, (ws, dg, db, nparts, _) in zip(arr, group):
+                e.ws, e.dgamma, e.dbeta, e.nparts = _ptr(ws), _ptr(dg), _ptr(db), nparts
+            _lib.check(_lib.lib().goat_ln_reduce_batched(_stream(), ctypes.addressof(arr), len(group), H), 'goat_ln_reduce_batched')
 
 
 def _sink(param):
@@ -996,11 +1031,20 @@ class _LnFn(torch.autograd.Function):
         # LN_DETERMINISTIC: per-block partials in a workspace + a second (reduction) launch; default: the blocks add their column
         # partials to dgamma / dbeta with float atomics (43 fewer launches per step; summation order is not reproducible)
         # (measured, scripts/ln_bench.py: atomics 15.8 vs 16.7 us at 3840 rows and one launch fewer; 26.3 vs 22.2 us at 8640 rows)
-        ws = torch.empty(L.goat_ln_bwd_ws_floats(H), dtype=torch.float32, device=z.device) if (LN_DETERMINISTIC or M > LN_ATOMIC_MAX_ROWS) else None
+        acc = int(sunk and not _first_touch(*ctx.gb))
+        defer = acc == 1 and LnReduceQueue.enabled and M >= LnReduceQueue.MIN_ROWS
+        if defer:       # arena slices (pre-zeroed, accumulating): leave the column partials behind, one reduction per backward pass
+            nparts = L.goat_ln_bwd_nparts(M)
+            ws = torch.empty(nparts * 2 * H, dtype=torch.float32, device=z.device)
+            acc = 2
+        else:
+            ws = torch.empty(L.goat_ln_bwd_ws_floats(H), dtype=torch.float32, device=z.device) if (LN_DETERMINISTIC or M > LN_ATOMIC_MAX_ROWS) else None
         st = L.goat_ln_bwd(_stream(), _dt(z), _ptr(dy2), _ptr(dyb) if dyb is not None else None, _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd),
                            p, seed, off, dev, _ptr(dx), _ptr(dres) if dres is not None else None,
-                           _ptr(dg), _ptr(db), _ptr(ws) if ws is not None else None, M, H, int(sunk and not _first_touch(*ctx.gb)))
+                           _ptr(dg), _ptr(db), _ptr(ws) if ws is not None else None, M, H, acc)
         _lib.check(st, 'goat_ln_bwd')
+        if defer:
+            LnReduceQueue.push(ws, dg, db, nparts, H)
         if sunk:
             dg = db = None
         dxv = dx.view(ctx.shape)

@@ -48,9 +48,12 @@ def compute_dtype():
 # A captured step reads the memoised tensors at fixed addresses: after new data has been copied into a static batch
 # (train_step.StaticBatch.commit) `refresh_masks()` recomputes the stale entries IN PLACE, sources before derived masks.
 _MASK_MEMO = {}
+_NO_MEMO = bool(os.environ.get('GOAT_NO_MASK_MEMO'))       # (diagnostics)
 
 
 def _memo(tag, t, extra, compute):
+    if _NO_MEMO:
+        return compute(t)
     key = (tag, id(t), extra)
     ent = _MASK_MEMO.get(key)
     if ent is not None and ent[0]() is t and ent[1] == t._version:
