@@ -741,6 +741,9 @@ def main():
     if args.leg:
         torch.cuda.set_device(0)
         print(json.dumps(config5_leg(args) if args.leg == 'config5' else config4_leg(args)))
+        if os.environ.get('GOAT_SAVE_TUNED'):
+            from vln_goat_amd import hipops
+            hipops.save_tuned(os.environ['GOAT_SAVE_TUNED'] + '.' + args.leg)
         return
     world, rank, local = setup_dist(args)
     wl = WORKLOADS[args.workload]

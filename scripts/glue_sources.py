@@ -10,7 +10,7 @@ from vln_goat_amd import hipops, dp
 class A: pass
 args = A(); args.batch = int(sys.argv[1]) if len(sys.argv) > 1 else 48; args.dtype = 'bf16'; args.layers = '6,3,2'
 torch.cuda.set_device(0)
-cfg, model, batch, gb = bench.build(args, 0)
+cfg, model, batch, gb, _static = bench.build(args, 0)
 hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')
 wrapper = dp.GoatDataParallel(model)
 for task in bench.TASKS:

@@ -555,6 +555,7 @@ def test_dict_weighted_sum(ops, dtype):
 @pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, True)])
 @pytest.mark.parametrize('bm,ns', [(64, 2), (64, 3), (64, 4), (128, 2), (128, 3), (128, 4), (256, 2), (256, 3),
                                    (128, 0x102), (128, 0x103), (128, 0x104),      # 0x100: the 128-row tile on eight waves
+                                   (96, 2), (96, 3), (96, 4),                      # 96 x 128 (non-transposed A only)
                                    (128 | 256 << 16, 2), (128 | 256 << 16, 3), (192 | 256 << 16, 2), (256 | 192 << 16, 2),
                                    (256 | 256 << 16, 2)])                          # rows | columns << 16: the 8-wave wide tiles
 def test_gemm_bf16_every_tile_configuration(ops, ta, tb, bm, ns):

@@ -52,6 +52,7 @@ static int pick_group_m(int tiles_m, int tiles_n, int bm, int bn) {
 
 // tile = bm | bn << 16 (bn = 0: 128 columns).  4-wave / 128-column tiles live here, the rest in gemm3.hip.
 static bool tile_ok(int bm, int bn, bool eight) {
+  if (bn == 128 && bm == 96) return !eight;
   if (bn == 128) return bm == 64 || bm == 128 || bm == 256 ? (!eight || bm == 128) : false;
   if (eight) return false;
   return (bm == 128 && bn == 256) || (bm == 192 && bn == 256) || (bm == 256 && bn == 192) || (bm == 256 && bn == 256);
@@ -99,7 +100,7 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   if (split_k > kt) split_k = kt;
   a.k_tiles_per_split = (kt + split_k - 1) / split_k;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (bn != 128) return goat_g3_dispatch(st, a, bm, bn, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
+  if (bn != 128 || bm == 96) return goat_g3_dispatch(st, a, bm, bn, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
   if (bm == 64) return dispatch_layout<T64>(st, a, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
   if (bm == 256) return dispatch_layout<T256>(st, a, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
   if (eight) return dispatch_layout<T128X8>(st, a, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);

@@ -63,6 +63,7 @@ typedef Cfg<2, 4, 2, 2> T128x256;   // 128 x 256, 8 waves
 typedef Cfg<2, 4, 3, 2> T192x256;   // 192 x 256, 8 waves  (M = 3840 = 20 x 192: 240 tiles at N = 3072)
 typedef Cfg<4, 2, 2, 3> T256x192;   // 256 x 192, 8 waves  (N = 2304 = 12 x 192)
 typedef Cfg<2, 4, 4, 2> T256x256;   // 256 x 256, 8 waves
+typedef Cfg<1, 4, 3, 1> T96;        //  96 x 128, 4 waves  (M = 3840 = 40 x 96: 240 tiles at N = 768 — one round on 256 CUs, against 180 tiles of 128 x 128)
 
 struct G2Args {
   const void* A; const void* B; void* C; const float* bias; void* aux;

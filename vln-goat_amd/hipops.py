@@ -224,6 +224,8 @@ def _tile_candidates(ta, tb, M, N):
     c = [(64, 2), (64, 3), (64, 4), (128, 2), (128, 3), (128, 4), (128, EIGHT_WAVES | 2), (128, EIGHT_WAVES | 3), (128, EIGHT_WAVES | 4)]
     if M >= 2048:
         c += [(256, 2), (256, 3)]
+    if not ta and M >= 960:              # 96-row tiles: 3840 / 96 = 40 tile rows -> 240 tiles at N = 768 (one round on 256 CUs)
+        c += [(96, 2), (96, 3), (96, 4)]
     if N >= 256 and M >= 512:
         c += [(tile(128, 256), 2), (tile(128, 256), 3)]
         if M >= 1024:
