@@ -58,6 +58,8 @@ int goat_gemm_nt(void* stream, int dtype_in, int dtype_out,
                  void* aux, int64_t ldaux, int split_k);
 
 #define GOAT_GEMM_8WAVES 0x100   /* flag in goat_gemm_bf16's nstage argument: run the 128-row tile with eight waves */
+#define GOAT_GEMM_WIDE_PATCH 0x200   /* flag in nstage: the 256 x 256 tile on FOUR waves (128 x 128 wave patches); weight-gradient layout
+                                      * only (trans_a and trans_b, float32 output, nstage 2) — goat_gemm_bf16 and goat_wgrad_grouped */
 
 /* Pipelined bf16 GEMM with direct-to-LDS (LDS-DMA) operand staging, all operand layouts (csrc/gemm2.hip):
  *   C[M,N] = epilogue( op(A) · op(B)ᵀ + bias ),  contraction length Kc

@@ -11,9 +11,16 @@ LAYER = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]          # (n_out, n
 GROUPS = {'text x4 layers (rows 3840)': [(3840, o, i) for _ in range(4) for (o, i) in LAYER],
           'pano x2 layers (rows 8640) + text x2': [(8640, o, i) for _ in range(2) for (o, i) in LAYER] + [(3840, o, i) for _ in range(2) for (o, i) in LAYER],
           'cross-modal (rows 1776 / 1056) x16': [(r, o, i) for r in (1776, 1056) for _ in range(2) for (o, i) in LAYER]}
-CFGS = [(64, 3), (128, 2), (128, 0x102), (128, 0x103), (128, 0x104), (256, 2), (256, 3), (T(128, 256), 2), (T(128, 256), 3), (T(256, 256), 2)]
+CFGS = [(64, 3), (128, 2), (128, 0x102), (128, 0x103), (128, 0x104), (256, 2), (256, 3), (T(128, 256), 2), (T(128, 256), 3), (T(256, 256), 2), (T(256, 256), 0x202)]
+GROUPS['text x2 layers (rows 3840), 8 problems'] = [(3840, o, i) for _ in range(2) for (o, i) in LAYER]
+if os.environ.get('WG_GROUP'):        # (PMC passes: one group, one configuration)
+    k = list(GROUPS)[int(os.environ['WG_GROUP'])]
+    GROUPS = {k: GROUPS[k]}
+if os.environ.get('WG_CFG'):
+    a, b = os.environ['WG_CFG'].split(',')
+    CFGS = [(int(a, 0), int(b, 0))]
 L = _lib.lib()
-ROT = 3
+ROT = int(os.environ.get('WG_ROT', '3'))      # operand sets rotated through (1: operands stay cache-resident where they fit)
 for gname, probs in GROUPS.items():
     fl = sum(2.0 * r * o * i for r, o, i in probs)
     sets = []
@@ -58,4 +65,4 @@ for gname, probs in GROUPS.items():
         res.append((us, hipops.tile_name(bm), ns, tiles))
     print('%s: %.1f GFLOP' % (gname, fl / 1e9))
     for us, name, ns, tiles in sorted(res):
-        print('   %-8s s%d%s  tiles %4d  %7.1f us  %6.0f TF' % (name, ns & 0xFF, ' 8w' if ns & 0x100 else '   ', tiles, us, fl / us / 1e6))
+        print('   %-8s s%d%s  tiles %4d  %7.1f us  %6.0f TF' % (name, ns & 0xFF, ' 8w' if ns & 0x100 else (' 4w' if ns & 0x200 else '   '), tiles, us, fl / us / 1e6))

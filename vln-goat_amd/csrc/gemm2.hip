@@ -64,7 +64,8 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
                               void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum) {
   if (!A || !B || !C) return GOAT_E_ARG;
   const bool eight = (nstage & GOAT_GEMM_8WAVES) != 0;
-  nstage &= ~GOAT_GEMM_8WAVES;
+  const bool wide = (nstage & GOAT_GEMM_WIDE_PATCH) != 0;
+  nstage &= ~(GOAT_GEMM_8WAVES | GOAT_GEMM_WIDE_PATCH);
   if (nstage < 2 || nstage > 4) return GOAT_E_ARG;
   int bn = (bm >> 16) & 0xFFFF;
   bm &= 0xFFFF;
@@ -81,6 +82,7 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   if (epilogue == GOAT_EPI_ACCUM && (dtype_out != GOAT_F32 || bias)) return GOAT_E_ARG;
   if (split_k > 1 && (dtype_out != GOAT_F32 || (epilogue != GOAT_EPI_NONE && epilogue != GOAT_EPI_ACCUM) || bias)) return GOAT_E_ARG;
   if (!tile_ok(bm, bn, eight)) return GOAT_E_ARG;
+  if (wide && !(bm == 256 && bn == 256 && trans_a && trans_b && dtype_out == GOAT_F32 && nstage == 2)) return GOAT_E_ARG;
   const int64_t a_rows = trans_a ? Kc : M, b_rows = trans_b ? Kc : N;
   const int64_t a_bytes = a_rows * lda * 2, b_bytes = b_rows * ldb * 2;
   if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) return GOAT_E_SHAPE;
@@ -100,6 +102,7 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   if (split_k > kt) split_k = kt;
   a.k_tiles_per_split = (kt + split_k - 1) / split_k;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (wide) return goat_g4_dispatch(st, a, split_k, nstage);
   if (bn != 128 || bm == 96) return goat_g3_dispatch(st, a, bm, bn, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
   if (bm == 64) return dispatch_layout<T64>(st, a, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
   if (bm == 256) return dispatch_layout<T256>(st, a, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
@@ -123,11 +126,13 @@ static int group_stages(hipStream_t st, const GroupArgs& g, int nstage) {
 extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs, int n, int bm, int nstage) {
   if (!probs || n < 1 || n > GROUP_MAX) return GOAT_E_ARG;
   const bool eight = (nstage & GOAT_GEMM_8WAVES) != 0;       // as in goat_gemm_bf16: the 128-row tile on eight waves
-  nstage &= ~GOAT_GEMM_8WAVES;
+  const bool wide = (nstage & GOAT_GEMM_WIDE_PATCH) != 0;   // 256 x 256 on four waves
+  nstage &= ~(GOAT_GEMM_8WAVES | GOAT_GEMM_WIDE_PATCH);
   int bn = (bm >> 16) & 0xFFFF;
   bm &= 0xFFFF;
   if (bn == 0) bn = 128;
   if (nstage < 2 || nstage > 4 || !tile_ok(bm, bn, eight) || (bm & (bm - 1)) || (bn & (bn - 1))) return GOAT_E_ARG;
+  if (wide && !(bm == 256 && bn == 256 && nstage == 2)) return GOAT_E_ARG;
   GroupArgs g;
   g.n = n;
   int tiles = 0;
@@ -155,6 +160,7 @@ extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs,
   }
   for (int i = n; i <= GROUP_MAX; ++i) g.tile_start[i] = tiles;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (wide) return goat_g4_group(st, g, nstage);
   if (bn != 128) return goat_g3_group(st, g, bm, bn, nstage);
   if (bm == 64) return group_stages<T64>(st, g, nstage);
   if (bm == 256) return group_stages<T256>(st, g, nstage);

@@ -63,6 +63,9 @@ typedef Cfg<2, 4, 2, 2> T128x256;   // 128 x 256, 8 waves
 typedef Cfg<2, 4, 3, 2> T192x256;   // 192 x 256, 8 waves  (M = 3840 = 20 x 192: 240 tiles at N = 3072)
 typedef Cfg<4, 2, 2, 3> T256x192;   // 256 x 192, 8 waves  (N = 2304 = 12 x 192)
 typedef Cfg<2, 4, 4, 2> T256x256;   // 256 x 256, 8 waves
+typedef Cfg<2, 2, 4, 4> T256x256W4; // 256 x 256, FOUR waves with 128 x 128 patches (GOAT_GEMM_WIDE_PATCH): the weight-gradient layout reads both
+                                   // operands with ds_read_b64_tr_b16 (~7 LDS cycles per wave-instruction, profiles/round2_gemm_mainloop_cycle_stamps.txt) and is
+                                   // LDS-read-bound on 64 x 64 patches; a 4 x 4 patch needs half the fragment reads per MFMA (256 accumulator registers)
 typedef Cfg<1, 4, 3, 1> T96;        //  96 x 128, 4 waves  (M = 3840 = 40 x 96: 240 tiles at N = 768 — one round on 256 CUs, against 180 tiles of 128 x 128)
 
 struct G2Args {
@@ -195,8 +198,10 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   // (the counted wait in front of k-step ks allows (FD-1)*RD reads to stay in flight: THAT must fit the 4-bit lgkmcnt; with more
   // than 15 reads issued the wave simply stalls at issue.  Round 1 required FD*RD <= 15 and ran every transposed-operand tile
   // — all weight gradients — one k-step ahead only.)
-  constexpr int FD = ((GOAT_GEMM_FRAG_DEPTH - 1) * RD <= 15) ? GOAT_GEMM_FRAG_DEPTH : (15 / RD + 1 >= 1 ? (15 / RD + 1 < 3 ? 15 / RD + 1 : 3) : 1);
-  static_assert(RD <= 15 && (FD - 1) * RD <= 15, "the reads a counted wait leaves in flight must fit the lgkmcnt counter");
+  // RD = 16 (the 4 x 4 patch with both operands transposed): one k-step ahead, the wait count clamped to 15 — LDS reads return
+  // in order, so waiting for "at most 15 outstanding" completes every read of the current k-step and the first of the next.
+  constexpr int FD = RD == 16 ? 2 : ((GOAT_GEMM_FRAG_DEPTH - 1) * RD <= 15) ? GOAT_GEMM_FRAG_DEPTH : (15 / RD + 1 >= 1 ? (15 / RD + 1 < 3 ? 15 / RD + 1 : 3) : 1);
+  static_assert(RD <= 16 && ((FD - 1) * RD <= 15 || RD == 16), "the reads a counted wait leaves in flight must fit the lgkmcnt counter");
 
   // `wave` through readfirstlane: the compiler then keeps every wave-uniform quantity (the LDS addresses of this wave's DMA
   // pieces, hence M0) in SGPRs instead of a v_add + v_readfirstlane + s_mov chain in front of every buffer_load ... lds
@@ -351,7 +356,7 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
 #define GOAT_KSTEP(ks_)                                                                                            \
   do {                                                                                                              \
     constexpr int left_ = (KSTEPS - (ks_) < FD ? KSTEPS - (ks_) : FD) - 1; /* later k-steps whose reads may stay in flight */ \
-    wait_lgkm<left_ * RD>();                                                                                        \
+    wait_lgkm<(left_ * RD > 15 ? 15 : left_ * RD)>();                                                                                        \
     if ((ks_) + FD < KSTEPS) GOAT_LOAD_FRAGS(sa, sb, (ks_) + FD < KSTEPS ? (ks_) + FD : 0, (ks_) + FD < KSTEPS ? (ks_) + FD : 0); \
     GOAT_MMA(ks_);                                                                                                  \
     GOAT_DMA_SLOT((ks_) + 1);                                                                                       \
@@ -424,7 +429,7 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
 #define GOAT_KSTEP(ks_)                                                                                            \
   do {                                                                                                              \
     constexpr int left_ = (KSTEPS - (ks_) < FD ? KSTEPS - (ks_) : FD) - 1;                                          \
-    wait_lgkm<left_ * RD>();                                                                                        \
+    wait_lgkm<(left_ * RD > 15 ? 15 : left_ * RD)>();                                                                                        \
     if ((ks_) + FD < KSTEPS) GOAT_LOAD_FRAGS(sa, sb, (ks_) + FD < KSTEPS ? (ks_) + FD : 0, (ks_) + FD < KSTEPS ? (ks_) + FD : 0); \
     GOAT_MMA(ks_);                                                                                                  \
     if (INTERLEAVE) {                                                                                               \
@@ -746,3 +751,6 @@ int launch_group(hipStream_t st, const GroupArgs& g) {
 int goat_g3_dispatch(hipStream_t st, const goat_g2::G2Args& a, int bm, int bn, int trans_a, int trans_b, int dtype_out, int epi,
                      int split, int nstage);
 int goat_g3_group(hipStream_t st, const goat_g2::GroupArgs& g, int bm, int bn, int nstage);
+// gemm4.hip: the 256 x 256 tile on four waves (weight-gradient layout only: transposed A and B, float32 output)
+int goat_g4_dispatch(hipStream_t st, const goat_g2::G2Args& a, int split, int nstage);
+int goat_g4_group(hipStream_t st, const goat_g2::GroupArgs& g, int nstage);
