@@ -490,11 +490,12 @@ def gemm_roofline(args, model, gb, arena=None):
     # comes from the committed rocprofv3 --pmc passes of this same step mix (scripts/collect_profiles.sh; FETCH_SIZE and
     # WRITE_SIZE in separate passes, gfx950 corrections applied as MI355X_MICROARCH.md prescribes) — null if absent.
     traffic, tsrc = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'round1_pmc_gemm_traffic.json')
-    if os.path.exists(tpath):
-        with open(tpath) as f:
+    import glob
+    tpaths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_gemm_traffic.json')))      # the latest round's passes
+    if tpaths:
+        with open(tpaths[-1]) as f:
             tj = json.load(f)
-        traffic, tsrc = round(tj['traffic_bytes_per_launch']), 'profiles/round1_pmc_gemm_traffic.json'
+        traffic, tsrc = round(tj['traffic_bytes_per_launch']), 'profiles/' + os.path.basename(tpaths[-1])
     algo_bytes = 0.0
     for r in recs:
         if r[3][0] == 'grouped wgrad':
@@ -597,21 +598,30 @@ def fresh_batch_leg(args, m):
     if sb is None:
         return {'error': 'no static batch'}
     B = args.batch or wl['per_rank']
-    K = 3
+    K = 4
     hosts = [synth.make_pretrain_batch(B=B, seed=500 + k, **wl['batch']) for k in range(K)]
     bufs = [sb.pack(h) for h in hosts]
     done = [None] * K
 
-    def run(i):
+    def prefetch(i):                                 # host index build + H2D of batch i (side stream), one step ahead of its use
         k = i % K
         if done[k] is not None:
             done[k].synchronize()                    # this buffer's previous H2D has been executed
         sb.pack(hosts[k], bufs[k], tensors=False)    # host: index build from the id strings
-        done[k] = sb.stage(bufs[k])                  # side stream: H2D
-        sb.commit()                                  # compute stream: swap in + masks
+        done[k] = sb.stage(bufs[k])                  # side stream: H2D (waits until the previous commit has read the staging buffer)
+    state = {'next': None}
+
+    def run(i):
+        if state['next'] != i:
+            prefetch(i)
+        sb.commit()                                  # compute stream: swap batch i in + masks
         steps[tasks[i % len(tasks)]]()
+        prefetch(i + 1)                              # overlaps the step just launched
+        state['next'] = i + 1
     n = max(6, min(args.steps, 30))
+    state['next'] = None
     dt = timed(run, n, 3, 1)
+    sb.commit()                                      # (drain the batch staged by the last step)
     out = {'ms_per_step': round(dt / n * 1e3, 3), 'value': round(m['n_traj'] * n / dt, 1), 'unit': 'trajectory-steps/s', 'steps': n,
            'h2d_bytes_per_step': sb.nbytes,
            'what': 'new host batch per step (fixed shape B=%d T=5 L=80): host index build + one pinned H2D (side stream) + one D2D swap '

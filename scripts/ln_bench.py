@@ -30,7 +30,7 @@ def timeit(fn, n=40):
 
 
 for M in (3840, 8640, 1776):
-    for det in (0, 1):
+    for det in (0, 1, 2):        # 0 atomics, 1 per-call partials + reduction launch, 2 partials left behind (one batched reduction per backward pass)
         sets = []
         for _ in range(ROT):
             x, r = (torch.randn(M, H, device='cuda').to(torch.bfloat16) for _ in range(2))
@@ -40,6 +40,7 @@ for M in (3840, 8640, 1776):
         gamma, beta = torch.ones(H, device='cuda'), torch.zeros(H, device='cuda')
         dg, db = torch.zeros(H, device='cuda'), torch.zeros(H, device='cuda')
         ws = torch.empty(L.goat_ln_bwd_ws_floats(H), device='cuda') if det else None
+        acc = 2 if det == 2 else 1
         i = [0]
 
         def fwd():
@@ -51,11 +52,11 @@ for M in (3840, 8640, 1776):
         def bwd():
             x, r, y, z, dy, dx, dres, mean, rstd = sets[i[0] % ROT]; i[0] += 1
             rc = L.goat_ln_bwd(st_holder[0], 1, dy.data_ptr(), None, z.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), 0.1, 1, 0, None,
-                               dx.data_ptr(), dres.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr() if ws is not None else None, M, H, 1)
+                               dx.data_ptr(), dres.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr() if ws is not None else None, M, H, acc)
             assert rc == 0
         for _ in range(ROT):
             fwd()
         tf, tb = timeit(fwd), timeit(bwd)
         print('M=%5d %s | fwd %5.1f us (%.1f MB -> %.2f TB/s) | bwd %5.1f us (%.1f MB -> %.2f TB/s)' % (
-            M, 'deterministic (partials + reduce)' if det else 'atomics                        ', tf, 4 * M * H * 2 / 1e6, 4 * M * H * 2 / 1e6 / tf,
+            M, ['atomics                          ', 'deterministic (partials + reduce)', 'partials only (deferred reduce)  '][det], tf, 4 * M * H * 2 / 1e6, 4 * M * H * 2 / 1e6 / tf,
             tb, 4 * M * H * 2 / 1e6, 4 * M * H * 2 / 1e6 / tb), flush=True)
