@@ -433,7 +433,7 @@ def cpu_baseline(args, cfg):
                       % (B, len(times), ncores, avail, cpu_model, time.time() - t_start)}
 
 
-def gemm_roofline(args, model, gb, arena=None):
+def gemm_roofline(args, model, gb, arena=None, tasks=None, cycle=None):
     """MFMA roofline of the dominant kernel family (goat_gemm_bf16 / goat_gemm_nt).
 
     One eager mlm+sap+cfp cycle records every GEMM launch (shape, pointers; the operand tensors are kept alive).
@@ -443,7 +443,9 @@ def gemm_roofline(args, model, gb, arena=None):
     (2*M*N*K per launch) / replay time."""
     from vln_goat_amd import hipops, _lib
     hipops.PROFILE = []
-    for task in TASKS:
+    if cycle is not None:                    # (config 4: one eager rollout instead of a pre-training task cycle)
+        cycle()
+    for task in (tasks if tasks is not None else (TASKS if cycle is None else ())):
         if arena is not None:
             arena.zero(task)                 # same launch set as the timed steps (grouped weight gradients included)
         else:
@@ -511,7 +513,8 @@ def gemm_roofline(args, model, gb, arena=None):
             'avg_launch_us': round(tot_ms * 1e3 / max(n, 1), 2),
             'algorithmic_gflop_per_launch': round(tot_fl / max(n, 1) / 1e9, 3),
             'gemm_ms_per_cycle': round(tot_ms, 3),
-            'method': 'HIP events around a hipGraph replay of the %d recorded GEMM launches of one mlm+sap+cfp cycle' % n}
+            'method': 'HIP events around a hipGraph replay of the %d recorded GEMM launches of one %s' % (
+                n, 'rollout' if cycle is not None else '+'.join(tasks if tasks is not None else TASKS) + ' cycle')}
 
 
 def measure_pretrain(args, world, rank, workload, n_steps, n_warmup):
@@ -561,6 +564,7 @@ def leg_process(args, name):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--leg', name, '--steps', str(args.steps), '--dtype', args.dtype, '--layers', args.layers]
     cmd += ['--no-graph'] if args.no_graph else []
+    cmd += ['--no-roofline'] if args.no_roofline else []
     cmd += ['--no-autotune'] if args.no_autotune else []
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
     try:
@@ -675,6 +679,11 @@ def config5_leg(args):
     out = {'value': round(m['n_traj'] * n / m['dt'], 1), 'unit': 'trajectory-steps/s', 'ms_per_step': round(m['dt'] / n * 1e3, 3),
            'steps': n, 'samples_per_s': round(m['n_traj'] * n / m['dt'] / 5.0, 1),
            'workload': WORKLOADS['config5']['text'] % {'layers': args.layers, 'batch': args.batch or 32} + ', fwd+bwd, hipGraph replay'}
+    if not args.no_roofline:
+        r = gemm_roofline(args, m['model'], m['gb'], m['wrapper'].arena, tasks=m['tasks'])
+        out['roofline'] = {k: r[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'launches_per_cycle', 'avg_launch_us',
+                                             'algorithmic_gflop_per_launch', 'algorithmic_bytes_per_launch', 'gemm_ms_per_cycle', 'method')}
+        out['roofline']['traffic'] = None      # (no PMC pass of this workload)
     m.clear()
     return out
 
@@ -734,8 +743,14 @@ def config4_leg(args):
             torch.cuda.synchronize()
     n = max(6, min(args.steps, 20))
     dt = timed(run, n, 2, 1)
+    roof = None
+    if not args.no_roofline:
+        r = gemm_roofline(args, model, None, None, cycle=episode)
+        roof = {k: r[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'launches_per_cycle', 'avg_launch_us',
+                                  'algorithmic_gflop_per_launch', 'algorithmic_bytes_per_launch', 'gemm_ms_per_cycle', 'method')}
+        roof['traffic'] = None
     return {'value': round(B * T * n / dt, 1), 'unit': 'trajectory-steps/s', 'ms_per_episode': round(dt / n * 1e3, 3), 'episodes': n,
-            'launch': launch,
+            'launch': launch, 'roofline': roof,
             'workload': 'map_nav_src fine-tune model calls of one rollout (run_r2r_goat.sh shapes): 6,3,2 layers, batch 12, L=200, 3 steps x '
                         '(panorama 36x768 + navigation, G=60), BACL+FACL on (type_2 / type_1 / door), dictionaries 35/39/50/24, dropout '
                         '0.1 / feat 0.5, BPTT through the [MEM] token, fwd+bwd, synthetic per-step inputs (no simulator)'}

@@ -83,6 +83,13 @@ int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_out,
 /* colsum[c] += sum_r x[r,c] (float32, atomic; caller zero-fills): bias gradient of a Linear. */
 int goat_colsum(void* stream, int dtype, const void* x, int64_t ld, int R, int C, float* colsum);
 
+/* Weight (and bias) gradient of a Linear with K <= 16 input features — the 7- / 14-wide position Linears
+ * (P/model/vilmodel_goat.py:300-303,406,475): dw[n, k] += sum_r dy[r, n] x[r, k], dbias[n] += sum_r dy[r, n] (dbias may be NULL).
+ * dy [rows, N] and x [rows, ld_x] in `dtype`, row strides in elements; x rows padded to whole 16-byte chunks and 16-byte aligned; dw float32 [N, K] with row stride ld_dw; both outputs are
+ * ADDED to (float atomics: gradient-arena slices cleared at step start, or zero-filled by the caller). */
+int goat_wgrad_smallk(void* stream, int dtype, const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, int rows, int N, int K,
+                      float* dw, int64_t ld_dw, float* dbias);
+
 /* out[c, r] = in[r, c] for r<R, c<C; out columns R..ld_out-1 are zero-filled (so the result can feed
  * goat_gemm_nt as a K-padded operand).  If colsum!=NULL, colsum[c] += sum_r in[r,c] (float32, atomic):
  * that is the bias gradient of a Linear (autograd of P/model/Bert_backbone.py:302 et al.). */
@@ -112,7 +119,10 @@ int goat_ln_fwd(void* stream, int dtype, const void* x, const void* residual,
  * accumulate == 2 (ws required, goat_ln_bwd_nparts(M) * 2 * H floats): the per-block partials are LEFT in ws and nothing is
  *   written to dgamma / dbeta; the caller sums the partials of many LayerNorm calls into their gradient vectors with ONE
  *   goat_ln_reduce_batched launch when the backward pass ends (the column reduction is 40 % of this kernel's time at the GOAT
- *   row counts; deterministic). */
+ *   row counts; deterministic).
+ * dx_add (may be NULL; same shape / dtype as dx): added to dx on store — the gradient that reaches the LayerNorm's INPUT through
+ *   its other consumer (the skip connection around a pre-LN sub-layer, P/model/transformer.py:170-182), so autograd launches no
+ *   add kernel for that junction (hipops.layer_norm(fork_in=True)). */
 typedef struct goat_ln_partial {
   const float* ws;         /* partials written by goat_ln_bwd(..., accumulate = 2): [nparts][2][H] float32 */
   float* dgamma;           /* float32[H], ADDED to */
@@ -126,7 +136,8 @@ int goat_ln_reduce_batched(void* stream, const goat_ln_partial* entries, int n, 
 int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* dy2, const void* z,
                 const float* gamma, const float* mean, const float* rstd,
                 float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev,
-                void* dx, void* d_res, float* dgamma, float* dbeta, float* ws, int M, int H, int accumulate);
+                void* dx, void* d_res, float* dgamma, float* dbeta, float* ws, int M, int H, int accumulate,
+                const void* dx_add);
 
 /* y = residual + dropout_p(x)  (residual may be NULL, y may alias x).  nn.Dropout + pre-LN residual adds
  * (P/model/transformer.py:177,181; P/model/vilmodel_goat.py:316). n = element count. */

@@ -52,7 +52,7 @@ for M in (3840, 8640, 1776):
         def bwd():
             x, r, y, z, dy, dx, dres, mean, rstd = sets[i[0] % ROT]; i[0] += 1
             rc = L.goat_ln_bwd(st_holder[0], 1, dy.data_ptr(), None, z.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), 0.1, 1, 0, None,
-                               dx.data_ptr(), dres.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr() if ws is not None else None, M, H, acc)
+                               dx.data_ptr(), dres.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr() if ws is not None else None, M, H, acc, None)
             assert rc == 0
         for _ in range(ROT):
             fwd()

@@ -148,6 +148,74 @@ def test_layer_norm_fwd_bwd(ops, dtype, with_res):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('K', [7, 14])
+@pytest.mark.parametrize('sunk', [False, True])
+def test_linear_short_input_weight_gradient(ops, dtype, K, sunk):
+    """Linear(7 | 14 -> 768) (the position-feature Linears): forward through the K-padded GEMM, weight / bias gradients by
+    goat_wgrad_smallk — returned to autograd, or added straight into bound gradient slices (as under the gradient arena)."""
+    rows, N = 1003, 768
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(rows, K, generator=g).to(DEV, dtype)
+    w = (0.2 * torch.randn(N, K, generator=g)).to(DEV).requires_grad_(True)
+    b = (0.1 * torch.randn(N, generator=g)).to(DEV).requires_grad_(True)
+    dy = torch.randn(rows, N, generator=g).to(DEV, dtype)
+    base_w, base_b = torch.randn(N, K, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    if sunk:
+        for prm, snk in ((w, base_w.clone()), (b, base_b.clone())):
+            prm.grad = snk
+            prm.__dict__['_goat_sink'] = snk
+            prm.__dict__['_goat_prezero'] = True          # "cleared at step start": the kernel only ever adds
+    try:
+        y = ops.linear(x, w, b)
+        y.backward(dy)
+        torch.cuda.synchronize()
+    finally:
+        for prm in (w, b):
+            prm.__dict__.pop('_goat_sink', None)
+            prm.__dict__.pop('_goat_prezero', None)
+    wr, br = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.linear(x.float(), wr, br)
+    yr.backward(dy.float())
+    _close(y, yr, dtype, 'short linear y')
+    _close(w.grad - (base_w if sunk else 0), wr.grad, dtype, 'short linear dW')
+    _close(b.grad - (base_b if sunk else 0), br.grad, dtype, 'short linear db')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_layer_norm_fork_in_sums_the_skip_gradient(ops, dtype):
+    """layer_norm(fork_in=True) -> (LN(x), x): the gradient of the second output (the skip connection of a pre-LN block) is added
+    to dx inside goat_ln_bwd (dx_add); also when only one of the two outputs carries a gradient."""
+    M, H = 777, 768
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(M, H, generator=g).to(DEV, dtype).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV).requires_grad_(True)
+    beta = (0.1 * torch.randn(H, generator=g)).to(DEV).requires_grad_(True)
+    d1 = torch.randn(M, H, generator=g).to(DEV, dtype)
+    d2 = torch.randn(M, H, generator=g).to(DEV, dtype)
+    y, skip = ops.layer_norm(x, gamma, beta, 1e-5, fork_in=True)
+    assert skip.data_ptr() == x.data_ptr()
+    torch.autograd.backward([y, skip], [d1, d2])
+    xr = x.detach().float().requires_grad_(True)
+    gr, br = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (H,), gr, br, 1e-5)
+    torch.autograd.backward([yr, xr * 1.0], [d1.float(), d2.float()])
+    _close(y, yr, dtype, 'ln fork_in y')
+    _close(x.grad, xr.grad, dtype, 'ln fork_in dx + skip')
+    _close(gamma.grad, gr.grad, dtype, 'ln fork_in dgamma')
+    _close(beta.grad, br.grad, dtype, 'ln fork_in dbeta')
+    x.grad = None
+    y, skip = ops.layer_norm(x, gamma, beta, 1e-5, fork_in=True)
+    skip.backward(d2)                                  # the LayerNorm branch unused
+    assert torch.equal(x.grad, d2)
+    x.grad = None
+    y, skip = ops.layer_norm(x, gamma, beta, 1e-5, fork_in=True)
+    y.backward(d1)                                     # the skip branch unused
+    xr.grad = None
+    torch.nn.functional.layer_norm(xr, (H,), gr, br, 1e-5).backward(d1.float())
+    _close(x.grad, xr.grad, dtype, 'ln fork_in dx only')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_layer_norm_deferred_column_reduction(ops, dtype):
     """goat_ln_bwd(accumulate = 2) + goat_ln_reduce_batched: two LayerNorm calls that share gamma / beta (bound to
     pre-zeroed gradient slices, as under the gradient arena) and a third with its own leave their column partials behind;

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(const T* __restrict__ 
                                                      uint64_t offset, const uint64_t* __restrict__ rng_dev,
                                                      T* __restrict__ dx, T* __restrict__ dres,
                                                      float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     int M, int H) {
+                                                     const T* __restrict__ dx_add, int M, int H) {
   constexpr int EPC = DT<T>::EPC;
   extern __shared__ float lsum[];  // [NWV][2][H]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -189,6 +189,12 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(const T* __restrict__ 
             const uint32_t km = rng.keep_bits<EPC>(offset + base, thr);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o.v[e] = ((km >> e) & 1u) ? o.v[e] * ks : 0.f;
+          }
+          if (dx_add) {     // gradient of x arriving through its OTHER consumer (the skip connection of a pre-LN block): summed on store
+            Chunk<T> t;
+            t.load(dx_add + base);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.v[e] += t.v[e];
           }
           if (dx) o.store_stream(dx + base);
         }
@@ -480,6 +486,68 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in
     csum[ty][tx] = acc;
     __syncthreads();
     if (ty == 0 && c0 + tx < C) atomicAdd(colsum + c0 + tx, csum[0][tx] + csum[1][tx] + csum[2][tx] + csum[3][tx]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ weight gradient of a short-input Linear
+// dW[n, k] += sum_r dy[r, n] x[r, k] ; dbias[n] += sum_r dy[r, n]   for K <= 16 input features (the 7- / 14-wide position Linears,
+// P/model/vilmodel_goat.py:300-303,406,475): block = 128 output columns x a chunk of rows, lane = 2 columns, wave = row phase.
+// Replaces a padded-K GEMM into a temporary + slice copy + autograd's `grad += dW` (4 launches per Linear and step).
+constexpr int SK_MAXK = 16, SK_ROWS = 128, SK_BATCH = 8;
+template <typename T, int KP>      // KP: padded input width in elements (one or two 16-byte chunks per row of x)
+__global__ __launch_bounds__(256) void wgrad_smallk_kernel(const T* __restrict__ dy, int64_t ld_dy, const T* __restrict__ x,
+                                                           int64_t ld_x, int rows, int N, int K, float* __restrict__ dw,
+                                                           int64_t ld_dw, float* __restrict__ dbias) {
+  __shared__ float sm[4][128][SK_MAXK + 1];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (row indices stay scalar: x rows
+  const int n0 = blockIdx.x * 128 + lane * 2;                                                    //  come through the scalar cache)
+  const int r0 = blockIdx.y * SK_ROWS, r1 = min(rows, r0 + SK_ROWS);
+  float acc[2][SK_MAXK], bsum[2] = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < SK_MAXK; ++k) { acc[0][k] = 0.f; acc[1][k] = 0.f; }
+  const bool in0 = n0 < N, in1 = n0 + 1 < N;
+  // SK_BATCH rows per trip: all their loads are issued before the first multiply (the kernel is latency-bound otherwise)
+  for (int rb = r0 + wave * SK_BATCH; rb < r1; rb += 4 * SK_BATCH) {
+    constexpr int EPC = DT<T>::EPC, NCH = KP / EPC;
+    float d0[SK_BATCH], d1[SK_BATCH], xv[SK_BATCH][KP];
+#pragma unroll
+    for (int u = 0; u < SK_BATCH; ++u) {
+      const int r = rb + u;
+      const bool live = r < r1;
+      d0[u] = (live && in0) ? to_f(dy[(int64_t)r * ld_dy + n0]) : 0.f;
+      d1[u] = (live && in1) ? to_f(dy[(int64_t)r * ld_dy + n0 + 1]) : 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {          // one 16-byte load per chunk of the row (same address in every lane)
+        Chunk<T> ch;
+        if (live) ch.load(x + (int64_t)r * ld_x + c * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) xv[u][c * EPC + e] = live ? ch.v[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SK_BATCH; ++u) {
+      bsum[0] += d0[u]; bsum[1] += d1[u];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        acc[0][k] += d0[u] * xv[u][k];
+        acc[1][k] += d1[u] * xv[u][k];
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int k = 0; k < SK_MAXK; ++k) sm[wave][lane * 2 + c][k] = acc[c][k];
+    sm[wave][lane * 2 + c][SK_MAXK] = bsum[c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 128 * (K + 1); i += 256) {
+    const int c = i / (K + 1), k = i % (K + 1), n = blockIdx.x * 128 + c;
+    if (n >= N) continue;
+    const int kk = k < K ? k : SK_MAXK;
+    const float v = sm[0][c][kk] + sm[1][c][kk] + sm[2][c][kk] + sm[3][c][kk];
+    if (k < K) atomicAdd(dw + (int64_t)n * ld_dw + k, v);
+    else if (dbias) atomicAdd(dbias + n, v);
   }
 }
 
@@ -989,7 +1057,7 @@ extern "C" int goat_ln_reduce_batched(void* stream, const goat_ln_partial* entri
 extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* dy2, const void* z, const float* gamma,
                            const float* mean, const float* rstd, float p, uint64_t seed, uint64_t offset,
                            const uint64_t* rng_dev, void* dx, void* d_res, float* dgamma, float* dbeta, float* ws,
-                           int M, int H, int accumulate) {
+                           int M, int H, int accumulate, const void* dx_add) {
   if (!dy || !z || !gamma || !mean || !rstd || !dgamma || !dbeta) return GOAT_E_ARG;
   if (M <= 0) return GOAT_E_SHAPE;
   // deterministic mode (ws): 4-wave blocks, up to 512 per-block partial rows reduced by a second kernel (round 1).
@@ -1022,7 +1090,7 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
       }                                                                                                                       \
     }                                                                                                                         \
     hipLaunchKernelGGL(kern_, dim3(nparts), dim3(64 * NWV_), sm, ST(stream), (const T_*)dy, (const T_*)dy2, (const T_*)z, gamma, mean, \
-                       rstd, p, seed, offset, rng_dev, (T_*)dx, (T_*)d_res, ws, dgamma, dbeta, M, H);                         \
+                       rstd, p, seed, offset, rng_dev, (T_*)dx, (T_*)d_res, ws, dgamma, dbeta, (const T_*)dx_add, M, H);      \
   } while (0)
   if (dtype == GOAT_BF16) {
     if (int e = ln_check<bf16_t>(H)) return e;
@@ -1165,6 +1233,30 @@ extern "C" int goat_transpose(void* stream, int dtype, const void* in, int64_t l
                        ld_out, R, C, colsum, RT);
   else
     return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_wgrad_smallk(void* stream, int dtype, const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, int rows,
+                                 int N, int K, float* dw, int64_t ld_dw, float* dbias) {
+  if (!dy || !x || !dw) return GOAT_E_ARG;
+  if (rows <= 0 || N <= 0 || K <= 0 || K > SK_MAXK) return GOAT_E_SHAPE;
+  dim3 grid((N + 127) / 128, (rows + SK_ROWS - 1) / SK_ROWS);
+  // x rows are read as whole 16-byte chunks (columns >= K are multiplied but never stored): rows padded and aligned to a chunk
+  const int epc = dtype == GOAT_BF16 ? 8 : 4, kp = (K + epc - 1) / epc * epc;
+  if (ld_x < kp || (ld_x % epc) || (reinterpret_cast<uintptr_t>(x) & 15)) return GOAT_E_SHAPE;
+#define GOAT_SK_LAUNCH(T_, KP_)                                                                                              \
+  hipLaunchKernelGGL((wgrad_smallk_kernel<T_, KP_>), grid, dim3(256), 0, ST(stream), (const T_*)dy, ld_dy, (const T_*)x, ld_x, rows, N, \
+                     K, dw, ld_dw, dbias)
+  if (dtype == GOAT_BF16) {
+    if (kp == 8) GOAT_SK_LAUNCH(bf16_t, 8); else GOAT_SK_LAUNCH(bf16_t, 16);
+  } else if (dtype == GOAT_F32) {
+    if (kp == 4) GOAT_SK_LAUNCH(float, 4); else if (kp == 8) GOAT_SK_LAUNCH(float, 8);
+    else if (kp == 12) GOAT_SK_LAUNCH(float, 12); else GOAT_SK_LAUNCH(float, 16);
+  } else {
+    return GOAT_E_ARG;
+  }
+#undef GOAT_SK_LAUNCH
   GOAT_LAUNCH_CHECK();
   return 0;
 }

@@ -469,6 +469,8 @@ class WgradQueue:
     enabled = os.environ.get('GOAT_WGRAD_GROUP', '1') != '0'
     cfg = tuple(int(v) for v in os.environ.get('GOAT_WGRAD_GROUP_CFG', '256,3').split(','))   # (tile = rows | cols << 16, ring stages | 0x100 = eight waves on 128x128): scripts/wgrad_group_bench.py, profiles/round2_wgrad_grouped.txt
     MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '16'))      # problems per launch (measured 8 / 12 / 16: 7.12 / 7.09 / 7.06 ms per step)
+    SIDE = os.environ.get('GOAT_WGRAD_SIDE', '0')      # '1': grouped launches go to a stream of their own (off the dgrad chain), 'lo': low priority
+    _wstreams = {}          # producing stream handle -> the stream its grouped launches run on (SIDE mode, during capture)
     queues = {}             # HIP stream handle -> (torch stream, [(dy, x, w_sink, b_sink, accumulate)]): tensors are kept alive until
     pending_ids = {}        # the launch, which happens on the stream the problems were produced on;  id(param) -> stream handle
     _callback_armed = False
@@ -513,6 +515,9 @@ class WgradQueue:
             st = cls.queues[h][0]
             cls.flush(h)
             cur = torch.cuda.current_stream()
+            w = cls._wstreams.get(h)
+            if w is not None:
+                cur.wait_stream(w)
             if cur.cuda_stream != h:
                 cur.wait_stream(st)
 
@@ -527,6 +532,20 @@ class WgradQueue:
             cls.queues[h] = (st, [])
             for pid in [k for k, v in cls.pending_ids.items() if v == h]:
                 del cls.pending_ids[pid]
+            if cls.SIDE != '0' and torch.cuda.is_current_stream_capturing():
+                # the weight gradients are not on the critical path (needed when the backward pass ends): their grouped launch runs
+                # beside the dgrad / LayerNorm / attention chain of the producing stream instead of inside it
+                w = cls._wstreams.get(h)
+                if w is None:
+                    w = cls._wstreams[h] = torch.cuda.Stream(priority=0) if cls.SIDE != 'hi' else torch.cuda.Stream(priority=-1)
+                w.wait_stream(st)
+                with torch.cuda.stream(w):
+                    cls._launch(q)
+                for dy, x, _, _, _ in q:
+                    dy.record_stream(w)
+                    x.record_stream(w)
+                Branch.used.add(w)          # joined with the side branches when the backward pass ends
+                continue
             with torch.cuda.stream(st):
                 cls._launch(q)
 
@@ -695,6 +714,10 @@ def _pad_k(x, e):
     return x, pad
 
 
+SMALLK_WGRAD = os.environ.get('GOAT_NO_SMALLK', '0') != '1'       # (diagnostics: A/B of the short-input weight-gradient kernel)
+PANO_SINK = os.environ.get('GOAT_NO_PANO_SINK', '0') != '1'
+
+
 class _LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b)   (F.linear + activation; P/model/Bert_backbone.py:302,348-357,362)."""
 
@@ -736,7 +759,28 @@ class _LinearFn(torch.autograd.Function):
             if ctx.pad:
                 dx = dx[:, :x2.shape[1] - ctx.pad]
             dx = dx.reshape(ctx.xshape)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if SMALLK_WGRAD and ctx.pad and x2.shape[1] - ctx.pad <= 16 and (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])):
+            # short-input Linear (7- / 14-wide position features, K padded to a 16-byte chunk for the GEMM): one kernel adds the
+            # weight and bias gradients straight into the arena slices (otherwise: padded GEMM into a temporary, slice copy, grad += dW)
+            K = x2.shape[1] - ctx.pad
+            w_sink = _sink(weight)
+            b_sink = _sink(ctx.bias) if (ctx.has_bias and w_sink is not None) else None
+            if w_sink is not None and (b_sink is not None or not ctx.has_bias):
+                if _first_touch(weight):
+                    w_sink.zero_()
+                if b_sink is not None and _first_touch(ctx.bias):
+                    b_sink.zero_()
+                dwt, dbt = w_sink, b_sink
+            else:
+                _prep_fallback(weight, *([ctx.bias] if ctx.has_bias else []))
+                dwt = torch.zeros(weight.shape, dtype=torch.float32, device=dy2.device)
+                dbt = torch.zeros(weight.shape[0], dtype=torch.float32, device=dy2.device) if ctx.has_bias else None
+            st = _lib.lib().goat_wgrad_smallk(_stream(), _dt(dy2), _ptr(dy2), dy2.stride(0), _ptr(x2), x2.stride(0), dy2.shape[0],
+                                              dy2.shape[1], K, _ptr(dwt), dwt.stride(0), _ptr(dbt) if dbt is not None else None)
+            _lib.check(st, 'goat_wgrad_smallk')
+            if dwt is not w_sink:
+                dw, db = dwt, dbt
+        elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             w_sink = None if ctx.pad else _sink(weight)
             b_sink = _sink(ctx.bias) if w_sink is not None else None
             first = w_sink is not None and _first_touch(weight)
@@ -973,9 +1017,12 @@ class _LnFn(torch.autograd.Function):
     load (goat_ln_bwd's dy2), which replaces the elementwise add autograd would otherwise launch for the shared tensor."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, p, fork=False):
+    def forward(ctx, x, residual, gamma, beta, eps, p, fork=False, fork_in=False):
         _need_gpu(x)
         ctx.set_materialize_grads(False)
+        if fork_in and (fork or residual is not None):
+            raise ValueError('fork_in is for the plain LayerNorm(x) of a pre-LN block')
+        ctx.fork_in = fork_in
         H = x.shape[-1]
         x2 = x.reshape(-1, H)
         if not x2.is_contiguous():
@@ -1002,10 +1049,17 @@ class _LnFn(torch.autograd.Function):
         ctx.gb = (gamma, beta)
         ctx.shape = x.shape
         yv = y.view(x.shape)
+        if fork_in:     # second output: x itself for the skip connection; its gradient comes back to THIS node (dx_add of the kernel)
+            return yv, x.view_as(x)
         return (yv, yv.view_as(yv)) if fork else yv
 
     @staticmethod
     def backward(ctx, dy, dyb=None):
+        dskip = None
+        if ctx.fork_in:
+            dskip, dyb = dyb, None
+            if dy is None:                     # only the skip connection carried a gradient
+                return dskip, None, None, None, None, None, None, None
         if dy is None:
             dy, dyb = dyb, None
         z, gamma, mean, rstd = ctx.saved_tensors
@@ -1014,6 +1068,12 @@ class _LnFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, H)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
+        if dskip is not None:
+            dskip = dskip.reshape(-1, H)
+            if dskip.dtype != z.dtype:
+                dskip = dskip.to(z.dtype)
+            if not dskip.is_contiguous():
+                dskip = dskip.contiguous()
         if dyb is not None:
             dyb = dyb.reshape(-1, H)
             if dyb.dtype != dy2.dtype:
@@ -1043,7 +1103,7 @@ class _LnFn(torch.autograd.Function):
             ws = torch.empty(L.goat_ln_bwd_ws_floats(H), dtype=torch.float32, device=z.device) if (LN_DETERMINISTIC or M > LN_ATOMIC_MAX_ROWS) else None
         st = L.goat_ln_bwd(_stream(), _dt(z), _ptr(dy2), _ptr(dyb) if dyb is not None else None, _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd),
                            p, seed, off, dev, _ptr(dx), _ptr(dres) if dres is not None else None,
-                           _ptr(dg), _ptr(db), _ptr(ws) if ws is not None else None, M, H, acc)
+                           _ptr(dg), _ptr(db), _ptr(ws) if ws is not None else None, M, H, acc, _ptr(dskip) if dskip is not None else None)
         _lib.check(st, 'goat_ln_bwd')
         if defer:
             LnReduceQueue.push(ws, dg, db, nparts, H)
@@ -1054,11 +1114,13 @@ class _LnFn(torch.autograd.Function):
             dr = dres.view(ctx.shape) if dres is not None else dxv
         else:
             dr = None
-        return dxv, dr, dg, db, None, None, None
+        return dxv, dr, dg, db, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps, residual=None, p=0.0, fork=False):
-    return _LnFn.apply(x, residual, gamma, beta, float(eps), float(p), bool(fork))
+def layer_norm(x, gamma, beta, eps, residual=None, p=0.0, fork=False, fork_in=False):
+    """fork_in=True (pre-LN blocks): returns (LayerNorm(x), x) — use the second output for the skip connection; the gradient it
+    receives is added inside the LayerNorm backward kernel instead of by an autograd add."""
+    return _LnFn.apply(x, residual, gamma, beta, float(eps), float(p), bool(fork), bool(fork_in))
 
 
 class _DropAddFn(torch.autograd.Function):
@@ -1203,6 +1265,7 @@ class _PanoFusionFn(torch.autograd.Function):
         _lib.check(st, 'goat_pano_fusion_fwd')
         ctx.save_for_backward(x, av, a_b, wsave)
         ctx.wshape = a_w.shape
+        ctx.params = (a_w, a_b)
         return fused
 
     @staticmethod
@@ -1211,11 +1274,22 @@ class _PanoFusionFn(torch.autograd.Function):
         N, V, H = x.shape
         df = df if df.is_contiguous() else df.contiguous()
         dx = torch.empty_like(x)
-        da = torch.zeros(H, dtype=torch.float32, device=x.device)
-        da0 = torch.zeros(1, dtype=torch.float32, device=x.device)
+        sa, sb = _sink(ctx.params[0]), _sink(ctx.params[1])
+        sunk = PANO_SINK and sa is not None and sb is not None and sa.is_contiguous()
+        if sunk:                 # arena slices: the kernel's atomics add straight into them
+            for prm, snk in zip(ctx.params, (sa, sb)):
+                if _first_touch(prm):
+                    snk.zero_()
+            da, da0 = sa.view(-1), sb.view(-1)
+        else:
+            _prep_fallback(*ctx.params)
+            da = torch.zeros(H, dtype=torch.float32, device=x.device)
+            da0 = torch.zeros(1, dtype=torch.float32, device=x.device)
         st = _lib.lib().goat_pano_fusion_bwd(_stream(), _dt(x), _ptr(x), _ptr(av), _ptr(a_b), _ptr(wsave), _ptr(df),
                                              _ptr(dx), _ptr(da), _ptr(da0), N, V, H)
         _lib.check(st, 'goat_pano_fusion_bwd')
+        if sunk:
+            return dx, None, None
         return dx, da.view(ctx.wshape), da0
 
 

@@ -103,12 +103,15 @@ class Linear(nn.Linear):
         return hipops.linear(x, self.weight, self.bias, act)
 
 
+_NO_FORK_IN = bool(os.environ.get('GOAT_NO_LN_FORK_IN'))
 _NO_FORK = bool(os.environ.get('GOAT_NO_LN_FORK'))      # (diagnostics: A/B of the forked LayerNorm outputs)
 
 
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x, residual=None, p=0.0, fork=False):
-        return hipops.layer_norm(x, self.weight, self.bias, self.eps, residual, p, fork and not _NO_FORK)
+    def forward(self, x, residual=None, p=0.0, fork=False, fork_in=False):
+        if fork_in and (_NO_FORK or _NO_FORK_IN):
+            return hipops.layer_norm(x, self.weight, self.bias, self.eps), x
+        return hipops.layer_norm(x, self.weight, self.bias, self.eps, residual, p, fork and not _NO_FORK, fork_in)
 
 
 def _pair(h):
@@ -368,11 +371,14 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, src, kmask):
         # forward_pre (P/model/transformer.py:170-182); attention-prob dropout = the layer's dropout value
         p_attn = self.self_attn.dropout if self.training else 0.0
-        a = self.self_attn(self.norm1(src), kmask, p_attn)
-        src = hipops.dropout_add(a, src, _p(self.dropout1))
-        y = hipops.ffn(self.norm2(src), self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+        # (fork_in: the LayerNorm hands its input back for the skip connection, so both gradients of `src` meet inside its backward)
+        n1, skip = self.norm1(src, fork_in=True)
+        a = self.self_attn(n1, kmask, p_attn)
+        src = hipops.dropout_add(a, skip, _p(self.dropout1))
+        n2, skip = self.norm2(src, fork_in=True)
+        y = hipops.ffn(n2, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                        'gelu', _p(self.dropout))
-        return hipops.dropout_add(y, src, _p(self.dropout2))
+        return hipops.dropout_add(y, skip, _p(self.dropout2))
 
 
 class TransformerEncoder(nn.Module):
