@@ -713,9 +713,14 @@ def config4_leg(args):
     hipops.manual_seed(4321)
     hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')       # per-replay dropout counter
 
+    arena = [None]
+
     def episode():
-        for p in params:
-            p.grad = None
+        if arena[0] is not None:
+            arena[0].zero('nav')             # gradient arena: weight gradients of the rollout's Linears are grouped (goat_wgrad_grouped)
+        else:
+            for p in params:
+                p.grad = None
         hipops.RngState.dev.add_(0x9E3779B1)
         loss, _ = synth.run_nav_episode(lambda m, b: model(m, b), ep, device='cuda')
         loss.backward()
@@ -723,7 +728,16 @@ def config4_leg(args):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for _ in range(3):
+        for _ in range(2):
+            episode()
+        if not args.no_arena:
+            from vln_goat_amd import dp
+            wrapper = dp.GoatDataParallel(model)
+            wrapper.record_usage('nav')
+            for p in params:
+                p.grad = None
+            arena[0] = wrapper.build_arena()
+        for _ in range(2):
             episode()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()

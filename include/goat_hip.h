@@ -132,6 +132,8 @@ typedef struct goat_ln_partial {
 } goat_ln_partial;
 int goat_ln_bwd_ws_floats(int H);
 int goat_ln_bwd_nparts(int M);
+/* entries with the same dgamma (a LayerNorm applied several times in one backward pass) must share dbeta; they are summed by one
+ * writer in call order. */
 int goat_ln_reduce_batched(void* stream, const goat_ln_partial* entries, int n, int H);
 int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* dy2, const void* z,
                 const float* gamma, const float* mean, const float* rstd,

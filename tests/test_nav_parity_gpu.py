@@ -217,3 +217,44 @@ def test_extract_cfp_features_and_zdict_update_match_reference_golden(dtype):
         assert np.abs(got - ref).max() / max(1.0, np.abs(ref).max()) < tol, k
     got, ref = z.float().cpu().numpy()[:, :, :32], gold['zdict_txt']
     assert np.abs(got - ref).max() / max(1.0, np.abs(ref).max()) < tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_nav_episode_gradient_arena_equals_autograd(dtype):
+    """The fine-tuning model under dp.GradArena: a 3-step rollout with BPTT writes every shared weight several times per
+    backward pass (first write overwrites its arena slice, later ones accumulate; the grouped weight-gradient queue is flushed in
+    between) — gradients must equal the ordinary autograd result, also on the second rollout (stale slices)."""
+    import vln_goat_amd
+    from vln_goat_amd import dp, synth
+    model, ep = _build('nav_type2_door')
+    vln_goat_amd.set_compute_dtype(dtype)
+    try:
+        model = model.cuda().eval()
+        mv = lambda x: x.cuda() if torch.is_tensor(x) else x
+        ep = {k: ([{kk: mv(vv) for kk, vv in st.items()} for st in v] if k == 'steps' else mv(v)) for k, v in ep.items()}
+
+        def rollout():
+            loss, _ = synth.run_nav_episode(lambda m, b: model(m, b), ep, device='cuda')
+            loss.backward()
+            torch.cuda.synchronize()
+        rollout()
+        ref = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+        wrapper = dp.GoatDataParallel(model)
+        wrapper.record_usage('nav')
+        for p in model.parameters():
+            p.grad = None
+        arena = wrapper.build_arena()
+        arena.flat.fill_(77.0)                       # stale garbage everywhere
+        gmax = max(float(g.abs().max()) for g in ref.values())
+        tol = 2e-5 if dtype == torch.float32 else 2e-5      # same kernels, same order of the bf16 roundings: only f32 summation order differs
+        for rep in range(2):
+            arena.zero('nav')
+            rollout()
+            for n, p in model.named_parameters():
+                if n not in ref:
+                    continue
+                assert p.grad is arena.views[id(p)], n
+                d = float((p.grad.float() - ref[n]).abs().max())
+                assert d <= tol * max(float(ref[n].abs().max()), 1e-3 * gmax) + 1e-9, (rep, n, d, float(ref[n].abs().max()))
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)

@@ -3,6 +3,8 @@
 // wavefront shuffles for the reductions, statistics in f32.
 #include <cstdlib>
 #include "common.hpp"
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -262,22 +264,28 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 struct LnPartial { const float* ws; float* dgamma; float* dbeta; int nparts; int pad; };
 struct LnReduceArgs { LnPartial e[64]; int n; int H; };
 __global__ __launch_bounds__(256) void ln_reduce_batched_kernel(LnReduceArgs a) {
+  // entries are sorted by destination: the first entry of a run of equal destinations (a LayerNorm applied several times in one
+  // backward pass: shared modules, BPTT) sums the whole run, the others leave — one writer per gradient word, fixed order
   __shared__ float red[16][17];
-  const LnPartial& en = a.e[blockIdx.y];
-  const float* __restrict__ ws = en.ws;
-  const int nparts = en.nparts, H = a.H;
+  const int e0 = blockIdx.y;
+  if (e0 > 0 && a.e[e0 - 1].dgamma == a.e[e0].dgamma) return;
+  const int H = a.H;
   const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + cx;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (i < 2 * H) {
-    int b = g;
-    for (; b + 48 < nparts; b += 64) {
-      s0 += ws[(int64_t)b * 2 * H + i];
-      s1 += ws[(int64_t)(b + 16) * 2 * H + i];
-      s2 += ws[(int64_t)(b + 32) * 2 * H + i];
-      s3 += ws[(int64_t)(b + 48) * 2 * H + i];
+  for (int e = e0; e < a.n && a.e[e].dgamma == a.e[e0].dgamma; ++e) {
+    const float* __restrict__ ws = a.e[e].ws;
+    const int nparts = a.e[e].nparts;
+    if (i < 2 * H) {
+      int b = g;
+      for (; b + 48 < nparts; b += 64) {
+        s0 += ws[(int64_t)b * 2 * H + i];
+        s1 += ws[(int64_t)(b + 16) * 2 * H + i];
+        s2 += ws[(int64_t)(b + 32) * 2 * H + i];
+        s3 += ws[(int64_t)(b + 48) * 2 * H + i];
+      }
+      for (; b < nparts; b += 16) s0 += ws[(int64_t)b * 2 * H + i];
     }
-    for (; b < nparts; b += 16) s0 += ws[(int64_t)b * 2 * H + i];
   }
   red[g][cx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256) void ln_reduce_batched_kernel(LnReduceArgs a) 
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][cx];
-    float* dst = (i < H) ? en.dgamma + i : en.dbeta + (i - H);
+    float* dst = (i < H) ? a.e[e0].dgamma + i : a.e[e0].dbeta + (i - H);
     *dst += t;
   }
 }
@@ -1039,12 +1047,20 @@ extern "C" int goat_ln_bwd_nparts(int M) {       // partial rows written by goat
 
 extern "C" int goat_ln_reduce_batched(void* stream, const goat_ln_partial* entries, int n, int H) {
   if (!entries || n < 0 || H <= 0) return GOAT_E_ARG;
+  // same destination -> adjacent (stable: call order kept inside a run); consecutive launches on one stream are ordered, so a run
+  // cut by the 64-entry limit is still summed by one writer at a time
+  std::vector<goat_ln_partial> sorted(entries, entries + n);
+  std::stable_sort(sorted.begin(), sorted.end(), [](const goat_ln_partial& x, const goat_ln_partial& y) {
+    return reinterpret_cast<uintptr_t>(x.dgamma) < reinterpret_cast<uintptr_t>(y.dgamma);
+  });
+  for (int k = 1; k < n; ++k)
+    if (sorted[k].dgamma == sorted[k - 1].dgamma && sorted[k].dbeta != sorted[k - 1].dbeta) return GOAT_E_ARG;
   for (int first = 0; first < n; first += 64) {
     LnReduceArgs a;
     a.n = n - first < 64 ? n - first : 64;
     a.H = H;
     for (int k = 0; k < a.n; ++k) {
-      const goat_ln_partial& e = entries[first + k];
+      const goat_ln_partial& e = sorted[first + k];
       if (!e.ws || !e.dgamma || !e.dbeta || e.nparts <= 0) return GOAT_E_ARG;
       a.e[k].ws = e.ws; a.e[k].dgamma = e.dgamma; a.e[k].dbeta = e.dbeta; a.e[k].nparts = e.nparts; a.e[k].pad = 0;
     }
