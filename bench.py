@@ -711,6 +711,7 @@ def config4_leg(args):
     ep = {k: ([{kk: mv(vv) for kk, vv in st.items()} for st in v] if k == 'steps' else mv(v)) for k, v in ep.items()}
     params = list(model.parameters())
     hipops.manual_seed(4321)
+    hipops.AUTOTUNE = not args.no_autotune     # first sight of a GEMM shape times (tile, LDS stages, split-K) candidates
     hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')       # per-replay dropout counter
 
     arena = [None]

@@ -501,8 +501,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in
 // dW[n, k] += sum_r dy[r, n] x[r, k] ; dbias[n] += sum_r dy[r, n]   for K <= 16 input features (the 7- / 14-wide position Linears,
 // P/model/vilmodel_goat.py:300-303,406,475): block = 128 output columns x a chunk of rows, lane = 2 columns, wave = row phase.
 // Replaces a padded-K GEMM into a temporary + slice copy + autograd's `grad += dW` (4 launches per Linear and step).
-constexpr int SK_MAXK = 16, SK_ROWS = 128, SK_BATCH = 8;
-template <typename T, int KP>      // KP: padded input width in elements (one or two 16-byte chunks per row of x)
+constexpr int SK_MAXK = 16, SK_BATCH = 8;
+template <typename T, int KP, int SK_ROWS>      // SK_ROWS: rows per block (128; 32 for short inputs so that the grid still covers the chip)
 __global__ __launch_bounds__(256) void wgrad_smallk_kernel(const T* __restrict__ dy, int64_t ld_dy, const T* __restrict__ x,
                                                            int64_t ld_x, int rows, int N, int K, float* __restrict__ dw,
                                                            int64_t ld_dw, float* __restrict__ dbias) {
@@ -1257,13 +1257,20 @@ extern "C" int goat_wgrad_smallk(void* stream, int dtype, const void* dy, int64_
                                  int N, int K, float* dw, int64_t ld_dw, float* dbias) {
   if (!dy || !x || !dw) return GOAT_E_ARG;
   if (rows <= 0 || N <= 0 || K <= 0 || K > SK_MAXK) return GOAT_E_SHAPE;
-  dim3 grid((N + 127) / 128, (rows + SK_ROWS - 1) / SK_ROWS);
+  const int rc = rows >= 2048 ? 128 : 32;          // rows per block
+  dim3 grid((N + 127) / 128, (rows + rc - 1) / rc);
   // x rows are read as whole 16-byte chunks (columns >= K are multiplied but never stored): rows padded and aligned to a chunk
   const int epc = dtype == GOAT_BF16 ? 8 : 4, kp = (K + epc - 1) / epc * epc;
   if (ld_x < kp || (ld_x % epc) || (reinterpret_cast<uintptr_t>(x) & 15)) return GOAT_E_SHAPE;
 #define GOAT_SK_LAUNCH(T_, KP_)                                                                                              \
-  hipLaunchKernelGGL((wgrad_smallk_kernel<T_, KP_>), grid, dim3(256), 0, ST(stream), (const T_*)dy, ld_dy, (const T_*)x, ld_x, rows, N, \
-                     K, dw, ld_dw, dbias)
+  do {                                                                                                                       \
+    if (rc == 128)                                                                                                           \
+      hipLaunchKernelGGL((wgrad_smallk_kernel<T_, KP_, 128>), grid, dim3(256), 0, ST(stream), (const T_*)dy, ld_dy, (const T_*)x, ld_x, \
+                         rows, N, K, dw, ld_dw, dbias);                                                                      \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((wgrad_smallk_kernel<T_, KP_, 32>), grid, dim3(256), 0, ST(stream), (const T_*)dy, ld_dy, (const T_*)x, ld_x, \
+                         rows, N, K, dw, ld_dw, dbias);                                                                      \
+  } while (0)
   if (dtype == GOAT_BF16) {
     if (kp == 8) GOAT_SK_LAUNCH(bf16_t, 8); else GOAT_SK_LAUNCH(bf16_t, 16);
   } else if (dtype == GOAT_F32) {
