@@ -299,7 +299,10 @@ def _attn_ref(q, k, v, kmask, bias, nh):
 @pytest.mark.parametrize('Lq,Lk,mode,use_bias,inf', [
     (80, 80, 'self', False, False), (36, 36, 'self', False, True), (22, 22, 'self', True, False),
     (37, 80, 'cross', False, False), (80, 23, 'cross', False, False), (130, 130, 'self', False, False),
-    (5, 200, 'cross', False, False), (33, 65, 'cross', False, False)])
+    (5, 200, 'cross', False, False), (33, 65, 'cross', False, False),
+    # 129..256-row sequences on the LDS-staged kernels: two query tiles per wave / several backward roles per wave
+    (160, 160, 'self', False, False), (60, 200, 'cross', False, False), (200, 38, 'cross', False, False), (256, 256, 'self', False, True),
+    (200, 200, 'self', True, False)])
 def test_attention_fwd_bwd(ops, dtype, Lq, Lk, mode, use_bias, inf):
     B, nh, H = 3, 12, 768
     g = torch.Generator().manual_seed(Lq * 131 + Lk)

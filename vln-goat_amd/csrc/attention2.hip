@@ -1,4 +1,4 @@
-// goat_attn2_fwd / goat_attn2_bwd: masked multi-head attention (head_dim 64, bf16) for GOAT's short sequences (<= 128 rows on
+// goat_attn2_fwd / goat_attn2_bwd: masked multi-head attention (head_dim 64, bf16) for GOAT's short sequences (<= 256 rows on
 // either side), one workgroup per (sample, head).
 //
 // Why a second set of kernels: the round-1 kernels (attention.hip) run one wave per 32-row tile and fetch their MFMA fragments
@@ -192,7 +192,13 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(AttnArgs p) {
   __syncthreads();
   GOAT_STAMP(2);
 
-  const int q0 = wave * 32, q = q0 + l31;
+  const bool drop = p.p > 0.f;
+  const uint32_t thr = goat_thr16(p.p);
+  const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
+  const HeadRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull), p.offset, (uint32_t)blockIdx.x);
+  // a wave takes query tiles wave, wave + #waves, ... (one each up to 128 queries; two for the 129..256-row sequences)
+  for (int qti = wave; qti < nqt; qti += (nth >> 6)) {
+  const int q0 = qti * 32, q = q0 + l31;
   const bool qv = q < p.Lq;
   bf16_t* qt = ql + q0 * LSTR;
   bf16x8 qf[KSTEPS];
@@ -249,10 +255,6 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(AttnArgs p) {
 
   GOAT_STAMP(4);
   // dropout: the keep bits of 4 consecutive keys from 2 pair hashes (3 when q * Lk is odd)
-  const bool drop = p.p > 0.f;
-  const uint32_t thr = goat_thr16(p.p);
-  const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
-  const HeadRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull), p.offset, (uint32_t)blockIdx.x);
   const uint32_t idx0 = (uint32_t)q * (uint32_t)p.Lk;
   if (drop) {
 #pragma unroll
@@ -286,11 +288,13 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(AttnArgs p) {
       for (int dt = 0; dt < 2; ++dt) mma32(o[dt], bfrag_crow(vl, jt * 32, st, dt, lane), pa);
     }
   GOAT_STAMP(6);
-  store_tile(qt, o, Ob, p.o_rs, q0, p.Lq, lane);          // this wave's Q tile is dead: nobody else reads it
+  store_tile(qt, o, Ob, p.o_rs, q0, p.Lq, lane);          // this query tile's Q rows are dead: nobody else reads them
   GOAT_STAMP(7);
+  }
 }
 
 // ======================================================================================== backward
+template <bool MULTI>      // MULTI: more roles than waves (129..256-row sequences)
 __global__ __launch_bounds__(512) void attn2_bwd_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x;
@@ -304,6 +308,11 @@ __global__ __launch_bounds__(512) void attn2_bwd_kernel(AttnArgs p) {
   float* Dl = reinterpret_cast<float*>(vl + nkt * TILE);      // D_q = sum_d dO[q,d] O[q,d]
   float* lsel = Dl + nqt * 32;
   float* kml = lsel + nqt * 32;
+  // more roles than waves (sequences of 129..256 rows): a wave runs roles wave, wave + #waves, ... and hands its results out
+  // through a staging tile of its own (the operand tiles are still being read by the other waves)
+  const int nroles = nqt + nkt, nw = nth >> 6;
+  constexpr bool multi = MULTI;
+  bf16_t* stg = reinterpret_cast<bf16_t*>(kml + nkt * 32) + wave * TILE;
 
   const bf16_t* Qb = reinterpret_cast<const bf16_t*>(p.Q) + b * p.q_bs + h * HD;
   const bf16_t* Kb = reinterpret_cast<const bf16_t*>(p.K) + b * p.k_bs + h * HD;
@@ -352,15 +361,20 @@ __global__ __launch_bounds__(512) void attn2_bwd_kernel(AttnArgs p) {
   const uint32_t thr = goat_thr16(p.p);
   const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
   const HeadRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull), p.offset, (uint32_t)blockIdx.x);
+#define GOAT_DQB (reinterpret_cast<bf16_t*>(p.dQ) + b * p.dq_bs + h * HD)      // (formed at the stores: not live across the role bodies)
+#define GOAT_DKB (reinterpret_cast<bf16_t*>(p.dK) + b * p.dk_bs + h * HD)
+#define GOAT_DVB (reinterpret_cast<bf16_t*>(p.dV) + b * p.dv_bs + h * HD)
   f32x16 ra[2], rb[2];           // results: dQ role uses ra (dQ); dK/dV role ra = dK, rb = dV
+  int role = wave;
+  for (; role < (MULTI ? nroles : wave + 1); role += (MULTI ? nw : 1)) {
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ra[dt][r] = 0.f; rb[dt][r] = 0.f; }
 
-  if (wave < nqt) {
+  if (role < nqt) {
     // ---- dQ role: lane = query.  S^T = K·Q^T, dP^T = V·dO^T per key tile; dQ^T += K^T·dS^T
-    const int q0 = wave * 32, q = q0 + l31;
+    const int q0 = role * 32, q = q0 + l31;
     const bool qv = q < p.Lq;
     bf16x8 qf[KSTEPS], dof[KSTEPS];
 #pragma unroll
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(512) void attn2_bwd_kernel(AttnArgs p) {
     }
   } else {
     // ---- dK / dV role: lane = key.  S = Q·K^T, dP = dO·V^T per query tile; dV^T += dO^T·Pd, dK^T += Q^T·dS
-    const int k0 = (wave - nqt) * 32, key = k0 + l31;
+    const int k0 = (role - nqt) * 32, key = k0 + l31;
     const bool kv = key < p.Lk;
     bf16x8 kf[KSTEPS], vf[KSTEPS];
 #pragma unroll
@@ -476,17 +490,27 @@ __global__ __launch_bounds__(512) void attn2_bwd_kernel(AttnArgs p) {
       }
     }
   }
+  if (!multi) break;      // one role per wave: results leave after the block barrier below, through the operand tiles
+  if (role < nqt) {
+    store_tile(stg, ra, GOAT_DQB, p.dq_rs, role * 32, p.Lq, lane);
+  } else {
+    const int kt = role - nqt;
+    store_tile(stg, ra, GOAT_DKB, p.dk_rs, kt * 32, p.Lk, lane);
+    store_tile(stg, rb, GOAT_DVB, p.dv_rs, kt * 32, p.Lk, lane);
+  }
+  }
+  if (multi) return;
   __syncthreads();      // every wave is done reading the staged operands: their tiles become the result staging areas
   if (wave < nqt) {
-    bf16_t* dQb = reinterpret_cast<bf16_t*>(p.dQ) + b * p.dq_bs + h * HD;
-    store_tile(ql + wave * TILE, ra, dQb, p.dq_rs, wave * 32, p.Lq, lane);
+    store_tile(ql + wave * TILE, ra, GOAT_DQB, p.dq_rs, wave * 32, p.Lq, lane);
   } else {
     const int kt = wave - nqt;
-    bf16_t* dKb = reinterpret_cast<bf16_t*>(p.dK) + b * p.dk_bs + h * HD;
-    bf16_t* dVb = reinterpret_cast<bf16_t*>(p.dV) + b * p.dv_bs + h * HD;
-    store_tile(kl + kt * TILE, ra, dKb, p.dk_rs, kt * 32, p.Lk, lane);
-    store_tile(vl + kt * TILE, rb, dVb, p.dv_rs, kt * 32, p.Lk, lane);
+    store_tile(kl + kt * TILE, ra, GOAT_DKB, p.dk_rs, kt * 32, p.Lk, lane);
+    store_tile(vl + kt * TILE, rb, GOAT_DVB, p.dv_rs, kt * 32, p.Lk, lane);
   }
+#undef GOAT_DQB
+#undef GOAT_DKB
+#undef GOAT_DVB
 }
 
 template <typename K>
@@ -505,7 +529,8 @@ int launch_fwd(hipStream_t st, const AttnArgs& a) {
   const size_t sm = (size_t)(2 * NKT + nqt) * TILE * 2 + NKT * 32 * 4;
   static size_t cur = 0;
   if (int e = set_smem(attn2_fwd_kernel<NKT>, sm, cur)) return e;
-  hipLaunchKernelGGL(attn2_fwd_kernel<NKT>, dim3(a.B * a.nh), dim3(64 * nqt), sm, st, a);
+  if (sm > 160 * 1024) return GOAT_E_SHAPE;
+  hipLaunchKernelGGL(attn2_fwd_kernel<NKT>, dim3(a.B * a.nh), dim3(64 * (nqt < 4 ? nqt : 4)), sm, st, a);
   GOAT_LAUNCH_CHECK();
   return 0;
 }
@@ -514,7 +539,7 @@ int launch_fwd(hipStream_t st, const AttnArgs& a) {
 
 int goat_attn2_fwd(hipStream_t st, const AttnArgs& a) {
   const int nkt = (a.Lk + 31) / 32, nqt = (a.Lq + 31) / 32;
-  if (nkt > 4 || nqt > 4) return GOAT_E_SHAPE;
+  if (nkt > 8 || nqt > 8) return GOAT_E_SHAPE;
   // 16-byte row segments on every operand and on O
   if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.q_bs | a.k_bs | a.v_bs | a.o_bs) & 7) return GOAT_E_SHAPE;
   if ((reinterpret_cast<uintptr_t>(a.Ow) & 15)) return GOAT_E_SHAPE;
@@ -523,23 +548,34 @@ int goat_attn2_fwd(hipStream_t st, const AttnArgs& a) {
     case 2: return launch_fwd<2>(st, a);
     case 3: return launch_fwd<3>(st, a);
     case 4: return launch_fwd<4>(st, a);
+    case 5: return launch_fwd<5>(st, a);
+    case 6: return launch_fwd<6>(st, a);
+    case 7: return launch_fwd<7>(st, a);
+    case 8: return launch_fwd<8>(st, a);
   }
   return GOAT_E_SHAPE;
 }
 
 int goat_attn2_bwd(hipStream_t st, const AttnArgs& a) {
   const int nkt = (a.Lk + 31) / 32, nqt = (a.Lq + 31) / 32;
-  if (nkt > 4 || nqt > 4) return GOAT_E_SHAPE;
+  if (nkt > 8 || nqt > 8) return GOAT_E_SHAPE;
   if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.do_rs | a.dq_rs | a.dk_rs | a.dv_rs | a.q_bs | a.k_bs | a.v_bs | a.o_bs | a.do_bs | a.dq_bs |
        a.dk_bs | a.dv_bs) & 7)
     return GOAT_E_SHAPE;
   if ((reinterpret_cast<uintptr_t>(a.O) & 15) || (reinterpret_cast<uintptr_t>(a.dO) & 15) || (reinterpret_cast<uintptr_t>(a.dQ) & 15) ||
       (reinterpret_cast<uintptr_t>(a.dK) & 15) || (reinterpret_cast<uintptr_t>(a.dV) & 15))
     return GOAT_E_SHAPE;
-  const size_t sm = (size_t)(2 * nqt + 2 * nkt) * TILE * 2 + (size_t)(2 * nqt + nkt) * 32 * 4;
-  static size_t cur = 0;
-  if (int e = set_smem(attn2_bwd_kernel, sm, cur)) return e;
-  hipLaunchKernelGGL(attn2_bwd_kernel, dim3(a.B * a.nh), dim3(64 * (nqt + nkt)), sm, st, a);
+  const int nwv = nqt + nkt <= 8 ? nqt + nkt : 8;
+  const size_t sm = (size_t)(2 * nqt + 2 * nkt) * TILE * 2 + (size_t)(2 * nqt + nkt) * 32 * 4 + (nqt + nkt > 8 ? (size_t)nwv * TILE * 2 : 0);
+  if (sm > 160 * 1024) return GOAT_E_SHAPE;          // (e.g. 200 x 200: the caller falls back to the streaming kernels of attention.hip)
+  static size_t cur = 0, cur_m = 0;
+  if (nqt + nkt > 8) {
+    if (int e = set_smem(attn2_bwd_kernel<true>, sm, cur_m)) return e;
+    hipLaunchKernelGGL(attn2_bwd_kernel<true>, dim3(a.B * a.nh), dim3(64 * nwv), sm, st, a);
+  } else {
+    if (int e = set_smem(attn2_bwd_kernel<false>, sm, cur)) return e;
+    hipLaunchKernelGGL(attn2_bwd_kernel<false>, dim3(a.B * a.nh), dim3(64 * nwv), sm, st, a);
+  }
   GOAT_LAUNCH_CHECK();
   return 0;
 }
