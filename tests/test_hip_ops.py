@@ -437,6 +437,15 @@ def test_embedding_tables(ops, dtype, with_types):
     _close(o2, F.embedding(sid, step), dtype, 'embedding single')
     o2.backward(torch.ones_like(o2))
     _close(step.grad, torch.bincount(sid.reshape(-1), minlength=15).float()[:, None].expand(15, H), torch.float32, 'step grad')
+    # many rows into a 3-row table (nav-type embeddings of a batch of panoramas): the LDS-accumulating backward kernel
+    small = torch.nn.Parameter(torch.randn(3, H, generator=g).to(DEV))
+    nid = torch.randint(0, 3, (240, 37), generator=g).to(DEV)
+    o3 = ops.embedding(nid, small, out_dtype=dtype)
+    d3 = torch.randn(240, 37, H, generator=g).to(DEV, dtype)
+    o3.backward(d3)
+    sr = small.detach().clone().requires_grad_(True)
+    F.embedding(nid, sr).backward(d3.float())
+    _close(small.grad, sr.grad, torch.float32, 'small-table grad')
     bad = sid.clone()
     bad[0, 0] = 15
     ops.embedding(bad, step, out_dtype=dtype)

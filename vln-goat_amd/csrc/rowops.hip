@@ -966,6 +966,34 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ do
   }
 }
 
+// Small tables (nav-type, step-id, object-name embeddings: 3..64 rows): every token row lands on a handful of table rows, so the
+// per-element atomics of the kernel above serialise on the same words (109 us for 8960 rows into a 3-row table).  Here a block
+// owns 64 columns x a chunk of token rows, accumulates in LDS ([row phase][table row][column], one owner per word) and issues one
+// atomic per table word and block.
+constexpr int ES_MAXV = 64, ES_ROWS = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_small_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids,
+                                                              float* __restrict__ dtab, int rows, int H, int vocab, int pad_id) {
+  extern __shared__ float es[];      // [4][vocab][64]
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  for (int i = threadIdx.x; i < 4 * vocab * 64; i += 256) es[i] = 0.f;
+  __syncthreads();
+  const int r0 = blockIdx.y * ES_ROWS, r1 = min(rows, r0 + ES_ROWS);
+  if (c < H)
+    for (int r = r0 + ph; r < r1; r += 4) {
+      const int64_t id = ids[r];
+      if (id < 0 || id >= vocab || id == pad_id) continue;
+      es[(ph * vocab + (int)id) * 64 + lane] += to_f(dout[(int64_t)r * H + c]);
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < vocab * 64; i += 256) {
+    const int v = i >> 6, l = i & 63;
+    const float t = es[(0 * vocab + v) * 64 + l] + es[(1 * vocab + v) * 64 + l] + es[(2 * vocab + v) * 64 + l] + es[(3 * vocab + v) * 64 + l];
+    if (t != 0.f && blockIdx.x * 64 + l < H) atomicAdd(dtab + (int64_t)v * H + blockIdx.x * 64 + l, t);
+  }
+}
+
 // ------------------------------------------------------------------------------------ tr16 probe
 __global__ void probe_tr16_kernel(uint16_t* out) {
   __shared__ __attribute__((aligned(16))) uint16_t sm[64 * 4];
@@ -1414,6 +1442,21 @@ extern "C" int goat_embed_bwd(void* stream, int dtype, const void* dout, const i
   if (rows <= 0 || H <= 0 || vocab <= 0 || (dpos && L <= 0)) return GOAT_E_SHAPE;
   const int epc = dtype == GOAT_BF16 ? 8 : 4;
   if (H % epc) return GOAT_E_SHAPE;
+  static const bool es_off = getenv("GOAT_NO_EMBED_SMALL") != nullptr;      // (diagnostics: A/B)
+  if (!es_off && dword && !dtype_tab && !dpos && vocab <= ES_MAXV && rows >= 512) {      // single small table: LDS accumulation per block
+    dim3 grid((H + 63) / 64, (rows + ES_ROWS - 1) / ES_ROWS);
+    const size_t sm = (size_t)4 * vocab * 64 * sizeof(float);
+    if (dtype == GOAT_BF16)
+      hipLaunchKernelGGL(embed_bwd_small_kernel<bf16_t>, grid, dim3(256), sm, ST(stream), (const bf16_t*)dout, ids, dword, rows, H, vocab,
+                         word_pad);
+    else if (dtype == GOAT_F32)
+      hipLaunchKernelGGL(embed_bwd_small_kernel<float>, grid, dim3(256), sm, ST(stream), (const float*)dout, ids, dword, rows, H, vocab,
+                         word_pad);
+    else
+      return GOAT_E_ARG;
+    GOAT_LAUNCH_CHECK();
+    return 0;
+  }
   int blocks = (rows + 3) / 4;
   if (blocks > 8192) blocks = 8192;
   if (dtype == GOAT_BF16)
