@@ -210,10 +210,13 @@ int goat_pano_fusion_bwd(void* stream, int dtype, const void* x, const float* a,
  * (idx = -1 contributes zero).  One launch replaces the host triple loop of
  * GlobalMapEncoder._aggregate_gmap_features (P/model/vilmodel_goat.py:438-460), the [stop]-token
  * concat/pad of vp_input_embedding (:377-391) and pad_tensors_wgrad (P/model/ops.py:46-68).
- * idx/start are int32 device arrays built once per batch on the host from the string ids. */
+ * idx/start are int32 device arrays built once per batch on the host from the string ids.
+ * tok_w (may be NULL): a weight per index entry, out[i] = scale[i] * sum_j tok_w[j] src[idx[j]].  With the INVERSE index of a
+ * gather (graphmap.inverse_index: for every source row the segments that read it, tok_w = their scales) this same entry point is
+ * the gather's backward pass — one writer per row, results in the activation dtype, no zero fill / atomics / cast. */
 int goat_gather_segmean_fwd(void* stream, int dtype, const void* src, int64_t src_rows,
                             const int32_t* idx, const int32_t* start, const float* scale,
-                            void* out, int n_out, int H);
+                            void* out, int n_out, int H, const float* tok_w);
 /* backward: dsrc[idx[j],:] += scale[i]*dout[i,:]  (float atomics into float32 dsrc32 [src_rows,H]). */
 int goat_gather_segmean_bwd(void* stream, int dtype, const void* dout,
                             const int32_t* idx, const int32_t* start, const float* scale,

@@ -400,6 +400,18 @@ def test_gather_segmean(ops, dtype):
     ref.backward(dout.float())
     _close(out, ref, dtype, 'gather')
     _close(src.grad, sr.grad, dtype, 'gather grad')
+    # with the inverse index the backward pass is a gather over dout (one writer per source row): same values, source dtype
+    from vln_goat_amd import graphmap
+    for sc in (scale, None):
+        inv = tuple(t.to(DEV) for t in graphmap.inverse_index(idx, start, sc, rows) if t is not None)
+        s2 = src.detach().clone().requires_grad_(True)
+        o2 = ops.gather_segmean(s2, idx, start, sc, n_out, inv)
+        o2.backward(dout)
+        s3 = src.detach().clone().requires_grad_(True)
+        ops.gather_segmean(s3, idx, start, sc, n_out).backward(dout)
+        assert s2.grad.dtype == dtype and s2.grad.shape == src.shape
+        _close(s2.grad, s3.grad, dtype, 'gather grad via inverse index')
+        assert float(s2.grad[20:49].abs().max()) == 0.0          # rows nobody reads: exact zeros, written (no stale memory)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

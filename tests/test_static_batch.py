@@ -55,6 +55,28 @@ def test_vectorised_index_builders_match_loops():
         graphmap.build_obj_concat_index([4], [3], 4, 3, 6)
 
 
+def test_inverse_gather_index_matches_brute_force():
+    from vln_goat_amd import graphmap
+    rs = np.random.RandomState(11)
+    for trial in range(40):
+        n_src, n_seg = rs.randint(1, 30), rs.randint(1, 12)
+        segs = [rs.randint(0, n_src, rs.randint(0, 5)).tolist() for _ in range(n_seg)]
+        flat = [i for s in segs for i in s]
+        idx = torch.tensor(flat or [-1], dtype=torch.int32)
+        start = torch.tensor(np.cumsum([0] + [len(s) for s in segs]), dtype=torch.int32)
+        scale = torch.tensor(rs.rand(n_seg).astype(np.float32))
+        inv_idx, inv_start, inv_w = graphmap.inverse_index(idx, start, scale, n_src)
+        assert inv_start.shape[0] == n_src + 1 and int(inv_start[-1]) == len(flat)
+        for r in range(n_src):
+            want = sorted((k, float(scale[k])) for k, s in enumerate(segs) for i in s if i == r)
+            a, b = int(inv_start[r]), int(inv_start[r + 1])
+            got = sorted((int(inv_idx[j]), float(inv_w[j])) for j in range(a, b))
+            assert got == want, (trial, r)
+        assert graphmap.inverse_index(idx, start, None, n_src)[2] is None
+    with pytest.raises(ValueError):
+        graphmap.inverse_index(torch.tensor([5], dtype=torch.int32), torch.tensor([0, 1], dtype=torch.int32), None, 3)
+
+
 def test_static_batch_pack_commit_and_shape_guard():
     from vln_goat_amd import config as gcfg, layers, synth, train_step
     cfg = gcfg.make_config(num_l_layers=1, num_top_layer=1, num_pano_layers=1, vocab_size=300)
@@ -80,7 +102,7 @@ def test_static_batch_pack_commit_and_shape_guard():
             assert torch.equal(sb.gb[k], v) and sb.gb[k].data_ptr() == addr[k], k
     idx = train_step.collate_indices(cfg, second)
     c = sb.gb['_goat_cache']
-    for k in ('gmap', 'vp', 'sap'):
+    for k in ('gmap', 'vp', 'sap', 'gmap_inv', 'vp_inv'):
         for a, b in zip(c[k], idx[k]):
             assert (torch.equal(a, b) if torch.is_tensor(a) else a == b), k
     assert torch.equal(c['mlm_idx'], idx['mlm_idx']) and torch.equal(c['mlm_tgt'], idx['mlm_tgt'])

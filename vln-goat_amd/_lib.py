@@ -48,7 +48,7 @@ SIGNATURES = {
     'goat_ce_bwd': [_vp, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64],
     'goat_pano_fusion_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_pano_fusion_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
-    'goat_gather_segmean_fwd': [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32],
+    'goat_gather_segmean_fwd': [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
     'goat_gather_segmean_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
     'goat_embed_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],
     'goat_embed_bwd': [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],

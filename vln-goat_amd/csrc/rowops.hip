@@ -838,7 +838,7 @@ __global__ __launch_bounds__(64 * PF_NW) void pano_fusion_bwd_kernel(const T* __
 template <typename T>
 __global__ __launch_bounds__(256) void gather_fwd_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx,
                                                          const int32_t* __restrict__ start, const float* __restrict__ scale,
-                                                         T* __restrict__ out, int n_out, int H) {
+                                                         const float* __restrict__ tok_w, T* __restrict__ out, int n_out, int H) {
   constexpr int EPC = DT<T>::EPC;
   const int nchunk = H / EPC;
   const int64_t total = (int64_t)n_out * nchunk;
@@ -852,8 +852,9 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(const T* __restrict__ s
       if (s >= 0) {
         Chunk<T> v;
         v.load(src + (int64_t)s * H + c * EPC);
+        const float w = tok_w ? tok_w[j] : 1.f;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) acc.v[e] += v.v[e];
+        for (int e = 0; e < EPC; ++e) acc.v[e] += v.v[e] * w;
       }
     }
     const float sc = scale ? scale[i] : 1.f;
@@ -1372,7 +1373,7 @@ extern "C" int goat_pano_fusion_bwd(void* stream, int dtype, const void* x, cons
 }
 
 extern "C" int goat_gather_segmean_fwd(void* stream, int dtype, const void* src, int64_t src_rows, const int32_t* idx,
-                                       const int32_t* start, const float* scale, void* out, int n_out, int H) {
+                                       const int32_t* start, const float* scale, void* out, int n_out, int H, const float* tok_w) {
   if (!src || !idx || !start || !out) return GOAT_E_ARG;
   if (n_out <= 0 || H <= 0 || src_rows <= 0) return GOAT_E_SHAPE;
   const int epc = dtype == GOAT_BF16 ? 8 : 4;
@@ -1382,10 +1383,10 @@ extern "C" int goat_gather_segmean_fwd(void* stream, int dtype, const void* src,
   if (blocks > 4096) blocks = 4096;
   if (dtype == GOAT_BF16)
     hipLaunchKernelGGL(gather_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST(stream), (const bf16_t*)src, idx, start,
-                       scale, (bf16_t*)out, n_out, H);
+                       scale, tok_w, (bf16_t*)out, n_out, H);
   else if (dtype == GOAT_F32)
     hipLaunchKernelGGL(gather_fwd_kernel<float>, dim3(blocks), dim3(256), 0, ST(stream), (const float*)src, idx, start,
-                       scale, (float*)out, n_out, H);
+                       scale, tok_w, (float*)out, n_out, H);
   else
     return GOAT_E_ARG;
   GOAT_LAUNCH_CHECK();

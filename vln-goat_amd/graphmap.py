@@ -132,3 +132,30 @@ def build_obj_concat_index(view_lens, obj_lens, V, O, W):
     if idx.size == 0:
         idx = np.array([-1])
     return torch.from_numpy(idx.astype(np.int32)), torch.from_numpy(start.astype(np.int32))
+
+
+def inverse_index(idx, start, scale, n_src):
+    """Inverse of a gather index (idx int32 [n_tok], start int32 [n_seg + 1], scale float32 [n_seg] | None): for every source row
+    the segments that read it -> (inv_idx int32 [n_used] = segment ids grouped by source row, inv_start int32 [n_src + 1],
+    inv_w float32 [n_used] = the segments' scales, or None when scale is None).  The gather's backward pass is then itself a
+    gather over the output gradient (hipops.gather_segmean(..., inverse=...)): one writer per source row, no atomics."""
+    idx = np.asarray(idx.cpu() if torch.is_tensor(idx) else idx, dtype=np.int64)
+    start = np.asarray(start.cpu() if torch.is_tensor(start) else start, dtype=np.int64)
+    n_seg = len(start) - 1
+    seg_of_tok = np.repeat(np.arange(n_seg, dtype=np.int64), np.diff(start)) if n_seg else np.zeros(0, dtype=np.int64)
+    idx = idx[:len(seg_of_tok)]                      # (an empty index is stored as [-1] with no segment pointing at it)
+    used = idx >= 0
+    src, seg = idx[used], seg_of_tok[used]
+    if src.size and (src.max() >= n_src):
+        raise ValueError('gather index refers to row %d of %d' % (int(src.max()), n_src))
+    order = np.argsort(src, kind='stable')
+    inv_idx = seg[order]
+    counts = np.bincount(src, minlength=n_src) if src.size else np.zeros(n_src, dtype=np.int64)
+    inv_start = np.concatenate([[0], np.cumsum(counts)])
+    inv_w = None
+    if scale is not None:
+        sc = np.asarray(scale.cpu() if torch.is_tensor(scale) else scale, dtype=np.float32)
+        inv_w = torch.from_numpy(sc[inv_idx].astype(np.float32)) if inv_idx.size else torch.zeros(1, dtype=torch.float32)
+    if inv_idx.size == 0:
+        inv_idx = np.array([-1])
+    return torch.from_numpy(inv_idx.astype(np.int32)), torch.from_numpy(inv_start.astype(np.int32)), inv_w

@@ -1301,17 +1301,18 @@ class _GatherFn(torch.autograd.Function):
     """out[i] = scale[i] * sum_{j in seg i} src[idx[j]]  (index tensors built on the host per batch)."""
 
     @staticmethod
-    def forward(ctx, src, idx, start, scale, n_out):
+    def forward(ctx, src, idx, start, scale, n_out, inverse):
         _need_gpu(src)
         src = src if src.is_contiguous() else src.contiguous()
         H = src.shape[-1]
         s2 = src.reshape(-1, H)
         out = torch.empty((n_out, H), dtype=src.dtype, device=src.device)
         st = _lib.lib().goat_gather_segmean_fwd(_stream(), _dt(s2), _ptr(s2), s2.shape[0], _ptr(idx), _ptr(start),
-                                                _ptr(scale) if scale is not None else None, _ptr(out), n_out, H)
+                                                _ptr(scale) if scale is not None else None, _ptr(out), n_out, H, None)
         _lib.check(st, 'goat_gather_segmean_fwd')
         ctx.save_for_backward(idx, start, scale)
         ctx.sshape, ctx.sdtype = src.shape, src.dtype
+        ctx.inverse = inverse
         return out
 
     @staticmethod
@@ -1322,15 +1323,28 @@ class _GatherFn(torch.autograd.Function):
         rows = 1
         for s in ctx.sshape[:-1]:
             rows *= s
+        if ctx.inverse is not None:          # inverse index built on the host with the forward one: the backward pass is a gather too
+            inv_idx, inv_start = ctx.inverse[0], ctx.inverse[1]
+            inv_w = ctx.inverse[2] if len(ctx.inverse) > 2 else None
+            if inv_start.numel() != rows + 1:
+                raise ValueError('inverse gather index covers %d rows, the source has %d' % (inv_start.numel() - 1, rows))
+            d2 = dout if dout.dtype == ctx.sdtype else dout.to(ctx.sdtype)
+            dsrc = torch.empty((rows, H), dtype=ctx.sdtype, device=dout.device)
+            st = _lib.lib().goat_gather_segmean_fwd(_stream(), _dt(d2), _ptr(d2), n_out, _ptr(inv_idx), _ptr(inv_start), None, _ptr(dsrc),
+                                                    rows, H, _ptr(inv_w) if inv_w is not None else None)
+            _lib.check(st, 'goat_gather_segmean_fwd (inverse)')
+            return dsrc.view(ctx.sshape), None, None, None, None, None
         d32 = torch.zeros((rows, H), dtype=torch.float32, device=dout.device)
         st = _lib.lib().goat_gather_segmean_bwd(_stream(), _dt(dout), _ptr(dout), _ptr(idx), _ptr(start),
                                                 _ptr(scale) if scale is not None else None, _ptr(d32), n_out, H)
         _lib.check(st, 'goat_gather_segmean_bwd')
-        return d32.to(ctx.sdtype).view(ctx.sshape), None, None, None, None
+        return d32.to(ctx.sdtype).view(ctx.sshape), None, None, None, None, None
 
 
-def gather_segmean(src, idx, start, scale, n_out):
-    return _GatherFn.apply(src, idx, start, scale, int(n_out))
+def gather_segmean(src, idx, start, scale, n_out, inverse=None):
+    """inverse: graphmap.inverse_index(idx, start, scale, n_src) on the device (optional) — the backward pass then gathers instead
+    of scatter-adding with float atomics into a zero-filled float32 buffer."""
+    return _GatherFn.apply(src, idx, start, scale, int(n_out), inverse)
 
 
 # ----------------------------------------------------------------------------- embedding tables

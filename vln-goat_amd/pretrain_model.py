@@ -213,8 +213,9 @@ class CausalImageEmbeddings(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, traj_view_img_fts, traj_loc_fts, traj_vp_view_lens, traj_nav_types=None, obj_fts=None, obj_lens=None,
-                obj_names=None, cat_index=None):
-        """-> (tokens [N,W,H], fused [N,H] | None).  cat_index = graphmap.build_obj_concat_index(...) on device."""
+                obj_names=None, cat_index=None, cat_inverse=None):
+        """-> (tokens [N,W,H], fused [N,H] | None).  cat_index = graphmap.build_obj_concat_index(...) on device (cat_inverse: its
+        graphmap.inverse_index, optional)."""
         dt = compute_dtype()
         x = self.img_layer_norm(self.img_linear(traj_view_img_fts.to(dt)))
         if not self.reverie:
@@ -230,7 +231,7 @@ class CausalImageEmbeddings(nn.Module):
             N, V, H = x.shape
             W = traj_nav_types.shape[1]
             src = torch.cat([x.reshape(N * V, H), o.reshape(-1, H)], 0)
-            x = hipops.gather_segmean(src, cat_index[0], cat_index[1], None, N * W).view(N, W, H)
+            x = hipops.gather_segmean(src, cat_index[0], cat_index[1], None, N * W, cat_inverse).view(N, W, H)
             x = x + hipops.embedding(traj_nav_types, self.nav_type_embedding.weight, out_dtype=dt) \
                 + self.loc_layer_norm(self.loc_linear(traj_loc_fts.to(dt)))
             x = hipops.dropout(self.layer_norm(x), _p(self.dropout))
@@ -251,11 +252,11 @@ class LocalVPEncoder(nn.Module):
         if 'cfp' in config.pretrain_tasks:
             self.tim_self_encoder = BertAttention(config)
 
-    def vp_input_embedding(self, pano_embeds, idx, vp_pos_fts):
-        """pano_embeds [N,V,H]; idx = graphmap.build_vp_index(...) on device."""
+    def vp_input_embedding(self, pano_embeds, idx, vp_pos_fts, inverse=None):
+        """pano_embeds [N,V,H]; idx = graphmap.build_vp_index(...) on device (inverse: its graphmap.inverse_index, optional)."""
         vidx, vstart, vp_lens, width = idx
         B = vp_pos_fts.shape[0]
-        vp_img = hipops.gather_segmean(pano_embeds, vidx, vstart, None, B * width).view(B, width, -1)
+        vp_img = hipops.gather_segmean(pano_embeds, vidx, vstart, None, B * width, inverse).view(B, width, -1)
         pos = self.vp_pos_embeddings[1](self.vp_pos_embeddings[0](vp_pos_fts[:, :width].to(vp_img.dtype)))
         return vp_img + pos, gen_seq_masks(vp_lens, width)
 
@@ -272,10 +273,10 @@ class GlobalMapEncoder(nn.Module):
             self.tim_self_encoder = BertAttention(config)
         self.sprel_linear = Linear(1, 1) if config.graph_sprels else None
 
-    def gmap_input_embedding(self, src_rows, idx, gmap_step_ids, gmap_pos_fts, gmap_lens):
+    def gmap_input_embedding(self, src_rows, idx, gmap_step_ids, gmap_pos_fts, gmap_lens, inverse=None):
         gidx, gstart, gscale = idx
         B, G = gmap_step_ids.shape
-        img = hipops.gather_segmean(src_rows, gidx, gstart, gscale, B * G).view(B, G, -1)
+        img = hipops.gather_segmean(src_rows, gidx, gstart, gscale, B * G, inverse).view(B, G, -1)
         pos = self.gmap_pos_embeddings[1](self.gmap_pos_embeddings[0](gmap_pos_fts.to(img.dtype)))
         e = img + hipops.embedding(gmap_step_ids, self.gmap_step_embeddings.weight, out_dtype=img.dtype) + pos
         return e, gen_seq_masks(gmap_lens, G)
@@ -313,6 +314,9 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
                 W = batch['traj_nav_types'].shape[1]
                 ci = graphmap.build_obj_concat_index(lens_cpu, obj_cpu, V, batch['traj_obj_img_fts'].shape[1], W)
                 cache['objcat'] = (ci[0].to(dev), ci[1].to(dev))
+                n_rows = int(lens_cpu.shape[0])
+                cache['objcat_inv'] = tuple(t.to(dev) for t in graphmap.inverse_index(
+                    ci[0], ci[1], None, n_rows * V + n_rows * batch['traj_obj_img_fts'].shape[1]) if t is not None)
                 cache['view_lens_cpu'], cache['obj_lens_cpu'] = lens_cpu, obj_cpu
                 lens_cpu, V = lens_cpu + obj_cpu, W
             g = graphmap.build_gmap_index(batch['traj_step_lens'], lens_cpu, batch['traj_vpids'],
@@ -320,6 +324,10 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
             v = graphmap.build_vp_index(batch['traj_step_lens'], lens_cpu, V)
             cache['gmap'] = tuple(t.to(dev) for t in g)
             cache['vp'] = (v[0].to(dev), v[1].to(dev), v[2].to(dev), v[3])
+            # inverse indices: the backward passes of the two gathers are gathers over the output gradients (no atomics / fills)
+            n_rows = int(lens_cpu.shape[0])
+            cache['gmap_inv'] = tuple(t.to(dev) for t in graphmap.inverse_index(g[0], g[1], g[2], n_rows * V + (n_rows if fused else 0)))
+            cache['vp_inv'] = tuple(t.to(dev) for t in graphmap.inverse_index(v[0], v[1], None, n_rows * V) if t is not None)
             batch['_goat_cache'] = cache
         return cache
 
@@ -340,7 +348,7 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
         x, fused = self.img_embeddings(batch['traj_view_img_fts'], batch['traj_loc_fts'], batch['traj_vp_view_lens'],
                                        batch.get('traj_nav_types'), batch.get('traj_obj_img_fts'),
                                        batch.get('traj_vp_obj_lens'), batch.get('traj_reverie_obj_names'),
-                                       cache.get('objcat'))
+                                       cache.get('objcat'), cache.get('objcat_inv'))
         N, V, H = x.shape
         rows = x.view(N * V, H)
         src = torch.cat([rows, fused], 0) if fused is not None else rows
@@ -348,10 +356,10 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
 
     def _gmap_in(self, batch, src, cache):
         return self.global_encoder.gmap_input_embedding(src, cache['gmap'], batch['gmap_step_ids'],
-                                                        batch['gmap_pos_fts'], batch['gmap_lens'])
+                                                        batch['gmap_pos_fts'], batch['gmap_lens'], cache.get('gmap_inv'))
 
     def _vp_in(self, batch, x, cache):
-        return self.local_encoder.vp_input_embedding(x, cache['vp'], batch['vp_pos_fts'])
+        return self.local_encoder.vp_input_embedding(x, cache['vp'], batch['vp_pos_fts'], cache.get('vp_inv'))
 
     # -- the three reference entry points ---------------------------------------------------------
     def forward(self, batch, return_gmap_embeds=True):

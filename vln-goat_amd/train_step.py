@@ -139,6 +139,10 @@ def collate_indices(config, batch, tasks=('mlm', 'sap', 'cfp')):
     out['gmap'] = graphmap.build_gmap_index(batch['traj_step_lens'], lens, batch['traj_vpids'], batch['traj_cand_vpids'],
                                             batch['gmap_vpids'], G, V, bool(config.adaptive_pano_fusion))
     out['vp'] = graphmap.build_vp_index(batch['traj_step_lens'], lens, V)
+    n_rows = int(batch['traj_view_img_fts'].shape[0])
+    fused = bool(config.adaptive_pano_fusion)
+    out['gmap_inv'] = graphmap.inverse_index(out['gmap'][0], out['gmap'][1], out['gmap'][2], n_rows * V + (n_rows if fused else 0))
+    out['vp_inv'] = tuple(t for t in graphmap.inverse_index(out['vp'][0], out['vp'][1], None, n_rows * V) if t is not None)
     W = out['vp'][3]
     if 'mlm' in tasks:
         labels = batch['txt_labels'].reshape(-1)
