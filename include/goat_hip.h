@@ -79,6 +79,16 @@ int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_out,
                    const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                    int M, int N, int Kc, const float* bias, int epilogue,
                    void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum);
+/* goat_gemm_bf16 with dropout fused into an activation epilogue (bf16 output, no split): GOAT_EPI_GELU / _RELU store
+ * C = dropout_p(act(u)) (aux still receives u); GOAT_EPI_MUL_DGELU / _MUL_DRELU store C = dropout_p-mask(A·B) x act'(aux) — the
+ * forward and backward of `linear2(dropout(act(linear1(x))))` (P/model/transformer.py:179) without the two elementwise passes
+ * over the [rows, 3072] tensor.  Element (row, col) draws counter offset + row * N + col of (seed + *rng_dev): the same masks as
+ * goat_dropout_add_fwd / goat_act_bwd on a contiguous [M, N] tensor.  offset and N must be multiples of 8; p = 0: plain call. */
+int goat_gemm_bf16_dropout(void* stream, int trans_a, int trans_b, int dtype_out,
+                   const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                   int M, int N, int Kc, const float* bias, int epilogue,
+                   void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum,
+                           float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev);
 
 /* colsum[c] += sum_r x[r,c] (float32, atomic; caller zero-fills): bias gradient of a Linear. */
 int goat_colsum(void* stream, int dtype, const void* x, int64_t ld, int R, int C, float* colsum);

@@ -31,6 +31,8 @@ SIGNATURES = {
     'goat_version': [],
     'goat_gemm_nt': [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i32],
     'goat_gemm_bf16': [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp],
+    'goat_gemm_bf16_dropout': [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp,
+                               _f32, _u64, _u64, _vp],
     'goat_colsum': [_vp, _i32, _vp, _i64, _i32, _i32, _vp],
     'goat_transpose': [_vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _vp],
     'goat_ln_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _i32],

@@ -58,10 +58,39 @@ static bool tile_ok(int bm, int bn, bool eight) {
   return (bm == 128 && bn == 256) || (bm == 192 && bn == 256) || (bm == 256 && bn == 192) || (bm == 256 && bn == 256);
 }
 
+static int gemm_bf16_impl(void* stream, int trans_a, int trans_b, int dtype_out,
+                          const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                          int M, int N, int Kc, const float* bias, int epilogue,
+                          void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum,
+                          float drop_p, uint64_t drop_seed, uint64_t drop_off, const uint64_t* drop_rng);
+
 extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_out,
                               const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                               int M, int N, int Kc, const float* bias, int epilogue,
                               void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum) {
+  return gemm_bf16_impl(stream, trans_a, trans_b, dtype_out, A, lda, B, ldb, C, ldc, M, N, Kc, bias, epilogue, aux, ldaux, split_k, bm,
+                        nstage, colsum, 0.f, 0, 0, nullptr);
+}
+
+extern "C" int goat_gemm_bf16_dropout(void* stream, int trans_a, int trans_b, int dtype_out,
+                                      const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                      int M, int N, int Kc, const float* bias, int epilogue,
+                                      void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum,
+                                      float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev) {
+  if (!(p >= 0.f && p < 1.f)) return GOAT_E_ARG;
+  if (p > 0.f) {
+    const bool act = epilogue == GOAT_EPI_GELU || epilogue == GOAT_EPI_RELU || epilogue == GOAT_EPI_MUL_DGELU || epilogue == GOAT_EPI_MUL_DRELU;
+    if (!act || dtype_out != GOAT_BF16 || split_k > 1 || (offset & 7) || (N & 7)) return GOAT_E_ARG;
+  }
+  return gemm_bf16_impl(stream, trans_a, trans_b, dtype_out, A, lda, B, ldb, C, ldc, M, N, Kc, bias, epilogue, aux, ldaux, split_k, bm,
+                        nstage, colsum, p, seed, offset, rng_dev);
+}
+
+static int gemm_bf16_impl(void* stream, int trans_a, int trans_b, int dtype_out,
+                          const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                          int M, int N, int Kc, const float* bias, int epilogue,
+                          void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum,
+                          float drop_p, uint64_t drop_seed, uint64_t drop_off, const uint64_t* drop_rng) {
   if (!A || !B || !C) return GOAT_E_ARG;
   const bool eight = (nstage & GOAT_GEMM_8WAVES) != 0;
   const bool wide = (nstage & GOAT_GEMM_WIDE_PATCH) != 0;
@@ -97,6 +126,9 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   a.colsum = colsum;
   a.accum = epilogue == GOAT_EPI_ACCUM;
   a.group_m = pick_group_m(a.tiles_m, a.tiles_n, bm, bn);
+  a.drop_thr = drop_p > 0.f ? goat_thr16(drop_p) : 0u;
+  a.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  a.drop_seed = drop_seed; a.drop_off = drop_off; a.drop_rng = drop_rng;
   const int kt = (Kc + BK - 1) / BK;
   if (split_k < 1) split_k = 1;
   if (split_k > kt) split_k = kt;
@@ -154,6 +186,7 @@ extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs,
     a.a_bytes = (uint32_t)a_bytes; a.b_bytes = (uint32_t)b_bytes;
     a.colsum = q.dbias;
     a.accum = q.accumulate ? 1 : 0;
+    a.drop_thr = 0; a.drop_scale = 1.f; a.drop_seed = 0; a.drop_off = 0; a.drop_rng = nullptr;
     a.group_m = pick_group_m(a.tiles_m, a.tiles_n, bm, bn);
     g.tile_start[i] = tiles;
     tiles += a.tiles_m * a.tiles_n;

@@ -78,6 +78,13 @@ struct G2Args {
   float* colsum;              // TA only: colsum[m] += sum_k A[k,m]  (bias gradient fused into wgrad)
   int accum;                  // f32 output, no split: C += A·B (read-modify-write) instead of C = A·B
   int group_m;                // tile order: column-major inside groups of group_m tile rows (L2-sized 2-D blocks per XCD)
+  // dropout fused into the activation epilogues (goat_gemm_bf16_dropout; drop_thr == 0: none): element (row, col) of C uses
+  // counter drop_off + row * N + col of the stream (drop_seed + *drop_rng) — the masks of goat_dropout_add_fwd / goat_act_bwd
+  // on a contiguous [M, N] tensor
+  uint32_t drop_thr;
+  float drop_scale;
+  uint64_t drop_seed, drop_off;
+  const uint64_t* drop_rng;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -545,6 +552,8 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   char* wsp = smem + wave * WSLICE;
   const int col_w = n0 + wn * WCOLS;                             // first column of the wave patch
   // bias of this lane's columns: block j, group q -> columns j*32 + 4*hi + 8*q + {0..3}
+  const bool drop = (ACT || DACT) && p.drop_thr != 0;
+  const GoatRng drng(drop ? p.drop_seed + (p.drop_rng ? *p.drop_rng : 0ull) : 0ull);
   f32x4 bv[NI][4];
 #pragma unroll
   for (int j = 0; j < NI; ++j)
@@ -592,6 +601,12 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
             const float av = (float)a4[e];
             u[e] = (EPI == GOAT_EPI_MUL_DGELU) ? u[e] * dgelu_fast(av) : (av > 0.f ? u[e] : 0.f);
           }
+          if (drop) {      // the forward mask of these 4 consecutive columns of this lane's row
+            const uint32_t km = drng.keep_bits<4>(p.drop_off + (uint64_t)(row_w + l31) * (uint64_t)p.N + (uint64_t)(col_w + j * 32 + 4 * hi + 8 * q),
+                                                  p.drop_thr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = ((km >> e) & 1u) ? u[e] * p.drop_scale : 0.f;
+          }
         }
         bf16x4 o4;
 #pragma unroll
@@ -618,10 +633,12 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
           }
         }
         bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
+        const uint32_t km = drop ? drng.keep_bits<EPC>(p.drop_off + (uint64_t)row * (uint64_t)p.N + (uint64_t)col, p.drop_thr) : 0xFFu;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
           const float u = (float)v[e];
-          v[e] = (bf16_t)((EPI == GOAT_EPI_GELU) ? gelu_fast(u) : fmaxf(u, 0.f));
+          const float h = (EPI == GOAT_EPI_GELU) ? gelu_fast(u) : fmaxf(u, 0.f);
+          v[e] = (bf16_t)(drop ? (((km >> e) & 1u) ? h * p.drop_scale : 0.f) : h);
         }
         raw = *reinterpret_cast<uint4*>(&v);
       }
