@@ -571,9 +571,49 @@ class WgradQueue:
             with torch.cuda.stream(st):
                 cls._launch(q)
 
+    CANDIDATES = ((256, 3), (128, EIGHT_WAVES | 2), (tile(256, 256), 2))      # tile configurations a group may run on
+    tuned = {}              # group signature (rows, n_out, n_in per problem) -> configuration, timed on first sight (AUTOTUNE)
+    TUNE = os.environ.get('GOAT_WGRAD_GROUP_TUNE', '1') != '0'
+
+    @classmethod
+    def _pick_cfg(cls, q):
+        """configuration of this group: how many whole rounds of tiles the 256 CUs run depends on the mix of problem sizes (e.g.
+        eight text-layer problems: 787 TFLOP/s on 128x128 / 8 waves against 720 on 256x128), so each distinct group is timed once on
+        scratch outputs, cold caches, when autotuning is on and no graph is being captured."""
+        if 'GOAT_WGRAD_GROUP_CFG' in os.environ or not cls.TUNE:
+            return cls.cfg
+        key = tuple((t[0].shape[0], t[0].shape[1], t[1].shape[1]) for t in q)
+        cfg = cls.tuned.get(key)
+        if cfg is not None:
+            return cfg
+        if not AUTOTUNE or PROFILE is not None or torch.cuda.is_current_stream_capturing():
+            return cls.cfg
+        n = len(q)
+        arr = (_lib.WgradProblem * n)()
+        scratch = []
+        for i, (dy, x, w, b, acc) in enumerate(q):
+            p = arr[i]
+            dw = torch.empty((dy.shape[1], x.shape[1]), dtype=torch.float32, device=dy.device)
+            scratch.append(dw)
+            p.dy, p.ld_dy, p.x, p.ld_x = _ptr(dy), dy.stride(0), _ptr(x), x.stride(0)
+            p.dw, p.ld_dw, p.dbias = _ptr(dw), dw.stride(0), None
+            p.rows, p.n_out, p.n_in, p.accumulate = dy.shape[0], dy.shape[1], x.shape[1], 0
+        best = None
+        for cand in cls.CANDIDATES:
+            try:
+                t = _time_cfg(lambda: _lib.check(_lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), n, cand[0], cand[1]),
+                                                 'goat_wgrad_grouped (tuning)'))
+            except RuntimeError:
+                continue
+            if best is None or t < best[0]:
+                best = (t, cand)
+        cfg = cls.tuned[key] = best[1] if best is not None else cls.cfg
+        return cfg
+
     @classmethod
     def _launch(cls, q):
         n = len(q)
+        cfg = cls._pick_cfg(q)
         arr = (_lib.WgradProblem * n)()
         for i, (dy, x, w, b, acc) in enumerate(q):
             p = arr[i]
@@ -583,13 +623,13 @@ class WgradQueue:
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        st = _lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), n, cls.cfg[0], cls.cfg[1])
+        st = _lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), n, cfg[0], cfg[1])
         if PROFILE is not None:
             e1.record()
             fl = sum(2.0 * t[0].shape[0] * t[0].shape[1] * t[1].shape[1] for t in q)
             by = sum((t[0].shape[0] * t[0].shape[1] + t[1].shape[0] * t[1].shape[1]) * 2 + t[0].shape[1] * t[1].shape[1] * 4 for t in q)
-            PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 %s s%d' % (tile_name(cls.cfg[0]), cls.cfg[1])),
-                            ('goat_wgrad_grouped', (ctypes.addressof(arr), n, cls.cfg[0], cls.cfg[1]), (arr, list(q)))))
+            PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 %s s%d' % (tile_name(cfg[0]), cfg[1] & 0xFF)),
+                            ('goat_wgrad_grouped', (ctypes.addressof(arr), n, cfg[0], cfg[1]), (arr, list(q)))))
         _lib.check(st, 'goat_wgrad_grouped(n=%d)' % n)
 
 
