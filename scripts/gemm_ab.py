@@ -15,6 +15,8 @@ def T(bm, bn):
 
 
 CASES = [  # ta, tb, M, N, K, epi, f32out, split, tile (rows | cols << 16), nstage (| 0x100: eight waves on 128x128)
+    (0, 0, 3840, 2304, 768, 0, 0, 1, T(192, 192), 2), (0, 0, 3840, 2304, 768, 0, 0, 1, T(192, 192), 3), (0, 0, 3840, 1536, 768, 0, 0, 1, T(192, 192), 3),
+    (0, 0, 3840, 1536, 768, 0, 0, 1, T(256, 192), 2), (0, 0, 3840, 1536, 768, 0, 0, 1, 128, 0x102),
     (0, 0, 3840, 768, 3072, 0, 0, 1, 96, 2), (0, 0, 3840, 768, 3072, 0, 0, 1, 96, 3), (0, 0, 3840, 768, 3072, 0, 0, 1, 96, 4),
     (0, 0, 3840, 768, 768, 0, 0, 1, 96, 3), (0, 0, 3840, 768, 768, 0, 0, 1, 96, 4), (0, 1, 3840, 768, 3072, 0, 0, 1, 96, 4),
     (0, 1, 3840, 768, 768, 0, 0, 1, 96, 4), (0, 1, 3840, 768, 768, 0, 0, 1, 128, 0x104), (0, 1, 3840, 768, 2304, 0, 0, 1, 96, 4),

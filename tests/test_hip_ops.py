@@ -649,7 +649,7 @@ def test_dict_weighted_sum(ops, dtype):
                                    (128, 0x102), (128, 0x103), (128, 0x104),      # 0x100: the 128-row tile on eight waves
                                    (96, 2), (96, 3), (96, 4),                      # 96 x 128 (non-transposed A only)
                                    (128 | 256 << 16, 2), (128 | 256 << 16, 3), (192 | 256 << 16, 2), (256 | 192 << 16, 2),
-                                   (256 | 256 << 16, 2)])                          # rows | columns << 16: the 8-wave wide tiles
+                                   (256 | 256 << 16, 2), (192 | 192 << 16, 2), (192 | 192 << 16, 3)])                          # rows | columns << 16: the 8-wave wide tiles
 def test_gemm_bf16_every_tile_configuration(ops, ta, tb, bm, ns):
     """Every (tile, ring depth) the autotuner may pick, on a ragged shape, incl. GELU / x GELU' / C += A·B / split-K epilogues."""
     from vln_goat_amd._lib import EPI_ACCUM, EPI_GELU, EPI_MUL_DGELU, EPI_NONE

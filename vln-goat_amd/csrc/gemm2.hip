@@ -55,7 +55,7 @@ static bool tile_ok(int bm, int bn, bool eight) {
   if (bn == 128 && bm == 96) return !eight;
   if (bn == 128) return bm == 64 || bm == 128 || bm == 256 ? (!eight || bm == 128) : false;
   if (eight) return false;
-  return (bm == 128 && bn == 256) || (bm == 192 && bn == 256) || (bm == 256 && bn == 192) || (bm == 256 && bn == 256);
+  return (bm == 128 && bn == 256) || (bm == 192 && bn == 256) || (bm == 256 && bn == 192) || (bm == 256 && bn == 256) || (bm == 192 && bn == 192);
 }
 
 static int gemm_bf16_impl(void* stream, int trans_a, int trans_b, int dtype_out,

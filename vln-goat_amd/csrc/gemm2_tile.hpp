@@ -66,6 +66,7 @@ typedef Cfg<2, 4, 4, 2> T256x256;   // 256 x 256, 8 waves
 typedef Cfg<2, 2, 4, 4> T256x256W4; // 256 x 256, FOUR waves with 128 x 128 patches (GOAT_GEMM_WIDE_PATCH): the weight-gradient layout reads both
                                    // operands with ds_read_b64_tr_b16 (~7 LDS cycles per wave-instruction, profiles/round2_gemm_mainloop_cycle_stamps.txt) and is
                                    // LDS-read-bound on 64 x 64 patches; a 4 x 4 patch needs half the fragment reads per MFMA (256 accumulator registers)
+typedef Cfg<2, 3, 3, 2> T192x192;   // 192 x 192, SIX waves (3840 x 2304: 20 x 12 = 240 tiles — one round on 256 CUs; 256 x 192 gives 180)
 typedef Cfg<1, 4, 3, 1> T96;        //  96 x 128, 4 waves  (M = 3840 = 40 x 96: 240 tiles at N = 768 — one round on 256 CUs, against 180 tiles of 128 x 128)
 
 struct G2Args {

@@ -10,6 +10,7 @@ int goat_g3_dispatch(hipStream_t st, const G2Args& a, int bm, int bn, int trans_
   if (bm == 192 && bn == 256) return dispatch_layout<T192x256>(st, a, trans_a, trans_b, dtype_out, epi, split, nstage);
   if (bm == 256 && bn == 192) return dispatch_layout<T256x192>(st, a, trans_a, trans_b, dtype_out, epi, split, nstage);
   if (bm == 128 && bn == 256) return dispatch_layout<T128x256>(st, a, trans_a, trans_b, dtype_out, epi, split, nstage);
+  if (bm == 192 && bn == 192) return dispatch_layout<T192x192>(st, a, trans_a, trans_b, dtype_out, epi, split, nstage);
   if (bm == 96 && bn == 128) return dispatch_layout<T96>(st, a, trans_a, trans_b, dtype_out, epi, split, nstage);
   return GOAT_E_ARG;
 }

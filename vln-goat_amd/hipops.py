@@ -233,7 +233,7 @@ def _tile_candidates(ta, tb, M, N):
             if not ta:
                 c += [(tile(192, 256), 2)]
     if N >= 384 and M >= 1024 and not ta and not tb:
-        c += [(tile(256, 192), 2)]
+        c += [(tile(256, 192), 2), (tile(192, 192), 2), (tile(192, 192), 3)]
     return c
 
 
