@@ -1,6 +1,7 @@
 """GPU parity tests of the individual HIP kernels (through the C ABI) against plain PyTorch fp32
 references of the same op.  Tolerances: fp32 path 1e-3 relative-to-scale (north_star), bf16 path 2e-2."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -826,3 +827,38 @@ def test_ffn_dropout_fused_into_the_gemm_epilogues(ops):
     ref = torch.nn.functional.gelu(u.float())
     nz = h != 0
     assert float((h.float()[nz] - ref[nz] / (1 - p)).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+def test_grouped_wgrad_tail_split_plan(ops):
+    """WgradQueue plans: a group whose 256x128 tiles leave a mostly empty last round is run as two launches (the tail problems on
+    128x128 tiles); results and accumulate flags are those of the single launch."""
+    W = ops.WgradQueue
+    g = torch.Generator().manual_seed(12)
+    layer = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
+    rows = 640
+    q, refs = [], []
+    for rep in range(2):
+        for n_out, n_in in layer:
+            dy = (torch.randn(rows, n_out, generator=g) * 0.3).to(DEV, torch.bfloat16)
+            x = torch.randn(rows, n_in, generator=g).to(DEV, torch.bfloat16)
+            acc = rep                                        # second layer's problems accumulate onto existing contents
+            w = torch.full((n_out, n_in), 2.0 if acc else 9.0, device=DEV)
+            b = torch.zeros(n_out, device=DEV)
+            q.append((dy, x, w, b, acc))
+            refs.append((dy.float().T @ x.float() + (2.0 if acc else 0.0), dy.float().sum(0)))
+    tail = W._tail_split(q)
+    assert tail is not None and 0 < len(tail) < len(q)
+    key = tuple((t[0].shape[0], t[0].shape[1], t[1].shape[1]) for t in q)
+    head = tuple(i for i in range(len(q)) if i not in tail)
+    keep_env = os.environ.pop('GOAT_WGRAD_GROUP_CFG', None)
+    try:
+        W.tuned[key] = [(head, (256, 3)), (tail, (128, ops.EIGHT_WAVES | 2))]
+        W._launch(q)
+        torch.cuda.synchronize()
+    finally:
+        W.tuned.pop(key, None)
+        if keep_env is not None:
+            os.environ['GOAT_WGRAD_GROUP_CFG'] = keep_env
+    for (dy, x, w, b, acc), (rw, rb) in zip(q, refs):
+        _close(w, rw, torch.bfloat16, 'tail-split dW')
+        _close(b, rb, torch.bfloat16, 'tail-split dbias')

@@ -575,62 +575,109 @@ class WgradQueue:
     tuned = {}              # group signature (rows, n_out, n_in per problem) -> configuration, timed on first sight (AUTOTUNE)
     TUNE = os.environ.get('GOAT_WGRAD_GROUP_TUNE', '1') != '0'
 
-    @classmethod
-    def _pick_cfg(cls, q):
-        """configuration of this group: how many whole rounds of tiles the 256 CUs run depends on the mix of problem sizes (e.g.
-        eight text-layer problems: 787 TFLOP/s on 128x128 / 8 waves against 720 on 256x128), so each distinct group is timed once on
-        scratch outputs, cold caches, when autotuning is on and no graph is being captured."""
-        if 'GOAT_WGRAD_GROUP_CFG' in os.environ or not cls.TUNE:
-            return cls.cfg
-        key = tuple((t[0].shape[0], t[0].shape[1], t[1].shape[1]) for t in q)
-        cfg = cls.tuned.get(key)
-        if cfg is not None:
-            return cfg
-        if not AUTOTUNE or PROFILE is not None or torch.cuda.is_current_stream_capturing():
-            return cls.cfg
-        n = len(q)
-        arr = (_lib.WgradProblem * n)()
-        scratch = []
-        for i, (dy, x, w, b, acc) in enumerate(q):
+    @staticmethod
+    def _fill(arr, items, scratch=None):
+        for i, (dy, x, w, b, acc) in enumerate(items):
             p = arr[i]
-            dw = torch.empty((dy.shape[1], x.shape[1]), dtype=torch.float32, device=dy.device)
-            scratch.append(dw)
             p.dy, p.ld_dy, p.x, p.ld_x = _ptr(dy), dy.stride(0), _ptr(x), x.stride(0)
-            p.dw, p.ld_dw, p.dbias = _ptr(dw), dw.stride(0), None
-            p.rows, p.n_out, p.n_in, p.accumulate = dy.shape[0], dy.shape[1], x.shape[1], 0
+            if scratch is None:
+                p.dw, p.ld_dw, p.dbias, p.accumulate = _ptr(w), w.stride(0), (_ptr(b) if b is not None else None), acc
+            else:
+                p.dw, p.ld_dw, p.dbias, p.accumulate = _ptr(scratch[i]), scratch[i].stride(0), None, 0
+            p.rows, p.n_out, p.n_in = dy.shape[0], dy.shape[1], x.shape[1]
+
+    @classmethod
+    def _tail_split(cls, q):
+        """indices of the problems to run in a second launch on small tiles, or None.  With 256x128 tiles a group is a whole number
+        of rounds over the 256 CUs plus a tail (e.g. sixteen text-layer problems: 864 tiles = 3.375 rounds, the last one 37 % full).
+        Problems whose tiles add up to just over the tail are taken out and run afterwards on 128x128 tiles (two workgroups per CU,
+        half the duration): 3 full rounds + half a round instead of 4."""
+        if len(q) < 2 or len({t[0].shape[0] for t in q}) != 1:        # tiles of equal duration only (same contraction length)
+            return None
+        tiles = [((t[0].shape[1] + 255) // 256) * ((t[1].shape[1] + 127) // 128) for t in q]
+        total, ncu = sum(tiles), 256
+        rem = total % ncu
+        if total < ncu or rem == 0 or rem > 208:
+            return None
+        best = None                                                   # smallest subset sum >= rem (n <= 16: dynamic programme over sums)
+        reach = {0: ()}
+        for i, t in enumerate(tiles):
+            for sm, idx in list(reach.items()):
+                if sm + t not in reach:
+                    reach[sm + t] = idx + (i,)
+        for sm in sorted(reach):
+            if sm >= rem:
+                best = reach[sm]
+                break
+        if not best or len(best) == len(q):
+            return None
+        return best
+
+    @classmethod
+    def _plans(cls, q):
+        n = len(q)
+        plans = [[(tuple(range(n)), c)] for c in cls.CANDIDATES]
+        tail = cls._tail_split(q)
+        if tail is not None:
+            head = tuple(i for i in range(n) if i not in tail)
+            plans.append([(head, (256, 3)), (tail, (128, EIGHT_WAVES | 2))])
+        return plans
+
+    @classmethod
+    def _pick_plan(cls, q):
+        """[(problem indices, tile configuration)]: the launches this group runs as.  Which plan is fastest depends on the mix of
+        problem sizes (whole rounds of tiles over the 256 CUs; e.g. eight text-layer problems: 787 TFLOP/s on 128x128 / 8 waves against
+        720 on 256x128), so each distinct group is timed once on scratch outputs, cold caches, when autotuning is on and no graph is
+        being captured."""
+        n = len(q)
+        default = [(tuple(range(n)), cls.cfg)]
+        if 'GOAT_WGRAD_GROUP_CFG' in os.environ or not cls.TUNE:
+            return default
+        key = tuple((t[0].shape[0], t[0].shape[1], t[1].shape[1]) for t in q)
+        plan = cls.tuned.get(key)
+        if plan is not None:
+            return plan
+        if not AUTOTUNE or PROFILE is not None or torch.cuda.is_current_stream_capturing():
+            return default
+        scratch = [torch.empty((t[0].shape[1], t[1].shape[1]), dtype=torch.float32, device=t[0].device) for t in q]
         best = None
-        for cand in cls.CANDIDATES:
+        for cand in cls._plans(q):
+            parts = []
+            for idx, cfg in cand:
+                arr = (_lib.WgradProblem * len(idx))()
+                cls._fill(arr, [q[i] for i in idx], [scratch[i] for i in idx])
+                parts.append((arr, len(idx), cfg))
+
+            def run():
+                for arr, m, cfg in parts:
+                    _lib.check(_lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), m, cfg[0], cfg[1]), 'goat_wgrad_grouped (tuning)')
             try:
-                t = _time_cfg(lambda: _lib.check(_lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), n, cand[0], cand[1]),
-                                                 'goat_wgrad_grouped (tuning)'))
+                t = _time_cfg(run)
             except RuntimeError:
                 continue
             if best is None or t < best[0]:
                 best = (t, cand)
-        cfg = cls.tuned[key] = best[1] if best is not None else cls.cfg
-        return cfg
+        plan = cls.tuned[key] = best[1] if best is not None else default
+        return plan
 
     @classmethod
     def _launch(cls, q):
-        n = len(q)
-        cfg = cls._pick_cfg(q)
-        arr = (_lib.WgradProblem * n)()
-        for i, (dy, x, w, b, acc) in enumerate(q):
-            p = arr[i]
-            p.dy, p.ld_dy, p.x, p.ld_x = _ptr(dy), dy.stride(0), _ptr(x), x.stride(0)
-            p.dw, p.ld_dw, p.dbias = _ptr(w), w.stride(0), (_ptr(b) if b is not None else None)
-            p.rows, p.n_out, p.n_in, p.accumulate = dy.shape[0], dy.shape[1], x.shape[1], acc
-        if PROFILE is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        st = _lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), n, cfg[0], cfg[1])
-        if PROFILE is not None:
-            e1.record()
-            fl = sum(2.0 * t[0].shape[0] * t[0].shape[1] * t[1].shape[1] for t in q)
-            by = sum((t[0].shape[0] * t[0].shape[1] + t[1].shape[0] * t[1].shape[1]) * 2 + t[0].shape[1] * t[1].shape[1] * 4 for t in q)
-            PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 %s s%d' % (tile_name(cfg[0]), cfg[1] & 0xFF)),
-                            ('goat_wgrad_grouped', (ctypes.addressof(arr), n, cfg[0], cfg[1]), (arr, list(q)))))
-        _lib.check(st, 'goat_wgrad_grouped(n=%d)' % n)
+        for idx, cfg in cls._pick_plan(q):
+            items = [q[i] for i in idx]
+            n = len(items)
+            arr = (_lib.WgradProblem * n)()
+            cls._fill(arr, items)
+            if PROFILE is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            st = _lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), n, cfg[0], cfg[1])
+            if PROFILE is not None:
+                e1.record()
+                fl = sum(2.0 * t[0].shape[0] * t[0].shape[1] * t[1].shape[1] for t in items)
+                by = sum((t[0].shape[0] * t[0].shape[1] + t[1].shape[0] * t[1].shape[1]) * 2 + t[0].shape[1] * t[1].shape[1] * 4 for t in items)
+                PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 %s s%d' % (tile_name(cfg[0]), cfg[1] & 0xFF)),
+                                ('goat_wgrad_grouped', (ctypes.addressof(arr), n, cfg[0], cfg[1]), (arr, items))))
+            _lib.check(st, 'goat_wgrad_grouped(n=%d)' % n)
 
 
 class LnReduceQueue:
