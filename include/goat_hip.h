@@ -171,7 +171,9 @@ int goat_act_bwd(void* stream, int dtype, const void* dy, const void* u, void* d
  * (P/model/transformer.py:172-176).  Q/K/V/O are [B, L, nh*64] views with explicit row and batch strides
  * (so q,k,v may be slices of one fused QKV projection).  kmask: float32 [B,Lk] additive or NULL;
  * bias: float32 [B,Lq,Lk] additive or NULL.  lse: float32 [B,nh,Lq] saved for backward.
- * Lk <= 256.  Rows whose keys are all -inf produce zeros. */
+ * Lk <= 256.  Rows whose keys are all -inf produce zeros.
+ * Dropout bits are a function of (seed + *rng_dev, offset, b, h, q, key) and of the dtype only — never of which kernel family
+ * (LDS-staged / streaming) served the call — so goat_attn_bwd regenerates goat_attn_fwd's mask for every shape. */
 int goat_attn_fwd(void* stream, int dtype,
                   const void* Q, int64_t q_rs, int64_t q_bs,
                   const void* K, int64_t k_rs, int64_t k_bs,
@@ -307,8 +309,9 @@ int goat_dict_wsum_bwd(void* stream, int dtype_dout, const void* dout, const flo
  *                      int32 pairs in device memory) of the tensors described by `tensors` (device memory).  The clip
  *                      coefficient min(1, max_norm / (sqrt(*sq_norm) + 1e-6)) is computed in the kernel from the device
  *                      scalar goat_grad_sqnorm produced (max_norm <= 0: no clipping), so the step needs no host
- *                      synchronisation.  shadow0 / shadow1 (optional): bf16 copies of the parameter (the operand "shadows"
- *                      the GEMMs read) refreshed in the same pass. */
+ *                      synchronisation.  shadow0 / shadow1 / shadow_f32 (optional): the copies of the parameter the GEMMs read
+ *                      (bf16 operand "shadows", the float32 image inside a concatenated QKV bias) refreshed in the same
+ *                      pass AT THEIR ADDRESSES — a captured hipGraph that reads them sees the updated weights. */
 typedef struct goat_adamw_tensor {
   float* param;            /* float32 master weights */
   void* shadow0;           /* bf16 copy, same element order, or NULL */
@@ -317,6 +320,9 @@ typedef struct goat_adamw_tensor {
   int64_t numel;
   float step_size;         /* lr * sqrt(1 - b2^t) / (1 - b1^t) for this tensor's step count t (or lr without bias correction) */
   float decay;             /* lr * weight_decay (0: no decay) */
+  float* shadow_f32;       /* float32 copy, same element order (a member of a concatenated bias), or NULL */
+  int32_t cols;            /* > 0: shadow0 is a row-padded image — element i goes to (i / cols) * ld0 + i % cols */
+  int32_t ld0;             /*      (the K-padded bf16 copies of the 7- / 14-wide position Linears) */
 } goat_adamw_tensor;
 int goat_grad_sqnorm(void* stream, const float* arena, const int64_t* ranges, int n_ranges, float* out_sq);
 int goat_adamw_step(void* stream, const float* grad_arena, float* exp_avg, float* exp_avg_sq, const goat_adamw_tensor* tensors,

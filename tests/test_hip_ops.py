@@ -339,6 +339,44 @@ def test_attention_fwd_bwd(ops, dtype, Lq, Lk, mode, use_bias, inf):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('L', [64, 160, 200, 256])
+def test_attention_dropout_backward_uses_the_forward_mask(ops, dtype, L):
+    """The backward pass must regenerate the FORWARD's dropout mask whatever kernel family serves each direction (the LDS-staged
+    backward needs more LDS than the staged forward: at L = 193..256 the forward runs staged and the backward streams).  The mask
+    is recovered from forward calls on one-hot V (O[q, d] != 0 <=> probability (q, 64 j + d) kept), then a torch reference with
+    that mask gives the expected gradients."""
+    B, nh, H, p = 2, 12, 768, 0.3
+    g = torch.Generator().manual_seed(L)
+    qk = (torch.randn(B, L, 2 * H, generator=g) * 0.5).to(DEV, dtype)
+    v = (torch.randn(B, L, H, generator=g) * 0.7).to(DEV, dtype)
+    keep = torch.zeros(B, nh, L, L, dtype=torch.bool, device=DEV)
+    for j in range((L + 63) // 64):
+        onehot = torch.zeros(B, L, nh, 64, device=DEV, dtype=dtype)
+        n = min(64, L - 64 * j)
+        onehot[:, 64 * j + torch.arange(n), :, torch.arange(n)] = 1
+        ops.manual_seed(1234)
+        o = ops.attention(torch.cat([qk, onehot.view(B, L, H)], -1), None, None, None, nh, p)
+        keep[:, :, :, 64 * j:64 * j + n] = (o.view(B, L, nh, 64).permute(0, 2, 1, 3)[..., :n] != 0)
+    rate = 1.0 - keep.float().mean().item()
+    assert abs(rate - p) < 0.02, rate
+    a = torch.cat([qk, v], -1).requires_grad_(True)
+    ops.manual_seed(1234)
+    o = ops.attention(a, None, None, None, nh, p)
+    do = torch.randn(B, L, H, generator=g).to(DEV, dtype)
+    o.backward(do)
+    af = a.detach().float().requires_grad_(True)
+
+    def sp(x):
+        return x.view(B, L, nh, 64).permute(0, 2, 1, 3)
+    qf, kf, vf = af.split(H, -1)
+    pr = torch.softmax(sp(qf) @ sp(kf).transpose(-1, -2) / 8.0, -1) * keep / (1.0 - p)
+    ref = (pr @ sp(vf)).permute(0, 2, 1, 3).reshape(B, L, H)
+    ref.backward(do.float())
+    _close(o, ref, dtype, 'attn dropout out')
+    _close(a.grad, af.grad, dtype, 'attn dropout grads')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_attention_dropout_is_unbiased_and_reproducible(ops, dtype):
     B, L, nh, H = 4, 64, 12, 768
     ops.manual_seed(99)

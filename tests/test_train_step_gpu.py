@@ -271,7 +271,8 @@ def test_fused_adamw_keeps_the_bf16_shadows_coherent():
                 assert step(name, gb)['updated']
         torch.cuda.synchronize()
         assert sum(1 for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n])) > 100
-        checked = {'plain': 0, 'cat': 0, 'rowpad': 0}
+        checked = {'plain': 0, 'cat': 0, 'rowpad': 0, 'catb': 0, 'kpad': 0}
+        assert opt.last_refreshed == 0          # every cached copy of the bf16 state is refreshed by the update kernel itself
         byid = {id(q): q for q in model.parameters()}
         for n, p in model.named_parameters():
             for k, (ver, t) in (p.__dict__.get('_goat_shadow') or {}).items():
@@ -281,10 +282,16 @@ def test_fused_adamw_keeps_the_bf16_shadows_coherent():
                 elif k[0] == 'rowpad':
                     assert torch.equal(t[:p.shape[0]], p.detach().to(torch.bfloat16)) and not bool(t[p.shape[0]:].any()), n
                     checked['rowpad'] += 1
+                elif k[0] == 'catb':
+                    assert torch.equal(t, torch.cat([byid[i].detach().float() for i in k[1]], 0)), n
+                    checked['catb'] += 1
                 elif k[0] == torch.bfloat16 and k[1] is False and k[2] == 0:
                     assert torch.equal(t, p.detach().to(torch.bfloat16)), n
                     checked['plain'] += 1
-        assert checked['plain'] > 10 and checked['cat'] > 3 and checked['rowpad'] == 1, checked
+                elif k[0] == torch.bfloat16 and k[1] is False and k[2] > 0:       # K-padded copies of the 7- / 14-wide position Linears
+                    assert torch.equal(t[:, :p.shape[1]], p.detach().to(torch.bfloat16)) and not bool(t[:, p.shape[1]:].any()), n
+                    checked['kpad'] += 1
+        assert checked['plain'] > 10 and checked['cat'] > 3 and checked['rowpad'] == 1 and checked['catb'] > 3 and checked['kpad'] >= 2, checked
         with torch.no_grad():
             cached = [model(gb, t, True).float().clone() for t in ('mlm', 'sap', 'cfp')]
             for p in model.parameters():
@@ -292,6 +299,70 @@ def test_fused_adamw_keeps_the_bf16_shadows_coherent():
             fresh = [model(gb, t, True).float() for t in ('mlm', 'sap', 'cfp')]
         for x, y in zip(cached, fresh):
             assert torch.equal(x, y)
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+def test_captured_step_replayed_after_fused_adamw_reads_the_updated_weights():
+    """A hipGraph has the addresses of the cached operand copies baked in (bf16 shadows, concatenated QKV weights AND biases, K-padded
+    position Linears).  FusedAdamW writes the masters through raw pointers and must refresh every copy at its address: after
+    opt.step() the replayed graph has to return what the eager model returns on the updated weights (the
+    concatenated biases and padded copies used to be dropped, so replays kept reading freed / stale memory)."""
+    import vln_goat_amd
+    from vln_goat_amd import config as gcfg, hipops, optim, pretrain_model, synth
+    cfg = gcfg.make_config(num_l_layers=2, num_top_layer=1, num_pano_layers=1, vocab_size=1000,
+                           hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    model = pretrain_model.GlocalTextPathCMTPreTraining(cfg).cuda().train()
+    gb = synth.batch_to(synth.make_pretrain_batch(B=4, T=[2, 3, 1, 2], L=[30, 22, 16, 25], seed=5, vocab_size=1000, style='rich'), 'cuda')
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        wrapper, arena = _arena_for(model, gb)
+        # a large step so that stale copies would be visible far above the bf16 noise
+        opt = optim.FusedAdamW(model.named_parameters(), arena, lr=2e-3, betas=(0.9, 0.98), weight_decay=0.01)
+        out = {}
+
+        def body(task):
+            arena.zero(task)
+            loss = model(gb, task, compute_loss=True)
+            loss.mean().backward()
+            out[task] = loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for t in ('mlm', 'sap', 'cfp'):
+                body(t)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs = {}
+        for t in ('mlm', 'sap', 'cfp'):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body(t)
+            graphs[t] = g
+        for rnd in range(2):
+            for t in ('mlm', 'sap', 'cfp'):
+                graphs[t].replay()
+                opt.step(t, max_norm=5.0)
+        torch.cuda.synchronize()
+        biases = [p for n, p in model.named_parameters() if n.endswith('query.bias')]
+        assert biases and all(float(b.detach().abs().max()) > 1e-3 for b in biases)      # the QKV biases did move
+        for t in ('mlm', 'sap', 'cfp'):
+            graphs[t].replay()
+            torch.cuda.synchronize()
+            got = out[t].detach().float().clone()
+            got_grad = arena.flat.detach().clone()
+            by_id = {id(p): p for p in model.parameters()}     # eager on copies rebuilt (in place) from the float32 masters
+            for p in model.parameters():
+                hipops.refresh_shadows(p, by_id)
+            arena.zero(t)
+            ref = model(gb, t, compute_loss=True)
+            ref.mean().backward()
+            torch.cuda.synchronize()
+            assert torch.allclose(got, ref.detach().float(), rtol=2e-2, atol=2e-2), (t, got, ref)
+            scale = float(arena.flat.abs().max())
+            assert float((got_grad - arena.flat).abs().max()) <= 3e-2 * scale, t
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
 

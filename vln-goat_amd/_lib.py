@@ -78,7 +78,8 @@ class LnPartial(ctypes.Structure):
 class AdamwTensor(ctypes.Structure):
     """struct goat_adamw_tensor (include/goat_hip.h)."""
     _fields_ = [('param', ctypes.c_void_p), ('shadow0', ctypes.c_void_p), ('shadow1', ctypes.c_void_p), ('arena_off', ctypes.c_int64),
-                ('numel', ctypes.c_int64), ('step_size', ctypes.c_float), ('decay', ctypes.c_float)]
+                ('numel', ctypes.c_int64), ('step_size', ctypes.c_float), ('decay', ctypes.c_float), ('shadow_f32', ctypes.c_void_p),
+                ('cols', ctypes.c_int32), ('ld0', ctypes.c_int32)]
 
 
 class WgradProblem(ctypes.Structure):

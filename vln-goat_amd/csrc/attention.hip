@@ -101,6 +101,25 @@ __device__ __forceinline__ void stage_rows(T* lds, const T* g, int64_t rs, int r
   }
 }
 
+// Dropout decision for probability (b, h, q, key).  bf16: the per-head 32-bit hash of the LDS-staged kernels (attention2.hip's
+// HeadRng) — goat_attn_fwd and goat_attn_bwd may be served by different kernel families for one call (the staged backward needs
+// more LDS than the staged forward), so both families must draw the same bits.  f32 (always these kernels): the 64-bit counter
+// stream of GoatRng, as documented in the header.
+template <typename T>
+struct AttnMask {
+  GoatRng g;
+  HeadRng hr;
+  uint64_t base;
+  __device__ __forceinline__ AttnMask(const AttnArgs& p, int b, int h)
+      : g(p.seed + (p.rng_dev ? *p.rng_dev : 0ull)),
+        hr(p.seed + (p.rng_dev ? *p.rng_dev : 0ull), p.offset, (uint32_t)(b * p.nh + h)),
+        base(p.offset + ((uint64_t)b * p.nh + h) * (uint64_t)p.Lq * (uint64_t)p.Lk) {}
+  __device__ __forceinline__ bool keep(const AttnArgs& p, int q, int key, uint32_t thr) const {
+    if (sizeof(T) == 2) return hr.keep((uint32_t)q * (uint32_t)p.Lk + (uint32_t)key, thr);
+    return g.keep(base + (uint64_t)q * (uint64_t)p.Lk + key, thr);
+  }
+};
+
 // ======================================================================================== forward
 template <typename T, int NKT>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
@@ -176,8 +195,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
   const bool drop = p.p > 0.f;
   const uint32_t thr = goat_thr16(p.p);
   const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
-  const uint64_t ctr0 = p.offset + (((uint64_t)b * p.nh + h) * p.Lq + q) * (uint64_t)p.Lk;
-  const GoatRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull));
+  const AttnMask<T> rng(p, b, h);
 #pragma unroll
   for (int jt = 0; jt < NKT; ++jt)
 #pragma unroll
@@ -185,7 +203,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
       float pv = s[jt][r] * inv;
       if (drop) {
         const int key = jt * 32 + c_row(r, lane);
-        pv = rng.keep(ctr0 + key, thr) ? pv * keep_scale : 0.f;
+        pv = rng.keep(p, q, key, thr) ? pv * keep_scale : 0.f;
       }
       s[jt][r] = pv;
     }
@@ -259,8 +277,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnArgs p) {
   const bool drop = p.p > 0.f;
   const uint32_t thr = goat_thr16(p.p);
   const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
-  const GoatRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull));
-  const uint64_t ctr0 = p.offset + (((uint64_t)b * p.nh + h) * p.Lq + q) * (uint64_t)p.Lk;
+  const AttnMask<T> rng(p, b, h);
   __syncthreads();
 
   f32x16 dq[2];
@@ -293,7 +310,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnArgs p) {
         pr = __expf(v - lse_q);
       }
       float keep = 1.f;
-      if (drop) keep = rng.keep(ctr0 + key, thr) ? keep_scale : 0.f;
+      if (drop) keep = rng.keep(p, q, key, thr) ? keep_scale : 0.f;
       const float d = pr * (dp[r] * keep - dsum);
       if (p.dbias && qv && key < p.Lk) atomicAdd(p.dbias + ((int64_t)b * p.Lq + q) * p.Lk + key, d);
       ds[r] = d * p.scale;
@@ -346,7 +363,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnArgs p) {
   const bool drop = p.p > 0.f;
   const uint32_t thr = goat_thr16(p.p);
   const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
-  const GoatRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull));
+  const AttnMask<T> rng(p, b, h);
 
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -405,7 +422,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnArgs p) {
         pr = __expf(v - lse_q);
       }
       float keep = 1.f;
-      if (drop) keep = rng.keep(p.offset + (((uint64_t)b * p.nh + h) * p.Lq + q) * (uint64_t)p.Lk + key, thr) ? keep_scale : 0.f;
+      if (drop) keep = rng.keep(p, q, key, thr) ? keep_scale : 0.f;
       pd[r] = pr * keep;
       ds[r] = pr * (dp[r] * keep - rowd[qr]) * p.scale;
     }

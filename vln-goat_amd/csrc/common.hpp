@@ -132,6 +132,45 @@ struct GoatRng {
     return m;
   }
 };
+// Dropout bits of one (sample, head): a 32-bit key per block (from the 64-bit seed / offset / device counter of common.hpp's
+// GoatRng, mixed once), then ONE 32-bit multiply-xorshift hash per PAIR of consecutive probability indices
+// idx = q * Lk + key; its 16-bit halves decide the two elements.  The first version hashed every element through
+// GoatRng::keep with 64-bit counters: 6 700 of 24 700 cycles of a forward block.  Forward and backward regenerate the same bits.
+struct HeadRng {
+  uint32_t k;
+  __device__ __forceinline__ HeadRng(uint64_t seed, uint64_t offset, uint32_t bh) {
+    uint64_t x = (seed + 0x9E3779B97F4A7C15ull * (offset + 1)) ^ ((uint64_t)bh * 0xD6E8FEB86659FD93ull);
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    k = (uint32_t)x;
+  }
+  __device__ __forceinline__ uint32_t pair(uint32_t pair_idx) const {
+    uint32_t x = pair_idx ^ k;
+    x *= 0x7FEB352Du; x ^= x >> 15;
+    x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+  }
+  __device__ __forceinline__ bool keep(uint32_t idx, uint32_t thr16) const {
+    const uint32_t h = pair(idx >> 1);
+    return ((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thr16;
+  }
+  // bit e = keep(idx0 + e), e < 4
+  __device__ __forceinline__ uint32_t keep4(uint32_t idx0, uint32_t thr16) const {
+    uint32_t m = 0;
+    if ((idx0 & 1u) == 0) {
+      const uint32_t h0 = pair(idx0 >> 1), h1 = pair((idx0 >> 1) + 1);
+      m |= ((h0 & 0xFFFFu) >= thr16 ? 1u : 0u) | ((h0 >> 16) >= thr16 ? 2u : 0u);
+      m |= ((h1 & 0xFFFFu) >= thr16 ? 4u : 0u) | ((h1 >> 16) >= thr16 ? 8u : 0u);
+    } else {
+      const uint32_t h0 = pair(idx0 >> 1), h1 = pair((idx0 >> 1) + 1), h2 = pair((idx0 >> 1) + 2);
+      m |= ((h0 >> 16) >= thr16 ? 1u : 0u) | ((h1 & 0xFFFFu) >= thr16 ? 2u : 0u);
+      m |= ((h1 >> 16) >= thr16 ? 4u : 0u) | ((h2 & 0xFFFFu) >= thr16 ? 8u : 0u);
+    }
+    return m;
+  }
+};
+
 __host__ __device__ __forceinline__ uint32_t goat_thr16(float p) {
   return (uint32_t)(p * 65536.0f + 0.5f);
 }

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(const float* __restrict__ gr
   const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
   bf16_t* s0 = reinterpret_cast<bf16_t*>(t.shadow0);
   bf16_t* s1 = reinterpret_cast<bf16_t*>(t.shadow1);
-  const bool vec = ((t.arena_off & 3) == 0) && ((reinterpret_cast<uintptr_t>(t.param) & 15) == 0) &&
+  float* sf = t.shadow_f32;
+  const bool padded = t.cols > 0;            // shadow0 = row-padded image (leading dimension ld0): scalar stores, tiny tensors
+  const bool vec = !padded && (sf == nullptr || (reinterpret_cast<uintptr_t>(sf) & 15) == 0) && ((t.arena_off & 3) == 0) && ((reinterpret_cast<uintptr_t>(t.param) & 15) == 0) &&
                    (s0 == nullptr || (reinterpret_cast<uintptr_t>(s0) & 7) == 0) && (s1 == nullptr || (reinterpret_cast<uintptr_t>(s1) & 7) == 0);
   for (int64_t i = first + threadIdx.x * 4; i < end; i += 256 * 4) {
     float g[4], m[4], v[4], p[4];
@@ -83,11 +85,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(const float* __restrict__ gr
       for (int k = 0; k < 4; ++k) b[k] = (bf16_t)p[k];
       if (s0) *reinterpret_cast<bf16x4*>(s0 + i) = b;
       if (s1) *reinterpret_cast<bf16x4*>(s1 + i) = b;
+      if (sf) *reinterpret_cast<f32x4*>(sf + i) = p4;
     } else {
       for (int k = 0; k < cnt; ++k) {
         m_[t.arena_off + i + k] = m[k]; v_[t.arena_off + i + k] = v[k]; t.param[i + k] = p[k];
-        if (s0) s0[i + k] = (bf16_t)p[k];
+        if (s0) s0[padded ? ((i + k) / t.cols) * (int64_t)t.ld0 + (i + k) % t.cols : i + k] = (bf16_t)p[k];
         if (s1) s1[i + k] = (bf16_t)p[k];
+        if (sf) sf[i + k] = p[k];
       }
     }
   }

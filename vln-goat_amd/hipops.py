@@ -75,6 +75,30 @@ def manual_seed(seed=None):
 
 
 # ----------------------------------------------------------------------------- weight shadows
+# Cached operand copies of the float32 master weights (bf16 casts, K-/row-padded and concatenated images).  A captured
+# hipGraph has their ADDRESSES baked in, so a stale copy is always rebuilt INTO ITS OWN STORAGE, never replaced by a new
+# tensor: graphs captured before an optimizer step read the updated weights after it (optim.FusedAdamW refreshes most copies
+# inside its update kernel and the rest through `refresh_shadows`).
+def _store_shadow(cache, key, ver, w):
+    ent = cache.get(key)
+    if ent is not None and ent[1].shape == w.shape and ent[1].dtype == w.dtype and ent[1].device == w.device:
+        ent[1].copy_(w)
+        cache[key] = (ver, ent[1])
+        return ent[1]
+    cache[key] = (ver, w)
+    return w
+
+
+def _build_shadow(param, dtype, transposed, pad_k):
+    with torch.no_grad():
+        w = param.detach()
+        if pad_k:
+            w = torch.nn.functional.pad(w, (0, pad_k))
+        if transposed:
+            w = w.t()
+        return w.to(dtype).contiguous()
+
+
 def _shadow(param, dtype, transposed=False, pad_k=0):
     """dtype-cast (and optionally transposed / K-padded) copy of a float32 master weight, cached."""
     key = (dtype, transposed, pad_k)
@@ -83,15 +107,15 @@ def _shadow(param, dtype, transposed=False, pad_k=0):
     ver = param._version
     if ent is not None and ent[0] == ver and ent[1].device == param.device:
         return ent[1]
+    return _store_shadow(cache, key, ver, _build_shadow(param, dtype, transposed, pad_k))
+
+
+def _build_cat(params, dtype, transposed):
     with torch.no_grad():
-        w = param.detach()
-        if pad_k:
-            w = torch.nn.functional.pad(w, (0, pad_k))
+        w = torch.cat([p.detach() for p in params], 0)
         if transposed:
             w = w.t()
-        w = w.to(dtype).contiguous()
-    cache[key] = (ver, w)
-    return w
+        return w.to(dtype).contiguous()
 
 
 def _shadow_cat(params, dtype, transposed=False):
@@ -102,13 +126,12 @@ def _shadow_cat(params, dtype, transposed=False):
     ent = cache.get(key)
     if ent is not None and ent[0] == ver and ent[1].device == params[0].device:
         return ent[1]
+    return _store_shadow(cache, key, ver, _build_cat(params, dtype, transposed))
+
+
+def _build_catb(biases):
     with torch.no_grad():
-        w = torch.cat([p.detach() for p in params], 0)
-        if transposed:
-            w = w.t()
-        w = w.to(dtype).contiguous()
-    cache[key] = (ver, w)
-    return w
+        return torch.cat([x.detach().float() for x in biases], 0).contiguous()
 
 
 def _cat_bias(biases):
@@ -118,10 +141,45 @@ def _cat_bias(biases):
     ent = cache.get(key)
     if ent is not None and ent[0] == ver and ent[1].device == biases[0].device:
         return ent[1]
+    return _store_shadow(cache, key, ver, _build_catb(biases))
+
+
+def _build_rows_padded(param, dtype, rows):
     with torch.no_grad():
-        b = torch.cat([x.detach().float() for x in biases], 0).contiguous()
-    cache[key] = (ver, b)
-    return b
+        w = torch.zeros((rows, param.shape[1]), dtype=dtype, device=param.device)
+        w[:param.shape[0]] = param.detach().to(dtype)
+        return w
+
+
+def refresh_shadows(param, by_id, done=()):
+    """Rebuild, in place, every cached copy hanging off `param` whose storage address is not in `done` (the copies an update
+    kernel has already refreshed).  For an optimizer that writes the masters through raw pointers (no version bump).
+    by_id: {id(parameter): parameter} of every parameter that may be a member of a concatenated copy."""
+    cache = param.__dict__.get('_goat_shadow')
+    if not cache:
+        return 0
+    n = 0
+    for key, (ver, t) in list(cache.items()):
+        if t.data_ptr() in done:
+            continue
+        if key[0] == 'cat':
+            members = [by_id.get(i) for i in key[3]]
+            if any(m is None for m in members):
+                del cache[key]          # a member is gone: nothing can read this copy any more
+                continue
+            t.copy_(_build_cat(members, key[1], key[2]))
+        elif key[0] == 'catb':
+            members = [by_id.get(i) for i in key[1]]
+            if any(m is None for m in members):
+                del cache[key]
+                continue
+            t.copy_(_build_catb(members))
+        elif key[0] == 'rowpad':
+            t.copy_(_build_rows_padded(param, key[1], key[2]))
+        else:
+            t.copy_(_build_shadow(param, key[0], key[1], key[2]))
+        n += 1
+    return n
 
 
 # ----------------------------------------------------------------------------- raw kernels
@@ -998,11 +1056,7 @@ def _shadow_rows_padded(param, dtype, rows):
     ent = cache.get(key)
     if ent is not None and ent[0] == param._version and ent[1].device == param.device:
         return ent[1]
-    with torch.no_grad():
-        w = torch.zeros((rows, param.shape[1]), dtype=dtype, device=param.device)
-        w[:param.shape[0]] = param.detach().to(dtype)
-    cache[key] = (param._version, w)
-    return w
+    return _store_shadow(cache, key, param._version, _build_rows_padded(param, dtype, rows))
 
 
 class _DecoderCeFn(torch.autograd.Function):

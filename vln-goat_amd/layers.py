@@ -48,6 +48,7 @@ def compute_dtype():
 # A captured step reads the memoised tensors at fixed addresses: after new data has been copied into a static batch
 # (train_step.StaticBatch.commit) `refresh_masks()` recomputes the stale entries IN PLACE, sources before derived masks.
 _MASK_MEMO = {}
+_MEMO_LIMIT = [512]
 _NO_MEMO = bool(os.environ.get('GOAT_NO_MASK_MEMO'))       # (diagnostics)
 
 
@@ -59,10 +60,20 @@ def _memo(tag, t, extra, compute):
     if ent is not None and ent[0]() is t and ent[1] == t._version:
         return ent[2]
     r = compute(t)
-    if len(_MASK_MEMO) > 512:
-        _MASK_MEMO.clear()
+    if len(_MASK_MEMO) > _MEMO_LIMIT[0]:
+        _prune_memo()
+        _MEMO_LIMIT[0] = max(512, 2 * len(_MASK_MEMO))      # (every entry alive: look again after the memo has doubled)
     _MASK_MEMO[key] = [weakref.ref(t), t._version, r, compute]
     return r
+
+
+def _prune_memo():
+    """Drop the entries whose source tensor is gone — and only those.  An entry of a LIVE tensor may be read by a captured step at
+    its fixed address (and must stay findable for refresh_masks()), so it is never evicted: the memo is bounded by the number of
+    live batch tensors, not by a count."""
+    for key in list(_MASK_MEMO):
+        if _MASK_MEMO[key][0]() is None:
+            del _MASK_MEMO[key]
 
 
 def refresh_masks():

@@ -50,6 +50,8 @@ class FusedAdamW:
         self.steps = {id(p): 0 for _, p in named}                                   # state['step'] of every parameter
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._plans = {}
+        self._by_id = {id(p): p for _, p in named}
+        self.last_refreshed = 0          # copies rebuilt by torch ops after the last step (0 in the steady bf16 state)
 
     # -- per-task plan (static): which tensors, their chunks, the arena ranges of the norm --------------------------------------
     def _plan(self, task):
@@ -77,65 +79,77 @@ class FusedAdamW:
         self._plans[key] = pl
         return pl
 
-    @staticmethod
-    def _shadows(p):
-        """bf16 copies of `p` the kernel can refresh in place (same element order): the plain shadow and the row-padded
-        decoder shadow.  Every other cached single-parameter shadow (transposed, K-padded, float32) is dropped so that its
-        next use rebuilds it from the updated master."""
-        out = []
-        cache = p.__dict__.get('_goat_shadow')
-        if cache:
-            for k in list(cache):
-                if k[0] in ('cat', 'catb'):
-                    continue
-                ver, t = cache[k]
-                ok = False
-                if t.dtype == torch.bfloat16 and t.is_contiguous():
-                    if len(k) == 3 and k[0] == torch.bfloat16 and k[1] is False and k[2] == 0:
-                        ok = True
-                    elif k[0] == 'rowpad' and t.shape[1:] == p.shape[1:] and t.shape[0] >= p.shape[0]:
-                        ok = True
-                if ok and len(out) < 2:
-                    out.append(t.data_ptr())
-                else:
-                    del cache[k]
-        return out
-
-    def _cat_members(self, plist):
-        """{id(param): [pointer into a row-concatenated bf16 shadow]} for the members of cached 'cat' shadows (fused QKV / KV
-        projections: the rows of parameter i start at sum of the rows before it)."""
+    def _copies(self, plist):
+        """Which cached operand copies the update kernel refreshes itself.  -> ({id(p): slots}, done) with slots =
+        {'s0', 's1': bf16 pointers in the parameter's element order, 'cols', 'ld0': s0 is a row-padded image, 'f32': float32
+        pointer} and done = the storage addresses of the copies that are COMPLETELY covered by the slots handed out (a
+        concatenated copy only when each of its members got one).  Everything else is rebuilt in place after the kernel by
+        hipops.refresh_shadows — a cached copy is never dropped: a captured hipGraph may read it at its address."""
         by_id = {id(p): p for p in plist}
-        out = {}
+        slots = {id(p): {'bf16': [], 'pad': None, 'f32': None} for p in plist}
+        whole = []            # (tensor, [(param id, kind, pointer)]) per cached copy
         for p in plist:
             cache = p.__dict__.get('_goat_shadow')
             if not cache:
                 continue
-            for k in list(cache):
-                if k[0] == 'catb':             # concatenated float32 biases: rebuilt on next use (tiny)
-                    del cache[k]
+            for k, (ver, t) in cache.items():
+                if not t.is_contiguous():
                     continue
-                if k[0] != 'cat':
-                    continue
-                ver, t = cache[k]
-                ids = k[3]
-                if k[1] != torch.bfloat16 or k[2] or not t.is_contiguous() or any(i not in by_id for i in ids):
-                    del cache[k]              # cannot be refreshed in place: rebuilt on next use
-                    continue
-                row = 0
-                for i in ids:
-                    out.setdefault(i, []).append(t.data_ptr() + row * t.shape[1] * 2)
-                    row += by_id[i].shape[0]
-        return out
+                if k[0] == 'cat':
+                    if k[1] != torch.bfloat16 or k[2] or any(i not in by_id for i in k[3]):
+                        continue
+                    row, members = 0, []
+                    for i in k[3]:
+                        members.append((i, 'bf16', t.data_ptr() + row * t.shape[1] * 2))
+                        row += by_id[i].shape[0]
+                    whole.append((t, members))
+                elif k[0] == 'catb':
+                    if t.dtype != torch.float32 or any(i not in by_id for i in k[1]):
+                        continue
+                    off, members = 0, []
+                    for i in k[1]:
+                        members.append((i, 'f32', t.data_ptr() + off * 4))
+                        off += by_id[i].numel()
+                    whole.append((t, members))
+                elif k[0] == 'rowpad':
+                    if t.dtype == torch.bfloat16 and t.shape[1:] == p.shape[1:] and t.shape[0] >= p.shape[0]:
+                        whole.append((t, [(id(p), 'bf16', t.data_ptr())]))
+                elif k[0] == torch.bfloat16 and k[1] is False and t.dtype == torch.bfloat16:
+                    if k[2] == 0:
+                        whole.append((t, [(id(p), 'bf16', t.data_ptr())]))
+                    elif p.dim() == 2:
+                        whole.append((t, [(id(p), 'pad', (t.data_ptr(), p.shape[1], p.shape[1] + k[2]))]))
+        done = set()
+        for t, members in whole:
+            ok = True
+            for i, kind, _ in members:        # does every member still have a free slot of that kind?
+                sl = slots[i]
+                if kind == 'bf16':
+                    ok &= len(sl['bf16']) < (1 if sl['pad'] is not None else 2)
+                elif kind == 'pad':
+                    ok &= sl['pad'] is None and len(sl['bf16']) < 2
+                else:
+                    ok &= sl['f32'] is None
+            if not ok:
+                continue
+            for i, kind, ptr in members:
+                if kind == 'bf16':
+                    slots[i]['bf16'].append(ptr)
+                else:
+                    slots[i][kind] = ptr
+            done.add(t.data_ptr())
+        return slots, done
 
     def step(self, task=None, max_norm=5.0):
         """clip_grad_norm_(max_norm) + AdamW on the parameters `task` uses (all arena parameters if None)."""
+        from . import hipops
         pl = self._plan(task)
         if not pl['params']:
             return
         arena, lib = self.arena, _lib.lib()
         st = torch.cuda.current_stream().cuda_stream
         b1, b2 = self.betas
-        cat = self._cat_members(pl['params'])
+        slots, done = self._copies(pl['params'])
         host = pl['host']
         for i, p in enumerate(pl['params']):
             self.steps[id(p)] += 1
@@ -143,20 +157,28 @@ class FusedAdamW:
             g = self.param_groups[self._group_of[self.names[id(p)]]]
             lr = g['lr']
             step_size = lr * ((1.0 - b2 ** t) ** 0.5) / (1.0 - b1 ** t) if self.correct_bias else lr
-            sh = self._shadows(p) + cat.get(id(p), [])
-            if len(sh) > 2:                    # more bf16 copies than the kernel refreshes: drop the caches, rebuilt lazily
-                p.__dict__.pop('_goat_shadow', None)
-                sh = []
+            sl = slots[id(p)]
             e = host[i]
             e.param, e.arena_off, e.numel = p.data_ptr(), arena.offsets[id(p)], p.numel()
-            e.shadow0 = sh[0] if len(sh) > 0 else None
-            e.shadow1 = sh[1] if len(sh) > 1 else None
+            bf = list(sl['bf16'])
+            if sl['pad'] is not None:
+                e.shadow0, e.cols, e.ld0 = sl['pad']
+                e.shadow1 = bf[0] if bf else None
+            else:
+                e.cols, e.ld0 = 0, 0
+                e.shadow0 = bf[0] if len(bf) > 0 else None
+                e.shadow1 = bf[1] if len(bf) > 1 else None
+            e.shadow_f32 = sl['f32']
             e.step_size, e.decay = step_size, lr * g['weight_decay']
         nbytes = ctypes.sizeof(host)
         raw = torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(ctypes.addressof(host)), dtype=torch.uint8)
         if pl['pinned'] is not None:
+            if pl.get('copied') is not None:
+                pl['copied'].synchronize()       # the previous step's H2D copy has read the pinned table (graph-replay loops never sync)
             pl['pinned'].copy_(raw)
             pl['dev'].copy_(pl['pinned'], non_blocking=True)
+            pl['copied'] = torch.cuda.Event()
+            pl['copied'].record()
         else:
             pl['dev'].copy_(raw)
         self._sq.zero_()
@@ -165,6 +187,9 @@ class FusedAdamW:
         _lib.check(lib.goat_adamw_step(st, arena.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), pl['dev'].data_ptr(),
                                        pl['chunks'].data_ptr(), pl['nchunks'], b1, b2, self.eps, float(max_norm) if clip else 0.0,
                                        self._sq.data_ptr()), 'goat_adamw_step')
+        # the copies the kernel did not cover (transposed / float32 images of the parity mode, a third bf16 copy): same storage, new values
+        by_id = self._by_id
+        self.last_refreshed = sum(hipops.refresh_shadows(p, by_id, done) for p in pl['params'])
 
     def last_grad_norm(self):
         """total gradient norm of the last step() (synchronises)."""
