@@ -1,0 +1,279 @@
+"""Golden vectors for the fine-tuning rollout machinery FROM THE IMPORTED REFERENCE (this container only):
+
+  * `GraphMap` / `FloydGraph` of /root/reference/map_nav_src/models/graph_utils.py:43-144 driven over a scripted walk on a synthetic
+    scan: distance matrix, `_point`-expanded path lengths, `get_pos_fts`, node-embedding means after the rewrite / accumulate calls of
+    the rollout loop (M/r2r/agent.py:549-557);
+  * the input builders of `GMapNavAgent` (M/r2r/agent.py): `_panorama_feature_variable_do` (:82-148), `_nav_gmap_variable`
+    (:151-237), `_nav_vp_variable_mem` (:271-304), `_teacher_action` (:306-347), called as plain functions on a stand-in `self`
+    (args only).  The module imports half a dozen packages this image lacks (MatterSim is not among them — it is imported by
+    r2r/env.py only); they are replaced by EMPTY modules for the import, none of their attributes is used by the four builders.
+    `.cuda()` is patched to the identity (no GPU in the build container).
+
+The observations come from vln_goat_amd.rollout.GraphSim (the graph-only navigator: MatterSim is absent), converted to the
+reference's observation format (feature arrays instead of feature-row numbers).  Output: tests/golden/rollout_walk.npz plus
+rollout_walk.json (the id strings).    python tests/golden/make_golden_rollout.py
+"""
+import json
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_shim  # noqa: E402
+
+D_FT = 16
+B, STEPS = 3, 5
+
+
+def import_agent():
+    ref_shim._install_common()
+    for name in ('jsonlines', 'h5py', 'spacy', 'nltk', 'line_profiler', 'sklearnex'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules['sklearnex'].patch_sklearn = lambda *a, **k: None
+    p = ref_shim.REF_ROOT + '/map_nav_src'
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    if not hasattr(np, 'bool'):
+        np.bool = bool
+    import r2r.agent as agent  # noqa
+    import models.graph_utils as gu  # noqa
+    return agent, gu
+
+
+def ref_obs(obs, feats):
+    """rollout.GraphSim observation -> the dict M/r2r/env.py:335-377 builds (feature arrays, not rows)."""
+    out = []
+    for ob in obs:
+        ft = feats[ob['feature_row']]                                             # [36, D]
+        feature = np.concatenate([ft, ob['view_angle_fts']], -1)
+        cands = []
+        for c in ob['candidate']:
+            cands.append({'viewpointId': c['viewpointId'], 'pointId': c['pointId'], 'heading': c['heading'], 'elevation': c['elevation'],
+                          'position': c['position'], 'feature': np.concatenate([ft[c['pointId']], c['angle_feat']], -1)})
+        out.append({'instr_id': ob['instr_id'], 'scan': ob['scan'], 'viewpoint': ob['viewpoint'], 'viewIndex': ob['viewIndex'],
+                    'position': ob['position'], 'heading': ob['heading'], 'elevation': ob['elevation'], 'feature': feature,
+                    'candidate': cands, 'gt_path': ob['gt_path'], 'instr_encoding': ob['instr_encoding']})
+    return out
+
+
+def main():
+    agent, gu = import_agent()
+    from vln_goat_amd import rollout, synth
+    rs = np.random.RandomState(3)
+    scan = rollout.ScanGraph.synthetic('scanA', n=28, seed=5, degree=3)
+    feats = rs.standard_normal((len(scan.vpids), 36, D_FT)).astype(np.float32)
+
+    class Rows:
+        def row(self, s, vp):
+            return scan.index[vp]
+    sim = rollout.GraphSim(Rows())
+    eps = synth.rollout_episodes(scan, rs, B, STEPS)
+    obs = sim.reset(eps)
+    me = SimpleNamespace(args=SimpleNamespace(image_feat_size=D_FT, act_visited_nodes=False, enc_full_graph=True, ignoreid=-100,
+                                              expert_policy='spl'),
+                         env=SimpleNamespace(shortest_distances={scan.name: {a: {b: float(scan.shortest()[0][i, j]) for j, b in enumerate(scan.vpids)}
+                                                                             for i, a in enumerate(scan.vpids)}}))
+    A = agent.GMapNavAgent
+    gmaps = [gu.GraphMap(ob['viewpoint']) for ob in obs]
+    for g, ob in zip(gmaps, ref_obs(obs, feats)):
+        g.update_graph(ob)
+    out, ids = {}, {'scan_vpids': scan.vpids, 'paths': [e['path'] for e in eps], 'headings': [e['heading'] for e in eps],
+                    'instr': [e['instr_encoding'] for e in eps], 'steps': []}
+    out['scan_pos'] = scan.pos
+    out['scan_edges'] = np.array([(i, j) for i in range(len(scan.vpids)) for j in scan.adj[i] if i < j], np.int64)
+    out['feats'] = feats
+    ended = np.zeros(B, bool)
+    last = None
+    H = 8
+    for t in range(STEPS):
+        robs = ref_obs(obs, feats)
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.node_step_ids[robs[i]['viewpoint']] = t + 1
+        pano = A._panorama_feature_variable_do(me, robs, None, noise=None)
+        W = pano['view_img_fts'].shape[1]
+        # stand-ins for the panorama encoder's outputs (any differentiable function of the step would do)
+        gen = torch.Generator().manual_seed(100 + t)
+        pano_embeds = torch.randn(B, W, H, generator=gen)
+        fused = torch.randn(B, H, generator=gen)
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.update_node_embed(robs[i]['viewpoint'], fused[i].clone(), rewrite=True)
+                for j, cvp in enumerate(pano['cand_vpids'][i]):
+                    if not g.graph.visited(cvp):
+                        g.update_node_embed(cvp, pano_embeds[i, j].clone())
+        nav = A._nav_gmap_variable(me, robs, gmaps, last)
+        nav.update(A._nav_vp_variable_mem(me, robs, gmaps, pano_embeds, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], last))
+        tgt_il = A._teacher_action(me, robs, nav['gmap_vpids'], ended, visited_masks=nav['gmap_visited_masks'], imitation_learning=True, t=t)
+        tgt_spl = A._teacher_action(me, robs, nav['gmap_vpids'], ended, visited_masks=nav['gmap_visited_masks'], imitation_learning=False, t=t,
+                                    traj=None)
+        k = 't%d_' % t
+        for name in ('view_img_fts', 'loc_fts', 'nav_types', 'view_lens'):
+            out[k + name] = pano[name].numpy()
+        for name in ('gmap_img_embeds', 'gmap_step_ids', 'gmap_pos_fts', 'gmap_visited_masks', 'gmap_pair_dists', 'gmap_masks',
+                     'vp_pos_fts', 'vp_masks', 'vp_nav_masks'):
+            out[k + name] = nav[name].numpy()
+        out[k + 'target_il'], out[k + 'target_spl'] = tgt_il.numpy(), tgt_spl.numpy()
+        out[k + 'pano_embeds'], out[k + 'fused'] = pano_embeds.numpy(), fused.numpy()
+        # the map itself: distances / path lengths between every pair of nodes in insertion order
+        for i, g in enumerate(gmaps):
+            names = list(g.node_positions.keys())
+            n = len(names)
+            Dm, Hm = np.zeros((n, n)), np.zeros((n, n), np.int64)
+            for a in range(n):
+                for c in range(n):
+                    Dm[a, c] = g.graph.distance(names[a], names[c])
+                    Hm[a, c] = len(g.graph.path(names[a], names[c]))
+            out[k + 'D%d' % i], out[k + 'hops%d' % i] = Dm, Hm
+        ids['steps'].append({'cand_vpids': pano['cand_vpids'], 'gmap_vpids': nav['gmap_vpids'], 'vp_cand_vpids': nav['vp_cand_vpids'],
+                             'no_vp_left': [bool(x) for x in nav['no_vp_left']],
+                             'node_order': [list(g.node_positions.keys()) for g in gmaps],
+                             'viewpoints': [ob['viewpoint'] for ob in obs], 'view_index': [int(ob['viewIndex']) for ob in obs]})
+        last = torch.randn(B, H, generator=gen)
+        out[k + 'last_embeds'] = last.numpy()
+        # teacher-forced move (M/r2r/agent.py:592-629 with feedback = 'teacher')
+        moves = []
+        for i in range(B):
+            stop = obs[i]['viewpoint'] == obs[i]['gt_path'][-1]
+            if stop or ended[i] or nav['no_vp_left'][i] or t == STEPS - 1:
+                moves.append(None)
+            else:
+                nxt = nav['gmap_vpids'][i][int(tgt_il[i])]
+                view = next(c['pointId'] for c in scan.candidates(obs[i]['viewpoint']) if c['viewpointId'] == nxt)
+                moves.append((nxt, view))
+        obs = sim.step(moves)
+        for i, ob in enumerate(ref_obs(obs, feats)):
+            if not ended[i]:
+                gmaps[i].update_graph(ob)
+        ended = np.logical_or(ended, np.array([m is None for m in moves]))
+    np.savez_compressed(os.path.join(HERE, 'rollout_walk.npz'), **out)
+    with open(os.path.join(HERE, 'rollout_walk.json'), 'w') as f:
+        json.dump(ids, f)
+    print('wrote rollout_walk.npz (%d arrays), %d steps' % (len(out), len(ids['steps'])))
+
+
+def fingerprint(g):
+    if g is None:
+        return np.zeros(9, dtype=np.float32)
+    flat = g.detach().float().reshape(-1)
+    first = torch.zeros(8)
+    first[:min(8, flat.numel())] = flat[:8]
+    return np.concatenate([[float(flat.double().norm())], first.numpy()]).astype(np.float32)
+
+
+EP_ARGS = dict(num_l_layers=2, num_x_layers=2, num_pano_layers=2, dropout=0.5, feat_dropout=0.4, do_back_img=True, do_back_txt=True,
+               do_front_img=True, do_front_his=True, do_front_txt=True, vocab_size=1200, mode='train', do_back_txt_type='type_2',
+               do_back_img_type='type_1', do_add_method='door')
+EP_WEIGHT_SEED = 11
+
+
+def episode_case():
+    """The teacher-forced rollout of M/r2r/agent.py:448-676 end to end on the REFERENCE model: reference builders, reference
+    GraphMap (embeddings with autograd history: gradients flow through the map into earlier panoramas), BACL + FACL on, loss and
+    the gradient fingerprint of every parameter.  -> rollout_episode.npz"""
+    agent, gu = import_agent()
+    import models.vilmodel_GOAT as vg
+    from collections import defaultdict
+    from vln_goat_amd import nav_model, rollout, synth
+    dd = lambda d: defaultdict(lambda: None, d)
+    args = SimpleNamespace(**EP_ARGS)
+    cfg = nav_model.nav_config_from_args(args)
+    torch.manual_seed(0)
+    ref = vg.GlocalTextPathNavCMT(cfg)
+    ours = nav_model.GlocalTextPathNavCMT(cfg)
+    ref.load_state_dict(synth.seeded_state_dict(ours, seed=EP_WEIGHT_SEED))
+    ref.eval()
+    scan, feats, eps, dicts = synth.make_rollout_case()
+
+    class Rows:
+        def row(self, s, vp):
+            return scan.index[vp]
+    sim = rollout.GraphSim(Rows())
+    obs = sim.reset(eps)
+    Bn = len(obs)
+    me = SimpleNamespace(args=SimpleNamespace(image_feat_size=768, act_visited_nodes=False, enc_full_graph=True, ignoreid=-100, expert_policy='spl'))
+    A = agent.GMapNavAgent
+    robs = ref_obs(obs, feats)
+    gmaps = [gu.GraphMap(ob['viewpoint']) for ob in robs]
+    for g, ob in zip(gmaps, robs):
+        g.update_graph(ob)
+    instr_zdict = {k: dicts[k] for k in ('instr_direction_features', 'instr_direction_pzs', 'instr_landmark_features', 'instr_landmark_pzs')}
+    img_zdict = {'img_features': dicts['img_features'], 'img_pzs': dicts['img_pzs']}
+    front = {k: torch.from_numpy(np.array([dicts[k]] * Bn)) for k in ('txt_feats', 'vp_feats', 'gmap_feats')}
+    lang = A._language_variable(me, robs, instr_zdict, front['txt_feats'])
+    txt_embeds = ref('language', dd(lang))
+    ended = np.zeros(Bn, bool)
+    last = None
+    ml_loss = 0.0
+    store = {}
+    max_len = 6
+    for t in range(max_len):
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.node_step_ids[robs[i]['viewpoint']] = t + 1
+        pano = A._panorama_feature_variable_do(me, robs, img_zdict, noise=None)
+        pano_embeds, pano_masks, fused = ref('panorama', dd(pano))
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.update_node_embed(robs[i]['viewpoint'], fused[i], rewrite=True)
+                for j, cvp in enumerate(pano['cand_vpids'][i]):
+                    if not g.graph.visited(cvp):
+                        g.update_node_embed(cvp, pano_embeds[i, j])
+        nav = A._nav_gmap_variable(me, robs, gmaps, last)
+        nav.update(A._nav_vp_variable_mem(me, robs, gmaps, pano_embeds, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], last))
+        nav.update({'txt_embeds': txt_embeds, 'txt_masks': lang['txt_masks'], 'front_txt_feats': front['txt_feats'],
+                    'front_vp_feats': front['vp_feats'], 'front_gmap_feats': front['gmap_feats']})
+        out = ref('navigation', dd(nav))
+        last = out['cls_embeds']
+        logits = out['fused_logits']
+        tgt = A._teacher_action(me, robs, nav['gmap_vpids'], ended, visited_masks=nav['gmap_visited_masks'], imitation_learning=True, t=t)
+        ml_loss = ml_loss + torch.nn.functional.cross_entropy(logits, tgt, reduction='sum', ignore_index=-100)
+        store['s%d_fused_logits' % t] = logits.detach().numpy()
+        store['s%d_cls_embeds' % t] = out['cls_embeds'].detach().numpy()
+        store['s%d_target' % t] = tgt.numpy()
+        store['s%d_gmap_img_embeds' % t] = nav['gmap_img_embeds'][:, :, :16].detach().numpy()
+        moves = []
+        for i in range(Bn):
+            stop = obs[i]['viewpoint'] == obs[i]['gt_path'][-1]
+            if stop or ended[i] or nav['no_vp_left'][i] or t == max_len - 1:
+                moves.append(None)
+            else:
+                nxt = nav['gmap_vpids'][i][int(tgt[i])]
+                view = next(c['pointId'] for c in scan.candidates(obs[i]['viewpoint']) if c['viewpointId'] == nxt)
+                moves.append((nxt, view))
+        obs = sim.step(moves)
+        robs = ref_obs(obs, feats)
+        for i, ob in enumerate(robs):
+            if not ended[i]:
+                gmaps[i].update_graph(ob)
+        ended = np.logical_or(ended, np.array([m is None for m in moves]))
+        if ended.all():
+            break
+    loss = ml_loss * 1.0 / Bn
+    loss.backward()
+    store['n_steps'] = np.array([t + 1])
+    store['loss'] = np.array([float(loss)], np.float32)
+    store['param_names'] = np.array([n for n, _ in ref.named_parameters()])
+    store['grad_fp'] = np.stack([fingerprint(p.grad) for _, p in ref.named_parameters()])
+    store['txt_embeds'] = txt_embeds[:, :, :16].detach().numpy()
+    path = os.path.join(HERE, 'rollout_episode.npz')
+    np.savez_compressed(path, **store)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB  loss', float(loss), 'steps', t + 1)
+
+
+if __name__ == '__main__':
+    if sys.argv[1:] == ['episode']:
+        episode_case()
+    else:
+        main()
+        if not sys.argv[1:]:
+            episode_case()

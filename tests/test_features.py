@@ -1,0 +1,70 @@
+"""the on-disk formats of the reference's feature / dictionary readers (P/data/dataset.py:67-131,820-834) and the
+bf16 feature table behind the batches."""
+import numpy as np
+import pytest
+import torch
+
+
+def _feats(n=5, D=24, seed=0):
+    rs = np.random.RandomState(seed)
+    return {'scan%d_vp%02d' % (i % 2, i): rs.standard_normal((36, D)).astype(np.float32) for i in range(n)}
+
+
+def test_tsv_round_trip_and_bf16_table(tmp_path):
+    from vln_goat_amd import features
+    feats = _feats()
+    path = str(tmp_path / 'fts.tsv')
+    features.FeatureStore.write_tsv(path, feats)
+    # the reference's own parsing of a line (P/data/dataset.py:826-831) reads back the float32 bytes
+    import base64, csv
+    with open(path) as f:
+        item = next(csv.DictReader(f, delimiter='\t', fieldnames=features.TSV_FIELDS))
+    ft = np.frombuffer(base64.decodebytes(item['features'].encode('ascii')), dtype=np.float32).reshape(36, -1)
+    assert np.array_equal(ft, feats[item['scanId'] + '_' + item['viewpointId']])
+    st32 = features.FeatureStore.from_tsv(path, dtype=torch.float32)
+    st16 = features.FeatureStore.from_tsv(path)
+    assert st32.keys == list(feats) and st16.table.dtype == torch.bfloat16
+    for k, v in feats.items():
+        scan, vp = k.split('_', 1)
+        assert np.array_equal(st32.view_block(scan, vp).numpy(), v)
+        assert torch.equal(st16.view_block(scan, vp), torch.from_numpy(v).to(torch.bfloat16))
+    cut = features.FeatureStore.from_tsv(path, dtype=torch.float32, image_feat_size=8)
+    assert cut.table.shape[1] == 8
+    rows = torch.tensor([[st16.row('scan0', 'vp02') * 36 + 5, -1], [0, 36 * 4 + 35]])
+    got = st16.host_rows(rows)
+    assert got.shape == (2, 2, 24) and not bool(got[0, 1].any())
+    assert torch.equal(got[0, 0], torch.from_numpy(feats['scan0_vp02'][5]).to(torch.bfloat16))
+    with pytest.raises(ImportError):
+        features.FeatureStore.from_hdf5(str(tmp_path / 'x.hdf5'))        # no h5py in this image: said loudly
+
+
+def test_zdict_tsv_readers(tmp_path):
+    from vln_goat_amd import features
+    rs = np.random.RandomState(1)
+    img = [{'roomtype': 'kitchen%d' % i, 'feature': rs.standard_normal(16).astype(np.float32), 'pz': float(rs.uniform())} for i in range(4)]
+    txt = [{'token_type': 'direction' if i % 3 else 'landmark', 'token': 'tok%d' % i, 'feature': rs.standard_normal(16).astype(np.float32),
+            'pz': float(rs.uniform())} for i in range(7)]
+    pi, pt = str(tmp_path / 'img.tsv'), str(tmp_path / 'txt.tsv')
+    features.write_zdict_tsv(pi, img, features.IMG_ZDICT_FIELDS)
+    features.write_zdict_tsv(pt, txt, features.TXT_ZDICT_FIELDS)
+    zi = features.load_img_zdict(pi)
+    assert zi['img_features'].shape == (4, 16) and np.array_equal(zi['img_features'].numpy(), np.stack([r['feature'] for r in img]))
+    assert np.allclose(zi['img_pzs'].numpy(), [r['pz'] for r in img])
+    zt = features.load_instr_zdict(pt)
+    d = [r for r in txt if r['token_type'] == 'direction']
+    l = [r for r in txt if r['token_type'] == 'landmark']
+    assert np.array_equal(zt['instr_direction_features'].numpy(), np.stack([r['feature'] for r in d]))
+    assert np.array_equal(zt['instr_landmark_features'].numpy(), np.stack([r['feature'] for r in l]))
+    assert zt['instr_direction_pzs'].shape == (len(d),) and zt['instr_landmark_pzs'].shape == (len(l),)
+
+
+@pytest.mark.gpu
+def test_device_gather_of_view_rows():
+    from vln_goat_amd import features
+    feats = _feats(n=6, D=768, seed=3)
+    for dtype in (torch.bfloat16, torch.float32):
+        st = features.FeatureStore.from_arrays(feats, dtype=dtype).to('cuda')
+        rows = torch.tensor([[0, 37, -1, 36 * 5 + 35], [-1, -1, 71, 3]], device='cuda')
+        got = st.gather(rows)
+        ref = st.host_rows(rows.cpu())
+        assert got.dtype == dtype and torch.equal(got.cpu(), ref)

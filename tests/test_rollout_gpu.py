@@ -1,0 +1,123 @@
+"""SURVEY §8f N4 end to end on the device: rollout.NavRollout (graph-only navigator + device-resident node embeddings + HIP model)
+against the teacher-forced rollout of the IMPORTED REFERENCE (reference model, reference GraphMap, reference input builders;
+tests/golden/rollout_episode.npz from tests/golden/make_golden_rollout.py): per-step logits, [MEM] states, loss and the gradient
+fingerprint of every parameter — the gradients include the paths through the map's node embeddings into earlier panoramas."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+EP_ARGS = dict(num_l_layers=2, num_x_layers=2, num_pano_layers=2, dropout=0.5, feat_dropout=0.4, do_back_img=True, do_back_txt=True,
+               do_front_img=True, do_front_his=True, do_front_txt=True, vocab_size=1200, mode='train', do_back_txt_type='type_2',
+               do_back_img_type='type_1', do_add_method='door')
+
+
+def _model():
+    from vln_goat_amd import nav_model, synth
+    cfg = nav_model.nav_config_from_args(SimpleNamespace(**EP_ARGS))
+    torch.manual_seed(0)
+    m = nav_model.GlocalTextPathNavCMT(cfg)
+    m.load_state_dict(synth.seeded_state_dict(m, seed=11))
+    return m.cuda().eval()
+
+
+def _store(scan, feats, dtype):
+    from vln_goat_amd import features
+    return features.FeatureStore.from_arrays({'%s_%s' % (scan.name, vp): feats[i] for i, vp in enumerate(scan.vpids)}, dtype=dtype).to('cuda')
+
+
+def test_nav_rollout_matches_the_reference_rollout():
+    from vln_goat_amd import rollout, synth
+    z = np.load(os.path.join(HERE, 'golden', 'rollout_episode.npz'))
+    scan, feats, eps, dicts = synth.make_rollout_case()
+    model = _model()
+    store = _store(scan, feats, torch.float32)
+    sim = rollout.GraphSim(store)
+    ro = rollout.NavRollout(lambda mode, batch: model(mode, batch), sim, store, max_action_len=6)
+    rec = []
+    inner = ro.model
+
+    def spy(mode, batch):
+        out = inner(mode, batch)
+        if mode == 'navigation':
+            rec.append((out, batch['gmap_img_embeds']))
+        return out
+    ro.model = spy
+    loss, traj = ro.run(eps, feedback='teacher', extras=synth.rollout_extras(dicts, len(eps), 'cuda'))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert ro.steps == int(z['n_steps'][0]) == len(rec)
+    for t, (out, gimg) in enumerate(rec):
+        ref = z['s%d_fused_logits' % t]
+        got = out['fused_logits'].detach().float().cpu().numpy()
+        fin = np.isfinite(ref)
+        assert np.array_equal(fin, np.isfinite(got)), t
+        assert np.abs(got[fin] - ref[fin]).max() <= 1e-3 * max(1.0, np.abs(ref[fin]).max()), t
+        assert np.abs(out['cls_embeds'].detach().float().cpu().numpy() - z['s%d_cls_embeds' % t]).max() <= 1e-3
+        assert np.abs(gimg[:, :, :16].detach().float().cpu().numpy() - z['s%d_gmap_img_embeds' % t]).max() <= 1e-3
+    assert abs(float(loss) - float(z['loss'][0])) <= 1e-3 * float(z['loss'][0])
+    names = [str(n) for n in z['param_names']]
+    params = dict(model.named_parameters())
+    top = float(z['grad_fp'][:, 0].max())
+    checked = 0
+    for n, fp in zip(names, z['grad_fp']):
+        g = params[n].grad
+        norm = 0.0 if g is None else float(g.double().norm())
+        assert abs(norm - float(fp[0])) <= 2e-3 * max(float(fp[0]), 1e-3 * top), (n, norm, float(fp[0]))
+        if g is not None and fp[0] > 1e-3 * top:
+            lead = g.detach().float().reshape(-1)[:8].cpu().numpy()
+            assert np.abs(lead - fp[1:1 + lead.size]).max() <= 2e-3 * max(float(np.abs(fp[1:]).max()), 1e-2 * float(fp[0])), n
+            checked += 1
+    assert checked > 100
+    # trajectories: the ground-truth paths, hop by hop
+    for ep, tr in zip(eps, traj):
+        assert [h[-1] for h in tr['path']] == ep['path']
+
+
+def test_nav_rollout_bf16_store_and_sampled_feedback():
+    """bf16 feature table + bf16 compute: same rollout within the bf16 tolerance of north_star (2e-2 on the logits); argmax /
+    sample feedback run to completion with one action read-back per step and valid trajectories."""
+    import vln_goat_amd
+    from vln_goat_amd import rollout, synth
+    z = np.load(os.path.join(HERE, 'golden', 'rollout_episode.npz'))
+    scan, feats, eps, dicts = synth.make_rollout_case()
+    model = _model()
+    store = _store(scan, feats, torch.bfloat16)
+    sim = rollout.GraphSim(store)
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        ro = rollout.NavRollout(lambda mode, batch: model(mode, batch), sim, store, max_action_len=6, gmap_buckets=(16, 32, 64), pano_width=40)
+        rec = []
+        inner = ro.model
+
+        def spy(mode, batch):
+            out = inner(mode, batch)
+            if mode == 'navigation':
+                rec.append(out['fused_logits'].detach().float().cpu().numpy())
+            return out
+        ro.model = spy
+        ex = synth.rollout_extras(dicts, len(eps), 'cuda')
+        loss, _ = ro.run(eps, feedback='teacher', extras=ex)
+        assert abs(float(loss) - float(z['loss'][0])) <= 3e-2 * float(z['loss'][0])
+        for t, got in enumerate(rec):
+            ref = z['s%d_fused_logits' % t]
+            G = ref.shape[1]
+            fin = np.isfinite(ref)
+            assert np.array_equal(fin, np.isfinite(got[:, :G])) and not np.isfinite(got[:, G:]).any(), t      # bucket padding is masked out
+            assert np.abs(got[:, :G][fin] - ref[fin]).max() <= 2e-2 * max(1.0, np.abs(ref[fin]).max()), t
+        for fb in ('argmax', 'sample'):
+            torch.manual_seed(1)
+            with torch.no_grad():
+                _, traj = ro.run(eps, feedback=fb, extras=ex, compute_loss=False)
+            for ep, tr in zip(eps, traj):
+                flat = [v for hop in tr['path'] for v in hop]
+                assert flat[0] == ep['path'][0] and len(tr['path']) <= 6
+                for a, b in zip(flat[:-1], flat[1:]):                    # every hop follows an edge of the scan
+                    assert scan.index[b] in scan.adj[scan.index[a]]
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)

@@ -1,0 +1,186 @@
+"""Input pipeline either side of the hot path: the pre-extracted 36-view features and the confounder
+dictionaries, read from the reference's on-disk formats into ONE bf16 table that stays resident in HBM.
+
+Reference (P/ = pretrain_src, M/ = map_nav_src):
+  * P/data/dataset.py:811-818  read_img_features_from_h5py : hdf5, key '<scan>_<viewpoint>' -> float32 [36, D]
+  * P/data/dataset.py:820-834  read_img_features_from_tsv  : TSV scanId / viewpointId / image_w / image_h / vfov / base64(float32 [36, D])
+    (M/utils/data.py:26-77 ImageFeaturesDB reads the same two formats lazily, one Python dict of float32 arrays)
+  * P/data/dataset.py:67-131   LoadZdict                   : base64 TSVs of the BACL dictionaries (roomtype / feature / pz and
+                                                             token_type / token / feature / pz)
+The reference keeps float32 arrays in a Python dict, stacks 36 x 768 rows per sample on the host for every batch and ships
+float32 over PCIe (27.4 MB per pre-training step at batch 48).  Here every viewpoint's [36, D] block is converted ONCE to bf16
+(the dtype the first Linear consumes anyway) and stored as one [n_viewpoints * 36, D] table — 10 567 R2R viewpoints x 36 x 768
+x 2 B = 0.58 GB, a rounding error of 288 GB of HBM — so a batch is a list of ROW NUMBERS (a few KB over PCIe) and one gather
+kernel; hosts without the memory to spare keep the table pinned (`device=None`) and ship bf16 rows, half the float32 bytes.
+hdf5: no h5py in this image — `from_hdf5` imports it lazily and raises ImportError with that explanation when it is missing."""
+import base64
+import csv
+import sys
+
+import numpy as np
+import torch
+
+TSV_FIELDS = ['scanId', 'viewpointId', 'image_w', 'image_h', 'vfov', 'features']     # P/data/dataset.py:824
+VIEWS = 36
+
+
+def _bf16_from_f32(a):
+    """float32 numpy -> torch bfloat16 (round to nearest even, what `tensor.to(bfloat16)` does on the device)."""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16)
+
+
+class FeatureStore:
+    """'<scan>_<viewpoint>' -> row block of a [n * 36, D] table (bf16 by default)."""
+
+    def __init__(self, keys, table, views=VIEWS):
+        self.keys = list(keys)
+        self.index = {k: i for i, k in enumerate(self.keys)}
+        self.views = views
+        self.table = table                      # [n * views, D], host (pinned if possible)
+        self.dev = None
+        assert table.shape[0] == len(self.keys) * views
+
+    # ---- constructors -----------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_arrays(cls, features, dtype=torch.bfloat16, image_feat_size=None):
+        """features: {'<scan>_<vp>': float32 [36, D]} (what both reference readers return)."""
+        keys = list(features)
+        D = image_feat_size or next(iter(features.values())).shape[1]
+        table = torch.empty((len(keys) * VIEWS, D), dtype=dtype)
+        for i, k in enumerate(keys):
+            blk = torch.from_numpy(np.ascontiguousarray(features[k][:, :D], dtype=np.float32))
+            table[i * VIEWS:(i + 1) * VIEWS] = blk.to(dtype)
+        return cls(keys, table)
+
+    @classmethod
+    def from_tsv(cls, path, dtype=torch.bfloat16, image_feat_size=None):
+        """P/data/dataset.py:820-834 / M/utils/data.py:47-77: one line per viewpoint, base64 float32 [36, D]."""
+        csv.field_size_limit(sys.maxsize)
+        keys, blocks = [], []
+        with open(path, 'r') as f:
+            for item in csv.DictReader(f, delimiter='\t', fieldnames=TSV_FIELDS):
+                ft = np.frombuffer(base64.decodebytes(item['features'].encode('ascii')), dtype=np.float32).reshape(VIEWS, -1)
+                if image_feat_size:
+                    ft = ft[:, :image_feat_size]
+                keys.append(item['scanId'] + '_' + item['viewpointId'])
+                blocks.append(torch.from_numpy(ft.copy()).to(dtype))
+        return cls(keys, torch.cat(blocks, 0) if blocks else torch.empty((0, image_feat_size or 0), dtype=dtype))
+
+    @classmethod
+    def from_hdf5(cls, path, dtype=torch.bfloat16, image_feat_size=None):
+        """P/data/dataset.py:811-818.  Needs h5py (absent from this image)."""
+        try:
+            import h5py
+        except ImportError as e:
+            raise ImportError('FeatureStore.from_hdf5 needs h5py, which this image does not ship; convert the file to the TSV format '
+                              '(FeatureStore.write_tsv) or install h5py') from e
+        feats = {}
+        with h5py.File(path, 'r') as f:
+            for key in f.keys():
+                feats[key] = f[key][...].astype(np.float32)
+        return cls.from_arrays(feats, dtype, image_feat_size)
+
+    @classmethod
+    def synthetic(cls, keys, D=768, seed=0, dtype=torch.bfloat16):
+        g = torch.Generator().manual_seed(seed)
+        keys = list(keys)
+        return cls(keys, torch.randn((len(keys) * VIEWS, D), generator=g).to(dtype))
+
+    @staticmethod
+    def write_tsv(path, features):
+        """inverse of from_tsv (test fixtures; converting an hdf5 store on a machine that has h5py)."""
+        with open(path, 'w') as f:
+            for key, ft in features.items():
+                scan, vp = key.split('_', 1)
+                b = base64.b64encode(np.ascontiguousarray(ft, dtype=np.float32).tobytes()).decode('ascii')
+                f.write('\t'.join([scan, vp, '640', '480', '60', b]) + '\n')
+
+    # ---- use --------------------------------------------------------------------------------------------------------------
+    def row(self, scan, viewpoint):
+        return self.index['%s_%s' % (scan, viewpoint)]
+
+    def pin(self):
+        if torch.cuda.is_available() and not self.table.is_pinned():
+            self.table = self.table.pin_memory()
+        return self
+
+    def to(self, device):
+        """make the table resident on `device` (one H2D copy of the whole store)."""
+        self.dev = self.table.to(device, non_blocking=True)
+        return self
+
+    def view_block(self, scan, viewpoint):
+        i = self.row(scan, viewpoint)
+        return self.table[i * self.views:(i + 1) * self.views]
+
+    def gather(self, view_rows, out_dtype=None):
+        """view_rows: int64 [..] of table rows (viewpoint row * 36 + view; -1 = padding) on the table's device -> [.., D].
+        One kernel (goat_gather_segmean_fwd with one-element segments; padding rows come out as zeros)."""
+        from . import hipops
+        if self.dev is None:
+            raise RuntimeError('FeatureStore.gather: call .to(device) first (or use host_rows for a pinned-memory store)')
+        shape = tuple(view_rows.shape)
+        flat = view_rows.reshape(-1).to(torch.int32)
+        n = flat.numel()
+        valid = flat >= 0
+        # CSR with one (or zero) element per segment: start = exclusive prefix sum of `valid`
+        start = torch.zeros(n + 1, dtype=torch.int32, device=flat.device)
+        start[1:] = torch.cumsum(valid.to(torch.int32), 0)
+        idx = flat[valid]
+        if idx.numel() == 0:
+            idx = torch.full((1,), -1, dtype=torch.int32, device=flat.device)
+        out = hipops.gather_segmean(self.dev, idx, start, None, n, None)
+        out = out.view(shape + (self.dev.shape[1],))
+        return out if out_dtype is None else out.to(out_dtype)
+
+    def host_rows(self, view_rows):
+        """host path for a pinned store: [.., D] rows in the store's dtype (bf16: half the PCIe bytes of the reference's float32)."""
+        flat = torch.as_tensor(view_rows).reshape(-1)
+        out = torch.zeros((flat.numel(), self.table.shape[1]), dtype=self.table.dtype)
+        valid = flat >= 0
+        out[valid] = self.table[flat[valid]]
+        return out.view(tuple(torch.as_tensor(view_rows).shape) + (self.table.shape[1],))
+
+
+# ------------------------------------------------------------------------------------------------ BACL dictionaries (LoadZdict)
+IMG_ZDICT_FIELDS = ['roomtype', 'feature', 'pz']                      # P/data/dataset.py:69
+TXT_ZDICT_FIELDS = ['token_type', 'token', 'feature', 'pz']           # :70
+
+
+def load_img_zdict(path):
+    """LoadZdict.load_img_tensor (P/data/dataset.py:98-109): {'img_features': float32 [K, D], 'img_pzs': float64 [K]}."""
+    csv.field_size_limit(sys.maxsize)
+    feats, pzs = [], []
+    with open(path, 'rt') as f:
+        for item in csv.DictReader(f, delimiter='\t', fieldnames=IMG_ZDICT_FIELDS):
+            feats.append(np.frombuffer(base64.b64decode(item['feature']), dtype=np.float32))
+            pzs.append(float(item['pz']))
+    return {'img_features': torch.from_numpy(np.array(feats)), 'img_pzs': torch.from_numpy(np.array(pzs))}
+
+
+def load_instr_zdict(path):
+    """LoadZdict.load_instr_tensor (P/data/dataset.py:111-131): direction / landmark dictionaries."""
+    csv.field_size_limit(sys.maxsize)
+    out = {'direction': ([], []), 'landmark': ([], [])}
+    with open(path, 'rt') as f:
+        for item in csv.DictReader(f, delimiter='\t', fieldnames=TXT_ZDICT_FIELDS):
+            if item['token_type'] in out:
+                out[item['token_type']][0].append(np.frombuffer(base64.b64decode(item['feature']), dtype=np.float32))
+                out[item['token_type']][1].append(float(item['pz']))
+    return {'instr_direction_features': torch.from_numpy(np.array(out['direction'][0])),
+            'instr_direction_pzs': torch.from_numpy(np.array(out['direction'][1])),
+            'instr_landmark_features': torch.from_numpy(np.array(out['landmark'][0])),
+            'instr_landmark_pzs': torch.from_numpy(np.array(out['landmark'][1]))}
+
+
+def write_zdict_tsv(path, rows, fields):
+    """rows: list of dicts with the reference's field names (feature: float32 array)."""
+    with open(path, 'w') as f:
+        for r in rows:
+            vals = []
+            for k in fields:
+                v = r[k]
+                if k == 'feature':
+                    v = base64.b64encode(np.ascontiguousarray(v, dtype=np.float32).tobytes()).decode('ascii')
+                vals.append(str(v))
+            f.write('\t'.join(vals) + '\n')

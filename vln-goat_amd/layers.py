@@ -180,15 +180,20 @@ class BertSelfAttention(nn.Module):
         self.value = Linear(config.hidden_size, self.all_head_size)
         self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
 
-    def forward(self, hidden, kmask=None, enc_hidden=None, enc_kmask=None, bias=None):
+    def project_kv(self, enc_hidden):
+        """K|V projection of the attended sequence, [B, Lk, 2H].  Depends on enc_hidden only: a caller that attends to the SAME
+        sequence many times (the instruction in every step of a navigation episode) computes it once and passes it as enc_kv."""
+        return hipops.multi_linear(enc_hidden, [self.key.weight, self.value.weight], [self.key.bias, self.value.bias])
+
+    def forward(self, hidden, kmask=None, enc_hidden=None, enc_kmask=None, bias=None, enc_kv=None):
         p = _p(self.dropout)
-        if enc_hidden is None:
+        if enc_hidden is None and enc_kv is None:
             qkv = hipops.multi_linear(hidden, [self.query.weight, self.key.weight, self.value.weight],
                                       [self.query.bias, self.key.bias, self.value.bias])
             return hipops.attention(qkv, None, kmask, bias, self.num_attention_heads, p)
         # cross-attention: the query-side mask is ignored (P/model/Bert_backbone.py:221-224)
         q = self.query(hidden)
-        kv = hipops.multi_linear(enc_hidden, [self.key.weight, self.value.weight], [self.key.bias, self.value.bias])
+        kv = enc_kv if enc_kv is not None else self.project_kv(enc_hidden)
         return hipops.attention(q, kv, enc_kmask, None, self.num_attention_heads, p)
 
 
@@ -209,9 +214,9 @@ class BertAttention(nn.Module):
         self.self = BertSelfAttention(config)
         self.output = BertSelfOutput(config)
 
-    def forward(self, hidden, kmask=None, enc_hidden=None, enc_kmask=None, bias=None, fork=False):
+    def forward(self, hidden, kmask=None, enc_hidden=None, enc_kmask=None, bias=None, fork=False, enc_kv=None):
         h, h_res = _pair(hidden)
-        return self.output(self.self(h, kmask, enc_hidden, enc_kmask, bias), h_res, fork)
+        return self.output(self.self(h, kmask, enc_hidden, enc_kmask, bias, enc_kv), h_res, fork)
 
 
 RobertaAttention = BertAttention
@@ -270,9 +275,9 @@ class BertCrossLayer(nn.Module):
             self.lang_inter = RobertaIntermediate(config)
             self.lang_output = RobertaOutput(config)
 
-    def forward(self, hidden, enc_hidden, kmask, enc_kmask, bias=None, fork=False):
+    def forward(self, hidden, enc_hidden, kmask, enc_kmask, bias=None, fork=False, enc_kv=None):
         a = self.attention(hidden, kmask, bias=bias, fork=True)
-        a = self.crossattention(a, None, enc_hidden, enc_kmask, fork=True)
+        a = self.crossattention(a, None, enc_hidden, enc_kmask, fork=True, enc_kv=enc_kv)
         return _ffn_block(self.intermediate, self.output, a, fork)
 
 
@@ -294,11 +299,15 @@ class CrossmodalEncoder(nn.Module):
         self.crossattention = nn.ModuleList([BertCrossLayer(config, with_lang_branch) for _ in range(self.num_top_layer)])
         self.crossattention.apply(init_weights)
 
-    def forward(self, q_embeds, q_kmask, kv_embeds, kv_kmask, bias=None):
-        """q_kmask / kv_kmask: additive float32 [B,L] key masks (already -10000-style)."""
+    def project_kv(self, kv_embeds):
+        """the K|V projections of every layer's cross-attention for one attended sequence (see BertSelfAttention.project_kv)."""
+        return [layer.crossattention.self.project_kv(kv_embeds) for layer in self.crossattention]
+
+    def forward(self, q_embeds, q_kmask, kv_embeds, kv_kmask, bias=None, kv_cache=None):
+        """q_kmask / kv_kmask: additive float32 [B,L] key masks (already -10000-style).  kv_cache: project_kv(kv_embeds)."""
         n = len(self.crossattention)
         for i, layer in enumerate(self.crossattention):
-            q_embeds = layer(q_embeds, kv_embeds, q_kmask, kv_kmask, bias, fork=i + 1 < n)
+            q_embeds = layer(q_embeds, kv_embeds, q_kmask, kv_kmask, bias, fork=i + 1 < n, enc_kv=None if kv_cache is None else kv_cache[i])
         return q_embeds
 
 

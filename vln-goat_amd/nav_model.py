@@ -339,8 +339,11 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
     def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
                                     gmap_pair_dists, gmap_visited_masks, gmap_vpids, vp_img_embeds, vp_pos_fts, vp_masks,
                                     vp_nav_masks, vp_obj_masks, vp_cand_vpids, front_vp_feats=None, front_gmap_feats=None,
-                                    flops_count=False, nav_fusion=None):
-        """nav_fusion: optional precomputed `nav_fusion_matrix(...)` on the device ([B, G, W] float32) — the agent knows the
+                                    flops_count=False, nav_fusion=None, txt_kv=None):
+        """txt_kv: optional `self.text_kv(txt_embeds)` — the instruction is constant over an episode, so the K|V projections the
+        six cross-modal layers apply to it (M/models/vilmodel_GOAT.py:739-839 recomputes them in every step) can be computed once;
+        identical outputs, the gradients of the steps are summed by autograd.
+        nav_fusion: optional precomputed `nav_fusion_matrix(...)` on the device ([B, G, W] float32) — the agent knows the
         id strings and the visited flags on the host when it collates the step, so the call itself needs no device -> host
         read (and can be captured into a hipGraph)."""
         dt = compute_dtype()
@@ -356,13 +359,13 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
             bias = gmap_pair_dists.float() * ge.sprel_linear.weight.view(()) + ge.sprel_linear.bias.view(())
         if front_gmap_feats is not None:
             gmap = self.front_global_encoder(gmap, front_gmap_feats, gmap_masks)
-        gmap = ge.encoder(gmap, neg_mask(gmap_masks), txt_embeds, txt_km, bias)
+        gmap = ge.encoder(gmap, neg_mask(gmap_masks), txt_embeds, txt_km, bias, kv_cache=None if txt_kv is None else txt_kv['global'])
 
         le = self.local_encoder
         vp = vp_img_embeds.to(dt) + le.vp_pos_embeddings[1](le.vp_pos_embeddings[0](vp_pos_fts.to(dt)))
         if front_vp_feats is not None:
             vp = self.front_local_encoder(vp, front_vp_feats, vp_masks)
-        vp = le.encoder(vp, neg_mask(vp_masks), txt_embeds, txt_km)
+        vp = le.encoder(vp, neg_mask(vp_masks), txt_embeds, txt_km, kv_cache=None if txt_kv is None else txt_kv['local'])
 
         if self.sap_fuse_linear is None:
             fw = 0.5
@@ -388,6 +391,11 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
         cls_embeds = self.local_his_ln(self.local_his_map(cls))
         return {'gmap_embeds': gmap, 'vp_embeds': vp, 'global_logits': gl, 'local_logits': ll, 'fused_logits': fused,
                 'obj_logits': obj_logits, 'txt_embeds': txt_embeds, 'cls_embeds': cls_embeds}
+
+    def text_kv(self, txt_embeds):
+        """per-episode K|V projections of the instruction for the cross-modal layers of the global and the local branch."""
+        t = txt_embeds.to(compute_dtype())
+        return {'global': self.global_encoder.encoder.project_kv(t), 'local': self.local_encoder.encoder.project_kv(t)}
 
     # ---- CFP feature extraction (builds the FACL dictionaries) -------------------------------------------------
     def extract_cfp_features(self, batch):
@@ -436,7 +444,9 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
                 batch['gmap_masks'], batch['gmap_pair_dists'], batch['gmap_visited_masks'], batch['gmap_vpids'],
                 batch['vp_img_embeds'], batch['vp_pos_fts'], batch['vp_masks'], batch['vp_nav_masks'], batch['vp_obj_masks'],
                 batch['vp_cand_vpids'], batch['front_vp_feats'], batch['front_gmap_feats'], flops_count=batch['flops_count'],
-                nav_fusion=batch.get('nav_fusion'))
+                nav_fusion=batch.get('nav_fusion'), txt_kv=batch.get('txt_kv'))
+        if mode == 'text_kv':               # (build-side extension: see forward_navigation_per_step)
+            return self.text_kv(batch['txt_embeds'])
         if mode == 'instr_zdict_update':
             return self.forward_text(batch['z_txt'], batch['z_txt_mask'], batch['instr_z_direction_features'],
                                      batch['instr_z_direction_pzs'], batch['instr_z_landmark_features'],

@@ -1,0 +1,749 @@
+"""Fine-tuning rollout without MatterSim (SURVEY §8f N4 + the fine-tuning half of N1).
+
+The reference drives its fine-tuning loop through MatterSim with rendering switched OFF (M/r2r/env.py:47-58): the simulator is
+used as a graph walker only — adjacency, headings, the 36 discretised view directions — and everything the model sees is
+assembled on the host by Python loops over viewpoint-id strings (M/r2r/agent.py:82-304) around a per-episode `GraphMap`
+(M/models/graph_utils.py:43-144) whose incremental Floyd update is an O(N^2) Python double loop per step.
+
+Here (M/ = /root/reference/map_nav_src):
+
+  * `ScanGraph` / `GraphSim`      the graph-only navigator: connectivity JSON (or a synthetic scan) -> positions, adjacency,
+                                  per-viewpoint candidate tables (M/r2r/env.py:241-333 `make_candidate` without the simulator),
+                                  observations of `_get_obs` (:335-377), teleport steps of `make_equiv_action` (M/r2r/agent.py:349-378).
+  * `FloydGraph` / `GraphMap`     the reference's map with the SAME update rule (single-pivot relaxation per visited node, the
+                                  95959595 default distance, lazily evaluated `_point` paths) as vectorised float64 numpy — decisions
+                                  are bit-identical to the reference's Python floats (tests/golden/rollout_walk.npz).
+  * `NodeEmbedStore`              the node-embedding half of GraphMap on the DEVICE: panorama outputs of every step stay in HBM as a
+                                  pool; "rewrite" / "sum + count" / "mean on read" (graph_utils.py:113-125) become a CSR gather /
+                                  segment-mean over that pool (goat_gather_segmean_*), differentiable, so the gradient of a later
+                                  step's map tokens reaches the panorama encoder of the step that produced them — as it does in the
+                                  reference through `pad_tensors_wgrad` (M/r2r/agent.py:211).
+  * `panorama_inputs`, `gmap_inputs`, `vp_inputs`, `teacher_action`   the builders of M/r2r/agent.py:82-148,151-237,271-304,306-347,
+                                  producing the `panorama` / `navigation` input dicts of VLNBert.forward — small integer / float32
+                                  tables built by numpy on the host; the 36 x 768 view features are never touched on the host: the
+                                  builders emit ROW INDICES into a device-resident feature table (features.FeatureStore) and one
+                                  gather kernel assembles the batch in HBM.
+  * `NavRollout`                  the rollout loop (M/r2r/agent.py:448-676) for feedback = teacher / argmax / sample.  Teacher
+                                  forcing needs no device->host copy at all (the next action comes from the ground-truth path), so the
+                                  host builds step t+1 while the GPU runs step t; sampled rollouts read back B action indices per
+                                  step, as the reference does.
+
+MatterSim itself is absent from this image: the candidate ORDER inside a panorama (first view index in which a neighbour falls
+inside the camera frustum, then angular distance) restates the simulator's documented behaviour and is pinned by this repo's own
+fixtures only; everything downstream of the observations is pinned to outputs of the imported reference
+(tests/golden/make_golden_rollout.py)."""
+import json
+import math
+import os
+
+import numpy as np
+import torch
+
+MAX_DIST = 30          # M/models/graph_utils.py:4-5
+MAX_STEP = 10
+FLOYD_INF = 95959595   # graph_utils.py:45 (the reference's "not connected" distance; also the never-written diagonal)
+HFOV = math.radians(80.0)      # 640 x 480 at VFOV 60 (M/r2r/env.py:41-44)
+VFOV = math.radians(60.0)
+
+
+# ------------------------------------------------------------------------------------------------ geometry (M/utils/data.py)
+def angle_feature(heading, elevation, angle_feat_size=4):
+    # M/utils/data.py:128-131
+    return np.array([math.sin(heading), math.cos(heading), math.sin(elevation), math.cos(elevation)] * (angle_feat_size // 4), dtype=np.float32)
+
+
+def get_angle_fts(headings, elevations, angle_feat_size=4):
+    # M/utils/data.py:177-183 (sin / cos of the float32 angles)
+    ang = np.vstack([np.sin(headings), np.cos(headings), np.sin(elevations), np.cos(elevations)]).transpose().astype(np.float32)
+    reps = angle_feat_size // 4
+    return np.concatenate([ang] * reps, 1) if reps > 1 else ang
+
+
+def view_angles(view_index):
+    """heading, elevation of discretised view 0..35 (12 headings x 3 elevations, M/r2r/env.py:71-74)."""
+    return (view_index % 12) * math.radians(30), (view_index // 12 - 1) * math.radians(30)
+
+
+def view_angle_feature_table(angle_feat_size=4):
+    """[36 base views][36 views, angle_feat_size]: get_all_point_angle_feature (M/utils/data.py:133-156) — the simulator is only
+    used there to enumerate the 36 (heading, elevation) pairs."""
+    out = np.empty((36, 36, angle_feat_size), np.float32)
+    for base in range(36):
+        bh, be = view_angles(base)
+        for ix in range(36):
+            h, e = view_angles(ix)
+            out[base, ix] = angle_feature(h - bh, e - be, angle_feat_size)
+    return out
+
+
+def rel_pos(a, b):
+    """absolute heading / elevation / distance of points b [n,3] seen from a [3] (calculate_vp_rel_pos_fts, M/utils/data.py:158-175,
+    before the base angles are subtracted), float64."""
+    b = np.asarray(b, np.float64).reshape(-1, 3)
+    a = np.asarray(a, np.float64)
+    dx, dy, dz = b[:, 0] - a[0], b[:, 1] - a[1], b[:, 2] - a[2]
+    xy = np.maximum(np.sqrt(dx ** 2 + dy ** 2), 1e-8)
+    xyz = np.maximum(np.sqrt(dx ** 2 + dy ** 2 + dz ** 2), 1e-8)
+    heading = np.arcsin(dx / xy)
+    heading = np.where(b[:, 1] < a[1], np.pi - heading, heading)
+    elevation = np.arcsin(dz / xyz)
+    return heading, elevation, xyz
+
+
+# ------------------------------------------------------------------------------------------------ the map (graph_utils.py)
+class FloydGraph:
+    """M/models/graph_utils.py:43-88 on dense float64 matrices.  `update(k)` is the reference's single-pivot relaxation: inside
+    its double loop only entries [x][k] and [k][y] are read and neither can improve (the diagonal keeps the 95959595 default), so
+    the loop is order-independent and one vectorised min; `_point` is kept as an index matrix and paths are expanded lazily from
+    its CURRENT state, exactly as `path()` recurses in the reference."""
+
+    def __init__(self, cap=32):
+        self.ids, self.names = {}, []
+        self.D = np.full((cap, cap), float(FLOYD_INF))
+        self.P = np.full((cap, cap), -1, np.int32)
+        self._visited = set()
+
+    def _ix(self, vp):
+        i = self.ids.get(vp)
+        if i is None:
+            i = self.ids[vp] = len(self.names)
+            self.names.append(vp)
+            if i >= self.D.shape[0]:
+                cap = 2 * self.D.shape[0]
+                D = np.full((cap, cap), float(FLOYD_INF))
+                P = np.full((cap, cap), -1, np.int32)
+                D[:i, :i], P[:i, :i] = self.D[:i, :i], self.P[:i, :i]
+                self.D, self.P = D, P
+        return i
+
+    def distance(self, x, y):
+        if x == y:
+            return 0
+        return self.D[self._ix(x), self._ix(y)]
+
+    def add_edge(self, x, y, dis):
+        i, j = self._ix(x), self._ix(y)
+        if dis < self.D[i, j]:
+            self.D[i, j] = self.D[j, i] = dis
+            self.P[i, j] = self.P[j, i] = -1
+
+    def update(self, k):
+        kk, n = self._ix(k), len(self.names)
+        D, P = self.D[:n, :n], self.P[:n, :n]
+        cand = D[:, kk][:, None] + D[kk, :][None, :]
+        better = cand < D
+        np.fill_diagonal(better, False)
+        D[better] = cand[better]
+        P[better] = kk
+        self._visited.add(k)
+
+    def visited(self, k):
+        return k in self._visited
+
+    def _hops(self, i, j, depth=0):
+        if i == j:
+            return 0
+        k = self.P[i, j]
+        if k < 0:
+            return 1
+        if depth > 4096:
+            raise RecursionError('FloydGraph: cyclic _point chain')
+        return self._hops(i, k, depth + 1) + self._hops(k, j, depth + 1)
+
+    def path_len(self, x, y):
+        return self._hops(self._ix(x), self._ix(y))
+
+    def path(self, x, y):
+        if x == y:
+            return []
+        i, j = self._ix(x), self._ix(y)
+        k = self.P[i, j]
+        if k < 0:
+            return [y]
+        return self.path(x, self.names[k]) + self.path(self.names[k], y)
+
+    def dist_rows(self, x, ys):
+        """distance(x, y) for every y of ys (vectorised read; 0 where y == x)."""
+        i = self._ix(x)
+        j = np.array([self._ix(y) for y in ys], dtype=np.int64)
+        d = self.D[i, j].copy()
+        d[j == i] = 0
+        return d
+
+
+class GraphMap:
+    """M/models/graph_utils.py:91-144 without the embeddings (those live on the device: NodeEmbedStore)."""
+
+    def __init__(self, start_vp):
+        self.start_vp = start_vp
+        self.node_positions = {}
+        self.graph = FloydGraph()
+        self.node_stop_scores = {}
+        self.node_step_ids = {}
+
+    def update_graph(self, ob):
+        self.node_positions[ob['viewpoint']] = ob['position']
+        p = np.asarray(ob['position'], np.float64)
+        for cc in ob['candidate']:
+            self.node_positions[cc['viewpointId']] = cc['position']
+            q = np.asarray(cc['position'], np.float64)
+            d = q - p
+            dist = np.sqrt(d[0] ** 2 + d[1] ** 2 + d[2] ** 2)          # calc_position_distance, :7-13
+            self.graph.add_edge(ob['viewpoint'], cc['viewpointId'], dist)
+        self.graph.update(ob['viewpoint'])
+
+    def get_pos_fts(self, cur_vp, gmap_vpids, cur_heading, cur_elevation, angle_feat_size=4):
+        """[n, angle_feat_size + 3]: sin / cos of the relative heading and elevation, line distance, map distance, map path length
+        (graph_utils.py:127-149); None entries ([stop] / [MEM]) give the angle features of (0, 0) and zero distances."""
+        n = len(gmap_vpids)
+        real = [i for i, vp in enumerate(gmap_vpids) if vp is not None]
+        ang = np.zeros((n, 2), np.float64)
+        dist = np.zeros((n, 3), np.float64)
+        if real:
+            vps = [gmap_vpids[i] for i in real]
+            pos = np.array([self.node_positions[vp] for vp in vps], np.float64)
+            h, e, d = rel_pos(self.node_positions[cur_vp], pos)
+            ang[real, 0], ang[real, 1] = h - cur_heading, e - cur_elevation
+            dist[real, 0] = d / MAX_DIST
+            dist[real, 1] = self.graph.dist_rows(cur_vp, vps) / MAX_DIST
+            dist[real, 2] = np.array([self.graph.path_len(cur_vp, vp) for vp in vps], np.float64) / MAX_STEP
+        ang = ang.astype(np.float32)
+        return np.concatenate([get_angle_fts(ang[:, 0], ang[:, 1], angle_feat_size), dist.astype(np.float32)], 1)
+
+    def pair_dists(self, gmap_vpids, first=2):
+        """symmetric [G, G] float32 of map distances between the real nodes gmap_vpids[first:] (M/r2r/agent.py:191-195)."""
+        G = len(gmap_vpids)
+        out = np.zeros((G, G), np.float32)
+        if G > first:
+            ix = np.array([self.graph._ix(vp) for vp in gmap_vpids[first:]], dtype=np.int64)
+            sub = self.graph.D[np.ix_(ix, ix)].astype(np.float32)
+            np.fill_diagonal(sub, 0)
+            out[first:, first:] = sub
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ node embeddings (device)
+class NodeEmbedStore:
+    """`node_embeds` of B GraphMaps (graph_utils.py:98,113-125) as index bookkeeping over a pool of device rows.
+
+    The panorama encoder's outputs of every step are appended to the pool ([B*W_t] view rows, then [B] fused rows); a node is either
+    ("set", row): rewritten by its own visit, or ("acc", [rows]): the running sum of the candidate views that saw it, read back as
+    the mean.  `gather` turns the current state into the CSR index of goat_gather_segmean_* over the concatenated pool; its backward
+    sends each map token's gradient to the rows it averaged (inverse index: one writer per pool row, no atomics)."""
+
+    def __init__(self, B):
+        self.B = B
+        self.state = [dict() for _ in range(B)]
+        self.pool, self.rows = [], 0
+        self._view_base = self._fused_base = self._W = None
+
+    def begin_step(self, pano_embeds, fused):
+        """register this step's panorama tokens [B, W, H] and fused / averaged panorama vectors [B, H]."""
+        B, W, H = pano_embeds.shape
+        self._view_base, self._W = self.rows, W
+        self.pool.append(pano_embeds.reshape(B * W, H))
+        self.rows += B * W
+        self._fused_base = self.rows
+        self.pool.append(fused.to(pano_embeds.dtype))
+        self.rows += B
+
+    def rewrite(self, b, vp):
+        """update_node_embed(vp, avg_pano_embeds[b], rewrite=True)"""
+        self.state[b][vp] = ('set', self._fused_base + b)
+
+    def accumulate(self, b, vp, j):
+        """update_node_embed(vp, pano_embeds[b, j])"""
+        row = self._view_base + b * self._W + j
+        cur = self.state[b].get(vp)
+        if cur is None:
+            self.state[b][vp] = ('acc', [row])
+        elif cur[0] == 'set':                       # [embed, 1] += embed: a rewritten node that is accumulated onto again
+            self.state[b][vp] = ('acc', [cur[1], row])
+        else:
+            cur[1].append(row)
+
+    def csr(self, gmap_vpids, G, mem_rows=None):
+        """-> (idx, start, scale) int32 / int32 / float32 numpy for output token (b, g) = segment b * G + g.  Slot 0 ([stop]) is
+        empty (zeros); slot 1 ([MEM]) reads pool row mem_rows[b] if given; slots >= 2 the node's rows."""
+        idx, start, scale = [], [0], []
+        for b in range(self.B):
+            vps = gmap_vpids[b]
+            for g in range(G):
+                rows, sc = (), 1.0
+                if g == 1 and mem_rows is not None:
+                    rows = (mem_rows[b],)
+                elif g >= 2 and g < len(vps) and vps[g] is not None:
+                    kind, r = self.state[b][vps[g]]
+                    if kind == 'set':
+                        rows = (r,)
+                    else:
+                        rows, sc = r, 1.0 / len(r)
+                idx.extend(rows)
+                scale.append(sc)
+                start.append(len(idx))
+        if not idx:
+            idx = [-1]
+        return np.asarray(idx, np.int32), np.asarray(start, np.int32), np.asarray(scale, np.float32)
+
+    def gather(self, gmap_vpids, G, last_embeds=None):
+        """gmap_img_embeds [B, G, H] (M/r2r/agent.py:180-185): zeros, the previous step's [MEM] state, then the node embeddings."""
+        from . import graphmap, hipops
+        pool = list(self.pool)
+        mem_rows = None
+        if last_embeds is not None:
+            mem_rows = [self.rows + b for b in range(self.B)]
+            pool.append(last_embeds.to(pool[0].dtype))
+        src = torch.cat(pool, 0)
+        idx, start, scale = self.csr(gmap_vpids, G, mem_rows)
+        inv = graphmap.inverse_index(idx, start, scale, src.shape[0])
+        dev = src.device
+        out = hipops.gather_segmean(src, torch.from_numpy(idx).to(dev), torch.from_numpy(start).to(dev), torch.from_numpy(scale).to(dev),
+                                    self.B * G, tuple(t.to(dev) for t in inv))
+        return out.view(self.B, G, src.shape[1])
+
+
+# ------------------------------------------------------------------------------------------------ the navigator
+class ScanGraph:
+    """One building: viewpoint ids, positions [N, 3] float64, undirected adjacency (M/utils/data.py:80-105 `load_nav_graphs`)."""
+
+    def __init__(self, name, vpids, positions, edges):
+        self.name, self.vpids = name, list(vpids)
+        self.index = {v: i for i, v in enumerate(self.vpids)}
+        self.pos = np.asarray(positions, np.float64).reshape(len(self.vpids), 3)
+        self.adj = [[] for _ in self.vpids]
+        for a, b in edges:
+            ia, ib = self.index[a], self.index[b]
+            if ib not in self.adj[ia]:
+                self.adj[ia].append(ib)
+                self.adj[ib].append(ia)
+        self._cands = {}
+        self._sp = None
+
+    @staticmethod
+    def from_connectivity(connectivity_dir, scan):
+        """Matterport3D `<scan>_connectivity.json` (list of {image_id, pose[16], included, unobstructed[]})."""
+        with open(os.path.join(connectivity_dir, '%s_connectivity.json' % scan)) as f:
+            data = json.load(f)
+        vpids, pos, edges = [], [], []
+        for i, item in enumerate(data):
+            if not item['included']:
+                continue
+            for j, conn in enumerate(item['unobstructed']):
+                if conn and data[j]['included']:
+                    if item['image_id'] not in vpids:
+                        vpids.append(item['image_id'])
+                        pos.append([item['pose'][3], item['pose'][7], item['pose'][11]])
+                    edges.append((item['image_id'], data[j]['image_id']))
+        keep = set(vpids)
+        return ScanGraph(scan, vpids, pos, [(a, b) for a, b in edges if a in keep and b in keep])
+
+    @staticmethod
+    def synthetic(name='scan0', n=40, seed=0, degree=3, extent=12.0):
+        """random planar-ish scan: points in a box, each joined to its `degree` nearest neighbours (connected by construction:
+        node i > 0 is also joined to its nearest predecessor)."""
+        rs = np.random.RandomState(seed)
+        pos = np.concatenate([rs.uniform(-extent, extent, (n, 2)), rs.uniform(-1.5, 1.5, (n, 1))], 1)
+        vpids = ['%s_vp%03d' % (name, i) for i in range(n)]
+        d = np.sqrt(((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1))
+        np.fill_diagonal(d, np.inf)
+        edges = set()
+        for i in range(n):
+            for j in np.argsort(d[i])[:degree]:
+                edges.add((min(i, int(j)), max(i, int(j))))
+            if i > 0:
+                j = int(np.argmin(d[i, :i]))
+                edges.add((j, i))
+        return ScanGraph(name, vpids, pos, [(vpids[a], vpids[b]) for a, b in sorted(edges)])
+
+    # all-pairs shortest distances / predecessor matrix (networkx all_pairs_dijkstra in M/r2r/env.py:183-189)
+    def shortest(self):
+        if self._sp is None:
+            from scipy.sparse import csr_matrix
+            from scipy.sparse.csgraph import dijkstra
+            n = len(self.vpids)
+            rows, cols, w = [], [], []
+            for i in range(n):
+                for j in self.adj[i]:
+                    rows.append(i)
+                    cols.append(j)
+                    w.append(float(np.sqrt(((self.pos[i] - self.pos[j]) ** 2).sum())))
+            dist, pred = dijkstra(csr_matrix((w, (rows, cols)), shape=(n, n)), directed=False, return_predecessors=True)
+            self._sp = (dist, pred)
+        return self._sp
+
+    def shortest_path(self, a, b):
+        dist, pred = self.shortest()
+        i, j = self.index[a], self.index[b]
+        out = [j]
+        while out[-1] != i:
+            out.append(int(pred[i, out[-1]]))
+        return [self.vpids[k] for k in reversed(out)]
+
+    def candidates(self, vp):
+        """make_candidate (M/r2r/env.py:241-333) for viewpoint `vp`, base-view independent part: one entry per neighbour with its
+        absolute heading / elevation ('normalized_*'), the view index that sees it closest to its centre ('pointId') and its
+        position, in the order the 36-view sweep first meets them."""
+        got = self._cands.get(vp)
+        if got is not None:
+            return got
+        i = self.index[vp]
+        nb = self.adj[i]
+        out = []
+        if nb:
+            h, e, _ = rel_pos(self.pos[i], self.pos[nb])
+            first = []
+            for n_i, (hh, ee) in enumerate(zip(h, e)):
+                best, best_d, first_ix, first_d = 0, float('inf'), None, None
+                for ix in range(36):
+                    vh, ve = view_angles(ix)
+                    rh = (hh - vh + math.pi) % (2 * math.pi) - math.pi
+                    re = ee - ve
+                    dd = math.sqrt(rh * rh + re * re)
+                    if dd < best_d:
+                        best, best_d = ix, dd
+                    if first_ix is None and abs(rh) < HFOV / 2 and abs(re) < VFOV / 2:
+                        first_ix, first_d = ix, dd
+                if first_ix is None:
+                    first_ix, first_d = best, best_d
+                first.append((first_ix, first_d, n_i))
+                out.append({'viewpointId': self.vpids[nb[n_i]], 'pointId': best, 'normalized_heading': float(hh),
+                            'normalized_elevation': float(ee), 'position': tuple(float(x) for x in self.pos[nb[n_i]]), 'scanId': self.name,
+                            'idx': n_i + 1})
+            out = [out[k] for _, _, k in sorted(first)]
+        self._cands[vp] = out
+        return out
+
+
+class GraphSim:
+    """The batch of simulators of EnvBatch + R2RNavBatch._get_obs (M/r2r/env.py:26-96,335-377) on ScanGraphs.
+
+    episodes: list of dicts {instr_id, scan (ScanGraph), path [vpids], heading, instr_encoding}.  `features`: an object with
+    `row(scan_name, vpid) -> int` (features.FeatureStore): observations carry feature ROW numbers, not feature arrays."""
+
+    def __init__(self, features=None, angle_feat_size=4):
+        self.features = features
+        self.angle_feat_size = angle_feat_size
+        self.view_angle_fts = view_angle_feature_table(angle_feat_size)
+        self.batch, self.state = [], []
+
+    @staticmethod
+    def _snap(heading, elevation):
+        """discretised viewing angles: heading / elevation snapped to the 30-degree grid, view index 0..35"""
+        hs = int(round(heading / math.radians(30))) % 12
+        es = min(2, max(0, int(round(elevation / math.radians(30))) + 1))
+        return es * 12 + hs
+
+    def reset(self, episodes):
+        self.batch = list(episodes)
+        self.state = [(ep['path'][0], self._snap(ep['heading'], 0.0)) for ep in self.batch]
+        return self.observe()
+
+    def step(self, moves):
+        """moves[i] = (viewpoint, view index) or None (stay): M/r2r/agent.py:349-378 teleports with newEpisode."""
+        for i, mv in enumerate(moves):
+            if mv is not None:
+                self.state[i] = mv
+        return self.observe()
+
+    def observe(self):
+        obs = []
+        for ep, (vp, view) in zip(self.batch, self.state):
+            scan = ep['scan']
+            bh, be = view_angles(view)
+            cands = []
+            for c in scan.candidates(vp):
+                c = dict(c)
+                c['heading'] = c['normalized_heading'] - bh
+                c['elevation'] = c['normalized_elevation'] - be
+                c['angle_feat'] = angle_feature(c['heading'], c['elevation'], self.angle_feat_size)
+                cands.append(c)
+            dist, _ = scan.shortest()
+            obs.append({'instr_id': ep['instr_id'], 'scan': scan.name, 'scan_graph': scan, 'viewpoint': vp, 'viewIndex': view,
+                        'position': tuple(float(x) for x in scan.pos[scan.index[vp]]), 'heading': bh, 'elevation': be,
+                        'feature_row': self.features.row(scan.name, vp) if self.features is not None else -1,
+                        'view_angle_fts': self.view_angle_fts[view], 'candidate': cands,
+                        'instr_encoding': ep['instr_encoding'], 'gt_path': ep['path'],
+                        'distance': float(dist[scan.index[vp], scan.index[ep['path'][-1]]])})
+        return obs
+
+
+# ------------------------------------------------------------------------------------------------ input builders (agent.py)
+def language_inputs(obs, pad_id=0):
+    """_language_variable (M/r2r/agent.py:38-65) without the dictionaries (the caller adds the BACL / FACL tensors)."""
+    lens = [len(ob['instr_encoding']) for ob in obs]
+    ids = np.full((len(obs), max(lens)), pad_id, np.int64)
+    mask = np.zeros((len(obs), max(lens)), bool)
+    for i, ob in enumerate(obs):
+        ids[i, :lens[i]] = ob['instr_encoding']
+        mask[i, :lens[i]] = True
+    return {'txt_ids': torch.from_numpy(ids), 'txt_masks': torch.from_numpy(mask)}
+
+
+def panorama_inputs(obs, angle_feat_size=4, width=None):
+    """_panorama_feature_variable_do (M/r2r/agent.py:82-148): candidate views first (nav type 1), then the views no candidate
+    used (nav type 0), padded to the longest panorama of the batch (or `width`).  The 768-wide image features are NOT assembled
+    here: `view_rows[b, j]` = feature_row * 36 + view index of token j (-1: padding) for a device gather."""
+    B = len(obs)
+    rows, locs, types, cand_vpids, lens = [], [], [], [], []
+    for ob in obs:
+        used, r, ang, ty, cv = set(), [], [], [], []
+        for cc in ob['candidate']:
+            r.append(ob['feature_row'] * 36 + cc['pointId'])
+            ang.append(cc['angle_feat'])
+            ty.append(1)
+            cv.append(cc['viewpointId'])
+            used.add(cc['pointId'])
+        for k in range(36):
+            if k not in used:
+                r.append(ob['feature_row'] * 36 + k)
+                ang.append(ob['view_angle_fts'][k])
+                ty.append(0)
+        ang = np.stack(ang, 0).astype(np.float32)
+        locs.append(np.concatenate([ang, np.ones((len(r), 3), np.float32)], 1))
+        rows.append(r)
+        types.append(ty)
+        cand_vpids.append(cv)
+        lens.append(len(r))
+    W = max(lens) if width is None else width
+    if W < max(lens):
+        raise ValueError('panorama_inputs: a panorama has %d tokens, the bucket holds %d' % (max(lens), W))
+    view_rows = np.full((B, W), -1, np.int64)
+    loc_fts = np.zeros((B, W, angle_feat_size + 3), np.float32)
+    nav_types = np.zeros((B, W), np.int64)
+    for b in range(B):
+        view_rows[b, :lens[b]] = rows[b]
+        loc_fts[b, :lens[b]] = locs[b]
+        nav_types[b, :lens[b]] = types[b]
+    return {'view_rows': torch.from_numpy(view_rows), 'loc_fts': torch.from_numpy(loc_fts), 'nav_types': torch.from_numpy(nav_types),
+            'view_lens': torch.tensor(lens, dtype=torch.int64), 'cand_vpids': cand_vpids}
+
+
+def gmap_order(gmap):
+    """[stop], [MEM], visited nodes, unvisited nodes in the insertion order of node_positions (M/r2r/agent.py:159-176,
+    enc_full_graph)."""
+    visited = [k for k in gmap.node_positions if gmap.graph.visited(k)]
+    unvisited = [k for k in gmap.node_positions if not gmap.graph.visited(k)]
+    return [None, None] + visited + unvisited, [0, 1] + [1] * len(visited) + [0] * len(unvisited), len(unvisited) == 0
+
+
+def gmap_inputs(obs, gmaps, width=None, angle_feat_size=4):
+    """_nav_gmap_variable (M/r2r/agent.py:151-237) without the embeddings (NodeEmbedStore.gather)."""
+    B = len(obs)
+    vpids, vis, no_left = zip(*[gmap_order(g) for g in gmaps])
+    lens = [len(v) for v in vpids]
+    G = max(lens) if width is None else width
+    if G < max(lens):
+        raise ValueError('gmap_inputs: a map has %d nodes, the bucket holds %d' % (max(lens), G))
+    step_ids = np.zeros((B, G), np.int64)
+    pos = np.zeros((B, G, angle_feat_size + 3), np.float32)
+    pair = np.zeros((B, G, G), np.float32)
+    vmask = np.zeros((B, G), bool)
+    gmask = np.zeros((B, G), bool)
+    for b, (ob, g) in enumerate(zip(obs, gmaps)):
+        n = lens[b]
+        step_ids[b, :n] = [g.node_step_ids.get(vp, 0) for vp in vpids[b]]
+        pos[b, :n] = g.get_pos_fts(ob['viewpoint'], vpids[b], ob['heading'], ob['elevation'], angle_feat_size)
+        pair[b, :n, :n] = g.pair_dists(vpids[b])
+        vmask[b, :n] = np.asarray(vis[b], bool)
+        gmask[b, :n] = True
+    gmask[:, 1] = False                 # the [MEM] token cannot be chosen (:209)
+    return {'gmap_vpids': [list(v) for v in vpids], 'gmap_step_ids': torch.from_numpy(step_ids), 'gmap_pos_fts': torch.from_numpy(pos),
+            'gmap_visited_masks': torch.from_numpy(vmask), 'gmap_pair_dists': torch.from_numpy(pair), 'gmap_masks': torch.from_numpy(gmask),
+            'gmap_lens': lens, 'no_vp_left': list(no_left)}
+
+
+def vp_inputs(obs, gmaps, cand_vpids, view_lens, nav_types, width, angle_feat_size=4):
+    """_nav_vp_variable_mem (M/r2r/agent.py:271-304) without the embeddings: [stop], [MEM], then the panorama tokens.
+    width = panorama width + 2."""
+    B = len(obs)
+    pos = np.zeros((B, width, 2 * (angle_feat_size + 3)), np.float32)
+    for b, (ob, g) in enumerate(zip(obs, gmaps)):
+        cand = g.get_pos_fts(ob['viewpoint'], cand_vpids[b], ob['heading'], ob['elevation'], angle_feat_size) if cand_vpids[b] else \
+            np.zeros((0, angle_feat_size + 3), np.float32)
+        start = g.get_pos_fts(ob['viewpoint'], [g.start_vp], ob['heading'], ob['elevation'], angle_feat_size)
+        pos[b, :, :angle_feat_size + 3] = start
+        pos[b, 2:len(cand) + 2, angle_feat_size + 3:] = cand
+    nav_types = torch.as_tensor(nav_types)
+    view_lens = torch.as_tensor(view_lens)
+    nav = torch.cat([torch.ones(B, 1, dtype=torch.bool), torch.zeros(B, 1, dtype=torch.bool), nav_types == 1], 1)
+    masks = torch.arange(width)[None, :] < (view_lens + 2)[:, None]
+    return {'vp_pos_fts': torch.from_numpy(pos), 'vp_masks': masks, 'vp_nav_masks': nav,
+            'vp_cand_vpids': [[None, None] + list(x) for x in cand_vpids]}
+
+
+def teacher_action(obs, vpids, ended, visited_masks=None, imitation_learning=False, t=None, ignoreid=-100):
+    """_teacher_action (M/r2r/agent.py:306-347), expert policy 'spl'."""
+    a = np.zeros(len(obs), dtype=np.int64)
+    for i, ob in enumerate(obs):
+        if ended[i]:
+            a[i] = ignoreid
+        elif imitation_learning:
+            assert ob['viewpoint'] == ob['gt_path'][t]
+            if t == len(ob['gt_path']) - 1:
+                a[i] = 0
+            else:
+                goal = ob['gt_path'][t + 1]
+                for j, vpid in enumerate(vpids[i]):
+                    if goal == vpid:
+                        a[i] = j
+                        break
+        elif ob['viewpoint'] == ob['gt_path'][-1]:
+            a[i] = 0
+        else:
+            scan = ob['scan_graph']
+            dist, _ = scan.shortest()
+            cur, goal = scan.index[ob['viewpoint']], scan.index[ob['gt_path'][-1]]
+            best, best_d = ignoreid, float('inf')
+            for j, vpid in enumerate(vpids[i]):
+                if j > 1 and ((visited_masks is None) or (not visited_masks[i][j])):
+                    k = scan.index[vpid]
+                    d = dist[k, goal] + dist[cur, k]
+                    if d < best_d:
+                        best_d, best = d, j
+            a[i] = best
+    return a
+
+
+# ------------------------------------------------------------------------------------------------ the rollout (agent.py:448-676)
+class NavRollout:
+    """One rollout of B episodes through a VLNBert-compatible `model(mode, batch)` (nav_model.VLNBert).
+
+        sim = GraphSim(store); ro = NavRollout(model, sim, store, max_action_len=15)
+        loss, traj = ro.run(episodes, feedback='teacher', extras={'language': {...BACL/FACL tensors...}, 'panorama': {...}, 'navigation': {...}})
+
+    extras: tensors added verbatim to the input dict of the given mode (the confounder dictionaries z_dicts / z_front_dict of
+    M/r2r/agent.py:486-511).  `pano_width` / `gmap_buckets`: pad every step's panorama to a fixed width and the map to the next
+    bucket (shape-stable steps: a captured step graph per bucket can be replayed; None = the reference's per-batch maxima)."""
+
+    def __init__(self, model, sim, features, max_action_len=15, fusion='dynamic', ignoreid=-100, pano_width=None, gmap_buckets=None,
+                 device='cuda', hoist_text_kv=True):
+        self.model, self.sim, self.features = model, sim, features
+        self.max_action_len, self.fusion, self.ignoreid = max_action_len, fusion, ignoreid
+        self.pano_width, self.gmap_buckets = pano_width, gmap_buckets
+        self.hoist_text_kv = hoist_text_kv      # K|V projections of the instruction once per episode (nav_model.text_kv) instead of per step
+        self.device = torch.device(device)
+        self.host_s = 0.0          # seconds spent in the host-side builders during the last run (diagnostics)
+
+    def _bucket(self, n):
+        if not self.gmap_buckets:
+            return None
+        for g in self.gmap_buckets:
+            if g >= n:
+                return g
+        raise ValueError('map with %d nodes exceeds the largest bucket %d' % (n, self.gmap_buckets[-1]))
+
+    def build_step(self, obs, gmaps, t, ended, imitation):
+        """every host-built table of step t (no device work, no dependence on model outputs)."""
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.node_step_ids[obs[i]['viewpoint']] = t + 1
+        pano = panorama_inputs(obs, self.sim.angle_feat_size, self.pano_width)
+        return pano
+
+    def run(self, episodes, feedback='teacher', extras=None, train_ml=1.0, compute_loss=True):
+        import time
+        from collections import defaultdict
+        dd = lambda d: defaultdict(lambda: None, d)
+        extras = extras or {}
+        dev = self.device
+        mv = lambda d: {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in d.items()}
+        t_host = time.perf_counter()
+        obs = self.sim.reset(episodes)
+        B = len(obs)
+        gmaps = [GraphMap(ob['viewpoint']) for ob in obs]
+        for g, ob in zip(gmaps, obs):
+            g.update_graph(ob)
+        traj = [{'instr_id': ob['instr_id'], 'path': [[ob['viewpoint']]]} for ob in obs]
+        lang = language_inputs(obs)
+        self.host_s = time.perf_counter() - t_host
+        lang_in = mv(lang)
+        lang_in.update(extras.get('language', {}))
+        txt_embeds = self.model('language', dd(lang_in))
+        txt_kv = self.model('text_kv', {'txt_embeds': txt_embeds}) if self.hoist_text_kv else None
+        store = NodeEmbedStore(B)
+        ended = np.zeros(B, bool)
+        just_ended = np.zeros(B, bool)
+        last_embeds = None
+        ml_loss = 0.0
+        steps = 0
+        for t in range(self.max_action_len):
+            t_host = time.perf_counter()
+            pano = self.build_step(obs, gmaps, t, ended, feedback == 'teacher')
+            self.host_s += time.perf_counter() - t_host
+            pin = {'view_img_fts': self.features.gather(pano['view_rows'].to(dev, non_blocking=True)), 'loc_fts': pano['loc_fts'].to(dev, non_blocking=True),
+                   'nav_types': pano['nav_types'].to(dev, non_blocking=True), 'view_lens': pano['view_lens'].to(dev, non_blocking=True),
+                   'already_dropout': False}
+            pin.update(extras.get('panorama', {}))
+            pano_embeds, pano_masks, fused = self.model('panorama', dd(pin))
+            if fused is None:                                   # not adaptive_pano_fusion: masked mean (M/r2r/agent.py:545-547)
+                fused = torch.sum(pano_embeds * pano_masks.unsqueeze(2), 1) / torch.sum(pano_masks, 1, keepdim=True)
+            t_host = time.perf_counter()
+            store.begin_step(pano_embeds, fused)
+            for i, g in enumerate(gmaps):
+                if not ended[i]:
+                    store.rewrite(i, obs[i]['viewpoint'])
+                    for j, cvp in enumerate(pano['cand_vpids'][i]):
+                        if not g.graph.visited(cvp):
+                            store.accumulate(i, cvp, j)
+            n_nodes = max(2 + len(g.node_positions) for g in gmaps)
+            gin = gmap_inputs(obs, gmaps, self._bucket(n_nodes), self.sim.angle_feat_size)
+            W = pano['view_rows'].shape[1]
+            vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], W + 2, self.sim.angle_feat_size)
+            G = gin['gmap_step_ids'].shape[1]
+            nav_vpids = gin['gmap_vpids'] if self.fusion != 'local' else vin['vp_cand_vpids']
+            target = None
+            if compute_loss or feedback == 'teacher':
+                target = teacher_action(obs, nav_vpids, ended, visited_masks=gin['gmap_visited_masks'].numpy() if self.fusion != 'local' else None,
+                                        imitation_learning=(feedback == 'teacher'), t=t, ignoreid=self.ignoreid)
+            self.host_s += time.perf_counter() - t_host
+            zero = pano_embeds.new_zeros(B, 1, pano_embeds.shape[-1])
+            memtok = zero if last_embeds is None else last_embeds.unsqueeze(1).to(pano_embeds.dtype)
+            nin = {'txt_embeds': txt_embeds, 'txt_masks': lang_in['txt_masks'],
+                   'gmap_img_embeds': store.gather(gin['gmap_vpids'], G, last_embeds),
+                   'vp_img_embeds': torch.cat([zero, memtok, pano_embeds], 1), 'vp_obj_masks': None, 'flops_count': False, 'txt_kv': txt_kv}
+            nin.update(mv({k: v for k, v in gin.items() if k not in ('gmap_lens', 'no_vp_left')}))
+            nin.update(mv(vin))
+            nin.update(extras.get('navigation', {}))
+            out = self.model('navigation', dd(nin))
+            last_embeds = out['cls_embeds']
+            logits = {'local': out['local_logits'], 'global': out['global_logits']}.get(self.fusion, out['fused_logits'])
+            steps += 1
+            if target is not None and compute_loss:
+                ml_loss = ml_loss + torch.nn.functional.cross_entropy(logits.float(), torch.from_numpy(target).to(dev, non_blocking=True),
+                                                                      reduction='sum', ignore_index=self.ignoreid)
+            if feedback == 'teacher':
+                a_t = target
+                stop = [ob['viewpoint'] == ob['gt_path'][-1] for ob in obs]
+            elif feedback == 'argmax':
+                a_t = logits.argmax(1).cpu().numpy()
+                stop = a_t == 0
+            elif feedback == 'sample':
+                probs = torch.softmax(logits.float(), 1)
+                a_t = torch.distributions.Categorical(probs).sample().cpu().numpy()
+                stop = [ob['viewpoint'] == ob['gt_path'][-1] for ob in obs]
+            else:
+                raise ValueError('invalid feedback option %r' % (feedback,))
+            t_host = time.perf_counter()
+            moves = []
+            for i in range(B):
+                if stop[i] or ended[i] or gin['no_vp_left'][i] or t == self.max_action_len - 1:
+                    moves.append(None)
+                    just_ended[i] = True
+                else:
+                    nxt = nav_vpids[i][int(a_t[i])]
+                    hop = gmaps[i].graph.path(obs[i]['viewpoint'], nxt)
+                    traj[i]['path'].append(hop)
+                    prev = traj[i]['path'][-2][-1] if len(hop) == 1 else hop[-2]
+                    view = next(c['pointId'] for c in obs[i]['scan_graph'].candidates(prev) if c['viewpointId'] == nxt)
+                    moves.append((nxt, view))
+            obs = self.sim.step(moves)
+            for i, ob in enumerate(obs):
+                if not ended[i]:
+                    gmaps[i].update_graph(ob)
+            ended = np.logical_or(ended, np.array([m is None for m in moves]))
+            self.host_s += time.perf_counter() - t_host
+            if ended.all():
+                break
+        loss = ml_loss * train_ml / B if compute_loss else None
+        self.steps = steps
+        return loss, traj

@@ -364,7 +364,7 @@ def make_nav_episode(B=2, L=44, V=36, n_steps=3, n_cand=4, seed=0, vocab_size=50
     return ep
 
 
-def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_float=True):
+def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_float=True, hoist_text_kv=False):
     """language once, then panorama + navigation per step with the [MEM] token carrying `cls_embeds` of the
     previous step (not detached: back-propagation through time, M/r2r/agent.py:592).  Returns (loss, records)."""
     from collections import defaultdict
@@ -377,6 +377,7 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
     if use_facl:
         lang['front_txt_feats'] = mv(ep['front_txt_feats'])
     txt = model('language', dd(lang))
+    txt_kv = model('text_kv', {'txt_embeds': txt}) if hoist_text_kv else None      # (HIP model only: the instruction's K|V once per episode)
     B = txt.shape[0]
     mem = None
     loss = 0.0
@@ -409,6 +410,8 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
                'vp_masks': mv(st['vp_masks']), 'vp_nav_masks': mv(st['vp_nav_masks']),
                'vp_obj_masks': mv(st['vp_obj_masks']) if has_obj else None,
                'vp_cand_vpids': st['vp_cand_vpids'], 'flops_count': False, 'nav_fusion': st.get('nav_fusion')}
+        if txt_kv is not None:
+            nin['txt_kv'] = txt_kv
         if use_facl:
             nin['front_vp_feats'], nin['front_gmap_feats'] = mv(ep['front_vp_feats']), mv(ep['front_gmap_feats'])
         out = model('navigation', dd(nin))
@@ -420,3 +423,57 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
             loss = loss + torch.nn.functional.cross_entropy(ol, mv(st['obj_target']), reduction='sum', ignore_index=-100)
         rec['steps'].append({'pano_embeds': pano, 'pano_fused': fused, **out})
     return loss, rec
+
+
+# ------------------------------------------------------------------------------------------------ rollout cases
+def rollout_episodes(scan, rs, B=3, max_steps=5, starts=None):
+    """B episodes on a rollout.ScanGraph: ground-truth path = shortest path from a start viewpoint to a distant one (cut to
+    max_steps viewpoints), random start heading, random instruction ids between <s> (0) and </s> (2)."""
+    eps = []
+    n = len(scan.vpids)
+    starts = starts if starts is not None else [(7 * b * b + 7 * b) % n if b else 0 for b in range(B)]
+    starts = [0, 7, 19][:B] if B <= 3 and n > 19 else starts
+    dist, _ = scan.shortest()
+    for b in range(B):
+        s = starts[b] % n
+        far = int(np.argsort(dist[s])[-((b % 5) + 2)])
+        path = scan.shortest_path(scan.vpids[s], scan.vpids[far])[:max_steps]
+        eps.append({'instr_id': 'ep%d' % b, 'scan': scan, 'path': path, 'heading': float(rs.uniform(0, 2 * np.pi)),
+                    'instr_encoding': [0] + rs.randint(3, 900, 6 + 3 * (b % 8)).tolist() + [2]})
+    return eps
+
+
+def make_rollout_case(seed=17, n_nodes=24, B=3, max_steps=5, scan_seed=9):
+    """scan, float32 features [n_vp, 36, 768], episodes and the BACL / FACL dictionaries (in the reference's on-disk shapes:
+    [K, 768] features, [K] probabilities) of the end-to-end rollout golden (tests/golden/rollout_episode.npz).  numpy
+    RandomState: bit-stable across machines."""
+    from . import rollout
+    rs = np.random.RandomState(seed)
+    scan = rollout.ScanGraph.synthetic('scanB', n=n_nodes, seed=scan_seed, degree=3)
+    feats = rs.standard_normal((len(scan.vpids), 36, 768)).astype(np.float32)
+    eps = rollout_episodes(scan, rs, B, max_steps)
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+    def pz(k):
+        p = rs.uniform(0.1, 1.0, k)
+        return f32(p / p.sum())
+    dicts = {'instr_direction_features': f32(rs.uniform(0, 1, (35, 768))), 'instr_direction_pzs': pz(35),
+             'instr_landmark_features': f32(rs.uniform(0, 1, (39, 768))), 'instr_landmark_pzs': pz(39),
+             'img_features': f32(rs.uniform(0, 1, (24, 768))), 'img_pzs': pz(24),
+             'txt_feats': rs.uniform(0, 1, (50, 768)).astype(np.float32), 'vp_feats': rs.uniform(0, 1, (50, 768)).astype(np.float32),
+             'gmap_feats': rs.uniform(0, 1, (50, 768)).astype(np.float32)}
+    return scan, feats, eps, dicts
+
+
+def rollout_extras(dicts, B, device):
+    """the confounder dictionaries as the per-mode extra inputs of rollout.NavRollout.run: what M/r2r/agent.py:53-58,138-140,
+    491-511 does with z_dicts / z_front_dict (repeat over the batch)."""
+    dev = torch.device(device)
+    rep = lambda t, w: t.to(dev).reshape(1, -1, w).repeat(B, 1, 1)
+    front = lambda k: torch.from_numpy(dicts[k]).to(dev).unsqueeze(0).repeat(B, 1, 1)
+    return {'language': {'instr_z_direction_features': rep(dicts['instr_direction_features'], 768),
+                         'instr_z_direction_pzs': rep(dicts['instr_direction_pzs'], 1),
+                         'instr_z_landmark_features': rep(dicts['instr_landmark_features'], 768),
+                         'instr_z_landmark_pzs': rep(dicts['instr_landmark_pzs'], 1), 'front_txt_feats': front('txt_feats')},
+            'panorama': {'z_img_features': rep(dicts['img_features'], 768), 'z_img_pzs': rep(dicts['img_pzs'], 1)},
+            'navigation': {'front_txt_feats': front('txt_feats'), 'front_vp_feats': front('vp_feats'), 'front_gmap_feats': front('gmap_feats')}}
