@@ -202,7 +202,8 @@ int goat_attn_bwd(void* stream, int dtype,
 /* Softmax cross-entropy (reduction none) on float32 logits [M, ld] with N valid columns (ld >= N may be padded):
  * loss[m] = logsumexp(logits[m,:N]) - logits[m,target[m]], lse saved.  Replaces F.cross_entropy on the 576 x 50265
  * MLM scores (P/model/pretrain_goat.py:213-215).  Backward writes dlogits (GOAT_BF16 or GOAT_F32) with row stride
- * ld_out, zeros in the padding columns [N, ld_out), ready to be the K-padded operand of the decoder's dgrad/wgrad. */
+ * ld_out, zeros in the padding columns [N, ld_out), ready to be the K-padded operand of the decoder's dgrad/wgrad.
+ * A negative target marks an ignored row (loss 0, zero gradient): the padding rows of a shape-bucketed static batch. */
 int goat_ce_fwd(void* stream, const float* logits, int64_t ld, int M, int N, const int64_t* targets,
                 float* loss, float* lse);
 int goat_ce_bwd(void* stream, int dtype_out, const float* logits, int64_t ld, int M, int N,
@@ -270,9 +271,12 @@ int goat_embed_bwd(void* stream, int dtype, const void* dout, const int64_t* ids
 /* ---- causal-learning heads (csrc/causal.hip) -------------------------------------------------------------------
  * tanh-attention pooling of the CFP heads: a = softmax_l(tanh(x[b,l,:])·w) over ALL L <= 256 slots (no padding mask,
  * as the reference), out[b,:] = tanh(sum_l a_l x[b,l,:])   (P/model/pretrain_goat.py:502-515,
- * M/models/vilmodel_GOAT.py:909-922).  x [B,L,H] in `dtype`; w float32 [H]; out float32 [B,H]; attn float32 [B,L] (saved). */
+ * M/models/vilmodel_GOAT.py:909-922).  x [B,L,H] in `dtype`; w float32 [H]; out float32 [B,H]; attn float32 [B,L] (saved).
+ * slot_mask (float32 [B,L], may be NULL): added to the scores before the softmax — 0 / -inf.  NULL = the reference: every slot
+ * of the batch's padded width takes part.  A shape-bucketed static batch is padded BEYOND that width; the mask removes exactly
+ * those extra slots, so the pooled vector is what the reference computes on the batch's own padding. */
 int goat_attn_pool_fwd(void* stream, int dtype, const void* x, const float* w, float* out, float* attn, float* ws, int B,
-                       int L, int H);   /* ws: float32 scratch of B*L elements */
+                       int L, int H, const float* slot_mask);   /* ws: float32 scratch of B*L elements */
 /* backward: dx [B,L,H] (dtype) overwritten; dw float32 [H] accumulated (atomics; caller zero-fills); ws: float32 scratch
  * of B*L elements.  H % 4 == 0. */
 int goat_attn_pool_bwd(void* stream, int dtype, const void* x, const float* w, const float* attn, const float* out,

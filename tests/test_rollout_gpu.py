@@ -116,7 +116,7 @@ def test_nav_rollout_bf16_store_and_sampled_feedback():
                 _, traj = ro.run(eps, feedback=fb, extras=ex, compute_loss=False)
             for ep, tr in zip(eps, traj):
                 flat = [v for hop in tr['path'] for v in hop]
-                assert flat[0] == ep['path'][0] and len(tr['path']) <= 6
+                assert flat[0] == ep["path"][0] and len(tr["path"]) <= 7
                 for a, b in zip(flat[:-1], flat[1:]):                    # every hop follows an edge of the scan
                     assert scan.index[b] in scan.adj[scan.index[a]]
     finally:

@@ -117,3 +117,117 @@ def test_static_batch_pack_commit_and_shape_guard():
         sb.pack(mk(3, L=20))
     with pytest.raises(RuntimeError):
         sb.commit()
+
+
+def _eval_csr(src, idx, start, scale, n_out):
+    idx, start = idx.numpy(), start.numpy()
+    out = np.zeros((n_out, src.shape[1]), np.float64)
+    for s in range(n_out):
+        seg = idx[start[s]:start[s + 1]]
+        if len(seg):
+            out[s] = src[seg].sum(0) * (1.0 if scale is None else float(scale[s]))
+    return out
+
+
+def test_shape_bucket_padding_keeps_every_real_token():
+    """pad_batch + capacity-padded indices (train_step.StaticBatch(bucket=...)): a RAGGED batch padded into a bucket yields, for
+    every real output slot, the same gathered rows as its own unpadded indices (evaluated with numpy on random source rows) —
+    map tokens (fused panorama rows moved behind the padded view rows), local tokens, inverse indices, MLM selection, SAP
+    fusion — and only ignorable padding elsewhere."""
+    from vln_goat_amd import config as gcfg, graphmap, synth, train_step
+    cfg = gcfg.make_config(num_l_layers=1, num_top_layer=1, num_pano_layers=1, vocab_size=300)
+    rs = np.random.RandomState(0)
+    for trial in range(6):
+        B = 4
+        T = rs.randint(1, 5, B).tolist()
+        L = rs.randint(8, 25, B).tolist()
+        batch = synth.make_pretrain_batch(B=B, T=T, L=L, seed=trial, vocab_size=300, style='rich')
+        own = train_step.collate_indices(cfg, batch)
+        N, V = batch['traj_view_img_fts'].shape[:2]
+        G, W = batch['gmap_step_ids'].shape[1], batch['vp_pos_fts'].shape[1]
+        bucket = dict(L=32, N=N + rs.randint(0, 5), G=G + rs.randint(0, 4), W=W)
+        padded = train_step.pad_batch(batch, **bucket)
+        assert padded['txt_ids'].shape == (B, 32) and padded['traj_view_img_fts'].shape[0] == bucket['N']
+        assert int((padded['txt_labels'] != -1).sum()) == int((batch['txt_labels'] != -1).sum())
+        caps = train_step.index_capacities(padded, ('mlm', 'sap', 'cfp'))
+        idx = train_step.collate_indices(cfg, padded, caps=caps, vp_width=W)
+        H = 5
+        Np = bucket['N']
+        views, fused = rs.standard_normal((N, V, H)), rs.standard_normal((N, H))
+        src_own = np.concatenate([views.reshape(N * V, H), fused], 0)
+        pv = np.concatenate([views, rs.standard_normal((Np - N, V, H))], 0)
+        pf = np.concatenate([fused, rs.standard_normal((Np - N, H))], 0)
+        src_pad = np.concatenate([pv.reshape(Np * V, H), pf], 0)
+        a = _eval_csr(src_own, own['gmap'][0], own['gmap'][1], own['gmap'][2], B * G).reshape(B, G, H)
+        b = _eval_csr(src_pad, idx['gmap'][0], idx['gmap'][1], idx['gmap'][2], B * bucket['G']).reshape(B, bucket['G'], H)
+        assert np.allclose(a, b[:, :G]) and not b[:, G:].any()
+        a = _eval_csr(views.reshape(N * V, H), own['vp'][0], own['vp'][1], None, B * W).reshape(B, W, H)
+        b = _eval_csr(pv.reshape(Np * V, H), idx['vp'][0], idx['vp'][1], None, B * W).reshape(B, W, H)
+        assert np.allclose(a, b) and idx['vp'][3] == W
+        assert idx['gmap'][0].shape[0] == caps['nnz_gmap'] and idx['gmap_inv'][0].shape[0] == caps['nnz_gmap']
+        # inverse index of the padded gather: source row r is read by exactly the segments that list it
+        inv_idx, inv_start, inv_w = idx['gmap_inv']
+        gi, gs = idx['gmap'][0].numpy(), idx['gmap'][1].numpy()
+        for r in rs.randint(0, src_pad.shape[0], 12):
+            want = sorted(s for s in range(len(gs) - 1) if r in gi[gs[s]:gs[s + 1]])
+            assert sorted(inv_idx[int(inv_start[r]):int(inv_start[r + 1])].tolist()) == want
+        # MLM: the real rows first, padding rows ignored; the scale restores the mean
+        n = int(own['mlm_idx'].shape[0])
+        rows_own = own['mlm_idx'].numpy()
+        b_own, pos_own = rows_own // batch['txt_ids'].shape[1], rows_own % batch['txt_ids'].shape[1]
+        rows_pad = idx['mlm_idx'].numpy()[:n]
+        assert np.array_equal(rows_pad // 32, b_own) and np.array_equal(rows_pad % 32, pos_own)
+        assert torch.equal(idx['mlm_tgt'][:n], own['mlm_tgt']) and bool((idx['mlm_tgt'][n:] == -100).all())
+        assert abs(float(idx['mlm_scale']) - caps['mlm'] / n) < 1e-6
+        assert torch.equal(idx['sap'][1][:, :G], own['sap'][1]) and not bool(idx['sap'][1][:, G:].any())
+    with pytest.raises(ValueError):
+        train_step.pad_batch(batch, L=4)
+
+
+def test_static_batch_bucket_accepts_ragged_batches():
+    from vln_goat_amd import config as gcfg, synth, train_step
+    cfg = gcfg.make_config(num_l_layers=1, num_top_layer=1, num_pano_layers=1, vocab_size=300)
+    mk = lambda seed, T, L: synth.make_pretrain_batch(B=4, T=T, L=L, seed=seed, vocab_size=300, style='survey')
+    first = mk(1, [3, 2, 4, 3], [20, 24, 9, 16])
+    bucket = dict(L=24, N=16, G=max(first['gmap_step_ids'].shape[1], 18))
+    sb = train_step.StaticBatch(cfg, first, device='cpu', bucket=bucket)
+    assert sb.gb['txt_ids'].shape == (4, 24) and sb.gb['traj_view_img_fts'].shape[0] == 16
+    other = mk(2, [1, 4, 2, 2], [24, 5, 12, 7])
+    assert sb.fits(other)
+    sb.stage(sb.pack(other))
+    sb.commit()
+    n = other['traj_view_img_fts'].shape[0]
+    assert torch.equal(sb.gb['traj_view_img_fts'][:n], other['traj_view_img_fts'])
+    assert torch.equal(sb.gb['txt_ids'][:, :other['txt_ids'].shape[1]], other['txt_ids'])
+    assert torch.equal(sb.gb['gmap_lens'], other['gmap_lens'])
+    too_long = mk(3, [5, 5, 5, 5], [24, 24, 24, 24])
+    assert not sb.fits(too_long)
+    with pytest.raises(ValueError):
+        sb.pack(too_long)
+
+
+def test_collate_indices_covers_object_batches():
+    """REVERIE / SOON batches (object tokens, OG and MRC heads): every index the model otherwise builds lazily on the device side
+    (pretrain_model._indices / forward_og / _mrc_rows) comes out of collate_indices on the host — compared with the model's own
+    lazily built cache on the same batch."""
+    from vln_goat_amd import config as gcfg, pretrain_model, synth, train_step
+    cfg = gcfg.make_config(num_l_layers=1, num_top_layer=1, num_pano_layers=1, vocab_size=300, dataset='reverie', obj_feat_size=768,
+                           pretrain_tasks=['mlm', 'mrc', 'sap', 'og', 'cfp'])
+    batch = synth.make_pretrain_batch(B=3, T=[2, 3, 1], L=[12, 9, 14], seed=4, vocab_size=300, style='rich', objects=4, mrc=True)
+    idx = train_step.collate_indices(cfg, batch, tasks=('mlm', 'mrc', 'sap', 'og', 'cfp'))
+    model = pretrain_model.GlocalTextPathCMTPreTraining(cfg)
+    b2 = dict(batch)
+    cache = model.bert._indices(b2)
+    for k in ('objcat', 'objcat_inv', 'gmap', 'gmap_inv', 'vp_inv'):
+        for a, b in zip(cache[k], idx[k]):
+            assert torch.equal(a, b) if torch.is_tensor(a) else a == b, k
+    for a, b in zip(cache['vp'], idx['vp']):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+    vl, ol = model._last_lens(b2)
+    W1 = idx['vp'][3]
+    for which in ('view', 'obj'):
+        rows, sel = model._mrc_rows(b2, which, W1)
+        assert torch.equal(rows.cpu(), idx['mrc_' + which][0]) and torch.equal(sel.cpu(), idx['mrc_' + which][1])
+    oi, om = idx['og_idx']
+    for b, (v, o) in enumerate(zip(vl, ol)):
+        assert oi[b, :o].tolist() == list(range(1 + v, 1 + v + o)) and om[b].tolist() == [True] * o + [False] * (om.shape[1] - o)

@@ -440,3 +440,79 @@ def test_static_batch_feeds_a_captured_step_with_new_batches():
             sb.pack(synth.make_pretrain_batch(B=4, T=2, L=30, seed=7, vocab_size=1000, style='survey'))
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+def test_shape_bucketed_static_batch_replays_ragged_batches():
+    """StaticBatch(bucket=...): ONE captured step per task serves RAGGED batches (other trajectory lengths, text lengths, map sizes,
+    bf16 features from a features.FeatureStore-style host table) padded into the bucket — loss mean and every gradient equal the
+    eager model on the UNPADDED batch (dropout off).  Covers the padded MLM selection (ignored rows + mean rescale), the fused
+    panorama rows behind padded view rows, and the CFP pooling masks that keep the reference's pooling width."""
+    import vln_goat_amd
+    from vln_goat_amd import config as gcfg, pretrain_model, synth, train_step
+    cfg = gcfg.make_config(num_l_layers=2, num_top_layer=2, num_pano_layers=1, vocab_size=1000,
+                           hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    model = pretrain_model.GlocalTextPathCMTPreTraining(cfg).cuda().eval()
+
+    def mk(seed, T, L):
+        b = synth.make_pretrain_batch(B=4, T=T, L=L, seed=seed, vocab_size=1000, style='rich')
+        b['traj_view_img_fts'] = b['traj_view_img_fts'].to(torch.bfloat16)          # the bf16 feature store's rows
+        return b
+    first, second, third = mk(5, [3, 2, 4, 3], [30, 22, 16, 25]), mk(6, [1, 4, 2, 2], [12, 28, 9, 20]), mk(7, [4, 4, 3, 4], [32, 32, 5, 17])
+    G = max(b['gmap_step_ids'].shape[1] for b in (first, second, third))
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        sb = train_step.StaticBatch(cfg, first, bucket=dict(L=32, N=16, G=G + 2))
+        params = [p for p in model.parameters() if p.requires_grad]
+        out = {}
+
+        def step(task):
+            for p in params:
+                p.grad = None
+            loss = model(sb.gb, task, compute_loss=True)
+            loss.mean().backward()
+            out[task] = loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for t in ('mlm', 'sap', 'cfp'):
+                step(t)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs, grads = {}, {}
+        for t in ('mlm', 'sap', 'cfp'):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step(t)
+            graphs[t] = g
+            grads[t] = {id(p): p.grad for p in params if p.grad is not None}
+        for host in (second, third, first):
+            assert sb.fits(host)
+            sb.stage(sb.pack(host))
+            sb.commit()
+            for t in ('mlm', 'sap', 'cfp'):
+                graphs[t].replay()
+                torch.cuda.synchronize()
+                got_mean = float(out[t].detach().float().mean())
+                got = {k: v.detach().float().clone() for k, v in grads[t].items()}
+                gb = synth.batch_to(host, 'cuda')                      # eager on the unpadded batch
+                for p in params:
+                    p.grad = None
+                ref = model(gb, t, compute_loss=True)
+                ref.mean().backward()
+                torch.cuda.synchronize()
+                ref_mean = float(ref.detach().float().mean())
+                assert abs(got_mean - ref_mean) <= 2e-2 * max(1.0, abs(ref_mean)), (t, got_mean, ref_mean)
+                top = max(float(p.grad.abs().max()) for p in params if p.grad is not None)
+                n = 0
+                for p in params:
+                    if p.grad is None:
+                        continue
+                    a, b = got[id(p)], p.grad.float()
+                    scale = max(float(b.abs().max()), 0.05 * top)
+                    assert float((a - b).abs().max()) <= 3e-2 * scale, (t, n)
+                    n += 1
+                assert n > 10
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)

@@ -54,7 +54,7 @@ SIGNATURES = {
     'goat_gather_segmean_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
     'goat_embed_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],
     'goat_embed_bwd': [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],
-    'goat_attn_pool_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
+    'goat_attn_pool_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'goat_attn_pool_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_door_gate_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
     'goat_door_gate_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32],

@@ -35,7 +35,8 @@ constexpr int POOL_MAXL = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void pool_score_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ out, const float* __restrict__ dout,
-                                                         float* __restrict__ score, int rows, int L, int H) {
+                                                         float* __restrict__ score, int rows, int L, int H,
+                                                         const float* __restrict__ smask = nullptr) {
   // forward (out == nullptr): score = tanh(x)·w ; backward: score = x·(dout (1 - out^2))
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void pool_score_kernel(const T* __restrict__ x
     }
   }
   s = wave_sum(s);
-  if (lane == 0) score[row] = s;
+  if (lane == 0) score[row] = smask != nullptr ? s + smask[row] : s;      // (-inf: a slot outside the batch's own padded width)
 }
 
 // block = 256 threads = 64 column quads x 4 row lanes; grid = (B, ceil(H/256))
@@ -338,16 +339,16 @@ __global__ __launch_bounds__(256) void infonce_bwd_kernel(NceBwdArgs q) {
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
 extern "C" int goat_attn_pool_fwd(void* stream, int dtype, const void* x, const float* w, float* out, float* attn,
-                                  float* ws, int B, int L, int H) {
+                                  float* ws, int B, int L, int H, const float* slot_mask) {
   if (!x || !w || !out || !attn || !ws) return GOAT_E_ARG;
   if (B <= 0 || L <= 0 || L > POOL_MAXL || H <= 0 || (H % 4)) return GOAT_E_SHAPE;
   const int rows = B * L;
   dim3 g1((rows + 3) / 4), g2(B, (H + 255) / 256);
   if (dtype == GOAT_BF16) {
-    hipLaunchKernelGGL(pool_score_kernel<bf16_t>, g1, dim3(256), 0, ST(stream), (const bf16_t*)x, w, nullptr, nullptr, ws, rows, L, H);
+    hipLaunchKernelGGL(pool_score_kernel<bf16_t>, g1, dim3(256), 0, ST(stream), (const bf16_t*)x, w, nullptr, nullptr, ws, rows, L, H, slot_mask);
     hipLaunchKernelGGL(pool_out_kernel<bf16_t>, g2, dim3(256), 0, ST(stream), (const bf16_t*)x, ws, out, attn, L, H);
   } else if (dtype == GOAT_F32) {
-    hipLaunchKernelGGL(pool_score_kernel<float>, g1, dim3(256), 0, ST(stream), (const float*)x, w, nullptr, nullptr, ws, rows, L, H);
+    hipLaunchKernelGGL(pool_score_kernel<float>, g1, dim3(256), 0, ST(stream), (const float*)x, w, nullptr, nullptr, ws, rows, L, H, slot_mask);
     hipLaunchKernelGGL(pool_out_kernel<float>, g2, dim3(256), 0, ST(stream), (const float*)x, ws, out, attn, L, H);
   } else {
     return GOAT_E_ARG;

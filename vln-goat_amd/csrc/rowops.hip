@@ -434,7 +434,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   if (threadIdx.x == 0) {
     const float l = mx + __logf(sum);
     lse[m] = l;
-    loss[m] = l - row[targets[m]];
+    const int64_t t = targets[m];
+    loss[m] = t < 0 ? 0.f : l - row[t];          // negative target: ignored row (F.cross_entropy's ignore_index), loss 0
   }
 }
 
@@ -445,8 +446,8 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
   const int m = blockIdx.x;
   const float* row = logits + (int64_t)m * ld;
   T* out = dlogits + (int64_t)m * ld_out;
-  const float l = lse[m], g = dloss[m];
   const int t = (int)targets[m];
+  const float l = lse[m], g = t < 0 ? 0.f : dloss[m];      // ignored row: zero gradient
   for (int c = threadIdx.x * 4; c < (int)ld_out; c += 256 * 4) {
     float v[4];
 #pragma unroll

@@ -1639,7 +1639,7 @@ class _AttnPoolFn(torch.autograd.Function):
     """out = tanh(sum_l softmax_l(tanh(x_l)·w) x_l), all slots, no padding mask (P/model/pretrain_goat.py:502-515)."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, smask=None):
         _need_gpu(x)
         x = x if x.is_contiguous() else x.contiguous()
         B, L, H = x.shape
@@ -1647,7 +1647,10 @@ class _AttnPoolFn(torch.autograd.Function):
         out = torch.empty((B, H), dtype=torch.float32, device=x.device)
         attn = torch.empty((B, L), dtype=torch.float32, device=x.device)
         ws = torch.empty(B * L, dtype=torch.float32, device=x.device)
-        st = _lib.lib().goat_attn_pool_fwd(_stream(), _dt(x), _ptr(x), _ptr(wv), _ptr(out), _ptr(attn), _ptr(ws), B, L, H)
+        if smask is not None:
+            assert smask.shape == (B, L) and smask.dtype == torch.float32 and smask.is_contiguous()
+        st = _lib.lib().goat_attn_pool_fwd(_stream(), _dt(x), _ptr(x), _ptr(wv), _ptr(out), _ptr(attn), _ptr(ws), B, L, H,
+                                           _ptr(smask) if smask is not None else None)
         _lib.check(st, 'goat_attn_pool_fwd')
         ctx.save_for_backward(x, wv, attn, out)
         ctx.wshape = w.shape
@@ -1664,11 +1667,13 @@ class _AttnPoolFn(torch.autograd.Function):
         st = _lib.lib().goat_attn_pool_bwd(_stream(), _dt(x), _ptr(x), _ptr(wv), _ptr(attn), _ptr(out), _ptr(dout), _ptr(dx),
                                            _ptr(dw), _ptr(ws), B, L, H)
         _lib.check(st, 'goat_attn_pool_bwd')
-        return dx, dw.view(ctx.wshape)
+        return dx, dw.view(ctx.wshape), None
 
 
-def attn_pool(x, w):
-    return _AttnPoolFn.apply(x, w)
+def attn_pool(x, w, smask=None):
+    """smask: optional float32 [B, L] of 0 / -inf added to the scores (slots beyond the batch's own padded width in a
+    shape-bucketed static batch); masked slots get weight 0 and a zero gradient."""
+    return _AttnPoolFn.apply(x, w, smask)
 
 
 class _DoorGateFn(torch.autograd.Function):

@@ -414,9 +414,10 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
         return gmap, vp, txt
 
 
-def attn_pool(x, w):
-    """tanh-attention pooling over ALL slots, no padding mask (P/model/pretrain_goat.py:502-515); float32 [B,H]."""
-    return hipops.attn_pool(x, w)
+def attn_pool(x, w, smask=None):
+    """tanh-attention pooling over ALL slots, no padding mask (P/model/pretrain_goat.py:502-515); float32 [B,H].
+    smask: see hipops.attn_pool (bucket padding only)."""
+    return hipops.attn_pool(x, w, smask)
 
 
 def cfp_losses(gmap_o, vp_o, fused_o, txt_o, temperature, gather=None):
@@ -519,7 +520,13 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
             return empty.sum(1) if compute_loss else empty.new_zeros((0, self.config.vocab_size))
         masked = txt.reshape(-1, txt.shape[-1]).index_select(0, cache['mlm_idx'])
         if compute_loss:
-            return self.mlm_head.predictions.loss(masked, cache['mlm_tgt'])
+            loss = self.mlm_head.predictions.loss(masked, cache['mlm_tgt'])
+            if cache.get('mlm_scale') is not None:
+                # shape-bucketed static batch (train_step.StaticBatch): the selection is padded to the bucket's capacity with ignored
+                # rows (loss 0); the vector is rescaled by capacity / real rows (a device scalar) so that its MEAN — what the trainer
+                # takes, P/train_r2r_goat.py:333 — is the mean over the real masked tokens
+                loss = loss * cache['mlm_scale']
+            return loss
         return self.mlm_head(masked)            # float32 logits
 
     # -- SAP ---------------------------------------------------------------------------------------
@@ -626,22 +633,31 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
             o_tgt = probs.reshape(-1, probs.shape[-1]).index_select(0, osel)
         if not compute_loss:
             return v_pred, v_tgt, o_pred, o_tgt
+        cache = batch['_goat_cache']
         loss = F.kl_div(F.log_softmax(v_pred, dim=-1), v_tgt.float(), reduction='none').sum(dim=1)
+        wv, wo = cache.get('mrc_view_w'), cache.get('mrc_obj_w')
+        if wv is not None:           # shape-bucketed static batch: selection padded to a capacity, padding rows weigh 0
+            loss = loss * wv
         if o_pred is not None:
-            loss = torch.cat([loss, F.kl_div(F.log_softmax(o_pred, dim=-1), o_tgt.float(), reduction='none').sum(dim=1)], 0)
+            lo = F.kl_div(F.log_softmax(o_pred, dim=-1), o_tgt.float(), reduction='none').sum(dim=1)
+            loss = torch.cat([loss, lo * wo if wo is not None else lo], 0)
+        if wv is not None:           # ... and the vector is rescaled so that its mean is the mean over the real rows
+            n_real = wv.sum() + (wo.sum() if (o_pred is not None and wo is not None) else 0.0)
+            loss = loss * (loss.shape[0] / n_real)
         return loss
 
     # -- CFP ---------------------------------------------------------------------------------------
     def forward_cfp(self, batch, compute_loss):
         gmap, vp, txt = self.bert.forward_cfp(batch)
+        cache = batch.get('_goat_cache') or {}
         with hipops.Branch('global') as bg:          # the three heads are independent: map / text on side streams
             if batch['extra_heads']:
                 gmap = self.tim_global_head(gmap)
-            go = attn_pool(gmap, self.tim_global_attn)
+            go = attn_pool(gmap, self.tim_global_attn, cache.get('cfp_gmap_mask'))
         with hipops.Branch('pano') as bt:
             if batch['extra_heads']:
                 txt = self.tim_txt_head(txt)
-            to = attn_pool(txt, self.tim_txt_attn)
+            to = attn_pool(txt, self.tim_txt_attn, cache.get('cfp_txt_mask'))
         if batch['extra_heads']:
             vp = self.tim_local_head(vp)
         vo = attn_pool(vp, self.tim_local_attn)

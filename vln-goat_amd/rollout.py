@@ -714,28 +714,37 @@ class NavRollout:
             if feedback == 'teacher':
                 a_t = target
                 stop = [ob['viewpoint'] == ob['gt_path'][-1] for ob in obs]
-            elif feedback == 'argmax':
-                a_t = logits.argmax(1).cpu().numpy()
-                stop = a_t == 0
-            elif feedback == 'sample':
+            elif feedback in ('argmax', 'sample'):
+                # ONE device -> host copy per step: the chosen actions and the stop probabilities (M/r2r/agent.py:575-580,601-607)
                 probs = torch.softmax(logits.float(), 1)
-                a_t = torch.distributions.Categorical(probs).sample().cpu().numpy()
-                stop = [ob['viewpoint'] == ob['gt_path'][-1] for ob in obs]
+                act = probs.argmax(1) if feedback == 'argmax' else torch.distributions.Categorical(probs).sample()
+                back = torch.stack([act.to(torch.float32), probs[:, 0]], 0).cpu().numpy()
+                a_t = back[0].astype(np.int64)
+                stop = (a_t == 0) if feedback == 'argmax' else [ob['viewpoint'] == ob['gt_path'][-1] for ob in obs]
+                for i, g in enumerate(gmaps):
+                    if not ended[i]:
+                        g.node_stop_scores[obs[i]['viewpoint']] = {'stop': float(back[1, i])}
             else:
                 raise ValueError('invalid feedback option %r' % (feedback,))
             t_host = time.perf_counter()
             moves = []
             for i in range(B):
-                if stop[i] or ended[i] or gin['no_vp_left'][i] or t == self.max_action_len - 1:
+                nxt = None if (stop[i] or ended[i] or gin['no_vp_left'][i] or t == self.max_action_len - 1) else nav_vpids[i][int(a_t[i])]
+                if nxt is None:                     # (a sampled action 0 is the [stop] token: nav_vpids[i][0] is None, M/r2r/agent.py:623-629)
                     moves.append(None)
                     just_ended[i] = True
                 else:
-                    nxt = nav_vpids[i][int(a_t[i])]
                     hop = gmaps[i].graph.path(obs[i]['viewpoint'], nxt)
                     traj[i]['path'].append(hop)
                     prev = traj[i]['path'][-2][-1] if len(hop) == 1 else hop[-2]
                     view = next(c['pointId'] for c in obs[i]['scan_graph'].candidates(prev) if c['viewpointId'] == nxt)
                     moves.append((nxt, view))
+            if feedback != 'teacher':                  # go back to the node with the best stop score (M/r2r/agent.py:633-642)
+                for i in range(B):
+                    if (not ended[i]) and just_ended[i] and gmaps[i].node_stop_scores:
+                        stop_node = max(gmaps[i].node_stop_scores.items(), key=lambda kv: kv[1]['stop'])[0]
+                        if obs[i]['viewpoint'] != stop_node:
+                            traj[i]['path'].append(gmaps[i].graph.path(obs[i]['viewpoint'], stop_node))
             obs = self.sim.step(moves)
             for i, ob in enumerate(obs):
                 if not ended[i]:

@@ -124,26 +124,115 @@ class PretrainStep:
         return info
 
 
-def collate_indices(config, batch, tasks=('mlm', 'sap', 'cfp')):
+import numpy as np      # noqa: E402
+_NP_OF = {torch.float32: np.float32, torch.bfloat16: np.uint16, torch.float16: np.float16, torch.int64: np.int64, torch.int32: np.int32,
+          torch.bool: np.bool_, torch.uint8: np.uint8}
+_INT_VIEW = {torch.bfloat16: torch.int16}        # numpy has no bfloat16: move the bits as 16-bit integers
+
+PAD_FILL = {'txt_labels': -1, 'traj_vp_view_lens': 1}          # every other tensor is padded with zeros
+
+
+BIG_TENSORS = ('traj_view_img_fts', 'traj_obj_img_fts')
+
+
+def pad_batch(batch, L=None, N=None, G=None, W=None, shape_only=()):
+    """shape_only: keys whose padded tensor is only needed for its SHAPE (a zero-stride view, no memory) — StaticBatch.pack writes
+    the real rows of the 27 MB feature tensor straight into the pinned buffer instead of padding a copy first.
+    Pad a host pre-training batch (the *_collate schema of P/data/tasks.py:110,392,618, which pads to the per-batch maxima) up to
+    a SHAPE BUCKET: text length L, panorama count N (= sum of trajectory lengths), map size G, local width W (views + [stop]).
+    Padding panoramas are appended after the last real one with view length 1 (no index ever refers to them), padded text slots
+    carry label -1, padded map slots lie beyond gmap_lens.  -> a new dict (tensors re-allocated only when they grow)."""
+    out = dict(batch)
+
+    def grow(key, dims, fill=None):
+        t = batch.get(key)
+        if t is None or not torch.is_tensor(t):
+            return
+        shape = list(t.shape)
+        for d, n in dims:
+            if n is not None:
+                if shape[d] > n:
+                    raise ValueError('pad_batch: %s has %d along dim %d, the bucket holds %d' % (key, shape[d], d, n))
+                shape[d] = n
+        if shape == list(t.shape):
+            return
+        if key in shape_only:
+            out[key] = torch.zeros((1,) * len(shape), dtype=t.dtype).expand(shape)
+            return
+        fill_v = PAD_FILL.get(key, 0) if fill is None else fill
+        new = torch.full(shape, fill_v, dtype=t.dtype) if fill_v else torch.zeros(shape, dtype=t.dtype)
+        new[tuple(slice(0, k) for k in t.shape)] = t
+        out[key] = new
+    for k in ('txt_ids', 'txt_labels'):
+        grow(k, [(1, L)])
+    for k in ('traj_view_img_fts', 'traj_loc_fts', 'traj_nav_types', 'traj_vp_view_lens', 'traj_obj_img_fts', 'traj_vp_obj_lens',
+              'traj_reverie_obj_names'):
+        grow(k, [(0, N)])
+    for k in ('gmap_step_ids', 'gmap_pos_fts', 'gmap_visited_masks'):
+        grow(k, [(1, G)])
+    grow('gmap_pair_dists', [(1, G), (2, G)])
+    grow('vp_pos_fts', [(1, W)])
+    # the batch's own padded widths: the reference's un-masked CFP pooling runs over exactly these (collate_indices -> cfp_*_mask)
+    out['_own'] = batch.get('_own') or {'L': int(batch['txt_ids'].shape[1]), 'G': int(batch['gmap_step_ids'].shape[1])}
+    return out
+
+
+def index_capacities(batch, tasks, mlm_rate=0.25):
+    """upper bounds of the variable-length index tensors of collate_indices for every batch that fits the shapes of `batch`."""
+    Nn, V = batch['traj_view_img_fts'].shape[:2]
+    B, Lb = batch['txt_ids'].shape
+    W = batch['vp_pos_fts'].shape[1]
+    return {'nnz_gmap': Nn * V + Nn, 'nnz_vp': B * W, 'mlm': max(8, int(mlm_rate * B * Lb))}
+
+
+def _pad1(t, n, fill):
+    if t.shape[0] > n:
+        raise ValueError('index tensor of %d entries exceeds the bucket capacity %d' % (t.shape[0], n))
+    if t.shape[0] == n:
+        return t
+    out = torch.full((n,) + tuple(t.shape[1:]), fill, dtype=t.dtype)
+    out[:t.shape[0]] = t
+    return out
+
+
+def collate_indices(config, batch, tasks=('mlm', 'sap', 'cfp'), caps=None, vp_width=None):
     """Everything a pre-training step derives from the id STRINGS and label positions of a batch, built on the host from the
     CPU batch (what pretrain_model.GlocalTextPathCMTPreTraining otherwise builds lazily on first use and caches in
-    batch['_goat_cache']): the graph-map / local-branch gather indices (graphmap.py; P/model/vilmodel_goat.py:377-391,430-468),
-    the MLM row selection (P/model/pretrain_goat.py:196-206) and the SAP fusion matrix (:329-345).  R2R batches (views only)."""
+    batch['_goat_cache']): the graph-map / local-branch gather indices (graphmap.py; P/model/vilmodel_goat.py:377-391,430-468), the
+    view + object row assembly of REVERIE / SOON batches (:331-341), the MLM row selection (P/model/pretrain_goat.py:196-206), the
+    SAP fusion matrix (:329-345) and the OG logit gather (:356-391).
+    caps (index_capacities): pad every variable-length index tensor to a fixed capacity — entries past the last segment are never
+    read, MLM padding rows select row 0 with target -100 (ignored by goat_ce_*) and `mlm_scale` = capacity / real rows restores the
+    mean — so that batches of one shape bucket share ONE device layout.  vp_width: local width of the bucket (default: the batch's own)."""
     from . import graphmap
-    if batch.get('traj_obj_img_fts') is not None:
-        raise NotImplementedError('collate_indices: object batches (REVERIE/SOON) build their indices lazily')
     V = batch['traj_view_img_fts'].shape[1]
     G = batch['gmap_step_ids'].shape[1]
     lens = batch['traj_vp_view_lens']
-    out = {}
-    out['gmap'] = graphmap.build_gmap_index(batch['traj_step_lens'], lens, batch['traj_vpids'], batch['traj_cand_vpids'],
-                                            batch['gmap_vpids'], G, V, bool(config.adaptive_pano_fusion))
-    out['vp'] = graphmap.build_vp_index(batch['traj_step_lens'], lens, V)
-    n_rows = int(batch['traj_view_img_fts'].shape[0])
     fused = bool(config.adaptive_pano_fusion)
-    out['gmap_inv'] = graphmap.inverse_index(out['gmap'][0], out['gmap'][1], out['gmap'][2], n_rows * V + (n_rows if fused else 0))
-    out['vp_inv'] = tuple(t for t in graphmap.inverse_index(out['vp'][0], out['vp'][1], None, n_rows * V) if t is not None)
-    W = out['vp'][3]
+    n_rows = int(batch['traj_view_img_fts'].shape[0])
+    out = {}
+    n_real = int(sum(batch['traj_step_lens']))            # (a padded batch carries dummy panoramas after the real ones)
+    if batch.get('traj_obj_img_fts') is not None:
+        obj = batch['traj_vp_obj_lens']
+        O = batch['traj_obj_img_fts'].shape[1]
+        Wp = batch['traj_nav_types'].shape[1]
+        ci = graphmap.build_obj_concat_index(lens, obj, V, O, Wp)
+        out['objcat'] = ci
+        out['objcat_inv'] = tuple(t for t in graphmap.inverse_index(ci[0], ci[1], None, n_rows * V + n_rows * O) if t is not None)
+        out['view_lens_cpu'], out['obj_lens_cpu'] = lens.clone(), obj.clone()
+        lens, V = lens + obj, Wp
+    g = graphmap.build_gmap_index(batch['traj_step_lens'], lens[:n_real], batch['traj_vpids'], batch['traj_cand_vpids'],
+                                  batch['gmap_vpids'], G, V, False) if not fused else None
+    if fused:
+        # the fused rows sit behind ALL view rows of the (possibly padded) batch: row n_rows * V + n
+        g = _gmap_index_fused(batch, lens[:n_real], G, V, n_rows)
+    v = graphmap.build_vp_index(batch['traj_step_lens'], lens[:n_real], V)
+    if vp_width is not None and v[3] != vp_width:
+        v = _vp_index_width(batch['traj_step_lens'], lens[:n_real], V, vp_width)
+    out['gmap'], out['vp'] = g, v
+    out['gmap_inv'] = graphmap.inverse_index(g[0], g[1], g[2], n_rows * V + (n_rows if fused else 0))
+    out['vp_inv'] = tuple(t for t in graphmap.inverse_index(v[0], v[1], None, n_rows * V) if t is not None)
+    W = v[3]
     if 'mlm' in tasks:
         labels = batch['txt_labels'].reshape(-1)
         idx = (labels != -1).nonzero().squeeze(1)
@@ -152,8 +241,104 @@ def collate_indices(config, batch, tasks=('mlm', 'sap', 'cfp')):
         last = torch.as_tensor(batch['traj_step_lens']).cumsum(0) - 1
         nav = batch['traj_nav_types'][last] != 1
         nav = torch.cat([torch.zeros(nav.shape[0], 1, dtype=torch.bool), nav], 1)[:, :W]
+        if nav.shape[1] < W:
+            nav = torch.cat([nav, torch.ones(nav.shape[0], W - nav.shape[1], dtype=torch.bool)], 1)
         out['sap'] = (nav, graphmap.build_sap_fusion(batch['traj_cand_vpids'], batch['gmap_vpids'], batch['gmap_visited_masks'], G, W))
+    has_obj = batch.get('traj_obj_img_fts') is not None
+    last = torch.as_tensor(batch['traj_step_lens']).cumsum(0) - 1
+    if 'og' in tasks and has_obj:
+        # OG logits gathered from the local tokens (pretrain_model.forward_og): object slots follow the [stop] token and the views
+        vl, ol = out['view_lens_cpu'][last].tolist(), out['obj_lens_cpu'][last].tolist()
+        O = batch['traj_obj_img_fts'].shape[1] if caps is not None else max(1, max(ol))
+        oi, om = torch.zeros(len(vl), O, dtype=torch.int64), torch.zeros(len(vl), O, dtype=torch.bool)
+        for b, (v_, o_) in enumerate(zip(vl, ol)):
+            oi[b, :o_] = torch.arange(1 + v_, 1 + v_ + o_)
+            om[b, :o_] = True
+        out['og_idx'] = (oi, om)
+    if 'mrc' in tasks:
+        vl = (out['view_lens_cpu'] if has_obj else batch['traj_vp_view_lens'])[last].tolist()
+        ol = out['obj_lens_cpu'][last].tolist() if has_obj else [0] * len(vl)
+        for which, mkey in (('view', 'vp_view_mrc_masks'), ('obj', 'vp_obj_mrc_masks')):
+            mask = batch.get(mkey)
+            if mask is None:
+                continue
+            rows = []
+            for b in range(mask.shape[0]):
+                n = vl[b] if which == 'view' else ol[b]
+                off = 1 if which == 'view' else 1 + vl[b]
+                for j in mask[b].nonzero().squeeze(1).tolist():
+                    if j >= n:
+                        raise ValueError('MRC mask selects a padded %s slot (sample %d, slot %d)' % (which, b, j))
+                    rows.append(b * W + off + j)
+            out['mrc_' + which] = (torch.tensor(rows, dtype=torch.int64), mask.reshape(-1).nonzero().squeeze(1))
+    if caps is not None:
+        c = caps
+        for which in ('view', 'obj'):
+            if 'mrc_' + which in out:
+                rows, sel = out['mrc_' + which]
+                n, cap = int(rows.shape[0]), c['mlm']
+                if n == 0:
+                    raise ValueError('collate_indices: a bucketed batch needs at least one masked %s region' % which)
+                w = torch.zeros(cap, dtype=torch.float32)
+                w[:n] = 1.0
+                out['mrc_' + which] = (_pad1(rows, cap, int(rows[0])), _pad1(sel, cap, int(sel[0])))
+                out['mrc_%s_w' % which] = w
+        out['gmap'] = (_pad1(g[0], c['nnz_gmap'], -1), g[1], g[2])
+        gi = out['gmap_inv']
+        out['gmap_inv'] = (_pad1(gi[0], c['nnz_gmap'], -1), gi[1], _pad1(gi[2], c['nnz_gmap'], 0.0))
+        out['vp'] = (_pad1(v[0], c['nnz_vp'], -1), v[1], v[2], v[3])
+        vi = out['vp_inv']
+        out['vp_inv'] = (_pad1(vi[0], c['nnz_vp'], -1),) + tuple(vi[1:])
+        if 'cfp' in tasks:
+            # the CFP heads pool over ALL slots of the batch's own padded width, padding included (reference quirk):
+            # bucket padding beyond that width must not take part
+            own = batch.get('_own') or {'L': batch['txt_ids'].shape[1], 'G': G}
+            B = batch['txt_ids'].shape[0]
+            tm = torch.zeros(B, batch['txt_ids'].shape[1], dtype=torch.float32)
+            tm[:, own['L']:] = float('-inf')
+            gm = torch.zeros(B, G, dtype=torch.float32)
+            gm[:, own['G']:] = float('-inf')
+            out['cfp_txt_mask'], out['cfp_gmap_mask'] = tm, gm
+        if 'mlm' in tasks:
+            n = int(out['mlm_idx'].shape[0])
+            if n == 0:
+                raise ValueError('collate_indices: a bucketed batch needs at least one masked token')
+            out['mlm_idx'] = _pad1(out['mlm_idx'], c['mlm'], 0)
+            out['mlm_tgt'] = _pad1(out['mlm_tgt'], c['mlm'], -100)
+            out['mlm_scale'] = torch.tensor([float(c['mlm']) / n], dtype=torch.float32)
     return out
+
+
+def _gmap_index_fused(batch, lens, G, V, n_rows):
+    from . import graphmap
+    n_real = len(lens)
+    idx, start, scale = graphmap.build_gmap_index(batch['traj_step_lens'], lens, batch['traj_vpids'], batch['traj_cand_vpids'],
+                                                  batch['gmap_vpids'], G, V, True)
+    if n_rows != n_real:                 # fused row n was addressed as n_real * V + n: move it behind the padded view rows
+        idx = idx.clone()
+        m = idx >= n_real * V
+        idx[m] += (n_rows - n_real) * V
+    return idx, start, scale
+
+
+def _vp_index_width(traj_step_lens, lens, V, width):
+    """graphmap.build_vp_index for a fixed local width (>= the batch's own): the extra slots are empty segments."""
+    import numpy as np
+    step_lens = np.asarray(list(traj_step_lens), dtype=np.int64)
+    view_lens = np.asarray(lens.tolist() if torch.is_tensor(lens) else list(lens), dtype=np.int64)
+    B = len(step_lens)
+    last = np.cumsum(step_lens) - 1
+    vp_lens = view_lens[last] + 1
+    own = int(vp_lens.max())
+    if own > width:
+        raise ValueError('local width %d exceeds the bucket width %d' % (own, width))
+    if width - 1 > V:
+        raise ValueError('bucket width %d needs %d view slots, the panoramas have %d' % (width, width - 1, V))
+    idx = (last[:, None] * V + np.arange(width - 1, dtype=np.int64)[None, :]).reshape(-1)
+    per_tok = np.ones((B, width), dtype=np.int64)
+    per_tok[:, 0] = 0
+    start = np.concatenate([[0], np.cumsum(per_tok.reshape(-1))])
+    return (torch.from_numpy(idx.astype(np.int32)), torch.from_numpy(start.astype(np.int32)), torch.from_numpy(vp_lens.astype(np.int64)), width)
 
 
 class StaticBatch:
@@ -172,9 +357,19 @@ class StaticBatch:
     """
     ALIGN = 256
 
-    def __init__(self, config, host_batch, tasks=('mlm', 'sap', 'cfp'), device='cuda'):
+    def __init__(self, config, host_batch, tasks=('mlm', 'sap', 'cfp'), device='cuda', bucket=None):
+        """bucket: None — the batch's own shapes, every later batch must match them exactly (round-2 behaviour) — or a dict
+        {'L': text length, 'N': panoramas, 'G': map size, 'W': local width} (any subset; missing entries = the first batch's own):
+        the object then accepts every RAGGED batch that fits (`pad_batch` + capacity-padded index tensors), so that one captured
+        step serves all batches of the bucket instead of falling back to the eager path."""
         self.config, self.tasks, self.device = config, tuple(tasks), torch.device(device)
-        idx = collate_indices(config, host_batch, self.tasks)
+        self.bucket = None
+        if bucket is not None:
+            self.bucket = {'L': bucket.get('L', host_batch['txt_ids'].shape[1]), 'N': bucket.get('N', host_batch['traj_view_img_fts'].shape[0]),
+                           'G': bucket.get('G', host_batch['gmap_step_ids'].shape[1]), 'W': bucket.get('W', host_batch['vp_pos_fts'].shape[1])}
+            host_batch = pad_batch(host_batch, **self.bucket)
+            self.caps = index_capacities(host_batch, self.tasks)
+        idx = self._collate(host_batch)
         self.layout = []                   # (key path, offset, shape, dtype)
         off = 0
         for path, t in self._tensors(host_batch, idx):
@@ -193,6 +388,24 @@ class StaticBatch:
         self.flat.copy_(first)
         self._pending = None
 
+    def _collate(self, host_batch):
+        if self.bucket is None:
+            return collate_indices(self.config, host_batch, self.tasks)
+        return collate_indices(self.config, host_batch, self.tasks, caps=self.caps, vp_width=self.bucket['W'])
+
+    def fits(self, host_batch):
+        """can `host_batch` be packed into this object's layout?"""
+        shape = (host_batch['txt_ids'].shape[1], host_batch['traj_view_img_fts'].shape[0], host_batch['gmap_step_ids'].shape[1],
+                 host_batch['vp_pos_fts'].shape[1])
+        if self.bucket is None:
+            want = (self.gb['txt_ids'].shape[1], self.gb['traj_view_img_fts'].shape[0], self.gb['gmap_step_ids'].shape[1],
+                    self.gb['vp_pos_fts'].shape[1])
+            return shape == want
+        b = self.bucket
+        return shape[0] <= b['L'] and shape[1] <= b['N'] and shape[2] <= b['G'] and shape[3] <= b['W'] and \
+            host_batch['txt_ids'].shape[0] == self.gb['txt_ids'].shape[0] and \
+            host_batch['traj_view_img_fts'].shape[1:] == self.gb['traj_view_img_fts'].shape[1:]
+
     @staticmethod
     def _tensors(batch, idx):
         for k in sorted(batch):
@@ -205,7 +418,7 @@ class StaticBatch:
                     yield ('idx', k, i), t
 
     def _views(self, flat, host_batch):
-        gb = {k: v for k, v in host_batch.items() if not torch.is_tensor(v) and k != '_goat_cache'}
+        gb = {k: v for k, v in host_batch.items() if not torch.is_tensor(v) and k not in ('_goat_cache', '_own')}
         parts = {}
         for path, off, shape, dtype in self.layout:
             n = 1
@@ -220,10 +433,12 @@ class StaticBatch:
         for k, d in parts.items():
             if k == 'vp':
                 cache[k] = (d[0], d[1], d[2], self.vp_width)
-            elif k in ('mlm_idx', 'mlm_tgt'):
+            elif k in ('mlm_idx', 'mlm_tgt', 'mlm_scale', 'view_lens_cpu', 'obj_lens_cpu', 'mrc_view_w', 'mrc_obj_w', 'cfp_txt_mask', 'cfp_gmap_mask'):
                 cache[k] = d[0]
             else:
                 cache[k] = tuple(d[i] for i in sorted(d))
+        for k in ('view_lens_cpu', 'obj_lens_cpu'):          # host-side bookkeeping of the object branch stays on the host
+            cache.pop(k, None)
         gb['_goat_cache'] = cache
         return gb
 
@@ -235,7 +450,10 @@ class StaticBatch:
         """host batch -> flat (pinned) buffer in the device layout; builds the batch's index tensors on the way.
         tensors=False: only the index tensors are (re)built and written — for a loader that collated the batch's tensors
         straight into `out` (its previous pack)."""
-        idx = _idx if _idx is not None else collate_indices(self.config, host_batch, self.tasks)
+        raw = host_batch
+        if self.bucket is not None and _idx is None:
+            host_batch = pad_batch(host_batch, **self.bucket, shape_only=BIG_TENSORS)
+        idx = _idx if _idx is not None else self._collate(host_batch)
         if idx['vp'][3] != self.vp_width:
             raise ValueError('StaticBatch: local-branch width %d != %d of the captured shape' % (idx['vp'][3], self.vp_width))
         out = out if out is not None else self.new_pinned()
@@ -247,6 +465,20 @@ class StaticBatch:
             if not tensors and path[0] == 'batch':
                 continue
             t = got.get(path)
+            if self.bucket is not None and path[0] == 'batch' and path[1] in BIG_TENSORS and t is not None and t.dtype == dtype:
+                # the real rows go straight into the corner of the padded slot, the padding slabs are zeroed
+                src = raw[path[1]]
+                if src.dim() == len(shape) and all(a <= b for a, b in zip(src.shape, shape)):
+                    n = 1
+                    for d_ in shape:
+                        n *= d_
+                    view = dst[off:off + n * t.element_size()].view(np.uint8).view(_NP_OF[dtype]).reshape(shape)
+                    view[tuple(slice(0, k) for k in src.shape)] = src.view(_INT_VIEW.get(dtype, dtype)).numpy().view(_NP_OF[dtype]) \
+                        if dtype in _INT_VIEW else src.numpy()
+                    for d_ in range(len(shape)):
+                        if src.shape[d_] < shape[d_]:
+                            view[tuple(slice(0, src.shape[i]) for i in range(d_)) + (slice(src.shape[d_], None),)] = 0
+                    continue
             if t is None or tuple(t.shape) != shape or t.dtype != dtype:
                 raise ValueError('StaticBatch: %s is %s %s, the captured shape is %s %s'
                                  % ('/'.join(map(str, path)), None if t is None else tuple(t.shape), None if t is None else t.dtype, shape, dtype))
