@@ -138,6 +138,12 @@ def build(args, rank, workload='config2'):
     model = model.cuda().train()
     vln_goat_amd.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
     batch = synth.make_pretrain_batch(B=args.batch or wl['per_rank'], seed=100 + rank, **wl['batch'])
+    if args.dtype == 'bf16' and not os.environ.get('GOAT_BENCH_F32_FEATURES'):
+        # the pre-extracted view features live in a bf16 table (features.FeatureStore: SURVEY 8f N2) — the dtype the first Linear of the
+        # bf16 model consumes; the float32 -> bf16 cast of the reference's float32 store happens once, when the store is built
+        for k in ('traj_view_img_fts', 'traj_obj_img_fts'):
+            if batch.get(k) is not None:
+                batch[k] = batch[k].to(torch.bfloat16)
     static = None
     if workload == 'config2' and not os.environ.get('GOAT_BENCH_NO_STATIC'):
         # the device batch lives at fixed addresses with its index tensors (train_step.StaticBatch): the captured steps can be
@@ -604,6 +610,8 @@ def fresh_batch_leg(args, m):
     B = args.batch or wl['per_rank']
     K = 4
     hosts = [synth.make_pretrain_batch(B=B, seed=500 + k, **wl['batch']) for k in range(K)]
+    for h in hosts:
+        h['traj_view_img_fts'] = h['traj_view_img_fts'].to(sb.gb['traj_view_img_fts'].dtype)      # (bf16 feature store rows)
     bufs = [sb.pack(h) for h in hosts]
     done = [None] * K
 
@@ -652,7 +660,91 @@ def fresh_batch_leg(args, m):
     out['ragged_eager'] = {'ms_per_step': round(dt2 / n2 * 1e3, 3), 'value': round(traj / dt2, 1), 'unit': 'trajectory-steps/s',
                            'steps': n2, 'what': 'B=%d, T ~ U{1..7}, L ~ U{20..80}, a new shape every step: pageable H2D + lazy index '
                                                 'build + eager launches (host-bound)' % B}
+    try:
+        out['ragged_bucketed'] = ragged_bucket_leg(args, m, B)
+    except Exception as e:      # noqa: BLE001  (never lose the headline to an auxiliary leg)
+        out['ragged_bucketed'] = {'error': '%s: %s' % (type(e).__name__, e)}
     return out
+
+
+def ragged_bucket_leg(args, m, B):
+    """RAGGED batches through captured steps: trajectory lengths T ~ U{3..6} and text lengths L ~ U{40..80} per sample —
+    every batch another shape, as P/data/tasks.py's collate functions produce them — padded into a small set of SHAPE BUCKETS
+    (train_step.StaticBatch(bucket=...): text 80, panoramas 224 / 256 / 288, map 32) with bf16 features as a
+    features.FeatureStore hands them out.  Per step, inside the timed region: host index build + padding into the pinned buffer
+    of the batch's bucket, one H2D, one D2D swap, mask refresh, replay of that bucket's hipGraph."""
+    import numpy as np
+    from vln_goat_amd import hipops, synth, train_step
+    model, arena, tasks, cfg = m['model'], m['wrapper'].arena, m['tasks'], m['cfg']
+    rs = np.random.RandomState(11)
+    wl = WORKLOADS['config2']
+    feat_dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+
+    def mk(k):
+        b = synth.make_pretrain_batch(B=B, T=rs.randint(3, 7, B).tolist(), L=rs.randint(40, 81, B).tolist(), seed=700 + k, style='survey')
+        b['traj_view_img_fts'] = b['traj_view_img_fts'].to(feat_dt)
+        return b
+    hosts = [mk(k) for k in range(8)]
+    n_buckets = (224, 256, 288)
+    G = 32
+    if max(h['gmap_step_ids'].shape[1] for h in hosts) > G or max(h['traj_view_img_fts'].shape[0] for h in hosts) > n_buckets[-1]:
+        raise ValueError('a synthetic batch exceeds the largest bucket')
+    which = [next(n for n in n_buckets if n >= h['traj_view_img_fts'].shape[0]) for h in hosts]
+    sbs, graphs = {}, {}
+    side = torch.cuda.Stream()
+    for nb in sorted(set(which)):
+        first = hosts[which.index(nb)]
+        sb = train_step.StaticBatch(cfg, first, tasks, bucket=dict(L=wl['batch']['L'], N=nb, G=G))
+        sbs[nb] = sb
+
+        def body(task, gb=sb.gb):
+            arena.zero(task)
+            hipops.RngState.dev.add_(0x9E3779B1)
+            model(gb, task, compute_loss=True).mean().backward()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                for t in tasks:
+                    body(t)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for t in tasks:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body(t)
+            graphs[(nb, t)] = g
+    bufs = [sbs[w].pack(h) for w, h in zip(which, hosts)]
+    K = len(hosts)
+    done = [None] * K
+    state = {'next': None}
+
+    def prefetch(i):
+        k = i % K
+        if done[k] is not None:
+            done[k].synchronize()
+        sbs[which[k]].pack(hosts[k], bufs[k])        # host: padding + index build of this ragged batch into its bucket's layout
+        done[k] = sbs[which[k]].stage(bufs[k])
+
+    def run(i):
+        k = i % K
+        if state['next'] != i:
+            prefetch(i)
+        sbs[which[k]].commit()
+        graphs[(which[k], tasks[i % len(tasks)])].replay()
+        prefetch(i + 1)
+        state['next'] = i + 1
+    n = 16
+    dt = timed(run, n, 4, 1)
+    for sb in sbs.values():
+        if sb._pending is not None:
+            sb.commit()
+    traj = sum(synth.n_traj_steps(hosts[i % K]) for i in range(n))
+    real = float(np.mean([h['traj_view_img_fts'].shape[0] for h in hosts]))
+    return {'ms_per_step': round(dt / n * 1e3, 3), 'value': round(traj / dt, 1), 'unit': 'trajectory-steps/s', 'steps': n,
+            'buckets': {'L': wl['batch']['L'], 'N': list(sorted(set(which))), 'G': G}, 'mean_panoramas_per_batch': round(real, 1),
+            'feature_dtype': str(feat_dt).replace('torch.', ''),
+            'what': 'B=%d, T ~ U{3..6}, L ~ U{40..80}: a new shape every step, padded into %d shape buckets; per step host padding + index '
+                    'build, one pinned H2D, D2D swap, mask refresh, hipGraph replay of the bucket (all inside the timed region)' % (B, len(set(which)))}
 
 
 def optimizer_leg(args, m):

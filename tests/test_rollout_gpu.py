@@ -121,3 +121,73 @@ def test_nav_rollout_bf16_store_and_sampled_feedback():
                     assert scan.index[b] in scan.adj[scan.index[a]]
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+def test_teacher_episode_graph_replays_new_episodes():
+    """rollout.TeacherEpisode: the whole teacher-forced episode (language, text K|V, T x (feature gather, panorama, node-embedding
+    gather, navigation), loss, backward) captured ONCE over an EpisodeBuffers and replayed on NEW episodes after one pinned H2D of
+    their host-built plan: loss and every gradient equal the eager NavRollout on the same episodes (dropout off, bf16)."""
+    import vln_goat_amd
+    from vln_goat_amd import rollout, synth
+    scan, feats, eps, dicts = synth.make_rollout_case()
+    rs = np.random.RandomState(5)
+    other = synth.rollout_episodes(scan, rs, B=3, max_steps=4, starts=[3, 11, 16])
+    model = _model()
+    store = _store(scan, feats, torch.bfloat16)
+    sim = rollout.GraphSim(store)
+    T = 4
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        ex = synth.rollout_extras(dicts, 3, 'cuda')
+        te = rollout.TeacherEpisode(sim, store, n_steps=T, text_len=32, pano_width=40)
+        bufs = rollout.EpisodeBuffers(te.plan(eps))
+        params = [p for p in model.parameters() if p.requires_grad]
+        call = lambda mode, batch: model(mode, batch)
+        out = {}
+
+        def step():
+            for p in params:
+                p.grad = None
+            loss = te.body(call, bufs, ex)
+            loss.backward()
+            out['loss'] = loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        out.clear()          # (no warm-up autograd graph alive during the capture)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        grads = {id(p): p.grad for p in params if p.grad is not None}
+        for batch in (other, eps):
+            plan = te.plan(batch)
+            bufs.load(plan)
+            g.replay()
+            torch.cuda.synchronize()
+            got_loss = float(out['loss'])
+            got = {k: v.detach().float().clone() for k, v in grads.items()}
+            for p in params:
+                p.grad = None
+            ro = rollout.NavRollout(call, sim, store, max_action_len=T, pano_width=40, gmap_buckets=(16, 32, 48, 64))
+            ref, traj = ro.run(batch, feedback='teacher', extras=ex)
+            ref.backward()
+            torch.cuda.synchronize()
+            assert abs(got_loss - float(ref)) <= 2e-2 * max(1.0, abs(float(ref))), (got_loss, float(ref))
+            assert [t['path'] for t in traj] == [t['path'] for t in plan['_traj']]
+            top = max(float(p.grad.abs().max()) for p in params if p.grad is not None)
+            n = 0
+            for p in params:
+                if p.grad is None:
+                    continue
+                a, b = got[id(p)], p.grad.float()
+                scale = max(float(b.abs().max()), 0.05 * top)
+                assert float((a - b).abs().max()) <= 3e-2 * scale, n
+                n += 1
+            assert n > 100
+    finally:
+        vln_goat_amd.set_compute_dtype(torch.float32)

@@ -335,6 +335,7 @@ def test_captured_step_replayed_after_fused_adamw_reads_the_updated_weights():
                 body(t)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        out.clear()          # (the warm-up's autograd graphs — AccumulateGrad nodes bound to the side stream — must not outlive into the capture)
         graphs = {}
         for t in ('mlm', 'sap', 'cfp'):
             g = torch.cuda.CUDAGraph()
@@ -401,6 +402,7 @@ def test_static_batch_feeds_a_captured_step_with_new_batches():
                 step(t)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        out.clear()          # (no warm-up autograd graph alive during the capture)
         grads = {}
         for t in ('mlm', 'sap', 'cfp'):
             g = torch.cuda.CUDAGraph()
@@ -480,6 +482,7 @@ def test_shape_bucketed_static_batch_replays_ragged_batches():
                 step(t)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        out.clear()          # (see above: no warm-up autograd graph alive during the capture)
         graphs, grads = {}, {}
         for t in ('mlm', 'sap', 'cfp'):
             g = torch.cuda.CUDAGraph()

@@ -458,6 +458,33 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
     return out
 
 
+# ----------------------------------------------------------------------------- hipGraph lifetime (runtime workaround)
+# ROCm 7.2 (libamdhip64 of this torch build): destroying a hipGraphExec whose graph had parallel branches (the side streams of
+# `Branch` below) leaves dangling entries in the runtime's pool of parallel launch streams; after two such graphs have been
+# destroyed, the launch of a LATER graph crashes on the host in hip::Graph::UpdateStreams (found by the test suite: capture A,
+# destroy; capture B, destroy; capture C -> segfault in hipGraphLaunch; scripts/dbg_graph_lifetime.py reproduces it).  Every
+# torch.cuda.CUDAGraph created after this package is imported is therefore kept alive for the life of the process — what a
+# trainer does anyway (its step graphs live as long as it does); the cost is the graphs' private memory pools.
+_RETAINED_GRAPHS = []
+
+
+def _retain_cuda_graphs():
+    if getattr(torch.cuda.CUDAGraph, '_goat_retained', False) or os.environ.get('GOAT_NO_GRAPH_RETAIN'):
+        return
+    orig_new = torch.cuda.CUDAGraph.__new__
+
+    def __new__(cls, *a, **k):
+        g = orig_new(cls, *a, **k)
+        _RETAINED_GRAPHS.append(g)
+        return g
+    torch.cuda.CUDAGraph.__new__ = __new__
+    torch.cuda.CUDAGraph._goat_retained = True
+
+
+if torch.cuda.is_available():
+    _retain_cuda_graphs()
+
+
 class Branch:
     """Run a block of ops as a parallel branch: `with Branch('pano') as br: ...; br.join(t1, t2)`.
 

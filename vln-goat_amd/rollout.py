@@ -237,15 +237,19 @@ class NodeEmbedStore:
         self.pool, self.rows = [], 0
         self._view_base = self._fused_base = self._W = None
 
+    def advance(self, B, W):
+        """row bookkeeping of one step without tensors (host-side planning: TeacherEpisode.plan)."""
+        self._view_base, self._W = self.rows, W
+        self.rows += B * W
+        self._fused_base = self.rows
+        self.rows += B
+
     def begin_step(self, pano_embeds, fused):
         """register this step's panorama tokens [B, W, H] and fused / averaged panorama vectors [B, H]."""
         B, W, H = pano_embeds.shape
-        self._view_base, self._W = self.rows, W
+        self.advance(B, W)
         self.pool.append(pano_embeds.reshape(B * W, H))
-        self.rows += B * W
-        self._fused_base = self.rows
         self.pool.append(fused.to(pano_embeds.dtype))
-        self.rows += B
 
     def rewrite(self, b, vp):
         """update_node_embed(vp, avg_pano_embeds[b], rewrite=True)"""
@@ -756,3 +760,212 @@ class NavRollout:
         loss = ml_loss * train_ml / B if compute_loss else None
         self.steps = steps
         return loss, traj
+
+
+# ------------------------------------------------------------------------------------------------ teacher-forced episodes as ONE graph
+def default_gmap_width(t, max_degree=7, granule=16):
+    """map bucket of step t: [stop], [MEM], t + 1 visited nodes and at most max_degree fresh candidates per visit, rounded up."""
+    n = 2 + (t + 1) * (1 + max_degree)
+    return (n + granule - 1) // granule * granule
+
+
+class TeacherEpisode:
+    """A teacher-forced rollout (imitation learning, feedback = 'teacher': M/r2r/agent.py:414-420,592-594) as shape-stable device
+    work.  With teacher forcing nothing the host builds depends on a model output: the walk follows the ground-truth paths, so the
+    maps, positions, masks, logit-fusion matrices, targets and the gather indices of the node embeddings of ALL steps are known
+    before the first kernel runs.  `plan()` builds them (numpy, fixed shapes: text bucket L, panorama width W, map width per
+    step), `EpisodeBuffers` holds them in one device buffer fed by one pinned H2D copy, and `body()` is pure device code over
+    those tensors — captured once into a hipGraph, it is replayed for every new batch of episodes.  Episodes shorter than the
+    plan's step count carry target -100 (ignored) after their end, as the reference's `ended` bookkeeping does."""
+
+    def __init__(self, sim, features, n_steps, text_len, pano_width=40, gmap_width=default_gmap_width, fusion='dynamic', ignoreid=-100):
+        self.sim, self.features = sim, features
+        self.T, self.L, self.W, self.gw = n_steps, text_len, pano_width, gmap_width
+        self.fusion, self.ignoreid = fusion, ignoreid
+
+    # ---- host ---------------------------------------------------------------------------------------------------------------
+    def plan(self, episodes):
+        from . import graphmap, nav_model
+        afs = self.sim.angle_feat_size
+        obs = self.sim.reset(episodes)
+        B = len(obs)
+        gmaps = [GraphMap(ob['viewpoint']) for ob in obs]
+        for g, ob in zip(gmaps, obs):
+            g.update_graph(ob)
+        lang = language_inputs(obs)
+        if lang['txt_ids'].shape[1] > self.L:
+            raise ValueError('instruction of %d tokens exceeds the text bucket %d' % (lang['txt_ids'].shape[1], self.L))
+        ids = torch.zeros(B, self.L, dtype=torch.int64)
+        msk = torch.zeros(B, self.L, dtype=torch.bool)
+        ids[:, :lang['txt_ids'].shape[1]], msk[:, :lang['txt_masks'].shape[1]] = lang['txt_ids'], lang['txt_masks']
+        out = {'txt_ids': ids, 'txt_masks': msk}
+        store = NodeEmbedStore(B)
+        ended = np.zeros(B, bool)
+        traj = [{'instr_id': ob['instr_id'], 'path': [[ob['viewpoint']]]} for ob in obs]
+        n_traj = 0
+        for t in range(self.T):
+            for i, g in enumerate(gmaps):
+                if not ended[i]:
+                    g.node_step_ids[obs[i]['viewpoint']] = t + 1
+            n_traj += int((~ended).sum())
+            pano = panorama_inputs(obs, afs, self.W)
+            store.advance(B, self.W)
+            for i, g in enumerate(gmaps):
+                if not ended[i]:
+                    store.rewrite(i, obs[i]['viewpoint'])
+                    for j, cvp in enumerate(pano['cand_vpids'][i]):
+                        if not g.graph.visited(cvp):
+                            store.accumulate(i, cvp, j)
+            G = self.gw(t)
+            gin = gmap_inputs(obs, gmaps, G, afs)
+            vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], self.W + 2, afs)
+            target = teacher_action(obs, gin['gmap_vpids'], ended, gin['gmap_visited_masks'].numpy(), True, t, self.ignoreid)
+            k = 's%d_' % t
+            # feature gather of the panorama tokens: compact CSR (padding slots = empty segments)
+            rows = pano['view_rows'].reshape(-1).numpy()
+            valid = rows >= 0
+            fidx = np.full(rows.shape[0], -1, np.int32)
+            fidx[:int(valid.sum())] = rows[valid]
+            out[k + 'feat_idx'] = torch.from_numpy(fidx)
+            out[k + 'feat_start'] = torch.from_numpy(np.concatenate([[0], np.cumsum(valid)]).astype(np.int32))
+            for name in ('loc_fts', 'nav_types', 'view_lens'):
+                out[k + name] = pano[name]
+            for name in ('gmap_step_ids', 'gmap_pos_fts', 'gmap_pair_dists', 'gmap_visited_masks', 'gmap_masks'):
+                out[k + name] = gin[name]
+            for name in ('vp_pos_fts', 'vp_masks', 'vp_nav_masks'):
+                out[k + name] = vin[name]
+            out[k + 'nav_fusion'] = nav_model.nav_fusion_matrix(vin['vp_cand_vpids'], gin['gmap_vpids'], gin['gmap_visited_masks'], G, self.W + 2)
+            out[k + 'target'] = torch.from_numpy(target)
+            # node embeddings: CSR over the pool of this and all earlier steps (+ the previous [MEM] state behind it)
+            n_src = store.rows + (B if t > 0 else 0)
+            mem_rows = [store.rows + b for b in range(B)] if t > 0 else None
+            idx, start, scale = store.csr(gin['gmap_vpids'], G, mem_rows)
+            inv = graphmap.inverse_index(idx, start, scale, n_src)
+            n_tok = int(start[-1])
+            out[k + 'csr_idx'] = _pad1np(idx[:n_tok] if n_tok else idx[:0], n_src, -1, np.int32)
+            out[k + 'csr_start'], out[k + 'csr_scale'] = torch.from_numpy(start), torch.from_numpy(scale)
+            out[k + 'inv_idx'] = _pad1np(inv[0].numpy()[:n_tok], n_src, -1, np.int32)
+            out[k + 'inv_start'] = inv[1]
+            out[k + 'inv_w'] = _pad1np(inv[2].numpy()[:n_tok], n_src, 0.0, np.float32)
+            # the teacher-forced move
+            moves = []
+            for i in range(B):
+                stop = obs[i]['viewpoint'] == obs[i]['gt_path'][-1]
+                if stop or ended[i] or gin['no_vp_left'][i] or t == self.T - 1:
+                    moves.append(None)
+                else:
+                    nxt = gin['gmap_vpids'][i][int(target[i])]
+                    hop = gmaps[i].graph.path(obs[i]['viewpoint'], nxt)
+                    traj[i]['path'].append(hop)
+                    prev = traj[i]['path'][-2][-1] if len(hop) == 1 else hop[-2]
+                    view = next(c['pointId'] for c in obs[i]['scan_graph'].candidates(prev) if c['viewpointId'] == nxt)
+                    moves.append((nxt, view))
+            obs = self.sim.step(moves)
+            for i, ob in enumerate(obs):
+                if not ended[i]:
+                    gmaps[i].update_graph(ob)
+            ended = np.logical_or(ended, np.array([m is None for m in moves]))
+        out['_traj'], out['_n_traj'] = traj, n_traj
+        return out
+
+    # ---- device -------------------------------------------------------------------------------------------------------------
+    def body(self, model, bufs, extras=None, hoist_text_kv=True):
+        """forward + imitation loss of the planned episodes from the tensors of `bufs` (EpisodeBuffers.t): no host data, no
+        device -> host copy.  -> loss (sum over steps and samples of the cross-entropy / B, M/r2r/agent.py:664-667)."""
+        from collections import defaultdict
+        from . import hipops
+        dd = lambda d: defaultdict(lambda: None, d)
+        extras = extras or {}
+        t_ = bufs.t
+        B = t_['txt_ids'].shape[0]
+        lang = {'txt_ids': t_['txt_ids'], 'txt_masks': t_['txt_masks']}
+        lang.update(extras.get('language', {}))
+        txt = model('language', dd(lang))
+        txt_kv = model('text_kv', {'txt_embeds': txt}) if hoist_text_kv else None
+        pool, last, loss = [], None, 0.0
+        for s in range(self.T):
+            k = 's%d_' % s
+            fts = hipops.gather_segmean(self.features.dev, t_[k + 'feat_idx'], t_[k + 'feat_start'], None, B * self.W, None)
+            pin = {'view_img_fts': fts.view(B, self.W, -1), 'loc_fts': t_[k + 'loc_fts'], 'nav_types': t_[k + 'nav_types'],
+                   'view_lens': t_[k + 'view_lens'], 'already_dropout': False}
+            pin.update(extras.get('panorama', {}))
+            pano, pmask, fused = model('panorama', dd(pin))
+            if fused is None:
+                fused = torch.sum(pano * pmask.unsqueeze(2), 1) / torch.sum(pmask, 1, keepdim=True)
+            H = pano.shape[-1]
+            pool += [pano.reshape(B * self.W, H), fused.to(pano.dtype)]
+            src = torch.cat(pool + ([last.to(pano.dtype)] if last is not None else []), 0)
+            G = t_[k + 'gmap_step_ids'].shape[1]
+            gimg = hipops.gather_segmean(src, t_[k + 'csr_idx'], t_[k + 'csr_start'], t_[k + 'csr_scale'], B * G,
+                                         (t_[k + 'inv_idx'], t_[k + 'inv_start'], t_[k + 'inv_w'])).view(B, G, H)
+            zero = pano.new_zeros(B, 1, H)
+            memtok = zero if last is None else last.unsqueeze(1).to(pano.dtype)
+            nin = {'txt_embeds': txt, 'txt_masks': t_['txt_masks'], 'gmap_img_embeds': gimg,
+                   'vp_img_embeds': torch.cat([zero, memtok, pano], 1), 'vp_obj_masks': None, 'flops_count': False, 'txt_kv': txt_kv,
+                   'nav_fusion': t_[k + 'nav_fusion']}
+            for name in ('gmap_step_ids', 'gmap_pos_fts', 'gmap_pair_dists', 'gmap_visited_masks', 'gmap_masks', 'vp_pos_fts', 'vp_masks',
+                         'vp_nav_masks'):
+                nin[name] = t_[k + name]
+            nin.update(extras.get('navigation', {}))
+            out = model('navigation', dd(nin))
+            last = out['cls_embeds']
+            logits = {'local': out['local_logits'], 'global': out['global_logits']}.get(self.fusion, out['fused_logits'])
+            loss = loss + torch.nn.functional.cross_entropy(logits.float(), t_[k + 'target'], reduction='sum', ignore_index=self.ignoreid)
+        return loss / B
+
+
+def _pad1np(a, n, fill, dtype):
+    out = np.full(n, fill, dtype)
+    out[:len(a)] = a
+    return torch.from_numpy(out)
+
+
+class EpisodeBuffers:
+    """the tensors of a TeacherEpisode.plan at FIXED device addresses (one flat buffer; one pinned H2D copy per new plan)."""
+    ALIGN = 256
+
+    def __init__(self, plan, device='cuda'):
+        self.device = torch.device(device)
+        self.layout, off = [], 0
+        for k in sorted(plan):
+            v = plan[k]
+            if torch.is_tensor(v):
+                self.layout.append((k, off, tuple(v.shape), v.dtype))
+                off += (v.numel() * v.element_size() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.nbytes = max(off, self.ALIGN)
+        self.flat = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
+        self.host = torch.zeros(self.nbytes, dtype=torch.uint8)
+        if self.device.type == 'cuda':
+            self.host = self.host.pin_memory()
+        self.t = {}
+        for k, off, shape, dtype in self.layout:
+            n = 1
+            for s in shape:
+                n *= s
+            self.t[k] = self.flat[off:off + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(shape)
+        self._copied = None
+        self.load(plan)
+
+    def load(self, plan, stream=None):
+        """pack `plan` into the pinned buffer and copy it to the device (asynchronously on `stream` / the current stream)."""
+        from . import layers
+        if self._copied is not None:
+            self._copied.synchronize()              # the previous H2D has read the pinned buffer
+        dst = self.host.numpy()
+        for k, off, shape, dtype in self.layout:
+            v = plan.get(k)
+            if v is None or tuple(v.shape) != shape or v.dtype != dtype:
+                raise ValueError('EpisodeBuffers: %s is %s %s, the captured layout has %s %s'
+                                 % (k, None if v is None else tuple(v.shape), None if v is None else v.dtype, shape, dtype))
+            n = v.numel() * v.element_size()
+            if n:
+                dst[off:off + n] = v.contiguous().view(-1).view(torch.uint8).numpy()
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                self.flat.copy_(self.host, non_blocking=True)
+        else:
+            self.flat.copy_(self.host, non_blocking=True)
+        if self.device.type == 'cuda':
+            self._copied = torch.cuda.Event()
+            self._copied.record(stream)
+        layers.refresh_masks()
