@@ -432,11 +432,32 @@ def cpu_baseline(args, cfg):
         times.append(one(TASKS[i % len(TASKS)]))
         i += 1
     med = sorted(times)[len(times) // 2]
-    return {'value': round(B * 5 / med, 2), 'unit': 'trajectory-steps/s', 'cores': ncores, 'kind': 'port',
+    all_cores = None
+    if avail > ncores and not os.environ.get('GOAT_CPU_NO_ALL_CORES'):
+        # SURVEY 8d names the host's core count: the same steps once more with EVERY core (3 timed steps after 1 warm-up; on a
+        # many-socket host the M = 3840-row GEMMs scale poorly past 64 threads, which is why the headline figure uses 64)
+        torch.set_num_threads(avail)
+        one('sap')
+        t_all = sorted(one(TASKS[k % len(TASKS)]) for k in range(3))[1]
+        all_cores = {'cores': avail, 'value': round(B * 5 / t_all, 2), 'median_s_per_step': round(t_all, 3)}
+        torch.set_num_threads(ncores)
+    return {'value': round(B * 5 / med, 2), 'unit': 'trajectory-steps/s', 'cores': ncores, 'kind': 'port', 'all_cores': all_cores,
             'cpu_model': cpu_model, 'cores_available': avail, 'median_s_per_step': round(med, 3),
             'sample': 'oracle/goat_oracle.py fp32 fwd+bwd, full R2R config, B=%d T=5 L=80, dropout on: median of %d timed steps '
                       '(mlm/sap/cfp cycled) after 2 warm-up steps, %d torch threads on %d available cores (%s), %.0f s of CPU work'
                       % (B, len(times), ncores, avail, cpu_model, time.time() - t_start)}
+
+
+def committed_traffic(suffix):
+    """fabric-side bytes per GEMM launch from the newest committed rocprofv3 --pmc passes of a workload
+    (profiles/round*_pmc_gemm_traffic<suffix>.json, written by scripts/collect_round3.sh) -> (bytes, source) or (None, None)."""
+    import glob
+    tpaths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_gemm_traffic%s.json' % suffix)))
+    if not tpaths:
+        return None, None
+    with open(tpaths[-1]) as f:
+        tj = json.load(f)
+    return round(tj['traffic_bytes_per_launch']), 'profiles/' + os.path.basename(tpaths[-1])
 
 
 def gemm_roofline(args, model, gb, arena=None, tasks=None, cycle=None):
@@ -497,13 +518,7 @@ def gemm_roofline(args, model, gb, arena=None, tasks=None, cycle=None):
     # HBM-side traffic per launch of this kernel family: PMC counters cannot be read from inside the process, so the value
     # comes from the committed rocprofv3 --pmc passes of this same step mix (scripts/collect_profiles.sh; FETCH_SIZE and
     # WRITE_SIZE in separate passes, gfx950 corrections applied as MI355X_MICROARCH.md prescribes) — null if absent.
-    traffic, tsrc = None, None
-    import glob
-    tpaths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_gemm_traffic.json')))      # the latest round's passes
-    if tpaths:
-        with open(tpaths[-1]) as f:
-            tj = json.load(f)
-        traffic, tsrc = round(tj['traffic_bytes_per_launch']), 'profiles/' + os.path.basename(tpaths[-1])
+    traffic, tsrc = committed_traffic('')
     algo_bytes = 0.0
     for r in recs:
         if r[3][0] == 'grouped wgrad':
@@ -775,7 +790,7 @@ def config5_leg(args):
         r = gemm_roofline(args, m['model'], m['gb'], m['wrapper'].arena, tasks=m['tasks'])
         out['roofline'] = {k: r[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'launches_per_cycle', 'avg_launch_us',
                                              'algorithmic_gflop_per_launch', 'algorithmic_bytes_per_launch', 'gemm_ms_per_cycle', 'method')}
-        out['roofline']['traffic'] = None      # (no PMC pass of this workload)
+        out['roofline']['traffic'], out['roofline']['traffic_source'] = committed_traffic('_config5')
     m.clear()
     return out
 
@@ -815,7 +830,9 @@ def config4_leg(args):
             for p in params:
                 p.grad = None
         hipops.RngState.dev.add_(0x9E3779B1)
-        loss, _ = synth.run_nav_episode(lambda m, b: model(m, b), ep, device='cuda')
+        # (the instruction's K|V projections of the six cross-modal layers once per episode instead of once per step: identical
+        #  outputs — tests/test_nav_parity_gpu.py holds both forms to the reference goldens)
+        loss, _ = synth.run_nav_episode(lambda m, b: model(m, b), ep, device='cuda', hoist_text_kv=not os.environ.get('GOAT_NAV_NO_HOIST'))
         loss.backward()
 
     side = torch.cuda.Stream()
@@ -855,12 +872,138 @@ def config4_leg(args):
         r = gemm_roofline(args, model, None, None, cycle=episode)
         roof = {k: r[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'launches_per_cycle', 'avg_launch_us',
                                   'algorithmic_gflop_per_launch', 'algorithmic_bytes_per_launch', 'gemm_ms_per_cycle', 'method')}
-        roof['traffic'] = None
+        roof['traffic'], roof['traffic_source'] = committed_traffic('_config4')
+    nav = None
+    if not args.no_graph and not os.environ.get('GOAT_BENCH_NO_NAVIGATOR'):
+        try:
+            nav = navigator_leg(args, model, ep, arena[0], B, T, dt / n)
+        except Exception as e:      # noqa: BLE001
+            nav = {'error': '%s: %s' % (type(e).__name__, e)}
     return {'value': round(B * T * n / dt, 1), 'unit': 'trajectory-steps/s', 'ms_per_episode': round(dt / n * 1e3, 3), 'episodes': n,
-            'launch': launch, 'roofline': roof,
+            'launch': launch, 'roofline': roof, 'navigator': nav,
             'workload': 'map_nav_src fine-tune model calls of one rollout (run_r2r_goat.sh shapes): 6,3,2 layers, batch 12, L=200, 3 steps x '
                         '(panorama 36x768 + navigation, G=60), BACL+FACL on (type_2 / type_1 / door), dictionaries 35/39/50/24, dropout '
                         '0.1 / feat 0.5, BPTT through the [MEM] token, fwd+bwd, synthetic per-step inputs (no simulator)'}
+
+
+def dp_diagnostics(args, m, world, rank, dt_step):
+    """N > 1 only — what makes the first multi-GPU run diagnosable from its one JSON line: the ranks RCCL actually sees (count,
+    backend, device of every rank), the same steps with the gradient exchange switched OFF (compute-only time per step; the
+    difference to the timed step is the EXPOSED communication), and the gradient all-reduce of each task run alone (its un-hidden
+    cost, bytes and bus bandwidth).  Collective on every rank; rank 0 reports."""
+    wrapper, tasks, steps = m['wrapper'], m['tasks'], m['steps']
+    info = [None] * world
+    dist.all_gather_object(info, {'rank': rank, 'device': torch.cuda.current_device(), 'name': torch.cuda.get_device_name(),
+                                  'pid': os.getpid()})
+    real = wrapper.reduce_gradients
+    wrapper.reduce_gradients = lambda *a, **k: None
+    try:
+        n = max(6, min(args.steps, 18))
+        dt_c = timed(lambda i: steps[tasks[i % len(tasks)]](), n, 3, world)
+    finally:
+        wrapper.reduce_gradients = real
+    alone = {}
+    for t in tasks:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            wrapper.reduce_gradients(t)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        nbytes = None
+        if wrapper.arena is not None:
+            try:
+                nbytes = int(sum((b - a) * 4 for a, b in wrapper.arena.ranges(t, None, frozenset())))
+            except Exception:      # noqa: BLE001
+                nbytes = None
+        alone[t] = {'ms': round(ms, 3), 'bytes': nbytes,
+                    'bus_GBps': round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1) if nbytes else None}
+    step_ms, comp_ms = dt_step / args.steps * 1e3, dt_c / n * 1e3
+    return {'ranks_seen_by_rccl': dist.get_world_size(), 'backend': dist.get_backend(), 'ranks': info, 'launch_mode': wrapper.launch_mode,
+            'n_phases': getattr(wrapper, 'n_phases', None), 'ms_per_step': round(step_ms, 3), 'compute_only_ms_per_step': round(comp_ms, 3),
+            'exposed_comm_ms_per_step': round(step_ms - comp_ms, 3), 'allreduce_alone': alone}
+
+
+def navigator_leg(args, model, ep, arena, B, T, frozen_s):
+    """The same rollout driven by the graph-only navigator: NEW episodes every iteration — start viewpoints, paths,
+    instructions, panoramas, growing maps — on synthetic scans.  Per iteration, inside the timed region: the host walks the B
+    ground-truth paths and builds every table of the T steps (rollout.TeacherEpisode.plan: candidates, maps with the reference's
+    Floyd update, position features, logit-fusion matrices, targets, node-embedding gather indices), one pinned H2D moves them
+    into the fixed-address episode buffers, and the captured episode graph (language, text K|V, T x (feature gather from the
+    bf16 feature table resident in HBM, panorama, map gather, navigation), loss, backward) is replayed.  The plan of episode
+    i + 1 is built while the GPU runs episode i."""
+    import numpy as np
+    from vln_goat_amd import features, hipops, rollout, synth
+    rs = np.random.RandomState(31)
+    scans = [rollout.ScanGraph.synthetic('scan%d' % k, n=60, seed=40 + k, degree=3) for k in range(4)]
+    keys = ['%s_%s' % (sc.name, vp) for sc in scans for vp in sc.vpids]
+    store = features.FeatureStore.synthetic(keys, D=768, seed=3, dtype=torch.bfloat16 if args.dtype == 'bf16' else torch.float32).to('cuda')
+    sim = rollout.GraphSim(store)
+    L = ep['txt_ids'].shape[1]
+
+    def batch_of_episodes(k):
+        eps = []
+        for b in range(B):
+            sc = scans[(k + b) % len(scans)]
+            dist, _ = sc.shortest()
+            while True:
+                s0 = int(rs.randint(len(sc.vpids)))
+                far = int(np.argsort(dist[s0])[-1 - int(rs.randint(6))])
+                path = sc.shortest_path(sc.vpids[s0], sc.vpids[far])
+                if len(path) >= T:
+                    break
+            n_tok = int(rs.randint(L // 2, L - 1))
+            eps.append({'instr_id': 'k%d_b%d' % (k, b), 'scan': sc, 'path': path[:T + 2], 'heading': float(rs.uniform(0, 2 * np.pi)),
+                        'instr_encoding': [0] + rs.randint(3, 50000, n_tok - 2).tolist() + [2]})
+        return eps
+    batches = [batch_of_episodes(k) for k in range(6)]
+    te = rollout.TeacherEpisode(sim, store, n_steps=T, text_len=L, pano_width=38, gmap_width=lambda t: 64)
+    extras = {'language': {k: ep[k] for k in ('instr_z_direction_features', 'instr_z_direction_pzs', 'instr_z_landmark_features',
+                                              'instr_z_landmark_pzs', 'front_txt_feats')},
+              'panorama': {'z_img_features': ep['z_img_features'], 'z_img_pzs': ep['z_img_pzs']},
+              'navigation': {'front_txt_feats': ep['front_txt_feats'], 'front_vp_feats': ep['front_vp_feats'],
+                             'front_gmap_feats': ep['front_gmap_feats']}}
+    import time
+    t0 = time.perf_counter()
+    plans = [te.plan(batches[0])]
+    plan_ms = (time.perf_counter() - t0) * 1e3
+    bufs = rollout.EpisodeBuffers(plans[0])
+    call = lambda mode, batch: model(mode, batch)
+    params = list(model.parameters())
+
+    def episode():
+        if arena is not None:
+            arena.zero('nav')
+        else:
+            for p in params:
+                p.grad = None
+        hipops.RngState.dev.add_(0x9E3779B1)
+        te.body(call, bufs, extras).backward()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            episode()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        episode()
+    state = {'plan': None}
+
+    def run(i):
+        plan = state['plan'] if state['plan'] is not None else te.plan(batches[i % len(batches)])
+        bufs.load(plan)                      # pinned H2D, enqueued behind the previous replay
+        g.replay()
+        state['plan'] = te.plan(batches[(i + 1) % len(batches)])       # host work of the next episode, under the replay just launched
+    n = 12
+    dt = timed(run, n, 3, 1)
+    n_traj = sum(te.plan(batches[i % len(batches)])['_n_traj'] for i in range(n))
+    return {'ms_per_episode': round(dt / n * 1e3, 3), 'value': round(n_traj / dt, 1), 'unit': 'trajectory-steps/s', 'episodes': n,
+            'vs_frozen_episode': round((dt / n) / frozen_s, 3), 'host_plan_ms': round(plan_ms, 2), 'h2d_bytes_per_episode': bufs.nbytes,
+            'what': 'graph-only navigator on 4 synthetic scans (60 viewpoints each), %d new episodes per iteration, teacher forcing, '
+                    'pano width 38, map width 64, text bucket %d; host plan + one pinned H2D + replay of the captured episode graph' % (B, L)}
 
 
 def main():
@@ -883,6 +1026,12 @@ def main():
     m = measure_pretrain(args, world, rank, args.workload, args.steps, args.warmup)
     dt, n_traj, wrapper = m['dt'], m['n_traj'], m['wrapper']
 
+    dp_diag = None
+    if world > 1 and not os.environ.get('GOAT_BENCH_NO_DP_DIAG'):
+        try:
+            dp_diag = dp_diagnostics(args, m, world, rank, dt)
+        except Exception as e:      # noqa: BLE001  (never lose the scaling point to the diagnostics)
+            dp_diag = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0:
         value = n_traj * world * args.steps / dt
         algo = sum(ALGO_GFLOP_PER_TRAJ_STEP.values()) / 3.0
@@ -900,6 +1049,8 @@ def main():
                                                                       if wrapper.launch_mode == 'phased' else 'hipGraph replay of forward + backward, then one gradient all-reduce (fallback path)')},
             'samples_per_s': round(value / 5.0, 1),
         }
+        if dp_diag is not None:
+            out['dp'] = dp_diag
         headline = args.workload == 'config2' and TASKS == ('mlm', 'sap', 'cfp')
         if headline:
             out['step_mfma_frac'] = round(value / world * algo * 1e9 / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4)

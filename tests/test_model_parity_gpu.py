@@ -320,7 +320,7 @@ def test_full_size_matches_reference_golden(case, task, dtype):
     params = dict(model.named_parameters())
     gmax = float(fp[:, 0].max())
     rtol, tiny = (2e-3, 1e-6) if dtype == torch.float32 else (None, 2e-3)
-    bad = []
+    bad, cosines = [], []
     for i, n in enumerate(names):
         refp, gotp = fp[i], fingerprint(params[n].grad)
         if refp[0] <= tiny * gmax:
@@ -334,7 +334,19 @@ def test_full_size_matches_reference_golden(case, task, dtype):
             # partly missing gradient moves it one-for-one).  Cancelling sums (the door gates) are excluded as in the small cases.
             if not any(k in n for k in ILL_CONDITIONED) and abs(gotp[0] / refp[0] - 1.0) > 0.06:
                 bad.append((n, gotp[0], refp[0]))
+            # ... and its DIRECTION: cosine between the leading elements of the bf16 gradient and the fp32 reference's (a norm
+            # cannot see a permuted / sign-flipped / half-missing gradient whose magnitude happens to fit).  Only where those
+            # leading elements carry signal (well above the tensor's own rounding floor).
+            a, b = gotp[1:].astype(np.float64), refp[1:].astype(np.float64)
+            rms = refp[0] / np.sqrt(max(1, params[n].numel()))
+            if not any(k in n for k in ILL_CONDITIONED) and refp[0] > 1e-3 * gmax and np.linalg.norm(b) / np.sqrt(min(8, params[n].numel())) > 0.5 * rms:
+                cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30))
+                cosines.append((cos, n))
+                if cos < 0.9:
+                    bad.append((n, 'cosine of the leading elements', cos))
     assert not bad, bad[:12]
+    if dtype == torch.bfloat16:
+        assert len(cosines) > 20, len(cosines)
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -181,12 +181,13 @@ def test_teacher_episode_graph_replays_new_episodes():
             assert [t['path'] for t in traj] == [t['path'] for t in plan['_traj']]
             top = max(float(p.grad.abs().max()) for p in params if p.grad is not None)
             n = 0
+            names = {id(p): k for k, p in model.named_parameters()}
             for p in params:
                 if p.grad is None:
                     continue
                 a, b = got[id(p)], p.grad.float()
                 scale = max(float(b.abs().max()), 0.05 * top)
-                assert float((a - b).abs().max()) <= 3e-2 * scale, n
+                assert float((a - b).abs().max()) <= 3e-2 * scale, (names[id(p)], tuple(p.shape))
                 n += 1
             assert n > 100
     finally:

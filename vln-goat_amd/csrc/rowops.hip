@@ -1100,6 +1100,13 @@ extern "C" int goat_ln_reduce_batched(void* stream, const goat_ln_partial* entri
   return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void zero2_kernel(float* __restrict__ a, float* __restrict__ b, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { a[i] = 0.f; b[i] = 0.f; }
+}
+}  // namespace
+
 extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* dy2, const void* z, const float* gamma,
                            const float* mean, const float* rstd, float p, uint64_t seed, uint64_t offset,
                            const uint64_t* rng_dev, void* dx, void* d_res, float* dgamma, float* dbeta, float* ws,
@@ -1119,10 +1126,11 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
   if (nparts > GOAT_LN_BWD_PARTS) nparts = GOAT_LN_BWD_PARTS;
   const size_t sm = (size_t)nwv * 2 * H * sizeof(float);
   if (sm > 160 * 1024) return GOAT_E_SHAPE;
-  if (!det && !defer && !accumulate) {      // atomic mode writes by accumulation: an overwrite clears the two vectors first
-    hipError_t e1 = hipMemsetAsync(dgamma, 0, (size_t)H * sizeof(float), ST(stream));
-    hipError_t e2 = hipMemsetAsync(dbeta, 0, (size_t)H * sizeof(float), ST(stream));
-    if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+  if (!det && !defer && !accumulate) {      // atomic mode writes by accumulation: an overwrite clears the two vectors first.
+    // A KERNEL, not hipMemsetAsync: captured into a hipGraph (ROCm 7.2) the two memset nodes left every fourth float of the
+    // vectors uncleared in a graph with parallel branches (found by tests/test_rollout_gpu.py: garbage in a LayerNorm weight
+    // gradient of a replayed episode; GOAT_LN_DETERMINISTIC=1, which does not clear, was clean).
+    hipLaunchKernelGGL(zero2_kernel, dim3((H + 255) / 256), dim3(256), 0, ST(stream), dgamma, dbeta, H);
   }
 #define GOAT_LN_BWD_LAUNCH(T_, RIF_, NWV_)                                                                                    \
   do {                                                                                                                        \
