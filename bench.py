@@ -733,11 +733,16 @@ def ragged_bucket_leg(args, m, B):
     done = [None] * K
     state = {'next': None}
 
+    host_t = [0.0, 0]
+
     def prefetch(i):
         k = i % K
         if done[k] is not None:
             done[k].synchronize()
+        t0 = time.perf_counter()
         sbs[which[k]].pack(hosts[k], bufs[k])        # host: padding + index build of this ragged batch into its bucket's layout
+        host_t[0] += time.perf_counter() - t0
+        host_t[1] += 1
         done[k] = sbs[which[k]].stage(bufs[k])
 
     def run(i):
@@ -753,11 +758,22 @@ def ragged_bucket_leg(args, m, B):
     for sb in sbs.values():
         if sb._pending is not None:
             sb.commit()
+    # the device side alone: replays of one bucket's three graphs (no new data)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nb0 = which[0]
+    torch.cuda.synchronize()
+    e0.record()
+    for r in range(6):
+        graphs[(nb0, tasks[r % len(tasks)])].replay()
+    e1.record()
+    torch.cuda.synchronize()
+    replay_ms = e0.elapsed_time(e1) / 6
     traj = sum(synth.n_traj_steps(hosts[i % K]) for i in range(n))
     real = float(np.mean([h['traj_view_img_fts'].shape[0] for h in hosts]))
     return {'ms_per_step': round(dt / n * 1e3, 3), 'value': round(traj / dt, 1), 'unit': 'trajectory-steps/s', 'steps': n,
             'buckets': {'L': wl['batch']['L'], 'N': list(sorted(set(which))), 'G': G}, 'mean_panoramas_per_batch': round(real, 1),
-            'feature_dtype': str(feat_dt).replace('torch.', ''),
+            'feature_dtype': str(feat_dt).replace('torch.', ''), 'host_pack_ms': round(host_t[0] / max(1, host_t[1]) * 1e3, 2),
+            'replay_only_ms_per_step': round(replay_ms, 3),
             'what': 'B=%d, T ~ U{3..6}, L ~ U{40..80}: a new shape every step, padded into %d shape buckets; per step host padding + index '
                     'build, one pinned H2D, D2D swap, mask refresh, hipGraph replay of the bucket (all inside the timed region)' % (B, len(set(which)))}
 
@@ -1065,7 +1081,7 @@ def main():
             from vln_goat_amd import hipops
             hipops.save_tuned(os.environ['GOAT_SAVE_TUNED'])
         cfg = m['cfg']
-        if world == 1 and headline and not args.no_extra_configs:
+        if world == 1 and headline and not args.no_extra_configs and not os.environ.get('GOAT_BENCH_ONLY_FRESH'):
             m.clear()
             out['config5_reverie'] = leg_process(args, 'config5')
             out['config4_nav'] = leg_process(args, 'config4')

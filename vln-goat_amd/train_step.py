@@ -160,9 +160,13 @@ def pad_batch(batch, L=None, N=None, G=None, W=None, shape_only=()):
             out[key] = torch.zeros((1,) * len(shape), dtype=t.dtype).expand(shape)
             return
         fill_v = PAD_FILL.get(key, 0) if fill is None else fill
-        new = torch.full(shape, fill_v, dtype=t.dtype) if fill_v else torch.zeros(shape, dtype=t.dtype)
-        new[tuple(slice(0, k) for k in t.shape)] = t
-        out[key] = new
+        # numpy, not torch: a torch copy of a few hundred KB wakes the intra-op thread pool (128 threads on the GPU box's host), which
+        # costs 80-90 ms every few calls — measured: 1.6 ms per pack with numpy, 26 ms on average with torch indexing
+        src = t.view(_INT_VIEW[t.dtype]).numpy() if t.dtype in _INT_VIEW else t.numpy()
+        arr = np.zeros(shape, dtype=src.dtype) if not fill_v else np.full(shape, fill_v, dtype=src.dtype)
+        arr[tuple(slice(0, k) for k in t.shape)] = src
+        new = torch.from_numpy(arr)
+        out[key] = new.view(t.dtype) if t.dtype in _INT_VIEW else new
     for k in ('txt_ids', 'txt_labels'):
         grow(k, [(1, L)])
     for k in ('traj_view_img_fts', 'traj_loc_fts', 'traj_nav_types', 'traj_vp_view_lens', 'traj_obj_img_fts', 'traj_vp_obj_lens',
