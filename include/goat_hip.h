@@ -58,8 +58,6 @@ int goat_gemm_nt(void* stream, int dtype_in, int dtype_out,
                  void* aux, int64_t ldaux, int split_k);
 
 #define GOAT_GEMM_8WAVES 0x100   /* flag in goat_gemm_bf16's nstage argument: run the 128-row tile with eight waves */
-#define GOAT_GEMM_WIDE_PATCH 0x200   /* flag in nstage: the 256 x 256 tile on FOUR waves (128 x 128 wave patches); weight-gradient layout
-                                      * only (trans_a and trans_b, float32 output, nstage 2) — goat_gemm_bf16 and goat_wgrad_grouped */
 
 /* Pipelined bf16 GEMM with direct-to-LDS (LDS-DMA) operand staging, all operand layouts (csrc/gemm2.hip):
  *   C[M,N] = epilogue( op(A) · op(B)ᵀ + bias ),  contraction length Kc
@@ -79,17 +77,6 @@ int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_out,
                    const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                    int M, int N, int Kc, const float* bias, int epilogue,
                    void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum);
-/* goat_gemm_bf16 with dropout fused into an activation epilogue (bf16 output, no split): GOAT_EPI_GELU / _RELU store
- * C = dropout_p(act(u)) (aux still receives u); GOAT_EPI_MUL_DGELU / _MUL_DRELU store C = dropout_p-mask(A·B) x act'(aux) — the
- * forward and backward of `linear2(dropout(act(linear1(x))))` (P/model/transformer.py:179) without the two elementwise passes
- * over the [rows, 3072] tensor.  Element (row, col) draws counter offset + row * N + col of (seed + *rng_dev): the same masks as
- * goat_dropout_add_fwd / goat_act_bwd on a contiguous [M, N] tensor.  offset and N must be multiples of 8; p = 0: plain call. */
-int goat_gemm_bf16_dropout(void* stream, int trans_a, int trans_b, int dtype_out,
-                   const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                   int M, int N, int Kc, const float* bias, int epilogue,
-                   void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum,
-                           float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev);
-
 /* colsum[c] += sum_r x[r,c] (float32, atomic; caller zero-fills): bias gradient of a Linear. */
 int goat_colsum(void* stream, int dtype, const void* x, int64_t ld, int R, int C, float* colsum);
 

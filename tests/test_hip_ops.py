@@ -823,50 +823,6 @@ def test_infonce_fused_matches_torch(ops, Bl, Ba, t0):
             _close(alls[k].grad, ra[k].grad, torch.float32, 'infonce dall %d' % k)
 
 
-def test_ffn_dropout_fused_into_the_gemm_epilogues(ops):
-    """ffn(x, ..., p > 0) (panorama encoder FFN: linear2(dropout(gelu(linear1(x))))): with the dropout mask applied inside the GELU
-    epilogue (forward) and the x GELU' epilogue (dgrad) the results equal the unfused path — same masks (same counters), values to
-    bf16 rounding — and the dropped positions are exactly the same."""
-    M, H, Fd, p = 1000, 768, 3072, 0.1
-    g = torch.Generator().manual_seed(5)
-    x0 = torch.randn(M, H, generator=g).to(DEV, torch.bfloat16)
-    w1 = (0.05 * torch.randn(Fd, H, generator=g)).to(DEV).requires_grad_(True)
-    b1 = (0.1 * torch.randn(Fd, generator=g)).to(DEV).requires_grad_(True)
-    w2 = (0.05 * torch.randn(H, Fd, generator=g)).to(DEV).requires_grad_(True)
-    b2 = (0.1 * torch.randn(H, generator=g)).to(DEV).requires_grad_(True)
-    dy = torch.randn(M, H, generator=g).to(DEV, torch.bfloat16)
-    res = {}
-    keep = ops.FUSE_FFN_DROPOUT
-    try:
-        for fused in (True, False):
-            ops.FUSE_FFN_DROPOUT = fused
-            ops.manual_seed(99)
-            x = x0.clone().requires_grad_(True)
-            for t in (w1, b1, w2, b2):
-                t.grad = None
-            y = ops.ffn(x, w1, b1, w2, b2, 'gelu', p)
-            y.backward(dy)
-            torch.cuda.synchronize()
-            res[fused] = [y.detach().float(), x.grad.float(), w1.grad.clone(), b1.grad.clone(), w2.grad.clone(), b2.grad.clone()]
-    finally:
-        ops.FUSE_FFN_DROPOUT = keep
-    for a, b, n in zip(res[True], res[False], ['y', 'dx', 'dw1', 'db1', 'dw2', 'db2']):
-        _close(a, b, torch.bfloat16, 'ffn fused dropout ' + n)
-    # and against torch with the mask recovered from the unfused hidden activation is covered by the dropout tests; here: rate
-    ops.manual_seed(99)
-    h = torch.empty(M, Fd, device=DEV, dtype=torch.bfloat16)
-    u = torch.empty_like(h)
-    from vln_goat_amd._lib import EPI_GELU
-    W1 = w1.detach().to(torch.bfloat16)
-    seed, off, dev = ops.RngState.next(h.numel())
-    ops.gemm(x0, W1, h, bias=b1.detach(), epi=EPI_GELU, aux=u, drop=(p, seed, off, dev))
-    rate = float((h == 0).float().mean())
-    assert abs(rate - p) < 5e-3, rate
-    ref = torch.nn.functional.gelu(u.float())
-    nz = h != 0
-    assert float((h.float()[nz] - ref[nz] / (1 - p)).abs().max()) < 2e-2 * float(ref.abs().max())
-
-
 def test_grouped_wgrad_tail_split_plan(ops):
     """WgradQueue plans: a group whose 256x128 tiles leave a mostly empty last round is run as two launches (the tail problems on
     128x128 tiles); results and accumulate flags are those of the single launch."""

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('GOAT_HIP_LIB') or os.path.join(CSRC, 'libgoat_hip.so')     # (override: kernel A/B experiments)
-SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm3.hip', 'gemm4.hip', 'attention.hip', 'attention2.hip', 'rowops.hip', 'causal.hip', 'optim.hip']
+SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm3.hip', 'attention.hip', 'attention2.hip', 'rowops.hip', 'causal.hip', 'optim.hip']
 
 GOAT_F32, GOAT_BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ACCUM = 0, 1, 2, 3, 4, 5
@@ -31,8 +31,6 @@ SIGNATURES = {
     'goat_version': [],
     'goat_gemm_nt': [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i32],
     'goat_gemm_bf16': [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp],
-    'goat_gemm_bf16_dropout': [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp,
-                               _f32, _u64, _u64, _vp],
     'goat_colsum': [_vp, _i32, _vp, _i64, _i32, _i32, _vp],
     'goat_transpose': [_vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _vp],
     'goat_ln_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _i32],

@@ -58,43 +58,13 @@ static bool tile_ok(int bm, int bn, bool eight) {
   return (bm == 128 && bn == 256) || (bm == 192 && bn == 256) || (bm == 256 && bn == 192) || (bm == 256 && bn == 256) || (bm == 192 && bn == 192);
 }
 
-static int gemm_bf16_impl(void* stream, int trans_a, int trans_b, int dtype_out,
-                          const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                          int M, int N, int Kc, const float* bias, int epilogue,
-                          void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum,
-                          float drop_p, uint64_t drop_seed, uint64_t drop_off, const uint64_t* drop_rng);
-
 extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_out,
                               const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                               int M, int N, int Kc, const float* bias, int epilogue,
                               void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum) {
-  return gemm_bf16_impl(stream, trans_a, trans_b, dtype_out, A, lda, B, ldb, C, ldc, M, N, Kc, bias, epilogue, aux, ldaux, split_k, bm,
-                        nstage, colsum, 0.f, 0, 0, nullptr);
-}
-
-extern "C" int goat_gemm_bf16_dropout(void* stream, int trans_a, int trans_b, int dtype_out,
-                                      const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                                      int M, int N, int Kc, const float* bias, int epilogue,
-                                      void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum,
-                                      float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev) {
-  if (!(p >= 0.f && p < 1.f)) return GOAT_E_ARG;
-  if (p > 0.f) {
-    const bool act = epilogue == GOAT_EPI_GELU || epilogue == GOAT_EPI_RELU || epilogue == GOAT_EPI_MUL_DGELU || epilogue == GOAT_EPI_MUL_DRELU;
-    if (!act || dtype_out != GOAT_BF16 || split_k > 1 || (offset & 7) || (N & 7)) return GOAT_E_ARG;
-  }
-  return gemm_bf16_impl(stream, trans_a, trans_b, dtype_out, A, lda, B, ldb, C, ldc, M, N, Kc, bias, epilogue, aux, ldaux, split_k, bm,
-                        nstage, colsum, p, seed, offset, rng_dev);
-}
-
-static int gemm_bf16_impl(void* stream, int trans_a, int trans_b, int dtype_out,
-                          const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                          int M, int N, int Kc, const float* bias, int epilogue,
-                          void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum,
-                          float drop_p, uint64_t drop_seed, uint64_t drop_off, const uint64_t* drop_rng) {
   if (!A || !B || !C) return GOAT_E_ARG;
   const bool eight = (nstage & GOAT_GEMM_8WAVES) != 0;
-  const bool wide = (nstage & GOAT_GEMM_WIDE_PATCH) != 0;
-  nstage &= ~(GOAT_GEMM_8WAVES | GOAT_GEMM_WIDE_PATCH);
+  nstage &= ~GOAT_GEMM_8WAVES;
   if (nstage < 2 || nstage > 4) return GOAT_E_ARG;
   int bn = (bm >> 16) & 0xFFFF;
   bm &= 0xFFFF;
@@ -111,7 +81,6 @@ static int gemm_bf16_impl(void* stream, int trans_a, int trans_b, int dtype_out,
   if (epilogue == GOAT_EPI_ACCUM && (dtype_out != GOAT_F32 || bias)) return GOAT_E_ARG;
   if (split_k > 1 && (dtype_out != GOAT_F32 || (epilogue != GOAT_EPI_NONE && epilogue != GOAT_EPI_ACCUM) || bias)) return GOAT_E_ARG;
   if (!tile_ok(bm, bn, eight)) return GOAT_E_ARG;
-  if (wide && !(bm == 256 && bn == 256 && trans_a && trans_b && dtype_out == GOAT_F32 && nstage == 2)) return GOAT_E_ARG;
   const int64_t a_rows = trans_a ? Kc : M, b_rows = trans_b ? Kc : N;
   const int64_t a_bytes = a_rows * lda * 2, b_bytes = b_rows * ldb * 2;
   if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) return GOAT_E_SHAPE;
@@ -126,15 +95,11 @@ static int gemm_bf16_impl(void* stream, int trans_a, int trans_b, int dtype_out,
   a.colsum = colsum;
   a.accum = epilogue == GOAT_EPI_ACCUM;
   a.group_m = pick_group_m(a.tiles_m, a.tiles_n, bm, bn);
-  a.drop_thr = drop_p > 0.f ? goat_thr16(drop_p) : 0u;
-  a.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  a.drop_seed = drop_seed; a.drop_off = drop_off; a.drop_rng = drop_rng;
   const int kt = (Kc + BK - 1) / BK;
   if (split_k < 1) split_k = 1;
   if (split_k > kt) split_k = kt;
   a.k_tiles_per_split = (kt + split_k - 1) / split_k;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (wide) return goat_g4_dispatch(st, a, split_k, nstage);
   if (bn != 128 || bm == 96) return goat_g3_dispatch(st, a, bm, bn, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
   if (bm == 64) return dispatch_layout<T64>(st, a, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
   if (bm == 256) return dispatch_layout<T256>(st, a, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
@@ -158,13 +123,11 @@ static int group_stages(hipStream_t st, const GroupArgs& g, int nstage) {
 extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs, int n, int bm, int nstage) {
   if (!probs || n < 1 || n > GROUP_MAX) return GOAT_E_ARG;
   const bool eight = (nstage & GOAT_GEMM_8WAVES) != 0;       // as in goat_gemm_bf16: the 128-row tile on eight waves
-  const bool wide = (nstage & GOAT_GEMM_WIDE_PATCH) != 0;   // 256 x 256 on four waves
-  nstage &= ~(GOAT_GEMM_8WAVES | GOAT_GEMM_WIDE_PATCH);
+  nstage &= ~GOAT_GEMM_8WAVES;
   int bn = (bm >> 16) & 0xFFFF;
   bm &= 0xFFFF;
   if (bn == 0) bn = 128;
   if (nstage < 2 || nstage > 4 || !tile_ok(bm, bn, eight) || (bm & (bm - 1)) || (bn & (bn - 1))) return GOAT_E_ARG;
-  if (wide && !(bm == 256 && bn == 256 && nstage == 2)) return GOAT_E_ARG;
   GroupArgs g;
   g.n = n;
   int tiles = 0;
@@ -186,14 +149,12 @@ extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs,
     a.a_bytes = (uint32_t)a_bytes; a.b_bytes = (uint32_t)b_bytes;
     a.colsum = q.dbias;
     a.accum = q.accumulate ? 1 : 0;
-    a.drop_thr = 0; a.drop_scale = 1.f; a.drop_seed = 0; a.drop_off = 0; a.drop_rng = nullptr;
     a.group_m = pick_group_m(a.tiles_m, a.tiles_n, bm, bn);
     g.tile_start[i] = tiles;
     tiles += a.tiles_m * a.tiles_n;
   }
   for (int i = n; i <= GROUP_MAX; ++i) g.tile_start[i] = tiles;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (wide) return goat_g4_group(st, g, nstage);
   if (bn != 128) return goat_g3_group(st, g, bm, bn, nstage);
   if (bm == 64) return group_stages<T64>(st, g, nstage);
   if (bm == 256) return group_stages<T256>(st, g, nstage);

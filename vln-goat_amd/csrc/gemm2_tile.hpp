@@ -63,9 +63,6 @@ typedef Cfg<2, 4, 2, 2> T128x256;   // 128 x 256, 8 waves
 typedef Cfg<2, 4, 3, 2> T192x256;   // 192 x 256, 8 waves  (M = 3840 = 20 x 192: 240 tiles at N = 3072)
 typedef Cfg<4, 2, 2, 3> T256x192;   // 256 x 192, 8 waves  (N = 2304 = 12 x 192)
 typedef Cfg<2, 4, 4, 2> T256x256;   // 256 x 256, 8 waves
-typedef Cfg<2, 2, 4, 4> T256x256W4; // 256 x 256, FOUR waves with 128 x 128 patches (GOAT_GEMM_WIDE_PATCH): the weight-gradient layout reads both
-                                   // operands with ds_read_b64_tr_b16 (~7 LDS cycles per wave-instruction, profiles/round2_gemm_mainloop_cycle_stamps.txt) and is
-                                   // LDS-read-bound on 64 x 64 patches; a 4 x 4 patch needs half the fragment reads per MFMA (256 accumulator registers)
 typedef Cfg<2, 3, 3, 2> T192x192;   // 192 x 192, SIX waves (3840 x 2304: 20 x 12 = 240 tiles — one round on 256 CUs; 256 x 192 gives 180)
 typedef Cfg<1, 4, 3, 1> T96;        //  96 x 128, 4 waves  (M = 3840 = 40 x 96: 240 tiles at N = 768 — one round on 256 CUs, against 180 tiles of 128 x 128)
 
@@ -79,13 +76,6 @@ struct G2Args {
   float* colsum;              // TA only: colsum[m] += sum_k A[k,m]  (bias gradient fused into wgrad)
   int accum;                  // f32 output, no split: C += A·B (read-modify-write) instead of C = A·B
   int group_m;                // tile order: column-major inside groups of group_m tile rows (L2-sized 2-D blocks per XCD)
-  // dropout fused into the activation epilogues (goat_gemm_bf16_dropout; drop_thr == 0: none): element (row, col) of C uses
-  // counter drop_off + row * N + col of the stream (drop_seed + *drop_rng) — the masks of goat_dropout_add_fwd / goat_act_bwd
-  // on a contiguous [M, N] tensor
-  uint32_t drop_thr;
-  float drop_scale;
-  uint64_t drop_seed, drop_off;
-  const uint64_t* drop_rng;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -582,8 +572,6 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   char* wsp = smem + wave * WSLICE;
   const int col_w = n0 + wn * WCOLS;                             // first column of the wave patch
   // bias of this lane's columns: block j, group q -> columns j*32 + 4*hi + 8*q + {0..3}
-  const bool drop = (ACT || DACT) && p.drop_thr != 0;
-  const GoatRng drng(drop ? p.drop_seed + (p.drop_rng ? *p.drop_rng : 0ull) : 0ull);
   f32x4 bv[NI][4];
 #pragma unroll
   for (int j = 0; j < NI; ++j)
@@ -622,12 +610,6 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
             const float av = (float)a4[e];
             u[e] = (EPI == GOAT_EPI_MUL_DGELU) ? u[e] * dgelu_fast(av) : (av > 0.f ? u[e] : 0.f);
           }
-          if (drop) {      // the forward mask of these 4 consecutive columns of this lane's row
-            const uint32_t km = drng.keep_bits<4>(p.drop_off + (uint64_t)(row_w + l31) * (uint64_t)p.N + (uint64_t)(col_w + j * 32 + 4 * hi + 8 * q),
-                                                  p.drop_thr);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) u[e] = ((km >> e) & 1u) ? u[e] * p.drop_scale : 0.f;
-          }
         }
         bf16x4 o4;
 #pragma unroll
@@ -654,12 +636,11 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
           }
         }
         bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
-        const uint32_t km = drop ? drng.keep_bits<EPC>(p.drop_off + (uint64_t)row * (uint64_t)p.N + (uint64_t)col, p.drop_thr) : 0xFFu;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
           const float u = (float)v[e];
           const float h = (EPI == GOAT_EPI_GELU) ? gelu_fast(u) : fmaxf(u, 0.f);
-          v[e] = (bf16_t)(drop ? (((km >> e) & 1u) ? h * p.drop_scale : 0.f) : h);
+          v[e] = (bf16_t)h;
         }
         raw = *reinterpret_cast<uint4*>(&v);
       }
@@ -789,6 +770,3 @@ int launch_group(hipStream_t st, const GroupArgs& g) {
 int goat_g3_dispatch(hipStream_t st, const goat_g2::G2Args& a, int bm, int bn, int trans_a, int trans_b, int dtype_out, int epi,
                      int split, int nstage);
 int goat_g3_group(hipStream_t st, const goat_g2::GroupArgs& g, int bm, int bn, int nstage);
-// gemm4.hip: the 256 x 256 tile on four waves (weight-gradient layout only: transposed A and B, float32 output)
-int goat_g4_dispatch(hipStream_t st, const goat_g2::G2Args& a, int split, int nstage);
-int goat_g4_group(hipStream_t st, const goat_g2::GroupArgs& g, int nstage);

@@ -308,17 +308,14 @@ def _heuristic_cfg(ta, tb, M, N, Kc, split_k):
     return 64, 2
 
 
-def _launch_gemm_bf16(a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_k, bm, nstage, colsum_out, drop=None):
+def _launch_gemm_bf16(a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_k, bm, nstage, colsum_out):
     args = (_stream(), int(ta), int(tb), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0),
             _ptr(out), out.stride(0), M, N, Kc,
             _ptr(bias) if bias is not None else None, epi,
             _ptr(aux) if aux is not None else None,
             aux.stride(0) if aux is not None else 0, split_k, bm, nstage,
             _ptr(colsum_out) if colsum_out is not None else None)
-    if drop is not None:        # (p, seed, offset, device counter): dropout fused into the activation epilogue
-        st = _lib.lib().goat_gemm_bf16_dropout(*args, float(drop[0]), drop[1], drop[2], drop[3])
-    else:
-        st = _lib.lib().goat_gemm_bf16(*args)
+    st = _lib.lib().goat_gemm_bf16(*args)
     _lib.check(st, 'goat_gemm_bf16(ta=%d,tb=%d,M=%d,N=%d,Kc=%d,bm=%d,ns=%d,split=%d)' % (ta, tb, M, N, Kc, bm, nstage, split_k))
 
 
@@ -363,22 +360,9 @@ def _tune_gemm(key, a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_opts, col
     return best[1:]
 
 
-def gemm_takes_dropout(a, b, out, ta, tb):
-    """True if gemm(a, b, out, ...) will run on the LDS-DMA kernel with a bf16 result, i.e. accepts `drop=`."""
-    Kc = a.shape[0] if ta else a.shape[1]
-    return (FUSE_FFN_DROPOUT and a.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and not (ta and not tb)
-            and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and ((ta and tb) or Kc % 64 == 0) and a.data_ptr() % 16 == 0
-            and b.data_ptr() % 16 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and out.is_contiguous() and out.shape[1] % 8 == 0)
-
-
-# dropout of the panorama FFN inside the GEMM epilogues (goat_gemm_bf16_dropout): removes two passes over the [rows, 3072] tensor per
-# layer, but the mask hash then runs inside the GEMM's epilogue — measured 6.25 vs 6.22 ms per step (config 2), 6.77 vs 6.79 (config 5):
-# off by default
-FUSE_FFN_DROPOUT = os.environ.get('GOAT_FFN_DROPOUT_FUSION', '0') == '1'
-
-
+# (Dropout inside the FFN GEMM epilogues — round 2's goat_gemm_bf16_dropout — measured 6.25 vs 6.22 ms per step: removed in round 3.)
 def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split_k=1, colsum_out=None, split_opts=None,
-         accumulate=False, zero_first=False, drop=None):
+         accumulate=False, zero_first=False):
     """out[M,N] = epi(op(a) @ op(b)^T + bias); ta: a is [Kc,M] (else [M,Kc]); tb: b is [Kc,N] (else [N,Kc]).
     bf16 -> pipelined LDS-DMA kernel (goat_gemm_bf16) whenever its layout rules hold; otherwise (f32 parity
     path, odd contraction lengths) explicit transposes + goat_gemm_nt.
@@ -398,8 +382,6 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
     fast = (a.dtype == torch.bfloat16 and not (ta and not tb) and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
             and ((ta and tb) or Kc % 64 == 0) and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
             and a.stride(1) == 1 and b.stride(1) == 1)
-    if drop is not None and (not fast or out.dtype != torch.bfloat16):
-        raise ValueError('gemm(drop=...) needs the bf16 LDS-DMA path (check gemm_takes_dropout first)')
     if not fast:
         if accumulate:       # f32 parity path / odd shapes: product into a temporary, then one add
             tmp = torch.zeros_like(out) if split_k > 1 else torch.empty_like(out)
@@ -444,17 +426,15 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _launch_gemm_bf16(a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_k, bm, nstage, colsum_out, drop)
+    _launch_gemm_bf16(a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_k, bm, nstage, colsum_out)
     if PROFILE is not None:
         e1.record()
         cargs = (int(ta), int(tb), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out),
                  out.stride(0), M, N, Kc, _ptr(bias) if bias is not None else None, epi,
                  _ptr(aux) if aux is not None else None, aux.stride(0) if aux is not None else 0,
                  split_k, bm, nstage, _ptr(colsum_out) if colsum_out is not None else None)
-        if drop is not None:
-            cargs = cargs + (float(drop[0]), drop[1], drop[2], drop[3])
         PROFILE.append((e0, e1, 2.0 * M * N * Kc, (M, N, Kc, epi, split_k, 'v2 t%d%d %s s%d' % (ta, tb, tile_name(bm), nstage)),
-                        ('goat_gemm_bf16_dropout' if drop is not None else 'goat_gemm_bf16', cargs, (a, b, out, bias, aux, colsum_out))))
+                        ('goat_gemm_bf16', cargs, (a, b, out, bias, aux, colsum_out))))
     return out
 
 
@@ -576,8 +556,8 @@ class WgradQueue:
     enabled = os.environ.get('GOAT_WGRAD_GROUP', '1') != '0'
     cfg = tuple(int(v) for v in os.environ.get('GOAT_WGRAD_GROUP_CFG', '256,3').split(','))   # (tile = rows | cols << 16, ring stages | 0x100 = eight waves on 128x128): scripts/wgrad_group_bench.py, profiles/round2_wgrad_grouped.txt
     MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '16'))      # problems per launch (measured 8 / 12 / 16: 7.12 / 7.09 / 7.06 ms per step)
-    SIDE = os.environ.get('GOAT_WGRAD_SIDE', '0')      # '1': grouped launches go to a stream of their own (off the dgrad chain), 'lo': low priority
-    _wstreams = {}          # producing stream handle -> the stream its grouped launches run on (SIDE mode, during capture)
+    # (round 2 also had a mode that ran the grouped launches on a stream of their own, off the dgrad chain: 6.52 vs 6.28 ms per step — the
+    #  kernels contend, they do not fill idle CUs: removed in round 3)
     queues = {}             # HIP stream handle -> (torch stream, [(dy, x, w_sink, b_sink, accumulate)]): tensors are kept alive until
     pending_ids = {}        # the launch, which happens on the stream the problems were produced on;  id(param) -> stream handle
     _callback_armed = False
@@ -622,9 +602,6 @@ class WgradQueue:
             st = cls.queues[h][0]
             cls.flush(h)
             cur = torch.cuda.current_stream()
-            w = cls._wstreams.get(h)
-            if w is not None:
-                cur.wait_stream(w)
             if cur.cuda_stream != h:
                 cur.wait_stream(st)
 
@@ -639,20 +616,6 @@ class WgradQueue:
             cls.queues[h] = (st, [])
             for pid in [k for k, v in cls.pending_ids.items() if v == h]:
                 del cls.pending_ids[pid]
-            if cls.SIDE != '0' and torch.cuda.is_current_stream_capturing():
-                # the weight gradients are not on the critical path (needed when the backward pass ends): their grouped launch runs
-                # beside the dgrad / LayerNorm / attention chain of the producing stream instead of inside it
-                w = cls._wstreams.get(h)
-                if w is None:
-                    w = cls._wstreams[h] = torch.cuda.Stream(priority=0) if cls.SIDE != 'hi' else torch.cuda.Stream(priority=-1)
-                w.wait_stream(st)
-                with torch.cuda.stream(w):
-                    cls._launch(q)
-                for dy, x, _, _, _ in q:
-                    dy.record_stream(w)
-                    x.record_stream(w)
-                Branch.used.add(w)          # joined with the side branches when the backward pass ends
-                continue
             with torch.cuda.stream(st):
                 cls._launch(q)
 
@@ -1018,19 +981,12 @@ class _FfnFn(torch.autograd.Function):
         M, F_ = x2.shape[0], W1.shape[0]
         u = torch.empty((M, F_), dtype=x2.dtype, device=x2.device)
         h = torch.empty_like(u)
-        rng = (0, 0, None)
-        ctx.fused_drop = False
+        rng = RngState.next(h.numel()) if p > 0 else (0, 0, None)
+        gemm(x2, W1, h, bias=b1.detach(), epi=_ACT_EPI[act], aux=u)
         if p > 0:
-            rng = RngState.next(h.numel())
-            ctx.fused_drop = gemm_takes_dropout(x2, W1, h, False, False)
-        if ctx.fused_drop:          # dropout inside the GELU epilogue: no pass over the [rows, F] tensor
-            gemm(x2, W1, h, bias=b1.detach(), epi=_ACT_EPI[act], aux=u, drop=(p,) + tuple(rng))
-        else:
-            gemm(x2, W1, h, bias=b1.detach(), epi=_ACT_EPI[act], aux=u)
-            if p > 0:
-                st = _lib.lib().goat_dropout_add_fwd(_stream(), _dt(h), _ptr(h), None, _ptr(h), h.numel(), p,
-                                                     rng[0], rng[1], rng[2])
-                _lib.check(st, 'goat_dropout_add_fwd')
+            st = _lib.lib().goat_dropout_add_fwd(_stream(), _dt(h), _ptr(h), None, _ptr(h), h.numel(), p,
+                                                 rng[0], rng[1], rng[2])
+            _lib.check(st, 'goat_dropout_add_fwd')
         y = torch.empty((M, W2.shape[0]), dtype=x2.dtype, device=x2.device)
         gemm(h, W2, y, bias=b2.detach())
         ctx.save_for_backward(x2, u, h)
@@ -1046,9 +1002,7 @@ class _FfnFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         W2 = _shadow(ctx.w2, x2.dtype)  # [H, F]
         du = torch.empty_like(u)
-        if ctx.p > 0 and ctx.fused_drop and gemm_takes_dropout(dy2, W2, du, False, True):
-            gemm(dy2, W2, du, tb=True, epi=_ACT_DEPI[ctx.act], aux=u, drop=(ctx.p,) + tuple(ctx.rng))     # mask x act' in the dgrad epilogue
-        elif ctx.p > 0:
+        if ctx.p > 0:
             gemm(dy2, W2, du, tb=True)
             du = act_bwd(du, u, ctx.act, ctx.p, ctx.rng)
         else:
