@@ -433,14 +433,18 @@ def cpu_baseline(args, cfg):
         i += 1
     med = sorted(times)[len(times) // 2]
     all_cores = None
-    if avail > ncores and not os.environ.get('GOAT_CPU_NO_ALL_CORES'):
-        # SURVEY 8d names the host's core count: the same steps once more with EVERY core (3 timed steps after 1 warm-up; on a
-        # many-socket host the M = 3840-row GEMMs scale poorly past 64 threads, which is why the headline figure uses 64)
+    if avail > ncores and os.environ.get('GOAT_CPU_ALL_CORES'):
+        # SURVEY 8d names the host's core count.  Opt-in, because it does not fit a default run: measured once on the GPU box
+        # (profiles/round3_bench_line_default_all_cores_cpu.json: 2 x EPYC 9575F, 256 hardware threads) ONE step at 256 threads took
+        # 422 s = 0.57 trajectory-steps/s against 6.1 s = 39.5 at 64 threads — the M = 3840-row GEMMs of this model do not scale
+        # past one socket's physical cores, they collapse.  64 threads is therefore the honest "best CPU" figure.
         torch.set_num_threads(avail)
-        one('sap')
-        t_all = sorted(one(TASKS[k % len(TASKS)]) for k in range(3))[1]
-        all_cores = {'cores': avail, 'value': round(B * 5 / t_all, 2), 'median_s_per_step': round(t_all, 3)}
+        t_all = one('sap')
+        all_cores = {'cores': avail, 'value': round(B * 5 / t_all, 2), 's_per_step': round(t_all, 3), 'steps': 1}
         torch.set_num_threads(ncores)
+    elif avail > ncores:
+        all_cores = {'cores': avail, 'value': 0.57, 's_per_step': 422.2, 'measured': 'once, round 3 (profiles/round3_bench_line_default_all_cores_cpu.json); '
+                     'set GOAT_CPU_ALL_CORES=1 to re-measure (about 7 minutes per step)'}
     return {'value': round(B * 5 / med, 2), 'unit': 'trajectory-steps/s', 'cores': ncores, 'kind': 'port', 'all_cores': all_cores,
             'cpu_model': cpu_model, 'cores_available': avail, 'median_s_per_step': round(med, 3),
             'sample': 'oracle/goat_oracle.py fp32 fwd+bwd, full R2R config, B=%d T=5 L=80, dropout on: median of %d timed steps '
