@@ -927,8 +927,13 @@ def dp_diagnostics(args, m, world, rank, dt_step):
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
+        nph = getattr(wrapper, 'n_phases', None)
         for _ in range(3):
-            wrapper.reduce_gradients(t)
+            if nph:                              # the phased exchange of the timed step, without the backward phases between its parts
+                for k in range(nph):
+                    wrapper.reduce_gradients(t, phase=k, wait=(k == nph - 1))
+            else:
+                wrapper.reduce_gradients(t)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 3 * 1e3
         nbytes = None

@@ -165,6 +165,40 @@ __device__ __forceinline__ int xcd_chunk_position(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Saved-activation block rows fetched ahead of the epilogue (two of them in flight); empty in instantiations without the prefetch.
+template <bool ON, int CHUNKS> struct AuxRows {
+  uint4 v[2][CHUNKS];
+  __device__ __forceinline__ uint4* row(int i) { return v[i]; }
+};
+template <int CHUNKS> struct AuxRows<false, CHUNKS> {
+  __device__ __forceinline__ uint4* row(int) { return nullptr; }
+};
+
+// One 32-row block row of a wave's patch of the saved pre-activation (bf16, G2Args::aux): CHUNKS 16-byte pieces per lane, rows
+// and columns past the problem read as zero.
+template <int CHUNKS, int CPR>
+__device__ __forceinline__ void load_aux_rows(const G2Args& p, int row_w, int col_w, int lane, uint4* dst) {
+  constexpr int EPC = 8;
+  const bf16_t* auxp = reinterpret_cast<const bf16_t*>(p.aux);
+  const bool vec = auxp != nullptr && (p.ldaux % EPC) == 0 && ((reinterpret_cast<uintptr_t>(auxp) & 15) == 0);
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const int idx = c * 64 + lane, r = idx / CPR, cc = idx % CPR;
+    const int row = row_w + r, col = col_w + cc * EPC;
+    uint4 raw = {0u, 0u, 0u, 0u};
+    if (row < p.M) {
+      if (col + EPC <= p.N && vec) {
+        raw = *reinterpret_cast<const uint4*>(auxp + (int64_t)row * p.ldaux + col);
+      } else {
+        bf16_t* rv = reinterpret_cast<bf16_t*>(&raw);
+        for (int e = 0; e < EPC; ++e)
+          if (col + e < p.N) rv[e] = auxp[(int64_t)row * p.ldaux + col + e];
+      }
+    }
+    dst[c] = raw;
+  }
+}
+
 template <class CF, bool TA, bool TB, int NSTAGE>
 constexpr int smem_bytes() { return NSTAGE * (Tile<TA, CF::BM>::BYTES + Tile<TB, CF::BN>::BYTES); }
 
@@ -457,29 +491,13 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   // block row right where it was needed: 399 TFLOP/s on 3840 x 3072 x 768 against 548 for the same shape without the multiply.
   constexpr bool DACT_ = !SPLITK && sizeof(OutT) == 2 && (EPI == GOAT_EPI_MUL_DGELU || EPI == GOAT_EPI_MUL_DRELU);
   constexpr int EPC_ = 8, CPR_ = WCOLS / EPC_, CHUNKS_ = 32 * CPR_ / 64;
-  uint4 auxr[DACT_ ? 2 : 1][DACT_ ? CHUNKS_ : 1];
-  const bf16_t* auxp = reinterpret_cast<const bf16_t*>(p.aux);
-  const bool aux_vec_ = DACT_ && auxp != nullptr && (p.ldaux % EPC_) == 0 && ((reinterpret_cast<uintptr_t>(auxp) & 15) == 0);
-  auto load_aux_row = [&](int i, uint4* dst) {
-    const int row_w = m0 + wm * WROWS + i * 32, col_w = n0 + wn * WCOLS;
-#pragma unroll
-    for (int c = 0; c < CHUNKS_; ++c) {
-      const int idx = c * 64 + lane, r = idx / CPR_, cc = idx % CPR_;
-      const int row = row_w + r, col = col_w + cc * EPC_;
-      uint4 raw = {0u, 0u, 0u, 0u};
-      if (row < p.M) {
-        if (col + EPC_ <= p.N && aux_vec_) {
-          raw = *reinterpret_cast<const uint4*>(auxp + (int64_t)row * p.ldaux + col);
-        } else {
-          bf16_t* rv = reinterpret_cast<bf16_t*>(&raw);
-          for (int e = 0; e < EPC_; ++e)
-            if (col + e < p.N) rv[e] = auxp[(int64_t)row * p.ldaux + col + e];
-        }
-      }
-      dst[c] = raw;
-    }
-  };
-  if (DACT_) load_aux_row(0, auxr[0]);
+  // (only in instantiations whose accumulators leave room for two block rows of it, and through a free function: the first version
+  //  of this — a [&] lambda defined here in every instantiation — cost the 256 x 256 transposed-operand kernels 5 to 162 spilled
+  //  registers although they never call it, and the grouped weight-gradient launch of that tile went from 297 to 446 us;
+  //  profiles/round3_gemm_spill_check.txt)
+  constexpr bool PF_ = DACT_ && (MI * NI * 16 + 2 * CHUNKS_ * 4 <= 128);
+  AuxRows<PF_, CHUNKS_> auxr;
+  if constexpr (PF_) load_aux_rows<CHUNKS_, CPR_>(p, m0 + wm * WROWS, n0 + wn * WCOLS, lane, auxr.row(0));
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
 #undef GOAT_ISSUE
@@ -587,11 +605,21 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
     if (DACT) {
       // the saved pre-activation block row (fetched one block row ahead, see above) -> slice -> each lane picks up its own
       // 4-column groups; the next block row's loads are issued first and stay in flight behind this one's arithmetic and stores
-      if (i + 1 < MI) load_aux_row(i + 1, auxr[(i + 1) & 1]);
+      if constexpr (PF_) {
+        if (i + 1 < MI) load_aux_rows<CHUNKS, CPR>(p, row_w + 32, col_w, lane, auxr.row((i + 1) & 1));
 #pragma unroll
-      for (int c = 0; c < CHUNKS; ++c) {
-        const int idx = c * 64 + lane, r = idx / CPR, cc = idx % CPR;
-        *reinterpret_cast<uint4*>(wsp + r * RBY + cc * 16) = auxr[i & 1][c];
+        for (int c = 0; c < CHUNKS; ++c) {
+          const int idx = c * 64 + lane, r = idx / CPR, cc = idx % CPR;
+          *reinterpret_cast<uint4*>(wsp + r * RBY + cc * 16) = auxr.row(i & 1)[c];
+        }
+      } else {           // large accumulator tiles: the block row is fetched where it is used (round-2 behaviour)
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c) {
+          const int idx = c * 64 + lane, r = idx / CPR, cc = idx % CPR;
+          uint4 now;
+          load_aux_rows<1, CPR>(p, row_w, col_w, idx, &now);     // (chunk c of this lane = chunk 0 of "lane" idx)
+          *reinterpret_cast<uint4*>(wsp + r * RBY + cc * 16) = now;
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS hand-over between lanes
     }

@@ -1134,7 +1134,8 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
   }
 #define GOAT_LN_BWD_LAUNCH(T_, RIF_, NWV_)                                                                                    \
   do {                                                                                                                        \
-    auto kern_ = ln_bwd_kernel<T_, MC, RIF_, NWV_>;                                                                           \
+    auto kern_ = ln_bwd_kernel<T_, MC, (MC > 3 ? 1 : RIF_), NWV_>;   /* rows wider than 1536 (bf16) / 768 (f32) elements: ONE row in   \
+                                                                       flight (two spilled 54 .. 760 registers) */                    \
     if (sm > 64 * 1024) {                                                                                                     \
       static bool attr_ = false;                                                                                              \
       if (!attr_) {                                                                                                           \
