@@ -852,7 +852,8 @@ def config4_leg(args):
         hipops.RngState.dev.add_(0x9E3779B1)
         # (the instruction's K|V projections of the six cross-modal layers once per episode instead of once per step: identical
         #  outputs — tests/test_nav_parity_gpu.py holds both forms to the reference goldens)
-        loss, _ = synth.run_nav_episode(lambda m, b: model(m, b), ep, device='cuda', hoist_text_kv=not os.environ.get('GOAT_NAV_NO_HOIST'))
+        loss, _ = synth.run_nav_episode(lambda m, b: model(m, b), ep, device='cuda', hoist_text_kv=not os.environ.get('GOAT_NAV_NO_HOIST'),
+                                        hoist_pano=not os.environ.get('GOAT_NAV_NO_HOIST') and not os.environ.get('GOAT_NAV_NO_PANO_HOIST'))
         loss.backward()
 
     side = torch.cuda.Stream()
@@ -1086,6 +1087,8 @@ def main():
             if 'ms_per_step' in out['fresh_batch']:
                 out['fresh_batch_ms_per_step'] = out['fresh_batch']['ms_per_step']
             out['with_optimizer'] = leg('with_optimizer', lambda: optimizer_leg(args, m))
+        from vln_goat_amd import hipops as _h
+        out['gemm_shapes_autotuned_in_this_run'] = _h.TUNE_EVENTS[0]      # 0: every shape came from vln-goat_amd/tuned_gfx950.json
         if os.environ.get('GOAT_SAVE_TUNED'):      # persist the autotuned GEMM table (copied to vln-goat_amd/tuned_gfx950.json)
             from vln_goat_amd import hipops
             hipops.save_tuned(os.environ['GOAT_SAVE_TUNED'])

@@ -6,19 +6,42 @@ import json
 import sys
 
 
-def fam_avg(d, counter):
-    n = s = 0
+def gemm_rows(d, counter):
+    rows = []
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             if ('gemm2_' in r['Kernel_Name'] or 'gemm_nt_kernel' in r['Kernel_Name']) and r['Counter_Name'] == counter:
-                n += 1
-                s += float(r['Counter_Value'])
-    return n, (s / n if n else None)
+                rows.append((int(r['Dispatch_Id']), r['Kernel_Name'], float(r['Counter_Value'])))
+    rows.sort()
+    return rows
 
 
-nf, f = fam_avg(sys.argv[1], 'FETCH_SIZE')
-nw, w = fam_avg(sys.argv[2], 'WRITE_SIZE')
-print(json.dumps({'kernel': 'gemm2_kernel + gemm2_group_kernel + gemm_nt_kernel', 'launches_counted': nf,
+def period(rows):
+    """length of the repeating tail of the GEMM dispatch sequence (one task cycle / one episode): smallest P >= 32 with the last
+    P kernel names equal to the P before them.  0 if the tail does not repeat."""
+    names = [r[1] for r in rows]
+    for P in range(32, len(names) // 2 + 1):
+        if names[-P:] == names[-2 * P:-P]:
+            return P
+    return 0
+
+
+def fam_avg(rows, last):
+    rows = rows[-last:] if last else rows
+    n = len(rows)
+    return n, (sum(r[2] for r in rows) / n if n else None)
+
+
+LAST = int(sys.argv[4]) if len(sys.argv) > 4 else 0       # N: the last N GEMM dispatches; -1: the repeating tail (auto-detected)
+RF, RW = gemm_rows(sys.argv[1], 'FETCH_SIZE'), gemm_rows(sys.argv[2], 'WRITE_SIZE')
+if LAST < 0:
+    LAST = period(RF)
+nf, f = fam_avg(RF, LAST)
+nw, w = fam_avg(RW, LAST)
+nf_all, f_all = fam_avg(RF, 0)
+nw_all, w_all = fam_avg(RW, 0)
+print(json.dumps({'kernel': 'gemm2_kernel + gemm2_group_kernel + gemm_nt_kernel', 'launches_counted': nf, 'selection': ('the last %d GEMM dispatches = the repeating tail of the dispatch sequence (one task cycle / episode; warm-up excluded)' % LAST) if LAST else 'every GEMM dispatch of the run',
+                  'all_dispatches': {'launches': nf_all, 'traffic_bytes_per_launch': f_all * 1024 * 2 + w_all * 1024},
                   'fetch_kb_per_launch_reported': f, 'write_kb_per_launch_reported': w,
                   'read_bytes_per_launch': f * 1024 * 2, 'write_bytes_per_launch': w * 1024,
                   'traffic_bytes_per_launch': f * 1024 * 2 + w * 1024,

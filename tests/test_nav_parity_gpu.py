@@ -55,7 +55,8 @@ def test_nav_episode_matches_reference_golden(case, dtype):
             ep[k] = ep[k].cuda().requires_grad_(True)
         # two of the four cases run with the instruction's K|V projections hoisted out of the step loop (nav_model.text_kv): the
         # reference recomputes them per step, the goldens pin both forms
-        loss, rec = synth.run_nav_episode(lambda m, b: model(m, b), ep, device='cuda', hoist_text_kv=case in ('nav_type1_add', 'nav_config4_full'))
+        loss, rec = synth.run_nav_episode(lambda m, b: model(m, b), ep, device='cuda', hoist_text_kv=case in ('nav_type1_add', 'nav_config4_full'),
+                                          hoist_pano=case == 'nav_config4_full')
         loss.backward()
         torch.cuda.synchronize()
     finally:

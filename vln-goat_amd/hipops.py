@@ -337,7 +337,11 @@ def _time_cfg(fn, reps=4):
     return ts[len(ts) // 2]
 
 
+TUNE_EVENTS = [0]        # shapes timed by the autotuner in this process (0 when tuned_gfx950.json covers the run: bench.py reports it)
+
+
 def _tune_gemm(key, a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_opts, colsum_out):
+    TUNE_EVENTS[0] += 1
     kt = (Kc + 63) // 64
     best = None
     scratch = torch.empty_like(out) if out.dtype == torch.float32 else out

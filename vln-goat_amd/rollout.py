@@ -865,13 +865,28 @@ class TeacherEpisode:
                 if not ended[i]:
                     gmaps[i].update_graph(ob)
             ended = np.logical_or(ended, np.array([m is None for m in moves]))
+        # the panoramas of all steps as ONE batch [T * B] (body(hoist_pano=True)): the compact feature-gather CSR of the steps joined
+        valid_rows, starts, off = [], [], 0
+        for t in range(self.T):
+            st = out['s%d_feat_start' % t].numpy()
+            valid_rows.append(out['s%d_feat_idx' % t].numpy()[:int(st[-1])])
+            starts.append(st[:-1] + off)
+            off += int(st[-1])
+        out['all_feat_idx'] = _pad1np(np.concatenate(valid_rows), self.T * B * self.W, -1, np.int32)
+        out['all_feat_start'] = torch.from_numpy(np.concatenate(starts + [[off]]).astype(np.int32))
+        for name in ('loc_fts', 'nav_types', 'view_lens'):
+            out['all_' + name] = torch.cat([out['s%d_%s' % (t, name)] for t in range(self.T)], 0)
         out['_traj'], out['_n_traj'] = traj, n_traj
         return out
 
     # ---- device -------------------------------------------------------------------------------------------------------------
-    def body(self, model, bufs, extras=None, hoist_text_kv=True):
+    def body(self, model, bufs, extras=None, hoist_text_kv=True, hoist_pano=True):
         """forward + imitation loss of the planned episodes from the tensors of `bufs` (EpisodeBuffers.t): no host data, no
-        device -> host copy.  -> loss (sum over steps and samples of the cross-entropy / B, M/r2r/agent.py:664-667)."""
+        device -> host copy.  -> loss (sum over steps and samples of the cross-entropy / B, M/r2r/agent.py:664-667).
+        hoist_pano: ONE panorama-encoder call over the T * B panoramas of the whole walk instead of one per step — the encoder sees
+        the observation only (M/r2r/agent.py:548-556), and with teacher forcing every observation is known before the first step, so
+        its T small launches-bound passes (B * W = 456 rows at B = 12) become one of T * B * W rows; the [MEM]-carrying navigation
+        steps stay sequential.  Same embeddings and gradients (summation order aside; dropout draws differ)."""
         from collections import defaultdict
         from . import hipops
         dd = lambda d: defaultdict(lambda: None, d)
@@ -883,13 +898,22 @@ class TeacherEpisode:
         txt = model('language', dd(lang))
         txt_kv = model('text_kv', {'txt_embeds': txt}) if hoist_text_kv else None
         pool, last, loss = [], None, 0.0
+
+        def panoramas(k, n):
+            fts = hipops.gather_segmean(self.features.dev, t_[k + 'feat_idx'], t_[k + 'feat_start'], None, n * self.W, None)
+            pin = {'view_img_fts': fts.view(n, self.W, -1), 'loc_fts': t_[k + 'loc_fts'], 'nav_types': t_[k + 'nav_types'],
+                   'view_lens': t_[k + 'view_lens'], 'already_dropout': False}
+            for name, z in extras.get('panorama', {}).items():      # per-sample dictionary copies ([B, K, ...]) follow the joint batch
+                pin[name] = z.repeat(n // B, *([1] * (z.dim() - 1))) if (torch.is_tensor(z) and n != B and z.dim() > 1 and z.shape[0] == B) else z
+            return model('panorama', dd(pin))
+
+        whole = panoramas('all_', self.T * B) if hoist_pano else None
         for s in range(self.T):
             k = 's%d_' % s
-            fts = hipops.gather_segmean(self.features.dev, t_[k + 'feat_idx'], t_[k + 'feat_start'], None, B * self.W, None)
-            pin = {'view_img_fts': fts.view(B, self.W, -1), 'loc_fts': t_[k + 'loc_fts'], 'nav_types': t_[k + 'nav_types'],
-                   'view_lens': t_[k + 'view_lens'], 'already_dropout': False}
-            pin.update(extras.get('panorama', {}))
-            pano, pmask, fused = model('panorama', dd(pin))
+            if whole is not None:
+                pano, pmask, fused = (None if x is None else x[s * B:(s + 1) * B] for x in whole)
+            else:
+                pano, pmask, fused = panoramas(k, B)
             if fused is None:
                 fused = torch.sum(pano * pmask.unsqueeze(2), 1) / torch.sum(pmask, 1, keepdim=True)
             H = pano.shape[-1]

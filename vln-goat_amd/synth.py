@@ -364,9 +364,13 @@ def make_nav_episode(B=2, L=44, V=36, n_steps=3, n_cand=4, seed=0, vocab_size=50
     return ep
 
 
-def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_float=True, hoist_text_kv=False):
+def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_float=True, hoist_text_kv=False, hoist_pano=False):
     """language once, then panorama + navigation per step with the [MEM] token carrying `cls_embeds` of the
-    previous step (not detached: back-propagation through time, M/r2r/agent.py:592).  Returns (loss, records)."""
+    previous step (not detached: back-propagation through time, M/r2r/agent.py:592).  Returns (loss, records).
+    hoist_pano: the panoramas of ALL steps through the panorama encoder in ONE call (batch T*B) before the first navigation step.
+    With teacher forcing the walk — hence every panorama — is known up front and the panorama encoder sees nothing of the
+    navigation state (M/r2r/agent.py:548-556 feeds it the observation only), so the embeddings are those of the per-step calls;
+    only the [MEM]-carrying navigation steps stay sequential."""
     from collections import defaultdict
     dd = lambda d: defaultdict(lambda: None, d)
     mv = lambda x: x.to(device) if torch.is_tensor(x) else x
@@ -383,16 +387,25 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
     loss = 0.0
     rec = {'txt_embeds': txt, 'steps': []}
     fused_hist = []
-    for t, st in enumerate(ep['steps']):
-        pin = {'view_img_fts': mv(st['view_img_fts']), 'loc_fts': mv(st['loc_fts']), 'nav_types': mv(st['nav_types']),
-               'view_lens': mv(st['view_lens']), 'already_dropout': True}
-        if use_bacl:
-            pin['z_img_features'], pin['z_img_pzs'] = mv(ep['z_img_features']), mv(ep['z_img_pzs'])
-        has_obj = 'reverie_obj_img_fts' in st
-        if has_obj:
+    def pano_inputs(sts):
+        cat = lambda k: mv(sts[0][k]) if len(sts) == 1 else torch.cat([mv(st[k]) for st in sts], 0)
+        pin = {'view_img_fts': cat('view_img_fts'), 'loc_fts': cat('loc_fts'), 'nav_types': cat('nav_types'),
+               'view_lens': cat('view_lens'), 'already_dropout': True}
+        if use_bacl:             # per-sample copies of the dictionary ([B, K, ...]): one per panorama of the joint batch
+            tile = lambda z: z if len(sts) == 1 or z.shape[0] != B else z.repeat(len(sts), *([1] * (z.dim() - 1)))
+            pin['z_img_features'], pin['z_img_pzs'] = tile(mv(ep['z_img_features'])), tile(mv(ep['z_img_pzs']))
+        if 'reverie_obj_img_fts' in sts[0]:
             for k in ('reverie_obj_img_fts', 'reverie_obj_lens', 'reverie_obj_names'):
-                pin[k] = mv(st[k])
-        pano, pmask, fused = model('panorama', dd(pin))
+                pin[k] = cat(k) if torch.is_tensor(sts[0][k]) else sum((list(st[k]) for st in sts), [])
+        return pin
+
+    hoisted = None
+    if hoist_pano and len({tuple(st['view_img_fts'].shape) for st in ep['steps']}) == 1:
+        pa, pm, fu = model('panorama', dd(pano_inputs(ep['steps'])))
+        hoisted = [(pa[i * B:(i + 1) * B], pm[i * B:(i + 1) * B], None if fu is None else fu[i * B:(i + 1) * B]) for i in range(len(ep['steps']))]
+    for t, st in enumerate(ep['steps']):
+        has_obj = 'reverie_obj_img_fts' in st
+        pano, pmask, fused = hoisted[t] if hoisted is not None else model('panorama', dd(pano_inputs([st])))
         fused_hist.append(fused)
         H = pano.shape[-1]
         zero = pano.new_zeros(B, 1, H)
