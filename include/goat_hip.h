@@ -320,6 +320,24 @@ int goat_adamw_step(void* stream, const float* grad_arena, float* exp_avg, float
                     const int32_t* chunks, int nchunks, float beta1, float beta2, float eps, float max_norm,
                     const float* sq_norm);
 
+/* Tail of the single-action-prediction head, one launch per direction (csrc/causal.hip).  gs [B,G] / ls [B,W]: raw scores of the
+ * global / local heads (dtype GOAT_BF16 | GOAT_F32); fwl [B]: fusion logit (fw = sigmoid(fwl) when fw_sigmoid, fwl itself otherwise;
+ * NULL: fw = 0.5).  Masks (bytes, any may be NULL): gvis 1 = visited, gvalid 0 = beyond the map, glens map lengths, lmask 1 = masked
+ * (1 = valid when lmask_is_valid).  M [B,G,W] float32 logit-fusion matrix (NULL: none).  Outputs float32:
+ *   gl = mask(gs * fw), ll = mask(ls * (1 - fw)), fused = gl + M · zero-filled(ll) (+ ll[0] on column 0 when add_stop),
+ *   loss[b] = CE(gl, ga) + CE(ll, la) + CE(fused, ga) when loss != NULL (negative label: 0), lse [B,3] saved for the backward.
+ * Replaces the reference's elementwise / masked_fill / bmm / log_softmax chain: P/model/pretrain_goat.py:375-413 (pre-training),
+ * M/models/vilmodel_GOAT.py:803-839 (fine-tuning: add_stop = 1, lmask = vp_nav_masks with lmask_is_valid = 1).
+ * Backward: upstream dloss [B] (with the labels) and / or dgl, dll, dfused (NULL = zero) -> dgs, dls (dtype), dfwl (when fwl). */
+int goat_sap_fuse_fwd(void* stream, int dtype, const void* gs, const void* ls, const void* fwl, int fw_sigmoid,
+                      const uint8_t* gvis, const uint8_t* gvalid, const int64_t* glens, const uint8_t* lmask, int lmask_is_valid,
+                      const float* M, int add_stop, const int64_t* ga, const int64_t* la, float* gl, float* ll, float* fused,
+                      float* loss, float* lse, int B, int G, int W);
+int goat_sap_fuse_bwd(void* stream, int dtype, const void* gs, const void* ls, const void* fwl, int fw_sigmoid,
+                      const uint8_t* gvis, const uint8_t* gvalid, const int64_t* glens, const uint8_t* lmask, int lmask_is_valid,
+                      const float* M, int add_stop, const int64_t* ga, const int64_t* la, const float* gl, const float* ll,
+                      const float* fused, const float* lse, const float* dloss, const float* dgl, const float* dll,
+                      const float* dfused, void* dgs, void* dls, void* dfwl, int B, int G, int W);
 /* CFP contrastive losses (P/model/pretrain_goat.py:519-534): loss[i] = sum over x in {gmap, vp, fused} of
  * 1/2 [CE(x_loc[i]·txt_allᵀ/τ, t_i) + CE(txt_loc[i]·x_allᵀ/τ, t_i)], t_i = target0 + i.  x_loc / x_all: arrays of 3 device
  * pointers ([Bl,H] / [Ba,H] float32; all = loc on one rank, the all-gathered rows under data parallelism); loss [Bl] is

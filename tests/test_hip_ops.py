@@ -856,3 +856,79 @@ def test_grouped_wgrad_tail_split_plan(ops):
     for (dy, x, w, b, acc), (rw, rb) in zip(q, refs):
         _close(w, rw, torch.bfloat16, 'tail-split dW')
         _close(b, rb, torch.bfloat16, 'tail-split dbias')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('form', ['pretrain', 'nav'])
+def test_sap_fuse_matches_the_reference_chain(ops, dtype, form):
+    """hipops.sap_fuse (one launch per direction) against the reference's spelling of the SAP head tail with torch ops: scaled by the
+    fusion weight, masked_fill x4, bmm with the logit-fusion matrix, (fine-tuning form: local stop logit added to the stop column),
+    three cross-entropies — P/model/pretrain_goat.py:375-413, M/models/vilmodel_GOAT.py:803-839.  Logits, loss and the gradients of
+    both score tensors and of the fusion logit; also with upstream gradients on the logits (no labels) and without a fusion Linear."""
+    g = torch.Generator().manual_seed(11)
+    B, G, W = 6, 23, 38
+    gs0 = torch.randn(B, G, generator=g).to(DEV, dtype)
+    ls0 = torch.randn(B, W, generator=g).to(DEV, dtype)
+    fwl0 = torch.randn(B, 1, generator=g).to(DEV, dtype)
+    glens = torch.tensor([23, 10, 17, 5, 23, 12], device=DEV)
+    valid = torch.arange(G, device=DEV)[None, :] < glens[:, None]
+    vis = (torch.rand(B, G, generator=g) < 0.3).to(DEV) & valid
+    vis[:, 0] = False
+    lvalid = (torch.rand(B, W, generator=g) < 0.6).to(DEV)
+    lvalid[:, 0] = True
+    M = (torch.rand(B, G, W, generator=g) < 0.05).float().to(DEV)
+    ga = torch.tensor([0, 3, 5, 1, 7, 2], device=DEV)
+    for b in range(B):                                            # labels on unmasked slots
+        ok = (~vis[b] & valid[b]).nonzero().flatten()
+        ga[b] = ok[int(ga[b]) % len(ok)]
+    la = torch.stack([lvalid[b].nonzero().flatten()[b % int(lvalid[b].sum())] for b in range(B)])
+    nav = form == 'nav'
+
+    def reference(gs, ls, fwl):
+        fw = 0.5 if fwl is None else torch.sigmoid(fwl.float())
+        gl = gs.float() * fw
+        ll = ls.float() * (1 - fw)
+        gl = gl.masked_fill(vis, -float('inf')).masked_fill(valid.logical_not(), -float('inf'))
+        navm = lvalid.logical_not()
+        ll = ll.masked_fill(navm, -float('inf'))
+        fused = gl.clone()
+        if nav:
+            add0 = torch.zeros_like(fused)
+            add0[:, 0] = ll[:, 0]
+            fused = fused + add0
+        fused = fused + torch.bmm(M, ll.masked_fill(navm, 0.0).unsqueeze(2)).squeeze(2)
+        return gl, ll, fused
+
+    F = torch.nn.functional
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    for with_fw in (True, False):
+        for labels in (True, False):
+            leaves = [gs0.clone().requires_grad_(True), ls0.clone().requires_grad_(True), fwl0.clone().requires_grad_(True) if with_fw else None]
+            rl, rll, rf = reference(*leaves)
+            wg, wl, wf = (torch.randn(B, G, generator=g).to(DEV), torch.randn(B, W, generator=g).to(DEV), torch.randn(B, G, generator=g).to(DEV))
+            fin = lambda t, w: (torch.where(torch.isfinite(t), t, torch.zeros_like(t)) * w).sum()
+            if labels:
+                rloss = F.cross_entropy(rl, ga, reduction='none') + F.cross_entropy(rll, la, reduction='none') + F.cross_entropy(rf, ga, reduction='none')
+                (rloss * torch.arange(1, B + 1, device=DEV)).sum().backward()
+            else:
+                (fin(rl, wg) + fin(rll, wl) + fin(rf, wf)).backward()
+            rgrads = [t.grad.float() if t is not None else None for t in leaves]
+            mine = [gs0.clone().requires_grad_(True), ls0.clone().requires_grad_(True), fwl0.clone().requires_grad_(True) if with_fw else None]
+            kw = dict(gvis=vis, lmask=lvalid, lmask_is_valid=True, M=M, add_stop=nav)
+            kw.update(dict(gvalid=valid) if nav else dict(glens=glens))
+            gl, ll, fu, loss = ops.sap_fuse(mine[0], mine[1], mine[2], labels=(ga, la) if labels else None, **kw)
+            for a, r in ((gl, rl), (ll, rll), (fu, rf)):
+                assert torch.equal(torch.isfinite(a), torch.isfinite(r))
+                m = torch.isfinite(r)
+                assert float((a[m] - r[m]).abs().max()) <= tol * max(1.0, float(r[m].abs().max()))
+            if labels:
+                assert float((loss - rloss).abs().max()) <= tol * max(1.0, float(rloss.abs().max()))
+                (loss * torch.arange(1, B + 1, device=DEV)).sum().backward()
+            else:
+                assert loss is None
+                (fin(gl, wg) + fin(ll, wl) + fin(fu, wf)).backward()
+            torch.cuda.synchronize()
+            for t, r, what in zip(mine, rgrads, ('d scores global', 'd scores local', 'd fusion logit')):
+                if r is None:
+                    continue
+                assert float((t.grad.float() - r).abs().max()) <= 2 * tol * max(1.0, float(r.abs().max())), (what, with_fw, labels)

@@ -61,6 +61,8 @@ SIGNATURES = {
     'goat_wgrad_grouped': [_vp, _vp, _i32, _i32, _i32],
     'goat_grad_sqnorm': [_vp, _vp, _vp, _i32, _vp],
     'goat_adamw_step': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _vp],
+    'goat_sap_fuse_fwd': [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
+    'goat_sap_fuse_bwd': [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_infonce_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32],
     'goat_infonce_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32],
     'goat_probe_tr16': [_vp, _vp],

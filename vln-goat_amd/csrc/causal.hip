@@ -334,6 +334,151 @@ __global__ __launch_bounds__(256) void infonce_bwd_kernel(NceBwdArgs q) {
   role.out[(int64_t)r * p.H + c] += tot;
 }
 
+
+// ------------------------------------------------------------------------------------ SAP logits / loss
+// The tail of the single-action-prediction head (P/model/pretrain_goat.py:375-413; M/models/vilmodel_GOAT.py:803-839), one wave per
+// sample.  With gs / ls the raw scores of the global / local heads and fw the fusion weight (sigmoid of fwl, or 0.5):
+//   gl[g]    = masked_g ? -inf : gs[g] * fw               masked_g = visited | beyond the map (gvalid == 0 / g >= glens)
+//   ll[w]    = masked_w ? -inf : ls[w] * (1 - fw)
+//   fused[g] = gl[g] + sum_w M[g,w] * (masked_w ? 0 : ls[w] * (1 - fw))  (+ ll[0] on g == 0 when add_stop: the fine-tuning model)
+//   loss     = CE(gl, ga) + CE(ll, la) + CE(fused, ga)    (labels given; a negative label contributes 0)
+// The reference spells this as ~25 elementwise / masked_fill / bmm / log_softmax launches on [B, 22..64] tensors and twice as many
+// in the backward pass; each masked_fill(...) is a clone (a memcpy node of the step graph) plus a kernel.
+struct SapArgs {
+  const void* gs; const void* ls; const void* fwl;           // scores [B,G] / [B,W], fusion logit [B] (nullptr: fw = 0.5)
+  const uint8_t* gvis; const uint8_t* gvalid; const int64_t* glens; const uint8_t* lmask;
+  const float* M; const int64_t* ga; const int64_t* la;
+  float* gl; float* ll; float* fused; float* loss; float* lse;   // lse: [B,3]
+  const float* dloss; const float* dgl; const float* dll; const float* dfused;
+  void* dgs; void* dls; void* dfwl;
+  int B, G, W, lmask_is_valid, add_stop, fw_sigmoid;
+};
+
+__device__ __forceinline__ bool sap_gmasked(const SapArgs& p, int b, int g) {
+  bool m = false;
+  if (p.gvis) m = m || p.gvis[(int64_t)b * p.G + g] != 0;
+  if (p.gvalid) m = m || p.gvalid[(int64_t)b * p.G + g] == 0;
+  if (p.glens) m = m || g >= (int)p.glens[b];
+  return m;
+}
+__device__ __forceinline__ bool sap_lmasked(const SapArgs& p, int b, int w) {
+  if (!p.lmask) return false;
+  const bool v = p.lmask[(int64_t)b * p.W + w] != 0;
+  return p.lmask_is_valid ? !v : v;
+}
+template <typename T>
+__device__ __forceinline__ float sap_fw(const SapArgs& p, int b) {
+  if (!p.fwl) return 0.5f;
+  const float x = (float)reinterpret_cast<const T*>(p.fwl)[b];
+  return p.fw_sigmoid ? 1.f / (1.f + __expf(-x)) : x;
+}
+// log-sum-exp of n values held one-per-(lane, iteration) in LDS row v (−inf entries allowed; all −inf -> −inf)
+__device__ __forceinline__ float sap_lse(const float* v, int n, int lane) {
+  float m = -INFINITY;
+  for (int i = lane; i < n; i += 64) m = fmaxf(m, v[i]);
+  m = wave_max(m);
+  if (m == -INFINITY) return -INFINITY;
+  float s = 0.f;
+  for (int i = lane; i < n; i += 64) s += __expf(v[i] - m);
+  return m + __logf(wave_sum(s));
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void sap_fwd_kernel(SapArgs p) {
+  extern __shared__ float sm[];              // [G] gl | [W] ll | [W] ll zero-filled | [G] fused
+  float* s_gl = sm; float* s_ll = sm + p.G; float* s_lz = s_ll + p.W; float* s_fu = s_lz + p.W;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float fw = sap_fw<T>(p, b);
+  const T* gs = reinterpret_cast<const T*>(p.gs) + (int64_t)b * p.G;
+  const T* ls = reinterpret_cast<const T*>(p.ls) + (int64_t)b * p.W;
+  for (int g = lane; g < p.G; g += 64) {
+    const float v = sap_gmasked(p, b, g) ? -INFINITY : (float)gs[g] * fw;
+    s_gl[g] = v;
+    p.gl[(int64_t)b * p.G + g] = v;
+  }
+  for (int w = lane; w < p.W; w += 64) {
+    const bool m = sap_lmasked(p, b, w);
+    const float r = (float)ls[w] * (1.f - fw);
+    s_ll[w] = m ? -INFINITY : r;
+    s_lz[w] = m ? 0.f : r;
+    p.ll[(int64_t)b * p.W + w] = s_ll[w];
+  }
+  __syncthreads();
+  for (int g = lane; g < p.G; g += 64) {
+    float acc = 0.f;
+    if (p.M) {
+      const float* mr = p.M + ((int64_t)b * p.G + g) * p.W;
+      for (int w = 0; w < p.W; ++w) acc += mr[w] * s_lz[w];
+    }
+    float v = s_gl[g] + acc;
+    if (p.add_stop && g == 0) v += s_ll[0];
+    s_fu[g] = v;
+    p.fused[(int64_t)b * p.G + g] = v;
+  }
+  __syncthreads();
+  if (p.lse) {
+    const float lg = sap_lse(s_gl, p.G, lane), lw = sap_lse(s_ll, p.W, lane), lf = sap_lse(s_fu, p.G, lane);
+    if (lane == 0) {
+      p.lse[b * 3] = lg; p.lse[b * 3 + 1] = lw; p.lse[b * 3 + 2] = lf;
+      if (p.loss) {
+        const int ga = p.ga ? (int)p.ga[b] : -1, la = p.la ? (int)p.la[b] : -1;
+        float l = 0.f;
+        if (ga >= 0 && ga < p.G) l += (lg - s_gl[ga]) + (lf - s_fu[ga]);
+        if (la >= 0 && la < p.W) l += lw - s_ll[la];
+        p.loss[b] = l;
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void sap_bwd_kernel(SapArgs p) {
+  extern __shared__ float sm[];              // [G] d fused (total)
+  float* s_df = sm;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float fw = sap_fw<T>(p, b);
+  const T* gs = reinterpret_cast<const T*>(p.gs) + (int64_t)b * p.G;
+  const T* ls = reinterpret_cast<const T*>(p.ls) + (int64_t)b * p.W;
+  T* dgs = reinterpret_cast<T*>(p.dgs) + (int64_t)b * p.G;
+  T* dls = reinterpret_cast<T*>(p.dls) + (int64_t)b * p.W;
+  const float dl = p.dloss ? p.dloss[b] : 0.f;
+  const int ga = (p.dloss && p.ga) ? (int)p.ga[b] : -1, la = (p.dloss && p.la) ? (int)p.la[b] : -1;
+  const bool use_g = ga >= 0 && ga < p.G, use_l = la >= 0 && la < p.W;
+  const float lg = p.lse ? p.lse[b * 3] : 0.f, lw = p.lse ? p.lse[b * 3 + 1] : 0.f, lf = p.lse ? p.lse[b * 3 + 2] : 0.f;
+  float acc_fw = 0.f;
+  for (int g = lane; g < p.G; g += 64) {
+    const int64_t o = (int64_t)b * p.G + g;
+    float dg = p.dgl ? p.dgl[o] : 0.f, df = p.dfused ? p.dfused[o] : 0.f;
+    if (use_g) {
+      const float glv = p.gl[o], fuv = p.fused[o];
+      dg += dl * ((glv == -INFINITY ? 0.f : __expf(glv - lg)) - (g == ga ? 1.f : 0.f));
+      df += dl * ((fuv == -INFINITY ? 0.f : __expf(fuv - lf)) - (g == ga ? 1.f : 0.f));
+    }
+    s_df[g] = df;
+    const float dr = sap_gmasked(p, b, g) ? 0.f : dg + df;
+    dgs[g] = (T)(dr * fw);
+    acc_fw += dr * (float)gs[g];
+  }
+  __syncthreads();
+  for (int w = lane; w < p.W; w += 64) {
+    const int64_t o = (int64_t)b * p.W + w;
+    float dw = p.dll ? p.dll[o] : 0.f;
+    if (use_l) {
+      const float llv = p.ll[o];
+      dw += dl * ((llv == -INFINITY ? 0.f : __expf(llv - lw)) - (w == la ? 1.f : 0.f));
+    }
+    if (p.M) {
+      const float* mc = p.M + (int64_t)b * p.G * p.W + w;
+      for (int g = 0; g < p.G; ++g) dw += mc[(int64_t)g * p.W] * s_df[g];
+    }
+    if (p.add_stop && w == 0) dw += s_df[0];
+    const float dr = sap_lmasked(p, b, w) ? 0.f : dw;
+    dls[w] = (T)(dr * (1.f - fw));
+    acc_fw -= dr * (float)ls[w];
+  }
+  acc_fw = wave_sum(acc_fw);
+  if (lane == 0 && p.dfwl) reinterpret_cast<T*>(p.dfwl)[b] = (T)(p.fw_sigmoid ? acc_fw * fw * (1.f - fw) : acc_fw);
+}
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -500,6 +645,50 @@ extern "C" int goat_infonce_bwd(void* stream, const float* const* x_loc, const f
   q.row_groups = (Ba + 3) / 4;
   hipLaunchKernelGGL(infonce_bwd_kernel, dim3(q.nroles * q.row_groups, (H + 63) / 64), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), q);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+static int sap_check(const SapArgs& a, int dtype) {
+  if (!a.gs || !a.ls || !a.gl || !a.ll || !a.fused) return GOAT_E_ARG;
+  if (dtype != GOAT_BF16 && dtype != GOAT_F32) return GOAT_E_ARG;
+  if (a.B <= 0 || a.G <= 0 || a.W <= 0 || (size_t)(2 * a.G + 2 * a.W) * 4 > 64 * 1024) return GOAT_E_SHAPE;
+  return 0;
+}
+
+extern "C" int goat_sap_fuse_fwd(void* stream, int dtype, const void* gs, const void* ls, const void* fwl, int fw_sigmoid,
+                                 const uint8_t* gvis, const uint8_t* gvalid, const int64_t* glens, const uint8_t* lmask,
+                                 int lmask_is_valid, const float* M, int add_stop, const int64_t* ga, const int64_t* la, float* gl,
+                                 float* ll, float* fused, float* loss, float* lse, int B, int G, int W) {
+  SapArgs a = {};
+  a.gs = gs; a.ls = ls; a.fwl = fwl; a.fw_sigmoid = fw_sigmoid; a.gvis = gvis; a.gvalid = gvalid; a.glens = glens; a.lmask = lmask;
+  a.lmask_is_valid = lmask_is_valid; a.M = M; a.add_stop = add_stop; a.ga = ga; a.la = la; a.gl = gl; a.ll = ll; a.fused = fused;
+  a.loss = loss; a.lse = lse; a.B = B; a.G = G; a.W = W;
+  if (int e = sap_check(a, dtype)) return e;
+  if (loss && !lse) return GOAT_E_ARG;
+  const size_t smem = (size_t)(2 * G + 2 * W) * 4;
+  if (dtype == GOAT_BF16) hipLaunchKernelGGL(sap_fwd_kernel<bf16_t>, dim3(B), dim3(64), smem, reinterpret_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(sap_fwd_kernel<float>, dim3(B), dim3(64), smem, reinterpret_cast<hipStream_t>(stream), a);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_sap_fuse_bwd(void* stream, int dtype, const void* gs, const void* ls, const void* fwl, int fw_sigmoid,
+                                 const uint8_t* gvis, const uint8_t* gvalid, const int64_t* glens, const uint8_t* lmask,
+                                 int lmask_is_valid, const float* M, int add_stop, const int64_t* ga, const int64_t* la,
+                                 const float* gl, const float* ll, const float* fused, const float* lse, const float* dloss,
+                                 const float* dgl, const float* dll, const float* dfused, void* dgs, void* dls, void* dfwl, int B, int G,
+                                 int W) {
+  SapArgs a = {};
+  a.gs = gs; a.ls = ls; a.fwl = fwl; a.fw_sigmoid = fw_sigmoid; a.gvis = gvis; a.gvalid = gvalid; a.glens = glens; a.lmask = lmask;
+  a.lmask_is_valid = lmask_is_valid; a.M = M; a.add_stop = add_stop; a.ga = ga; a.la = la;
+  a.gl = const_cast<float*>(gl); a.ll = const_cast<float*>(ll); a.fused = const_cast<float*>(fused); a.lse = const_cast<float*>(lse);
+  a.dloss = dloss; a.dgl = dgl; a.dll = dll; a.dfused = dfused; a.dgs = dgs; a.dls = dls; a.dfwl = dfwl; a.B = B; a.G = G; a.W = W;
+  if (int e = sap_check(a, dtype)) return e;
+  if (!dgs || !dls || (dloss && !lse) || (fwl && !dfwl)) return GOAT_E_ARG;
+  const size_t smem = (size_t)G * 4;
+  if (dtype == GOAT_BF16) hipLaunchKernelGGL(sap_bwd_kernel<bf16_t>, dim3(B), dim3(64), smem, reinterpret_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(sap_bwd_kernel<float>, dim3(B), dim3(64), smem, reinterpret_cast<hipStream_t>(stream), a);
   GOAT_LAUNCH_CHECK();
   return 0;
 }

@@ -1743,6 +1743,77 @@ if not os.environ.get('GOAT_RETUNE'):       # (GOAT_RETUNE=1: start from an empt
     load_tuned()
 
 
+# ----------------------------------------------------------------------------- SAP logits / loss
+def _u8(t):
+    """bool / uint8 mask -> contiguous byte tensor (a view for bool: same storage)."""
+    if t is None:
+        return None
+    t = t if t.is_contiguous() else t.contiguous()
+    return t.view(torch.uint8) if t.dtype == torch.bool else t
+
+
+class _SapFuseFn(torch.autograd.Function):
+    """Tail of the single-action-prediction head in one launch per direction (goat_sap_fuse_fwd / _bwd; formulas in include/goat_hip.h;
+    P/model/pretrain_goat.py:375-413, M/models/vilmodel_GOAT.py:803-839).  -> (gl, ll, fused, loss); loss is None without labels."""
+
+    @staticmethod
+    def forward(ctx, gs, ls, fwl, fw_sigmoid, gvis, gvalid, glens, lmask, lmask_is_valid, M, add_stop, ga, la):
+        _need_gpu(gs)
+        ctx.set_materialize_grads(False)
+        B, G = gs.shape
+        W = ls.shape[1]
+        dt = gs.dtype
+        gs = gs.contiguous()
+        ls = ls.to(dt).contiguous()
+        ctx.fw_shape = None if fwl is None else fwl.shape
+        fwl = None if fwl is None else fwl.reshape(B).to(dt).contiguous()
+        gvis, gvalid, lmask = _u8(gvis), _u8(gvalid), _u8(lmask)
+        glens = None if glens is None else glens.to(torch.int64).contiguous()
+        M = None if M is None else M.float().contiguous()
+        ga = None if ga is None else ga.to(torch.int64).contiguous()
+        la = None if la is None else la.to(torch.int64).contiguous()
+        dev = gs.device
+        gl = torch.empty((B, G), dtype=torch.float32, device=dev)
+        ll = torch.empty((B, W), dtype=torch.float32, device=dev)
+        fused = torch.empty((B, G), dtype=torch.float32, device=dev)
+        labels = ga is not None
+        loss = torch.empty(B, dtype=torch.float32, device=dev) if labels else None
+        lse = torch.empty((B, 3), dtype=torch.float32, device=dev) if labels else None
+        P = lambda t: _ptr(t) if t is not None else None
+        ctx.cfg = (_dt(gs), int(bool(fw_sigmoid)), int(bool(lmask_is_valid)), int(bool(add_stop)), B, G, W)
+        st = _lib.lib().goat_sap_fuse_fwd(_stream(), ctx.cfg[0], _ptr(gs), _ptr(ls), P(fwl), ctx.cfg[1], P(gvis), P(gvalid), P(glens),
+                                          P(lmask), ctx.cfg[2], P(M), ctx.cfg[3], P(ga), P(la), _ptr(gl), _ptr(ll), _ptr(fused),
+                                          P(loss), P(lse), B, G, W)
+        _lib.check(st, 'goat_sap_fuse_fwd')
+        ctx.opt = (fwl, gvis, gvalid, glens, lmask, M, ga, la, lse)
+        ctx.save_for_backward(gs, ls, gl, ll, fused)
+        return gl, ll, fused, loss
+
+    @staticmethod
+    def backward(ctx, dgl, dll, dfused, dloss):
+        gs, ls, gl, ll, fused = ctx.saved_tensors
+        fwl, gvis, gvalid, glens, lmask, M, ga, la, lse = ctx.opt
+        dtc, fw_sig, lvalid, add_stop, B, G, W = ctx.cfg
+        f = lambda t: None if t is None else t.float().contiguous()
+        dgl, dll, dfused, dloss = f(dgl), f(dll), f(dfused), f(dloss)
+        dgs, dls = torch.empty_like(gs), torch.empty_like(ls)
+        dfw = torch.empty_like(fwl) if fwl is not None else None
+        P = lambda t: _ptr(t) if t is not None else None
+        st = _lib.lib().goat_sap_fuse_bwd(_stream(), dtc, _ptr(gs), _ptr(ls), P(fwl), fw_sig, P(gvis), P(gvalid), P(glens), P(lmask), lvalid,
+                                          P(M), add_stop, P(ga), P(la), _ptr(gl), _ptr(ll), _ptr(fused), P(lse), P(dloss), P(dgl), P(dll),
+                                          P(dfused), _ptr(dgs), _ptr(dls), P(dfw), B, G, W)
+        _lib.check(st, 'goat_sap_fuse_bwd')
+        return dgs, dls, (None if dfw is None else dfw.view(ctx.fw_shape)), None, None, None, None, None, None, None, None, None, None
+
+
+def sap_fuse(gs, ls, fwl=None, fw_sigmoid=True, gvis=None, gvalid=None, glens=None, lmask=None, lmask_is_valid=False, M=None,
+             add_stop=False, labels=None):
+    """gs [B,G] / ls [B,W] head scores, fwl [B] or [B,1] fusion logit (None: weight 0.5) -> (global logits, local logits, fused logits,
+    loss [B] or None), all float32.  labels = (global_act_labels, local_act_labels) adds the three cross-entropies."""
+    ga, la = labels if labels is not None else (None, None)
+    return _SapFuseFn.apply(gs, ls, fwl, fw_sigmoid, gvis, gvalid, glens, lmask, lmask_is_valid, M, add_stop, ga, la)
+
+
 # ----------------------------------------------------------------------------- CFP contrastive losses
 class _InfoNceFn(torch.autograd.Function):
     """loss[i] = sum_{x in gmap, vp, fused} 1/2 [CE(x_loc[i]·txt_all^T/tau, t0+i) + CE(txt_loc[i]·x_all^T/tau, t0+i)]

@@ -367,23 +367,16 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
             vp = self.front_local_encoder(vp, front_vp_feats, vp_masks)
         vp = le.encoder(vp, neg_mask(vp_masks), txt_embeds, txt_km, kv_cache=None if txt_kv is None else txt_kv['local'])
 
-        if self.sap_fuse_linear is None:
-            fw = 0.5
-        else:
-            fw = torch.sigmoid(self.sap_fuse_linear(torch.cat([gmap[:, 0], vp[:, 0]], 1)).float())
-        gl = self.global_sap_head(gmap).squeeze(2).float() * fw
-        ll = self.local_sap_head(vp).squeeze(2).float() * (1 - fw)
-        gl = gl.masked_fill(gmap_visited_masks, -float('inf')).masked_fill(gmap_masks.logical_not(), -float('inf'))
-        navm = vp_nav_masks.logical_not()
-        ll = ll.masked_fill(navm, -float('inf'))
-        fused = gl.clone()
-        add0 = torch.zeros_like(fused)
-        add0[:, 0] = ll[:, 0]
-        fused = fused + add0
+        # scores of the two heads -> masked global / local / fused logits in one launch per direction (hipops.sap_fuse; the
+        # reference's chain: M/models/vilmodel_GOAT.py:803-839).  The stop column of the fused logits takes the local stop logit.
+        fwl = None if self.sap_fuse_linear is None else self.sap_fuse_linear(torch.cat([gmap[:, 0], vp[:, 0]], 1))
+        M = None
         if not flops_count:
             M = nav_fusion if nav_fusion is not None else \
-                nav_fusion_matrix(vp_cand_vpids, gmap_vpids, gmap_visited_masks, G, ll.shape[1]).to(gl.device)
-            fused = fused + torch.bmm(M, ll.masked_fill(navm, 0.0).unsqueeze(2)).squeeze(2)
+                nav_fusion_matrix(vp_cand_vpids, gmap_vpids, gmap_visited_masks, G, vp.shape[1]).to(gmap.device)
+        gl, ll, fused, _ = hipops.sap_fuse(self.global_sap_head(gmap).squeeze(2), self.local_sap_head(vp).squeeze(2), fwl,
+                                           gvis=gmap_visited_masks, gvalid=gmap_masks, lmask=vp_nav_masks, lmask_is_valid=True, M=M,
+                                           add_stop=True)
         obj_logits = None
         if vp_obj_masks is not None and getattr(self.config, 'dataset', 'r2r') in ('reverie', 'soon'):
             obj_logits = self.og_head(vp).squeeze(2).float().masked_fill(vp_obj_masks.logical_not(), -float('inf'))

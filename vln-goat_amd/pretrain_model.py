@@ -540,26 +540,24 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
         cache = batch['_goat_cache']
         B, G = gmap.shape[:2]
         W = vp.shape[1]
-        fw = self._fuse_weights(gmap, vp)
-        gl = self.global_sap_head(gmap).squeeze(2).float() * fw
-        gl = gl.masked_fill(batch['gmap_visited_masks'], -float('inf'))
-        gl = gl.masked_fill(gen_seq_masks(batch['gmap_lens'], G).logical_not(), -float('inf'))
-        ll = self.local_sap_head(vp).squeeze(2).float() * (1 - fw)
         if 'sap' not in cache:
             step_lens = batch['traj_step_lens']
             last = torch.as_tensor(step_lens).cumsum(0) - 1
             nav = batch['traj_nav_types'][last.to(batch['traj_nav_types'].device)] != 1     # [B, V]
             nav = torch.cat([torch.zeros(B, 1, dtype=torch.bool, device=nav.device), nav], 1)[:, :W]
             M = graphmap.build_sap_fusion(batch['traj_cand_vpids'], batch['gmap_vpids'], batch['gmap_visited_masks'], G, W)
-            cache['sap'] = (nav, M.to(gl.device))
+            cache['sap'] = (nav, M.to(gmap.device))
         nav, M = cache['sap']
-        ll = ll.masked_fill(nav, -float('inf'))
-        fused = gl + torch.bmm(M, ll.masked_fill(nav, 0.0).unsqueeze(2)).squeeze(2)
+        # scores of the two heads -> masked global / local / fused logits (and the three cross-entropies) in ONE launch per direction
+        # (hipops.sap_fuse: the reference's * fw, masked_fill x4, bmm, log_softmax x3 ... are ~25 launches on [48, 22..37] tensors)
+        fwl = None if self.sap_fuse_linear is None else self.sap_fuse_linear(torch.cat([gmap[:, 0], vp[:, 0]], 1))
+        ga, la = batch['global_act_labels'], batch['local_act_labels']
+        gl, ll, fused, loss = hipops.sap_fuse(self.global_sap_head(gmap).squeeze(2), self.local_sap_head(vp).squeeze(2), fwl,
+                                              gvis=batch['gmap_visited_masks'], glens=batch['gmap_lens'], lmask=nav, M=M,
+                                              labels=(ga, la) if compute_loss else None)
         if compute_loss:
-            ga, la = batch['global_act_labels'], batch['local_act_labels']
-            return F.cross_entropy(gl, ga, reduction='none') + F.cross_entropy(ll, la, reduction='none') \
-                + F.cross_entropy(fused, ga, reduction='none')
-        return gl, ll, fused, batch['global_act_labels'], batch['local_act_labels']
+            return loss
+        return gl, ll, fused, ga, la
 
     # -- OG / MRC (local stream only) ---------------------------------------------------------------
     def _last_lens(self, batch):
