@@ -482,12 +482,15 @@ class Branch:
     _streams = {}                                                 # (eager launches are host-bound: no gain, more syncs); 'always'; '0'
     used = set()            # side streams with work since the last join_all()
 
-    def __init__(self, name):
+    off = set(filter(None, os.environ.get('GOAT_BRANCH_OFF', '').split(',')))     # (diagnostics: sites that run on the caller's stream)
+
+    def __init__(self, name, site=None):
         self.name = name
+        self.site = site
         self.side = None
 
     def __enter__(self):
-        if Branch.mode == '0' or not torch.cuda.is_available():
+        if Branch.mode == '0' or not torch.cuda.is_available() or self.site in Branch.off:
             return self
         if Branch.mode != 'always' and not torch.cuda.is_current_stream_capturing():
             return self

@@ -405,7 +405,7 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
             x, src = self._pano(batch)
         txt, _ = self._text(batch)
         br.join(x, src)
-        with hipops.Branch('global') as bg:
+        with hipops.Branch('global', 'cfp_enc') as bg:
             g, gm = self._gmap_in(batch, src, cache)
             gmap = self.global_encoder.tim_self_encoder(g, neg_mask(gm))
         v, vm = self._vp_in(batch, x, cache)
@@ -648,11 +648,11 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
     def forward_cfp(self, batch, compute_loss):
         gmap, vp, txt = self.bert.forward_cfp(batch)
         cache = batch.get('_goat_cache') or {}
-        with hipops.Branch('global') as bg:          # the three heads are independent: map / text on side streams
+        with hipops.Branch('global', 'cfp_heads') as bg:          # the three heads are independent: map / text on side streams
             if batch['extra_heads']:
                 gmap = self.tim_global_head(gmap)
             go = attn_pool(gmap, self.tim_global_attn, cache.get('cfp_gmap_mask'))
-        with hipops.Branch('pano') as bt:
+        with hipops.Branch('pano', 'cfp_heads') as bt:
             if batch['extra_heads']:
                 txt = self.tim_txt_head(txt)
             to = attn_pool(txt, self.tim_txt_attn, cache.get('cfp_txt_mask'))
