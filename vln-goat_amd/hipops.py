@@ -176,6 +176,8 @@ def refresh_shadows(param, by_id, done=()):
             t.copy_(_build_catb(members))
         elif key[0] == 'rowpad':
             t.copy_(_build_rows_padded(param, key[1], key[2]))
+        elif key[0] == 'bpad':
+            t.copy_(_build_bias_padded(param, key[1]))
         else:
             t.copy_(_build_shadow(param, key[0], key[1], key[2]))
         n += 1
@@ -1037,6 +1039,24 @@ def ffn(x, w1, b1, w2, b2, act='gelu', p=0.0):
 
 
 # ----------------------------------------------------------------------------- tied decoder + cross-entropy (MLM)
+def _build_bias_padded(bias, n):
+    with torch.no_grad():
+        b = torch.zeros(n, dtype=torch.float32, device=bias.device)
+        b[:bias.numel()] = bias.detach().float()
+        return b
+
+
+def _bias_padded(bias, n):
+    """float32 [n] copy of a bias with zeros behind it (the 64-padded vocabulary of the MLM decoder), cached like _shadow: built
+    once, refreshed in place — not a fill + a copy in every step."""
+    key = ('bpad', n)
+    cache = bias.__dict__.setdefault('_goat_shadow', {})
+    ent = cache.get(key)
+    if ent is not None and ent[0] == bias._version and ent[1].device == bias.device:
+        return ent[1]
+    return _store_shadow(cache, key, bias._version, _build_bias_padded(bias, n))
+
+
 def _shadow_rows_padded(param, dtype, rows):
     """[rows, K] copy of a [N, K] weight (N <= rows, extra rows zero), cached like _shadow."""
     key = ('rowpad', dtype, rows)
@@ -1064,8 +1084,7 @@ class _DecoderCeFn(torch.autograd.Function):
         Np = (N + 63) // 64 * 64
         W = _shadow_rows_padded(weight, h2.dtype, Np)
         Nl = W.shape[0]
-        bpad = torch.zeros(Nl, dtype=torch.float32, device=h.device)
-        bpad[:N] = bias.detach()
+        bpad = _bias_padded(bias, Nl)
         logits = torch.empty((M, Nl), dtype=torch.float32, device=h.device)
         gemm(h2, W, logits, bias=bpad)
         loss = torch.empty(M, dtype=torch.float32, device=h.device)

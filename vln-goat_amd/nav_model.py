@@ -379,7 +379,7 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
                                            add_stop=True)
         obj_logits = None
         if vp_obj_masks is not None and getattr(self.config, 'dataset', 'r2r') in ('reverie', 'soon'):
-            obj_logits = self.og_head(vp).squeeze(2).float().masked_fill(vp_obj_masks.logical_not(), -float('inf'))
+            obj_logits = torch.where(vp_obj_masks, self.og_head(vp).squeeze(2).float(), -float('inf'))      # (no clone: see pretrain_model.forward_og)
         cls = torch.cat((self.gmap_pooler(gmap), self.vp_pooler(vp), self.txt_pooler(txt_embeds)), dim=-1)
         cls_embeds = self.local_his_ln(self.local_his_map(cls))
         return {'gmap_embeds': gmap, 'vp_embeds': vp, 'global_logits': gl, 'local_logits': ll, 'fused_logits': fused,

@@ -114,6 +114,9 @@ class FusedAdamW:
                 elif k[0] == 'rowpad':
                     if t.dtype == torch.bfloat16 and t.shape[1:] == p.shape[1:] and t.shape[0] >= p.shape[0]:
                         whole.append((t, [(id(p), 'bf16', t.data_ptr())]))
+                elif k[0] == 'bpad':          # zero-padded float32 image of a bias: the leading numel(p) floats are the bias
+                    if t.dtype == torch.float32 and t.numel() >= p.numel():
+                        whole.append((t, [(id(p), 'f32', t.data_ptr())]))
                 elif k[0] == torch.bfloat16 and k[1] is False and t.dtype == torch.bfloat16:
                     if k[2] == 0:
                         whole.append((t, [(id(p), 'bf16', t.data_ptr())]))

@@ -586,7 +586,8 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
                 msk[b, :o] = True
             cache['og_idx'] = (idx.to(vp.device), msk.to(vp.device))
         idx, msk = cache['og_idx']
-        logits = self.og_head(vp).squeeze(2).float().gather(1, idx).masked_fill(msk.logical_not(), -float('inf'))
+        # (torch.where, not masked_fill: the latter clones first, and a clone is a memcpy NODE of the captured step graph — §4c of DESIGN.md)
+        logits = torch.where(msk, self.og_head(vp).squeeze(2).float().gather(1, idx), -float('inf'))
         if compute_loss:
             return F.cross_entropy(logits, batch['obj_labels'], reduction='none')
         return logits
