@@ -991,9 +991,13 @@ def navigator_leg(args, model, ep, arena, B, T, frozen_s):
               'navigation': {'front_txt_feats': ep['front_txt_feats'], 'front_vp_feats': ep['front_vp_feats'],
                              'front_gmap_feats': ep['front_gmap_feats']}}
     import time
-    t0 = time.perf_counter()
-    plans = [te.plan(batches[0])]
-    plan_ms = (time.perf_counter() - t0) * 1e3
+    plans = [te.plan(batches[0])]              # (cold: shortest-path tables of the scans are built on first use)
+    ts = []
+    for k in (1, 2, 3):
+        t0 = time.perf_counter()
+        te.plan(batches[k])
+        ts.append((time.perf_counter() - t0) * 1e3)
+    plan_ms = sorted(ts)[1]                     # steady-state host work per batch of episodes (hidden under the previous replay)
     bufs = rollout.EpisodeBuffers(plans[0])
     call = lambda mode, batch: model(mode, batch)
     params = list(model.parameters())
