@@ -119,7 +119,12 @@ int goat_ln_fwd(void* stream, int dtype, const void* x, const void* residual,
  *   row counts; deterministic).
  * dx_add (may be NULL; same shape / dtype as dx): added to dx on store — the gradient that reaches the LayerNorm's INPUT through
  *   its other consumer (the skip connection around a pre-LN sub-layer, P/model/transformer.py:170-182), so autograd launches no
- *   add kernel for that junction (hipops.layer_norm(fork_in=True)). */
+ *   add kernel for that junction (hipops.layer_norm(fork_in=True)).
+ *   accumulate | GOAT_LN_ADD_BEFORE: dx_add is instead the gradient that reaches the PRE-NORM SUM z = residual + dropout(x) through
+ *   its other consumer and joins before the residual / dropout split: d_res <- dz + dx_add, dx <- (dz + dx_add) * mask / (1 - p).
+ *   With it one goat_ln_fwd / goat_ln_bwd pair serves "src = skip + dropout(a); n = LayerNorm(src)" of a pre-LN block, where src
+ *   itself continues as the next skip connection (hipops.layer_norm(z_out=True)). */
+#define GOAT_LN_ADD_BEFORE 4
 typedef struct goat_ln_partial {
   const float* ws;         /* partials written by goat_ln_bwd(..., accumulate = 2): [nparts][2][H] float32 */
   float* dgamma;           /* float32[H], ADDED to */

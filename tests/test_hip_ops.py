@@ -931,3 +931,42 @@ def test_sap_fuse_matches_the_reference_chain(ops, dtype, form, B, G, W):
                 if r is None:
                     continue
                 assert float((t.grad.float() - r).abs().max()) <= 2 * tol * max(1.0, float(r.abs().max())), (what, with_fw, labels)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('p', [0.0, 0.3])
+def test_layer_norm_z_out_fuses_the_residual_junction_in_front(ops, dtype, p):
+    """hipops.layer_norm(x, residual, p, z_out=True) -> (LayerNorm(z), z), z = residual + dropout_p(x): the junction of a pre-LN block
+    (P/model/transformer.py:172-176) and the LayerNorm behind it in one launch per direction.  z is used twice downstream (skip
+    connection + through the norm): its second gradient joins inside the backward kernel (GOAT_LN_ADD_BEFORE).  Checked against
+    torch with the dropout mask recovered from the zeros of dx."""
+    g = torch.Generator().manual_seed(9)
+    M, H = 300, 768
+    x0 = torch.randn(2, M // 2, H, generator=g).to(DEV, dtype)
+    r0 = torch.randn(2, M // 2, H, generator=g).to(DEV, dtype)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV).requires_grad_(True)
+    beta = (0.1 * torch.randn(H, generator=g)).to(DEV).requires_grad_(True)
+    wy = torch.randn(2, M // 2, H, generator=g).to(DEV)
+    wz = torch.randn(2, M // 2, H, generator=g).to(DEV)
+    x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+    ops.manual_seed(77)
+    y, z = ops.layer_norm(x, gamma, beta, 1e-5, r, p, z_out=True)
+    ((y.float() * wy).sum() + (z.float() * wz).sum()).backward()
+    got = [t.grad.float().clone() for t in (x, r, gamma, beta)]
+    # reference with the same mask
+    # (a dropped element receives exactly zero gradient; a kept one a non-zero one up to measure-zero coincidences)
+    keep = torch.ones(x0.shape, dtype=torch.bool, device=DEV) if p == 0 else (got[0] != 0)
+    scale = 1.0 / (1.0 - p)
+    if p > 0:
+        frac = float(keep.float().mean())
+        assert abs(frac - (1 - p)) < 0.02
+    xr, rr = x0.float().clone().requires_grad_(True), r0.float().clone().requires_grad_(True)
+    g2, b2 = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    zr = rr + torch.where(keep, xr * scale, torch.zeros_like(xr))
+    yr = torch.nn.functional.layer_norm(zr, (H,), g2, b2, 1e-5)
+    ((yr * wy).sum() + (zr * wz).sum()).backward()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert float((z.float() - zr).abs().max()) <= tol * max(1.0, float(zr.abs().max()))
+    assert float((y.float() - yr).abs().max()) <= tol * max(1.0, float(yr.abs().max()))
+    for a, b, what in zip(got, (xr.grad, rr.grad, g2.grad, b2.grad), ('dx', 'dresidual', 'dgamma', 'dbeta')):
+        assert float((a - b).abs().max()) <= 2 * tol * max(1.0, float(b.abs().max())), what

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(const T* __restrict__ 
                                                      uint64_t offset, const uint64_t* __restrict__ rng_dev,
                                                      T* __restrict__ dx, T* __restrict__ dres,
                                                      float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     const T* __restrict__ dx_add, int M, int H) {
+                                                     const T* __restrict__ dx_add, int pre_add, int M, int H) {
   constexpr int EPC = DT<T>::EPC;
   extern __shared__ float lsum[];  // [NWV][2][H]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -182,6 +182,12 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(const T* __restrict__ 
           asm volatile("" ::"v"(o.v[0]), "v"(o.v[EPC - 1]));
           continue;
 #endif
+          if (dx_add && pre_add) {     // gradient arriving at the PRE-NORM SUM z = residual + dropout(x) through its other consumer (the
+            Chunk<T> t;                // skip connection that continues behind this LayerNorm): joins before the residual / dropout split
+            t.load(dx_add + base);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.v[e] += t.v[e];
+          }
           if (dres) o.store_stream(dres + base);
 #if GOAT_LN_ABL & 2
           if (false) {
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(const T* __restrict__ 
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o.v[e] = ((km >> e) & 1u) ? o.v[e] * ks : 0.f;
           }
-          if (dx_add) {     // gradient of x arriving through its OTHER consumer (the skip connection of a pre-LN block): summed on store
+          if (dx_add && !pre_add) {     // gradient of x arriving through its OTHER consumer (the skip connection of a pre-LN block): summed on store
             Chunk<T> t;
             t.load(dx_add + base);
 #pragma unroll
@@ -1118,6 +1124,8 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
   // 512 four-wave blocks made the kernel 20 us instead of 12 + 5 (profiles/round2_ln_bench.txt)
   // accumulate == 2: the per-block partials stay in ws (goat_ln_bwd_nparts(M) rows of 2*H floats) and the caller reduces them
   // later with goat_ln_reduce_batched — the column reduction was 6.8 of the kernel's 15.8 us at 3840 rows (profiles/round2_ln_bench.txt)
+  const int pre_add = (accumulate & 4) ? 1 : 0;      // GOAT_LN_ADD_BEFORE: dx_add joins the gradient of the pre-norm sum (see goat_hip.h)
+  accumulate &= 3;
   const bool defer = accumulate == 2;
   if (defer && ws == nullptr) return GOAT_E_ARG;
   const bool det = ws != nullptr && !defer;
@@ -1145,7 +1153,7 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
       }                                                                                                                       \
     }                                                                                                                         \
     hipLaunchKernelGGL(kern_, dim3(nparts), dim3(64 * NWV_), sm, ST(stream), (const T_*)dy, (const T_*)dy2, (const T_*)z, gamma, mean, \
-                       rstd, p, seed, offset, rng_dev, (T_*)dx, (T_*)d_res, ws, dgamma, dbeta, (const T_*)dx_add, M, H);      \
+                       rstd, p, seed, offset, rng_dev, (T_*)dx, (T_*)d_res, ws, dgamma, dbeta, (const T_*)dx_add, pre_add, M, H); \
   } while (0)
   if (dtype == GOAT_BF16) {
     if (int e = ln_check<bf16_t>(H)) return e;

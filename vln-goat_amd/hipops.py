@@ -1195,12 +1195,14 @@ class _LnFn(torch.autograd.Function):
     load (goat_ln_bwd's dy2), which replaces the elementwise add autograd would otherwise launch for the shared tensor."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, p, fork=False, fork_in=False):
+    def forward(ctx, x, residual, gamma, beta, eps, p, fork=False, fork_in=False, z_out=False):
         _need_gpu(x)
         ctx.set_materialize_grads(False)
         if fork_in and (fork or residual is not None):
             raise ValueError('fork_in is for the plain LayerNorm(x) of a pre-LN block')
-        ctx.fork_in = fork_in
+        if z_out and (fork or fork_in or residual is None):
+            raise ValueError('z_out returns the pre-norm sum residual + dropout(x): it needs a residual')
+        ctx.fork_in, ctx.z_out = fork_in, z_out
         H = x.shape[-1]
         x2 = x.reshape(-1, H)
         if not x2.is_contiguous():
@@ -1227,6 +1229,8 @@ class _LnFn(torch.autograd.Function):
         ctx.gb = (gamma, beta)
         ctx.shape = x.shape
         yv = y.view(x.shape)
+        if z_out:       # second output: the pre-norm sum z = residual + dropout(x), the hidden state of a pre-LN stack; the gradient it
+            return yv, z.view(x.shape)      # collects behind this LayerNorm comes back to THIS node (GOAT_LN_ADD_BEFORE)
         if fork_in:     # second output: x itself for the skip connection; its gradient comes back to THIS node (dx_add of the kernel)
             return yv, x.view_as(x)
         return (yv, yv.view_as(yv)) if fork else yv
@@ -1234,13 +1238,16 @@ class _LnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dyb=None):
         dskip = None
-        if ctx.fork_in:
+        if ctx.fork_in or ctx.z_out:
             dskip, dyb = dyb, None
-            if dy is None:                     # only the skip connection carried a gradient
-                return dskip, None, None, None, None, None, None, None
-        if dy is None:
-            dy, dyb = dyb, None
+            if dy is None and ctx.fork_in:     # only the skip connection carried a gradient
+                return dskip, None, None, None, None, None, None, None, None
         z, gamma, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            if ctx.z_out:                      # the normalised output went unused: only the pre-norm sum carried a gradient
+                dy = torch.zeros(ctx.shape, dtype=z.dtype, device=z.device)
+            else:
+                dy, dyb = dyb, None
         p, seed, off, dev = ctx.rng
         H = z.shape[-1]
         dy2 = dy.reshape(-1, H)
@@ -1281,7 +1288,8 @@ class _LnFn(torch.autograd.Function):
             ws = torch.empty(L.goat_ln_bwd_ws_floats(H), dtype=torch.float32, device=z.device) if (LN_DETERMINISTIC or M > LN_ATOMIC_MAX_ROWS) else None
         st = L.goat_ln_bwd(_stream(), _dt(z), _ptr(dy2), _ptr(dyb) if dyb is not None else None, _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd),
                            p, seed, off, dev, _ptr(dx), _ptr(dres) if dres is not None else None,
-                           _ptr(dg), _ptr(db), _ptr(ws) if ws is not None else None, M, H, acc, _ptr(dskip) if dskip is not None else None)
+                           _ptr(dg), _ptr(db), _ptr(ws) if ws is not None else None, M, H,
+                           acc | (4 if (ctx.z_out and dskip is not None) else 0), _ptr(dskip) if dskip is not None else None)
         _lib.check(st, 'goat_ln_bwd')
         if defer:
             LnReduceQueue.push(ws, dg, db, nparts, H)
@@ -1292,13 +1300,16 @@ class _LnFn(torch.autograd.Function):
             dr = dres.view(ctx.shape) if dres is not None else dxv
         else:
             dr = None
-        return dxv, dr, dg, db, None, None, None, None
+        return dxv, dr, dg, db, None, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps, residual=None, p=0.0, fork=False, fork_in=False):
+def layer_norm(x, gamma, beta, eps, residual=None, p=0.0, fork=False, fork_in=False, z_out=False):
     """fork_in=True (pre-LN blocks): returns (LayerNorm(x), x) — use the second output for the skip connection; the gradient it
-    receives is added inside the LayerNorm backward kernel instead of by an autograd add."""
-    return _LnFn.apply(x, residual, gamma, beta, float(eps), float(p), bool(fork), bool(fork_in))
+    receives is added inside the LayerNorm backward kernel instead of by an autograd add.
+    z_out=True (pre-LN blocks, with residual): returns (LayerNorm(z), z) with z = residual + dropout_p(x) — the residual junction in
+    FRONT of the LayerNorm and the LayerNorm in one launch per direction; z continues as the block's hidden state and the gradient
+    it collects later joins inside this LayerNorm's backward kernel."""
+    return _LnFn.apply(x, residual, gamma, beta, float(eps), float(p), bool(fork), bool(fork_in), bool(z_out))
 
 
 class _DropAddFn(torch.autograd.Function):

@@ -116,13 +116,17 @@ class Linear(nn.Linear):
 
 _NO_FORK_IN = bool(os.environ.get('GOAT_NO_LN_FORK_IN'))
 _NO_FORK = bool(os.environ.get('GOAT_NO_LN_FORK'))      # (diagnostics: A/B of the forked LayerNorm outputs)
+_NO_ZOUT = bool(os.environ.get('GOAT_NO_LN_ZOUT'))      # (diagnostics: the pre-LN residual junctions as kernels of their own)
 
 
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x, residual=None, p=0.0, fork=False, fork_in=False):
+    def forward(self, x, residual=None, p=0.0, fork=False, fork_in=False, z_out=False):
         if fork_in and (_NO_FORK or _NO_FORK_IN):
             return hipops.layer_norm(x, self.weight, self.bias, self.eps), x
-        return hipops.layer_norm(x, self.weight, self.bias, self.eps, residual, p, fork and not _NO_FORK, fork_in)
+        if z_out and (_NO_FORK or _NO_FORK_IN or _NO_ZOUT):          # (diagnostics: the junction as its own kernel again)
+            z = hipops.dropout_add(x, residual, p)
+            return hipops.layer_norm(z, self.weight, self.bias, self.eps), z
+        return hipops.layer_norm(x, self.weight, self.bias, self.eps, residual, p, fork and not _NO_FORK, fork_in, z_out)
 
 
 def _pair(h):
@@ -388,17 +392,23 @@ class TransformerEncoderLayer(nn.Module):
         self.dropout1 = nn.Dropout(dropout)
         self.dropout2 = nn.Dropout(dropout)
 
-    def forward(self, src, kmask):
-        # forward_pre (P/model/transformer.py:170-182); attention-prob dropout = the layer's dropout value
+    def forward(self, src, kmask, normed=None, next_norm=None):
+        """forward_pre (P/model/transformer.py:170-182); attention-prob dropout = the layer's dropout value.
+        Each residual junction `src + dropout(sub-layer)` is computed by the LayerNorm kernel that FOLLOWS it (z_out): norm2 for the
+        attention junction, `next_norm` (the next layer's norm1 or the stack's final norm) for the feed-forward junction.
+        normed: norm1(src) if the previous layer already computed it.  -> (src, next_norm(src) or None)"""
         p_attn = self.self_attn.dropout if self.training else 0.0
-        # (fork_in: the LayerNorm hands its input back for the skip connection, so both gradients of `src` meet inside its backward)
-        n1, skip = self.norm1(src, fork_in=True)
-        a = self.self_attn(n1, kmask, p_attn)
-        src = hipops.dropout_add(a, skip, _p(self.dropout1))
-        n2, skip = self.norm2(src, fork_in=True)
+        if normed is None:
+            # (fork_in: the LayerNorm hands its input back for the skip connection, so both gradients of `src` meet inside its backward)
+            normed, src = self.norm1(src, fork_in=True)
+        a = self.self_attn(normed, kmask, p_attn)
+        n2, src = self.norm2(a, residual=src, p=_p(self.dropout1), z_out=True)
         y = hipops.ffn(n2, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                        'gelu', _p(self.dropout))
-        return hipops.dropout_add(y, skip, _p(self.dropout2))
+        if next_norm is None:
+            return hipops.dropout_add(y, src, _p(self.dropout2)), None
+        nxt, src = next_norm(y, residual=src, p=_p(self.dropout2), z_out=True)
+        return src, nxt
 
 
 class TransformerEncoder(nn.Module):
@@ -414,12 +424,11 @@ class TransformerEncoder(nn.Module):
     def forward(self, src, valid_masks):
         """src [N,V,H] batch-first; valid_masks bool [N,V] (True = real view)."""
         kmask = inf_mask(valid_masks)
-        out = src
-        for layer in self.layers:
-            out = layer(out, kmask)
-        if self.norm is not None:
-            out = self.norm(out)
-        return out
+        out, normed = src, None
+        for i, layer in enumerate(self.layers):
+            nxt = self.layers[i + 1].norm1 if i + 1 < len(self.layers) else self.norm
+            out, normed = layer(out, kmask, normed, nxt)
+        return normed if self.norm is not None else out
 
 
 def create_transformer_encoder(config, num_layers, norm=False):
