@@ -970,3 +970,29 @@ def test_layer_norm_z_out_fuses_the_residual_junction_in_front(ops, dtype, p):
     assert float((y.float() - yr).abs().max()) <= tol * max(1.0, float(yr.abs().max()))
     for a, b, what in zip(got, (xr.grad, rr.grad, g2.grad, b2.grad), ('dx', 'dresidual', 'dgamma', 'dbeta')):
         assert float((a - b).abs().max()) <= 2 * tol * max(1.0, float(b.abs().max())), what
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_layer_norm_output_dropout_in_the_same_launch(ops, dtype):
+    """hipops.layer_norm(..., p_out): y = dropout(LayerNorm(x)) (the embedding blocks, P/model/Bert_backbone.py:108-110) in one launch per
+    direction; mask recovered from the zeros of y, forward and all gradients against torch with that mask; keep rate checked."""
+    g = torch.Generator().manual_seed(4)
+    M, H, p = 260, 768, 0.25
+    x0 = torch.randn(M, H, generator=g).to(DEV, dtype)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV).requires_grad_(True)
+    beta = (0.5 + 0.1 * torch.randn(H, generator=g)).to(DEV).requires_grad_(True)
+    w = torch.randn(M, H, generator=g).to(DEV)
+    x = x0.clone().requires_grad_(True)
+    ops.manual_seed(5)
+    y = ops.layer_norm(x, gamma, beta, 1e-12, p_out=p)
+    (y.float() * w).sum().backward()
+    keep = y.detach() != 0
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
+    xr = x0.float().clone().requires_grad_(True)
+    g2, b2 = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    yr = torch.where(keep, torch.nn.functional.layer_norm(xr, (H,), g2, b2, 1e-12) / (1 - p), torch.zeros_like(xr))
+    (yr * w).sum().backward()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert float((y.float() - yr).abs().max()) <= tol * max(1.0, float(yr.abs().max()))
+    for a, b, what in ((x.grad.float(), xr.grad, 'dx'), (gamma.grad, g2.grad, 'dgamma'), (beta.grad, b2.grad, 'dbeta')):
+        assert float((a - b).abs().max()) <= 2 * tol * max(1.0, float(b.abs().max())), what

@@ -1195,7 +1195,7 @@ class _LnFn(torch.autograd.Function):
     load (goat_ln_bwd's dy2), which replaces the elementwise add autograd would otherwise launch for the shared tensor."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, p, fork=False, fork_in=False, z_out=False):
+    def forward(ctx, x, residual, gamma, beta, eps, p, fork=False, fork_in=False, z_out=False, p_out=0.0):
         _need_gpu(x)
         ctx.set_materialize_grads(False)
         if fork_in and (fork or residual is not None):
@@ -1219,12 +1219,19 @@ class _LnFn(torch.autograd.Function):
         mean = torch.empty(M, dtype=torch.float32, device=x.device)
         rstd = torch.empty(M, dtype=torch.float32, device=x.device)
         seed, off, dev = RngState.next(x2.numel()) if p > 0 else (0, 0, None)
-        st = _lib.lib().goat_ln_fwd(_stream(), _dt(x2), _ptr(x2), _ptr(r2) if r2 is not None else None,
-                                    _ptr(gamma), _ptr(beta), eps, p, seed, off, dev,
-                                    _ptr(y), _ptr(z) if z is not None else None, _ptr(mean), _ptr(rstd), M, H)
+        off_out = 0
+        if p_out > 0:                        # dropout on the output: a second counter range of the same stream
+            s2, off_out, d2 = RngState.next(x2.numel())
+            if p > 0:
+                assert s2 == seed
+            seed, dev = s2, d2
+        st = _lib.lib().goat_ln_fwd_do(_stream(), _dt(x2), _ptr(x2), _ptr(r2) if r2 is not None else None,
+                                       _ptr(gamma), _ptr(beta), eps, p, seed, off, dev,
+                                       _ptr(y), _ptr(z) if z is not None else None, _ptr(mean), _ptr(rstd), M, H, p_out, off_out)
         _lib.check(st, 'goat_ln_fwd')
         ctx.save_for_backward(z if z is not None else x2, gamma, mean, rstd)
         ctx.rng = (p, seed, off, dev)
+        ctx.out_drop = (p_out, off_out)
         ctx.has_res = residual is not None
         ctx.gb = (gamma, beta)
         ctx.shape = x.shape
@@ -1241,7 +1248,7 @@ class _LnFn(torch.autograd.Function):
         if ctx.fork_in or ctx.z_out:
             dskip, dyb = dyb, None
             if dy is None and ctx.fork_in:     # only the skip connection carried a gradient
-                return dskip, None, None, None, None, None, None, None, None
+                return dskip, None, None, None, None, None, None, None, None, None
         z, gamma, mean, rstd = ctx.saved_tensors
         if dy is None:
             if ctx.z_out:                      # the normalised output went unused: only the pre-norm sum carried a gradient
@@ -1286,10 +1293,11 @@ class _LnFn(torch.autograd.Function):
             acc = 2
         else:
             ws = torch.empty(L.goat_ln_bwd_ws_floats(H), dtype=torch.float32, device=z.device) if (LN_DETERMINISTIC or M > LN_ATOMIC_MAX_ROWS) else None
-        st = L.goat_ln_bwd(_stream(), _dt(z), _ptr(dy2), _ptr(dyb) if dyb is not None else None, _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd),
-                           p, seed, off, dev, _ptr(dx), _ptr(dres) if dres is not None else None,
-                           _ptr(dg), _ptr(db), _ptr(ws) if ws is not None else None, M, H,
-                           acc | (4 if (ctx.z_out and dskip is not None) else 0), _ptr(dskip) if dskip is not None else None)
+        st = L.goat_ln_bwd_do(_stream(), _dt(z), _ptr(dy2), _ptr(dyb) if dyb is not None else None, _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd),
+                              p, seed, off, dev, _ptr(dx), _ptr(dres) if dres is not None else None,
+                              _ptr(dg), _ptr(db), _ptr(ws) if ws is not None else None, M, H,
+                              acc | (4 if (ctx.z_out and dskip is not None) else 0), _ptr(dskip) if dskip is not None else None,
+                              ctx.out_drop[0], ctx.out_drop[1])
         _lib.check(st, 'goat_ln_bwd')
         if defer:
             LnReduceQueue.push(ws, dg, db, nparts, H)
@@ -1300,16 +1308,17 @@ class _LnFn(torch.autograd.Function):
             dr = dres.view(ctx.shape) if dres is not None else dxv
         else:
             dr = None
-        return dxv, dr, dg, db, None, None, None, None, None
+        return dxv, dr, dg, db, None, None, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps, residual=None, p=0.0, fork=False, fork_in=False, z_out=False):
+def layer_norm(x, gamma, beta, eps, residual=None, p=0.0, fork=False, fork_in=False, z_out=False, p_out=0.0):
     """fork_in=True (pre-LN blocks): returns (LayerNorm(x), x) — use the second output for the skip connection; the gradient it
     receives is added inside the LayerNorm backward kernel instead of by an autograd add.
     z_out=True (pre-LN blocks, with residual): returns (LayerNorm(z), z) with z = residual + dropout_p(x) — the residual junction in
     FRONT of the LayerNorm and the LayerNorm in one launch per direction; z continues as the block's hidden state and the gradient
-    it collects later joins inside this LayerNorm's backward kernel."""
-    return _LnFn.apply(x, residual, gamma, beta, float(eps), float(p), bool(fork), bool(fork_in), bool(z_out))
+    it collects later joins inside this LayerNorm's backward kernel.
+    p_out: dropout on the LayerNorm's output in the same launch (the embedding blocks' dropout(LayerNorm(e)))."""
+    return _LnFn.apply(x, residual, gamma, beta, float(eps), float(p), bool(fork), bool(fork_in), bool(z_out), float(p_out))
 
 
 class _DropAddFn(torch.autograd.Function):

@@ -120,13 +120,16 @@ _NO_ZOUT = bool(os.environ.get('GOAT_NO_LN_ZOUT'))      # (diagnostics: the pre-
 
 
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x, residual=None, p=0.0, fork=False, fork_in=False, z_out=False):
+    def forward(self, x, residual=None, p=0.0, fork=False, fork_in=False, z_out=False, p_out=0.0):
+        """p_out: dropout on the output, in the same launch (dropout(LayerNorm(x)) of the embedding blocks)."""
+        if p_out and _NO_ZOUT:                           # (diagnostics: the output dropout as a kernel of its own)
+            return hipops.dropout(self.forward(x, residual, p, fork, fork_in, z_out), p_out)
         if fork_in and (_NO_FORK or _NO_FORK_IN):
             return hipops.layer_norm(x, self.weight, self.bias, self.eps), x
         if z_out and (_NO_FORK or _NO_FORK_IN or _NO_ZOUT):          # (diagnostics: the junction as its own kernel again)
             z = hipops.dropout_add(x, residual, p)
             return hipops.layer_norm(z, self.weight, self.bias, self.eps), z
-        return hipops.layer_norm(x, self.weight, self.bias, self.eps, residual, p, fork and not _NO_FORK, fork_in, z_out)
+        return hipops.layer_norm(x, self.weight, self.bias, self.eps, residual, p, fork and not _NO_FORK, fork_in, z_out, p_out)
 
 
 def _pair(h):
@@ -167,8 +170,7 @@ class RobertaEmbeddings(nn.Module):
         e = hipops.embedding(input_ids, self.word_embeddings.weight, self.token_type_embeddings.weight, token_type_ids,
                              self.position_embeddings.weight, out_dtype=compute_dtype(),
                              word_pad=self.word_embeddings.padding_idx, pos_pad=self.position_embeddings.padding_idx)
-        e = self.LayerNorm(e)
-        return hipops.dropout(e, _p(self.dropout))
+        return self.LayerNorm(e, p_out=_p(self.dropout))       # dropout(LayerNorm(e)) in one launch per direction
 
 
 class BertSelfAttention(nn.Module):

@@ -208,7 +208,7 @@ class CausalImageEmbeddings(nn.Module):
             x = hipops.gather_segmean(src, ci[0].to(x.device), ci[1].to(x.device), None, N * W).view(N, W, H)
             x = x + self.loc_layer_norm(self.loc_linear(loc_fts.to(dt))) \
                 + hipops.embedding(nav_types, self.nav_type_embedding.weight, out_dtype=dt)
-            x = hipops.dropout(self.layer_norm(x), _p(self.dropout))
+            x = self.layer_norm(x, p_out=_p(self.dropout))
             masks = gen_seq_masks(view_lens + obj_lens, W)
             x = self.pano_encoder(x, masks)
         else:

@@ -234,7 +234,7 @@ class CausalImageEmbeddings(nn.Module):
             x = hipops.gather_segmean(src, cat_index[0], cat_index[1], None, N * W, cat_inverse).view(N, W, H)
             x = x + hipops.embedding(traj_nav_types, self.nav_type_embedding.weight, out_dtype=dt) \
                 + self.loc_layer_norm(self.loc_linear(traj_loc_fts.to(dt)))
-            x = hipops.dropout(self.layer_norm(x), _p(self.dropout))
+            x = self.layer_norm(x, p_out=_p(self.dropout))
             x = self.pano_encoder(x, gen_seq_masks(traj_vp_view_lens + obj_lens, W))
         fused = None
         if self.config.adaptive_pano_fusion:
