@@ -737,7 +737,7 @@ def ragged_bucket_leg(args, m, B):
     done = [None] * K
     state = {'next': None}
 
-    host_t = [0.0, 0]
+    host_t = [0.0, 0, 0.0]
 
     def prefetch(i):
         k = i % K
@@ -747,6 +747,7 @@ def ragged_bucket_leg(args, m, B):
         sbs[which[k]].pack(hosts[k], bufs[k])        # host: padding + index build of this ragged batch into its bucket's layout
         host_t[0] += time.perf_counter() - t0
         host_t[1] += 1
+        host_t[2] = max(host_t[2], time.perf_counter() - t0)
         done[k] = sbs[which[k]].stage(bufs[k])
 
     def run(i):
@@ -757,8 +758,8 @@ def ragged_bucket_leg(args, m, B):
         graphs[(which[k], tasks[i % len(tasks)])].replay()
         prefetch(i + 1)
         state['next'] = i + 1
-    n = 16
-    dt = timed(run, n, 4, 1)
+    n = 36          # (a single host stall — 40-90 ms ones were seen on the pool's boxes — weighs 1-2 ms in the mean of 36 steps; the
+    dt = timed(run, n, 4, 1)      #  worst pack time of the run is reported next to the mean)
     for sb in sbs.values():
         if sb._pending is not None:
             sb.commit()
@@ -776,7 +777,7 @@ def ragged_bucket_leg(args, m, B):
     real = float(np.mean([h['traj_view_img_fts'].shape[0] for h in hosts]))
     return {'ms_per_step': round(dt / n * 1e3, 3), 'value': round(traj / dt, 1), 'unit': 'trajectory-steps/s', 'steps': n,
             'buckets': {'L': wl['batch']['L'], 'N': list(sorted(set(which))), 'G': G}, 'mean_panoramas_per_batch': round(real, 1),
-            'feature_dtype': str(feat_dt).replace('torch.', ''), 'host_pack_ms': round(host_t[0] / max(1, host_t[1]) * 1e3, 2),
+            'feature_dtype': str(feat_dt).replace('torch.', ''), 'host_pack_ms': round(host_t[0] / max(1, host_t[1]) * 1e3, 2), 'host_pack_ms_max': round(host_t[2] * 1e3, 2),
             'replay_only_ms_per_step': round(replay_ms, 3),
             'what': 'B=%d, T ~ U{3..6}, L ~ U{40..80}: a new shape every step, padded into %d shape buckets; per step host padding + index '
                     'build, one pinned H2D, D2D swap, mask refresh, hipGraph replay of the bucket (all inside the timed region)' % (B, len(set(which)))}
