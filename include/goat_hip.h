@@ -144,14 +144,17 @@ int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* dy2, const 
                 const void* dx_add);
 /* The same pair with dropout on the LayerNorm's OUTPUT as well: y = dropout_{p_out}(LayerNorm(z)) (the embedding blocks,
  * P/model/Bert_backbone.py:108-110, P/model/vilmodel_goat.py:228-237: `dropout(layer_norm(x))`), mask from counter offset_out of the
- * same seed; the backward masks dy (+ dy2) the same way before anything else.  p_out == 0: exactly goat_ln_fwd / goat_ln_bwd. */
+ * same seed; the backward masks dy (+ dy2) the same way before anything else.  post_add (may be NULL; shape / dtype of y): a second
+ * summand behind the norm, y = dropout_{p_out}(LayerNorm(z) + post_add) — the image embedding block's normalised view features plus
+ * normalised location features (P/model/vilmodel_goat.py:340-344); its gradient (the masked dy) is written to d_post.
+ * p_out == 0 and post_add == NULL: exactly goat_ln_fwd / goat_ln_bwd. */
 int goat_ln_fwd_do(void* stream, int dtype, const void* x, const void* residual, const float* gamma, const float* beta, float eps,
                    float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev, void* y, void* z_out, float* mean, float* rstd,
-                   int M, int H, float p_out, uint64_t offset_out);
+                   int M, int H, float p_out, uint64_t offset_out, const void* post_add);
 int goat_ln_bwd_do(void* stream, int dtype, const void* dy, const void* dy2, const void* z, const float* gamma, const float* mean,
                    const float* rstd, float p, uint64_t seed, uint64_t offset, const uint64_t* rng_dev, void* dx, void* d_res,
                    float* dgamma, float* dbeta, float* ws, int M, int H, int accumulate, const void* dx_add, float p_out,
-                   uint64_t offset_out);
+                   uint64_t offset_out, void* d_post);
 
 /* y = residual + dropout_p(x)  (residual may be NULL, y may alias x).  nn.Dropout + pre-LN residual adds
  * (P/model/transformer.py:177,181; P/model/vilmodel_goat.py:316). n = element count. */

@@ -982,17 +982,27 @@ def test_layer_norm_output_dropout_in_the_same_launch(ops, dtype):
     gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV).requires_grad_(True)
     beta = (0.5 + 0.1 * torch.randn(H, generator=g)).to(DEV).requires_grad_(True)
     w = torch.randn(M, H, generator=g).to(DEV)
-    x = x0.clone().requires_grad_(True)
-    ops.manual_seed(5)
-    y = ops.layer_norm(x, gamma, beta, 1e-12, p_out=p)
-    (y.float() * w).sum().backward()
-    keep = y.detach() != 0
-    assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
-    xr = x0.float().clone().requires_grad_(True)
-    g2, b2 = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
-    yr = torch.where(keep, torch.nn.functional.layer_norm(xr, (H,), g2, b2, 1e-12) / (1 - p), torch.zeros_like(xr))
-    (yr * w).sum().backward()
-    tol = 1e-4 if dtype == torch.float32 else 2e-2
-    assert float((y.float() - yr).abs().max()) <= tol * max(1.0, float(yr.abs().max()))
-    for a, b, what in ((x.grad.float(), xr.grad, 'dx'), (gamma.grad, g2.grad, 'dgamma'), (beta.grad, b2.grad, 'dbeta')):
-        assert float((a - b).abs().max()) <= 2 * tol * max(1.0, float(b.abs().max())), what
+    for with_post in (False, True):
+        # post_add: dropout(LayerNorm(x) + post) — the image embedding block's sum of two normalised tensors (P/model/vilmodel_goat.py:340-344)
+        x = x0.clone().requires_grad_(True)
+        post = (2 + torch.randn(M, H, generator=g)).to(DEV, dtype).requires_grad_(True) if with_post else None
+        gamma.grad = beta.grad = None
+        ops.manual_seed(5)
+        y = ops.layer_norm(x, gamma, beta, 1e-12, p_out=p, post_add=post)
+        (y.float() * w).sum().backward()
+        keep = y.detach() != 0
+        assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
+        xr = x0.float().clone().requires_grad_(True)
+        pr = post.detach().float().clone().requires_grad_(True) if with_post else None
+        g2, b2 = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+        pre = torch.nn.functional.layer_norm(xr, (H,), g2, b2, 1e-12)
+        pre = pre + pr if with_post else pre
+        yr = torch.where(keep, pre / (1 - p), torch.zeros_like(xr))
+        (yr * w).sum().backward()
+        tol = 1e-4 if dtype == torch.float32 else 2e-2
+        assert float((y.float() - yr).abs().max()) <= tol * max(1.0, float(yr.abs().max()))
+        pairs = [(x.grad.float(), xr.grad, 'dx'), (gamma.grad, g2.grad, 'dgamma'), (beta.grad, b2.grad, 'dbeta')]
+        if with_post:
+            pairs.append((post.grad.float(), pr.grad, 'dpost'))
+        for a, b, what in pairs:
+            assert float((a - b).abs().max()) <= 2 * tol * max(1.0, float(b.abs().max())), (what, with_post)

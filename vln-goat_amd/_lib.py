@@ -39,8 +39,8 @@ SIGNATURES = {
     'goat_ln_bwd_nparts': [_i32],
     'goat_ln_reduce_batched': [_vp, _vp, _i32, _i32],
     'goat_ln_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
-    'goat_ln_fwd_do': [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _u64],
-    'goat_ln_bwd_do': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _f32, _u64],
+    'goat_ln_fwd_do': [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _u64, _vp],
+    'goat_ln_bwd_do': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _f32, _u64, _vp],
     'goat_dropout_add_fwd': [_vp, _i32, _vp, _vp, _vp, _i64, _f32, _u64, _u64, _vp],
     'goat_dropout_bwd': [_vp, _i32, _vp, _vp, _i64, _f32, _u64, _u64, _vp],
     'goat_act_bwd': [_vp, _i32, _vp, _vp, _vp, _i64, _i32, _f32, _u64, _u64, _vp],

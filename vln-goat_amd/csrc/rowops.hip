@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float p, uint64_t seed, uint64_t offset,
                                                      const uint64_t* __restrict__ rng_dev, T* __restrict__ y, T* __restrict__ zout, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int M, int H, float p_out, uint64_t offset_out) {
+                                                     float* __restrict__ rstd, int M, int H, float p_out, uint64_t offset_out,
+                                                     const T* __restrict__ post_add) {
   constexpr int EPC = DT<T>::EPC;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -76,6 +77,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       Chunk<T> o;
 #pragma unroll
       for (int e = 0; e < EPC; ++e) o.v[e] = (v[i].v[e] - mu) * rs * gamma[c * EPC + e] + beta[c * EPC + e];
+      if (post_add) {          // a second summand behind the norm: y = dropout(LayerNorm(z) + post_add) — the image embedding block adds
+        Chunk<T> t;            // the normalised location features to the normalised view features (P/model/vilmodel_goat.py:340-344)
+        t.load(post_add + (int64_t)row * H + c * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.v[e] += t.v[e];
+      }
       if (p_out > 0.f) {       // dropout on the OUTPUT (embeddings: dropout(LayerNorm(e)), P/model/Bert_backbone.py:108-110)
         const uint32_t km = rng.keep_bits<EPC>(offset_out + (int64_t)row * H + c * EPC, goat_thr16(p_out));
         const float ko = 1.f / (1.f - p_out);
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(const T* __restrict__ 
                                                      T* __restrict__ dx, T* __restrict__ dres,
                                                      float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      const T* __restrict__ dx_add, int pre_add, int M, int H, float p_out,
-                                                     uint64_t offset_out) {
+                                                     uint64_t offset_out, T* __restrict__ d_post) {
   constexpr int EPC = DT<T>::EPC;
   extern __shared__ float lsum[];  // [NWV][2][H]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -151,6 +158,7 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(const T* __restrict__ 
 #pragma unroll
             for (int e = 0; e < EPC; ++e) vdy[u][i].v[e] = ((km >> e) & 1u) ? vdy[u][i].v[e] * ko : 0.f;
           }
+          if (d_post) vdy[u][i].store_stream(d_post + base);      // gradient of the summand added behind the norm (post_add)
         }
       }
     }
@@ -1058,7 +1066,7 @@ extern "C" int goat_version(void) { return 101; }
 extern "C" int goat_ln_fwd_do(void* stream, int dtype, const void* x, const void* residual, const float* gamma,
                               const float* beta, float eps, float p, uint64_t seed, uint64_t offset,
                               const uint64_t* rng_dev, void* y, void* z_out, float* mean, float* rstd, int M, int H, float p_out,
-                              uint64_t offset_out) {
+                              uint64_t offset_out, const void* post_add) {
   if (!x || !gamma || !beta || !y || !mean || !rstd) return GOAT_E_ARG;
   if (M <= 0 || !(p_out >= 0.f && p_out < 1.f)) return GOAT_E_SHAPE;
   if ((residual || p > 0.f) && !z_out) return GOAT_E_ARG;
@@ -1067,12 +1075,14 @@ extern "C" int goat_ln_fwd_do(void* stream, int dtype, const void* x, const void
     if (int e = ln_check<bf16_t>(H)) return e;
     GOAT_LN_DISPATCH(bf16_t, H, hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, MC>), grid, dim3(256), 0, ST(stream),
                                                     (const bf16_t*)x, (const bf16_t*)residual, gamma, beta, eps, p, seed,
-                                                    offset, rng_dev, (bf16_t*)y, (bf16_t*)z_out, mean, rstd, M, H, p_out, offset_out));
+                                                    offset, rng_dev, (bf16_t*)y, (bf16_t*)z_out, mean, rstd, M, H, p_out, offset_out,
+                                                    (const bf16_t*)post_add));
   } else if (dtype == GOAT_F32) {
     if (int e = ln_check<float>(H)) return e;
     GOAT_LN_DISPATCH(float, H, hipLaunchKernelGGL((ln_fwd_kernel<float, MC>), grid, dim3(256), 0, ST(stream),
                                                    (const float*)x, (const float*)residual, gamma, beta, eps, p, seed,
-                                                   offset, rng_dev, (float*)y, (float*)z_out, mean, rstd, M, H, p_out, offset_out));
+                                                   offset, rng_dev, (float*)y, (float*)z_out, mean, rstd, M, H, p_out, offset_out,
+                                                   (const float*)post_add));
   } else {
     return GOAT_E_ARG;
   }
@@ -1083,7 +1093,8 @@ extern "C" int goat_ln_fwd_do(void* stream, int dtype, const void* x, const void
 extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* residual, const float* gamma,
                            const float* beta, float eps, float p, uint64_t seed, uint64_t offset,
                            const uint64_t* rng_dev, void* y, void* z_out, float* mean, float* rstd, int M, int H) {
-  return goat_ln_fwd_do(stream, dtype, x, residual, gamma, beta, eps, p, seed, offset, rng_dev, y, z_out, mean, rstd, M, H, 0.f, 0);
+  return goat_ln_fwd_do(stream, dtype, x, residual, gamma, beta, eps, p, seed, offset, rng_dev, y, z_out, mean, rstd, M, H, 0.f, 0,
+                        nullptr);
 }
 
 #define GOAT_LN_BWD_PARTS 512
@@ -1136,7 +1147,7 @@ __global__ __launch_bounds__(256) void zero2_kernel(float* __restrict__ a, float
 extern "C" int goat_ln_bwd_do(void* stream, int dtype, const void* dy, const void* dy2, const void* z, const float* gamma,
                               const float* mean, const float* rstd, float p, uint64_t seed, uint64_t offset,
                               const uint64_t* rng_dev, void* dx, void* d_res, float* dgamma, float* dbeta, float* ws,
-                              int M, int H, int accumulate, const void* dx_add, float p_out, uint64_t offset_out) {
+                              int M, int H, int accumulate, const void* dx_add, float p_out, uint64_t offset_out, void* d_post) {
   if (!dy || !z || !gamma || !mean || !rstd || !dgamma || !dbeta) return GOAT_E_ARG;
   if (M <= 0 || !(p_out >= 0.f && p_out < 1.f)) return GOAT_E_SHAPE;
   // deterministic mode (ws): 4-wave blocks, up to 512 per-block partial rows reduced by a second kernel (round 1).
@@ -1174,7 +1185,7 @@ extern "C" int goat_ln_bwd_do(void* stream, int dtype, const void* dy, const voi
     }                                                                                                                         \
     hipLaunchKernelGGL(kern_, dim3(nparts), dim3(64 * NWV_), sm, ST(stream), (const T_*)dy, (const T_*)dy2, (const T_*)z, gamma, mean, \
                        rstd, p, seed, offset, rng_dev, (T_*)dx, (T_*)d_res, ws, dgamma, dbeta, (const T_*)dx_add, pre_add, M, H, \
-                       p_out, offset_out);                                                                                    \
+                       p_out, offset_out, (T_*)d_post);                                                                       \
   } while (0)
   if (dtype == GOAT_BF16) {
     if (int e = ln_check<bf16_t>(H)) return e;
@@ -1202,7 +1213,7 @@ extern "C" int goat_ln_bwd(void* stream, int dtype, const void* dy, const void* 
                            const uint64_t* rng_dev, void* dx, void* d_res, float* dgamma, float* dbeta, float* ws,
                            int M, int H, int accumulate, const void* dx_add) {
   return goat_ln_bwd_do(stream, dtype, dy, dy2, z, gamma, mean, rstd, p, seed, offset, rng_dev, dx, d_res, dgamma, dbeta, ws, M, H,
-                        accumulate, dx_add, 0.f, 0);
+                        accumulate, dx_add, 0.f, 0, nullptr);
 }
 
 extern "C" int goat_dropout_add_fwd(void* stream, int dtype, const void* x, const void* residual, void* y, int64_t n,

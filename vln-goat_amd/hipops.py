@@ -1195,7 +1195,7 @@ class _LnFn(torch.autograd.Function):
     load (goat_ln_bwd's dy2), which replaces the elementwise add autograd would otherwise launch for the shared tensor."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, p, fork=False, fork_in=False, z_out=False, p_out=0.0):
+    def forward(ctx, x, residual, gamma, beta, eps, p, fork=False, fork_in=False, z_out=False, p_out=0.0, post_add=None):
         _need_gpu(x)
         ctx.set_materialize_grads(False)
         if fork_in and (fork or residual is not None):
@@ -1225,9 +1225,15 @@ class _LnFn(torch.autograd.Function):
             if p > 0:
                 assert s2 == seed
             seed, dev = s2, d2
+        pa = None
+        if post_add is not None:             # y = dropout_out(LayerNorm(z) + post_add)
+            pa = post_add.reshape(-1, H).to(x2.dtype)
+            pa = pa if pa.is_contiguous() else pa.contiguous()
+        ctx.has_post = pa is not None
         st = _lib.lib().goat_ln_fwd_do(_stream(), _dt(x2), _ptr(x2), _ptr(r2) if r2 is not None else None,
                                        _ptr(gamma), _ptr(beta), eps, p, seed, off, dev,
-                                       _ptr(y), _ptr(z) if z is not None else None, _ptr(mean), _ptr(rstd), M, H, p_out, off_out)
+                                       _ptr(y), _ptr(z) if z is not None else None, _ptr(mean), _ptr(rstd), M, H, p_out, off_out,
+                                       _ptr(pa) if pa is not None else None)
         _lib.check(st, 'goat_ln_fwd')
         ctx.save_for_backward(z if z is not None else x2, gamma, mean, rstd)
         ctx.rng = (p, seed, off, dev)
@@ -1248,7 +1254,7 @@ class _LnFn(torch.autograd.Function):
         if ctx.fork_in or ctx.z_out:
             dskip, dyb = dyb, None
             if dy is None and ctx.fork_in:     # only the skip connection carried a gradient
-                return dskip, None, None, None, None, None, None, None, None, None
+                return dskip, None, None, None, None, None, None, None, None, None, None
         z, gamma, mean, rstd = ctx.saved_tensors
         if dy is None:
             if ctx.z_out:                      # the normalised output went unused: only the pre-norm sum carried a gradient
@@ -1276,6 +1282,7 @@ class _LnFn(torch.autograd.Function):
         L = _lib.lib()
         dx = torch.empty_like(z)
         dres = torch.empty_like(z) if (ctx.has_res and p > 0) else None
+        dpost = torch.empty_like(z) if ctx.has_post else None       # gradient of the summand behind the norm: the (masked) dy
         sg, sb = _sink(ctx.gb[0]), _sink(ctx.gb[1])
         sunk = sg is not None and sb is not None
         if not sunk:
@@ -1297,7 +1304,7 @@ class _LnFn(torch.autograd.Function):
                               p, seed, off, dev, _ptr(dx), _ptr(dres) if dres is not None else None,
                               _ptr(dg), _ptr(db), _ptr(ws) if ws is not None else None, M, H,
                               acc | (4 if (ctx.z_out and dskip is not None) else 0), _ptr(dskip) if dskip is not None else None,
-                              ctx.out_drop[0], ctx.out_drop[1])
+                              ctx.out_drop[0], ctx.out_drop[1], _ptr(dpost) if dpost is not None else None)
         _lib.check(st, 'goat_ln_bwd')
         if defer:
             LnReduceQueue.push(ws, dg, db, nparts, H)
@@ -1308,17 +1315,18 @@ class _LnFn(torch.autograd.Function):
             dr = dres.view(ctx.shape) if dres is not None else dxv
         else:
             dr = None
-        return dxv, dr, dg, db, None, None, None, None, None, None
+        return dxv, dr, dg, db, None, None, None, None, None, None, (dpost.view(ctx.shape) if dpost is not None else None)
 
 
-def layer_norm(x, gamma, beta, eps, residual=None, p=0.0, fork=False, fork_in=False, z_out=False, p_out=0.0):
+def layer_norm(x, gamma, beta, eps, residual=None, p=0.0, fork=False, fork_in=False, z_out=False, p_out=0.0, post_add=None):
     """fork_in=True (pre-LN blocks): returns (LayerNorm(x), x) — use the second output for the skip connection; the gradient it
     receives is added inside the LayerNorm backward kernel instead of by an autograd add.
     z_out=True (pre-LN blocks, with residual): returns (LayerNorm(z), z) with z = residual + dropout_p(x) — the residual junction in
     FRONT of the LayerNorm and the LayerNorm in one launch per direction; z continues as the block's hidden state and the gradient
     it collects later joins inside this LayerNorm's backward kernel.
-    p_out: dropout on the LayerNorm's output in the same launch (the embedding blocks' dropout(LayerNorm(e)))."""
-    return _LnFn.apply(x, residual, gamma, beta, float(eps), float(p), bool(fork), bool(fork_in), bool(z_out), float(p_out))
+    p_out: dropout on the LayerNorm's output in the same launch (the embedding blocks' dropout(LayerNorm(e)));
+    post_add: a summand added behind the norm and in front of that dropout: dropout(LayerNorm(z) + post_add)."""
+    return _LnFn.apply(x, residual, gamma, beta, float(eps), float(p), bool(fork), bool(fork_in), bool(z_out), float(p_out), post_add)
 
 
 class _DropAddFn(torch.autograd.Function):

@@ -120,16 +120,19 @@ _NO_ZOUT = bool(os.environ.get('GOAT_NO_LN_ZOUT'))      # (diagnostics: the pre-
 
 
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x, residual=None, p=0.0, fork=False, fork_in=False, z_out=False, p_out=0.0):
-        """p_out: dropout on the output, in the same launch (dropout(LayerNorm(x)) of the embedding blocks)."""
-        if p_out and _NO_ZOUT:                           # (diagnostics: the output dropout as a kernel of its own)
-            return hipops.dropout(self.forward(x, residual, p, fork, fork_in, z_out), p_out)
+    def forward(self, x, residual=None, p=0.0, fork=False, fork_in=False, z_out=False, p_out=0.0, post_add=None):
+        """p_out: dropout on the output, in the same launch (dropout(LayerNorm(x)) of the embedding blocks); post_add: a summand added
+        behind the norm, in front of that dropout."""
+        if (p_out or post_add is not None) and _NO_ZOUT:  # (diagnostics: the add / the output dropout as kernels of their own)
+            y = self.forward(x, residual, p, fork, fork_in, z_out)
+            y = y if post_add is None else post_add + y
+            return hipops.dropout(y, p_out)
         if fork_in and (_NO_FORK or _NO_FORK_IN):
             return hipops.layer_norm(x, self.weight, self.bias, self.eps), x
         if z_out and (_NO_FORK or _NO_FORK_IN or _NO_ZOUT):          # (diagnostics: the junction as its own kernel again)
             z = hipops.dropout_add(x, residual, p)
             return hipops.layer_norm(z, self.weight, self.bias, self.eps), z
-        return hipops.layer_norm(x, self.weight, self.bias, self.eps, residual, p, fork and not _NO_FORK, fork_in, z_out, p_out)
+        return hipops.layer_norm(x, self.weight, self.bias, self.eps, residual, p, fork and not _NO_FORK, fork_in, z_out, p_out, post_add)
 
 
 def _pair(h):

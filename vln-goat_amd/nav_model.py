@@ -212,14 +212,15 @@ class CausalImageEmbeddings(nn.Module):
             masks = gen_seq_masks(view_lens + obj_lens, W)
             x = self.pano_encoder(x, masks)
         else:
-            loc = self.loc_layer_norm(self.loc_linear(loc_fts.to(dt)))
+            loc_in = self.loc_linear(loc_fts.to(dt))
             if loc_before:
-                x = x + loc
+                x = x + self.loc_layer_norm(loc_in)
             if z_img_features is not None:
                 x = self.intervene(x, z_img_features, z_img_pzs)
-            if not loc_before:
-                x = x + loc
-            x = hipops.dropout(x, _p(self.dropout))
+            if not loc_before:       # dropout(x + loc_LN(...)): the sum and the dropout inside the LayerNorm's launch
+                x = self.loc_layer_norm(loc_in, post_add=x, p_out=_p(self.dropout))
+            else:
+                x = hipops.dropout(x, _p(self.dropout))
             masks = gen_seq_masks(view_lens, view_img_fts.shape[1])
             x = self.img_self_encoder(x, masks)
         fused = None

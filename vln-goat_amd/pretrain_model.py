@@ -219,8 +219,8 @@ class CausalImageEmbeddings(nn.Module):
         dt = compute_dtype()
         x = self.img_layer_norm(self.img_linear(traj_view_img_fts.to(dt)))
         if not self.reverie:
-            x = x + self.loc_layer_norm(self.loc_linear(traj_loc_fts.to(dt)))
-            x = hipops.dropout(x, _p(self.dropout))
+            # dropout(img_LN(...) + loc_LN(...)): the sum and the dropout inside the second LayerNorm's launch
+            x = self.loc_layer_norm(self.loc_linear(traj_loc_fts.to(dt)), post_add=x, p_out=_p(self.dropout))
             img_masks = gen_seq_masks(traj_vp_view_lens, traj_view_img_fts.shape[1])
             x = self.img_self_encoder(x, img_masks)
         if obj_fts is not None:
