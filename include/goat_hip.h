@@ -58,6 +58,9 @@ int goat_gemm_nt(void* stream, int dtype_in, int dtype_out,
                  void* aux, int64_t ldaux, int split_k);
 
 #define GOAT_GEMM_8WAVES 0x100   /* flag in goat_gemm_bf16's nstage argument: run the 128-row tile with eight waves */
+#define GOAT_GEMM_PP 0x200       /* flag in nstage: the "ping-pong" main loop (csrc/gemm5_tile.hpp) — two groups of four waves half a
+                                    K-tile out of phase, one feeding the matrix pipe while the other loads; tiles 256x256, 192x256 (K-contiguous
+                                    A only), 128x256, 256x128, 128x128, nstage 2; same operands, epilogues and (bit-identical) results */
 
 /* Pipelined bf16 GEMM with direct-to-LDS (LDS-DMA) operand staging, all operand layouts (csrc/gemm2.hip):
  *   C[M,N] = epilogue( op(A) · op(B)ᵀ + bias ),  contraction length Kc

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('GOAT_HIP_LIB') or os.path.join(CSRC, 'libgoat_hip.so')     # (override: kernel A/B experiments)
-SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm3.hip', 'attention.hip', 'attention2.hip', 'rowops.hip', 'causal.hip', 'optim.hip']
+SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm3.hip', 'gemm5.hip', 'attention.hip', 'attention2.hip', 'rowops.hip', 'causal.hip', 'optim.hip']
 
 GOAT_F32, GOAT_BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ACCUM = 0, 1, 2, 3, 4, 5
@@ -94,7 +94,7 @@ class WgradProblem(ctypes.Structure):
 def build(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into csrc/libgoat_hip.so (in-tree, travels with the repo snapshot)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'gemm2_tile.hpp'), os.path.join(CSRC, 'attn_args.hpp'), os.path.join(_HERE, '..', 'include', 'goat_hip.h')]
+    deps = srcs + [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'gemm2_tile.hpp'), os.path.join(CSRC, 'gemm5_tile.hpp'), os.path.join(CSRC, 'attn_args.hpp'), os.path.join(_HERE, '..', 'include', 'goat_hip.h')]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

@@ -1,6 +1,6 @@
 // goat_gemm_bf16 / goat_wgrad_grouped: C entry points, tile-order choice, and the instantiations of the 4-wave and
 // 128-column tiles.  The tile code itself is gemm2_tile.hpp; the 8-wave 192/256-wide tiles are instantiated in gemm3.hip.
-#include "gemm2_tile.hpp"
+#include "gemm5_tile.hpp"
 
 using namespace goat_g2;
 
@@ -58,13 +58,19 @@ static bool tile_ok(int bm, int bn, bool eight) {
   return (bm == 128 && bn == 256) || (bm == 192 && bn == 256) || (bm == 256 && bn == 192) || (bm == 256 && bn == 256) || (bm == 192 && bn == 192);
 }
 
+// tiles of the ping-pong main loop: 64*MI x 128*NI, nstage = number of B buffers
+static bool pp_tile_ok(int bm, int bn, int nstage) {
+  return nstage == 2 && ((bm == 256 && bn == 256) || (bm == 192 && bn == 256) || (bm == 128 && bn == 256) || (bm == 256 && bn == 128) || (bm == 128 && bn == 128));
+}
+
 extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_out,
                               const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                               int M, int N, int Kc, const float* bias, int epilogue,
                               void* aux, int64_t ldaux, int split_k, int bm, int nstage, float* colsum) {
   if (!A || !B || !C) return GOAT_E_ARG;
   const bool eight = (nstage & GOAT_GEMM_8WAVES) != 0;
-  nstage &= ~GOAT_GEMM_8WAVES;
+  const bool pp = (nstage & GOAT_GEMM_PP) != 0;               // the ping-pong main loop (gemm5_tile.hpp)
+  nstage &= ~(GOAT_GEMM_8WAVES | GOAT_GEMM_PP);
   if (nstage < 2 || nstage > 4) return GOAT_E_ARG;
   int bn = (bm >> 16) & 0xFFFF;
   bm &= 0xFFFF;
@@ -80,7 +86,7 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   if ((epilogue == GOAT_EPI_MUL_DGELU || epilogue == GOAT_EPI_MUL_DRELU) && !aux) return GOAT_E_ARG;
   if (epilogue == GOAT_EPI_ACCUM && (dtype_out != GOAT_F32 || bias)) return GOAT_E_ARG;
   if (split_k > 1 && (dtype_out != GOAT_F32 || (epilogue != GOAT_EPI_NONE && epilogue != GOAT_EPI_ACCUM) || bias)) return GOAT_E_ARG;
-  if (!tile_ok(bm, bn, eight)) return GOAT_E_ARG;
+  if (pp ? (eight || !pp_tile_ok(bm, bn, nstage)) : !tile_ok(bm, bn, eight)) return GOAT_E_ARG;
   const int64_t a_rows = trans_a ? Kc : M, b_rows = trans_b ? Kc : N;
   const int64_t a_bytes = a_rows * lda * 2, b_bytes = b_rows * ldb * 2;
   if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) return GOAT_E_SHAPE;
@@ -100,6 +106,7 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   if (split_k > kt) split_k = kt;
   a.k_tiles_per_split = (kt + split_k - 1) / split_k;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (pp) return goat_g5_dispatch(st, a, bm, bn, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
   if (bn != 128 || bm == 96) return goat_g3_dispatch(st, a, bm, bn, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
   if (bm == 64) return dispatch_layout<T64>(st, a, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
   if (bm == 256) return dispatch_layout<T256>(st, a, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
@@ -123,11 +130,13 @@ static int group_stages(hipStream_t st, const GroupArgs& g, int nstage) {
 extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs, int n, int bm, int nstage) {
   if (!probs || n < 1 || n > GROUP_MAX) return GOAT_E_ARG;
   const bool eight = (nstage & GOAT_GEMM_8WAVES) != 0;       // as in goat_gemm_bf16: the 128-row tile on eight waves
-  nstage &= ~GOAT_GEMM_8WAVES;
+  const bool pp = (nstage & GOAT_GEMM_PP) != 0;
+  nstage &= ~(GOAT_GEMM_8WAVES | GOAT_GEMM_PP);
   int bn = (bm >> 16) & 0xFFFF;
   bm &= 0xFFFF;
   if (bn == 0) bn = 128;
-  if (nstage < 2 || nstage > 4 || !tile_ok(bm, bn, eight) || (bm & (bm - 1)) || (bn & (bn - 1))) return GOAT_E_ARG;
+  if (nstage < 2 || nstage > 4 || (bm & (bm - 1)) || (bn & (bn - 1))) return GOAT_E_ARG;
+  if (pp ? (eight || !pp_tile_ok(bm, bn, nstage) || (bm == 128 && bn == 128)) : !tile_ok(bm, bn, eight)) return GOAT_E_ARG;
   GroupArgs g;
   g.n = n;
   int tiles = 0;
@@ -155,6 +164,7 @@ extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs,
   }
   for (int i = n; i <= GROUP_MAX; ++i) g.tile_start[i] = tiles;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (pp) return goat_g5_group(st, g, bm, bn, nstage);
   if (bn != 128) return goat_g3_group(st, g, bm, bn, nstage);
   if (bm == 64) return group_stages<T64>(st, g, nstage);
   if (bm == 256) return group_stages<T256>(st, g, nstage);

@@ -1,0 +1,604 @@
+// Device code of the "ping-pong" bf16 MFMA GEMM tile for gfx950 (goat_gemm_bf16 / goat_wgrad_grouped with nstage | GOAT_GEMM_PP).
+//
+//   C[M,N] = epilogue( op(A) · op(B)^T ),  same operand layouts, argument block (G2Args), tile order and epilogues as
+//   gemm2_tile.hpp; what differs is the main loop.
+//
+// Why a second main loop.  gemm2_tile.hpp runs its eight waves in lockstep: one s_barrier per K-tile, after which every wave
+// first issues its LDS-DMA and fragment reads and then its MFMAs.  The two waves that share a SIMD therefore want the memory
+// pipes at the same time and the matrix pipe at the same time; cycle stamps (profiles/round2_gemm_mainloop_cycle_stamps.txt)
+// show the older wave of a SIMD computing for ~1700 cycles of a 2048-cycle K-tile and then waiting ~900 cycles at the barrier
+// for the younger one: 75 % MFMA efficiency between barriers at 8192^3 on the 256 x 256 tile.
+//
+// Here the workgroup (512 threads) is two GROUPS of four waves — wave w and wave w + 4 share SIMD w % 4 — that run half a
+// K-tile period out of phase, separated by one s_barrier per SLOT:
+//
+//        slot      2t                2t+1               2t+2               2t+3
+//   group 0   MEM  (tile t)     MFMA (tile t)      MEM  (tile t+1)    MFMA (tile t+1)
+//   group 1   MFMA (tile t-1)   MEM  (tile t)      MFMA (tile t)      MEM  (tile t+1)
+//
+//   MEM  = issue this group's LDS-DMA pieces of a future K-tile, read ALL fragments of tile t (4 k-steps) into registers,
+//          s_waitcnt lgkmcnt(0);
+//   MFMA = nothing but the tile's MI*NI*4 v_mfma_f32_32x32x16_bf16 under s_setprio 1, then s_waitcnt vmcnt(0) for the pieces
+//          issued one slot earlier (they had a whole MFMA phase to land).
+// On every SIMD one wave feeds the matrix pipe while its partner uses the LDS / texture path, in every slot.
+//
+// The 64*MI x 128*NI tile is cut so that the groups share only the B block: group g owns tile rows [g*32*MI, (g+1)*32*MI)
+// (its own A half-block, A_g) and all columns (wave patch 32*MI x 32*NI).  LDS: two buffers per A half-block, NB (2 or 3) buffers
+// for B.  Who loads what, and when a buffer is free:
+//   B[t]   is read by group 0 in slot 2t and by group 1 in slot 2t+1  -> group 0 issues B[t+1] (NB = 2) at the top of slot 2t,
+//          waits for it at the end of slot 2t+1;
+//   A_0[t] is read by group 0 in slot 2t                              -> group 1 issues A_0[t+2] in slot 2t+1 (its MEM phase);
+//   A_1[t] is read by group 1 in slot 2t+1                            -> group 1 issues A_1[t+1] in slot 2t+1 (other buffer).
+// Every wave issues the same number of pieces per period (group 0: the B block, group 1: both A half-blocks) and every piece has
+// at least one full MFMA phase (>= 1024 cycles on 256 x 256) in flight before anyone waits for it.
+#pragma once
+#include "gemm2_tile.hpp"
+
+namespace goat_g5 {
+using namespace goat_g2;
+
+#ifndef GOAT_G5_SETPRIO
+#define GOAT_G5_SETPRIO 1
+#endif
+
+#ifndef GOAT_G5_TIMING       // experiments only: per-wave cycle sums of the phases, written to `aux` as uint32[(block * 8 + wave) * 8 + i],
+#define GOAT_G5_TIMING 0     // i = {DMA issue, fragment reads, barrier after MEM, MFMAs, vmcnt wait, barrier after MFMA, total} (epilogue NONE)
+#endif
+__device__ __forceinline__ uint32_t g5_now() {
+  uint64_t t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return (uint32_t)t;
+}
+
+// VAR (experiments; the product instantiates the measured best): bits 0-1 = where the MEM phase issues its LDS-DMA pieces
+//   0: all pieces first, then the fragment reads      1: one piece after every three fragment reads
+//   2: all fragment reads first, then the pieces (before the lgkmcnt wait)
+template <int MI_, int NI_, int NB_, int VAR_ = 0>
+struct PCfg {
+  static constexpr int MI = MI_, NI = NI_, NB = NB_, VAR = VAR_;
+  static constexpr int BM = 64 * MI, BN = 128 * NI, NTH = 512;
+  static constexpr int AH = MI * 4096;     // bytes of one A half-block (32*MI rows x 64 k)
+  static constexpr int BSZ = NI * 16384;   // bytes of one B block (128*NI columns x 64 k)
+  static constexpr int SMEM = 4 * AH + NB * BSZ;
+};
+// Product tiles (DMA placement 1: measured equal to or ahead of the other two, profiles/round4_gemm_pp_cycle_stamps.txt; a third B
+// buffer — PCfg<4, 2, 3>, 160 KiB — buys nothing: the pieces already have a whole MFMA phase to land).
+typedef PCfg<4, 2, 2, 1> P256x256;   // 128 KiB
+typedef PCfg<3, 2, 2, 1> P192x256;   // 112 KiB  (M = 3840 = 20 x 192: 240 tiles at N = 3072; K-contiguous A only)
+typedef PCfg<2, 2, 2, 1> P128x256;   //  96 KiB
+typedef PCfg<4, 1, 2, 1> P256x128;   //  96 KiB
+typedef PCfg<2, 1, 2, 1> P128x128;   //  64 KiB (two workgroups per CU)
+
+template <int OFF> __device__ __forceinline__ uint4 lds_read_b128_o(uint32_t addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int OFF> __device__ __forceinline__ uint2 lds_read_tr16_o(uint32_t addr) {
+  uint2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+
+// One operand block of a K-tile: R "major" elements (rows of a K-contiguous operand / columns of a transposed one) x 64 k,
+// R*128 bytes, moved as 1-KiB LDS-DMA pieces.  LDS images are lane-linear (DMA constraint); bank conflicts of the fragment reads
+// are removed by XOR-swizzling the SOURCE address of every 16-byte (K-contiguous) / 64-byte (transposed) chunk and applying the
+// same involution in the fragment read address (gemm2_tile.hpp uses the same images).
+//   K-contiguous: image [R rows][128 B]; 16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7).
+//   transposed  : image [64 k-rows][W = 2R bytes]; 64-byte chunk c of k-row kr is stored at chunk c ^ x(kr),
+//                 x = kr & 3 (W >= 256: four k-rows of a tr read land in four different 64-byte bank groups), (kr >> 1) & 1 (W = 128).
+template <bool T, int R>
+struct Blk {
+  static constexpr int BYTES = R * 128;
+  static constexpr int NP = BYTES / 1024;                                         // DMA pieces per block
+  static constexpr int W = T ? R * 2 : 128;                                       // bytes per LDS row
+  static constexpr int RPP = 1024 / W > 0 ? 1024 / W : 1;                         // LDS rows per piece
+  static constexpr int NPAR = T ? (RPP == 2 ? 2 : (RPP == 1 ? 4 : 1)) : 2;        // distinct per-lane source offsets (piece number mod NPAR)
+  static_assert(!T || (W >= 128 && W <= 1024 && (W & (W - 1)) == 0), "transposed blocks: 64..512 columns, a power of two");
+  // per-lane source byte offset relative to the piece's origin, for pieces with (piece % NPAR) == par
+  __device__ static __forceinline__ uint32_t lane_off(int lane, int par, int64_t ld) {
+    if (!T) {
+      const int r = lane >> 3, s = lane & 7;
+      return (uint32_t)(r * ld * 2) + (uint32_t)((s ^ (r >> 1) ^ (par << 2)) << 4);
+    } else {
+      const int o = lane * 16, krl = o / W, bir = o % W, c64 = bir >> 6, sub = (bir >> 4) & 3;
+      const int x = W == 128 ? ((krl >> 1) & 1) : ((par * RPP + krl) & 3);
+      return (uint32_t)(krl * ld * 2) + (uint32_t)(((c64 ^ x) << 6) + (sub << 4));
+    }
+  }
+  // wave-uniform source byte offset of piece pc of the block whose first major element is mn0, at contraction offset k0
+  __device__ static __forceinline__ uint32_t piece_org(int pc, int mn0, int k0, int64_t ld) {
+    if (!T) return (uint32_t)((((int64_t)(mn0 + 8 * pc)) * ld + k0) * 2);
+    return (uint32_t)((((int64_t)(k0 + pc * RPP)) * ld + mn0) * 2);
+  }
+  // lane part of the fragment read address.  K-contiguous: index = k-step; transposed: index = 32-column group q of the block.
+  __device__ static __forceinline__ uint32_t frag_lane(int lane, int idx) {
+    if (!T) {
+      const int l31 = lane & 31, hi = lane >> 5;
+      return (uint32_t)(l31 * 128 + ((((idx << 1) | hi) ^ ((l31 >> 1) & 7)) << 4));
+    } else {
+      const int t15 = lane & 15, g = lane >> 4;
+      const int x = W == 128 ? ((t15 >> 3) & 1) : (t15 >> 2);
+      return (uint32_t)((8 * (g >> 1) + (t15 >> 2)) * W + ((idx ^ x) << 6) + (g & 1) * 32 + (t15 & 3) * 8);
+    }
+  }
+};
+
+// fragment of k-step KS, 32-element group Q (compile-time part; the run-time part of the group is folded into v[])
+template <bool T, int W, int KS, int Q>
+__device__ __forceinline__ bf16x8 pp_frag(const uint32_t (&v)[4], uint32_t off) {
+  if constexpr (!T) {
+    uint4 r = lds_read_b128_o<Q * 4096>(v[KS] + off);
+    return *reinterpret_cast<bf16x8*>(&r);
+  } else {
+    const uint32_t a = v[Q] + off;
+    uint2 r0 = lds_read_tr16_o<(KS * 16) * W>(a);
+    uint2 r1 = lds_read_tr16_o<(KS * 16 + 4) * W>(a);
+    uint4 r = {r0.x, r0.y, r1.x, r1.y};
+    return *reinterpret_cast<bf16x8*>(&r);
+  }
+}
+
+template <class CF, bool TA, bool TB, typename OutT, int EPI, bool SPLITK>
+__device__ __forceinline__ void pp_tile(const G2Args& p, int bid, int split) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int MI = CF::MI, NI = CF::NI, NB = CF::NB, BM = CF::BM, BN = CF::BN, AH = CF::AH, BSZ = CF::BSZ;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef Blk<TA, 32 * MI> BA;      // one A half-block
+  typedef Blk<TB, 128 * NI> BB;     // the B block
+  static_assert(BA::BYTES == AH && BB::BYTES == BSZ, "block sizes");
+  constexpr int PPW_A = BA::NP / 4, PPW_B = BB::NP / 4;     // pieces per wave: A half-block (group 1 issues two of them), B block (group 0)
+  static_assert(PPW_A * 4 == BA::NP && PPW_B * 4 == BB::NP, "pieces divide over the four waves of a group");
+  constexpr int WROWS = 32 * MI, WCOLS = 32 * NI;
+  constexpr bool SWAP = !SPLITK && sizeof(OutT) == 2;
+  constexpr uint32_t B_BASE = 4 * AH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int gsz = p.group_m * p.tiles_n;
+  const int grpi = bid / gsz, gi = bid - grpi * gsz;
+  const int gm = min(p.tiles_m - grpi * p.group_m, p.group_m);
+  const int tn = gi / gm, tm = grpi * p.group_m + (gi - tn * gm);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  int kt_begin = 0, kt_end = (p.Kc + BK - 1) / BK;
+  if (SPLITK) {
+    kt_begin = split * p.k_tiles_per_split;
+    kt_end = min(kt_end, kt_begin + p.k_tiles_per_split);
+    if (kt_begin >= kt_end) return;
+  }
+  const int nkt = kt_end - kt_begin;
+
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)p.b_bytes, 0x00020000);
+
+  // fragment read addresses (lane parts): A of this group's half-block, B of this wave's column patch
+  uint32_t va[4], vb[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    va[x] = BA::frag_lane(lane, x) + (uint32_t)(grp * 2 * AH);
+    if (!TB) vb[x] = BB::frag_lane(lane, x) + (uint32_t)(wn * WCOLS * 128) + B_BASE;
+    else vb[x] = BB::frag_lane(lane, wn * NI + (x < NI ? x : 0)) + B_BASE;
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bf16x8 fa[4][MI], fb[4][NI];
+
+  const bool do_colsum = TA && p.colsum != nullptr && tn == 0 && wn == 0;
+  float bsum[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
+
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_void*)smem;
+  const uint32_t ka = TA ? (uint32_t)(BK * p.lda * 2) : (uint32_t)(BK * 2);     // source advance per K-tile
+  const uint32_t kb = TB ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
+  const int k0 = kt_begin * BK;
+
+  // all fragments of the K-tile in A buffer ab_ (byte offset inside this group's pair of buffers) and B buffer bb_
+#define PP_FRAGS_KS(KS, ao_, bo_)                                                                  \
+  do {                                                                                             \
+    fa[KS][0] = pp_frag<TA, BA::W, KS, 0>(va, ao_);                                                \
+    if constexpr (MI > 1) fa[KS][1 < MI ? 1 : 0] = pp_frag<TA, BA::W, KS, 1>(va, ao_);             \
+    if constexpr (MI > 2) fa[KS][2 < MI ? 2 : 0] = pp_frag<TA, BA::W, KS, 2>(va, ao_);             \
+    if constexpr (MI > 3) fa[KS][3 < MI ? 3 : 0] = pp_frag<TA, BA::W, KS, 3>(va, ao_);             \
+    fb[KS][0] = pp_frag<TB, BB::W, KS, 0>(vb, bo_);                                                \
+    if constexpr (NI > 1) fb[KS][1 < NI ? 1 : 0] = pp_frag<TB, BB::W, KS, 1>(vb, bo_);             \
+  } while (0)
+#define PP_MMA_ALL()                                                                               \
+  do {                                                                                             \
+    if (TA && do_colsum) {                                                                         \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                             \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                             \
+          _Pragma("unroll") for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[ks][i][e];            \
+    }                                                                                              \
+    if (GOAT_G5_SETPRIO) __builtin_amdgcn_s_setprio(1);                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                               \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                               \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                           \
+          if (SWAP) mma32(acc[i][j], fb[ks][j], fa[ks][i]);                                        \
+          else mma32(acc[i][j], fa[ks][i], fb[ks][j]);                                             \
+        }                                                                                          \
+    if (GOAT_G5_SETPRIO) __builtin_amdgcn_s_setprio(0);                                            \
+  } while (0)
+
+  static_assert(NI <= 2 && MI <= 4, "fragment macros are written for MI <= 4, NI <= 2");
+
+  constexpr int DPL = CF::VAR & 3;            // LDS-DMA placement inside the MEM phase (see PCfg)
+#if GOAT_G5_TIMING
+  uint32_t tms[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) tms[i] = 0;
+  const uint32_t tm_start = g5_now();
+  uint32_t tm_c = tm_start;
+#define PP_STAMP(i_) do { const uint32_t n_ = g5_now(); tms[i_] += n_ - tm_c; tm_c = n_; } while (0)
+#else
+#define PP_STAMP(i_) do { } while (0)
+#endif
+  // One slot pair of a group.  PP_ISSUE_RANGE(lo, hi) issues this wave's LDS-DMA pieces [lo, hi) of the period; LOADS of them.
+#define PP_PERIOD(LOADS_, ao_, bo_, WAITVM_, LASTBAR_)                                             \
+  do {                                                                                             \
+    if (DPL == 0) PP_ISSUE_RANGE(0, LOADS_);                                                       \
+    PP_STAMP(0);                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    PP_FRAGS_KS(0, ao_, bo_);                                                                      \
+    if (DPL == 1) { __builtin_amdgcn_sched_barrier(0); PP_ISSUE_RANGE(0, LOADS_ / 4); __builtin_amdgcn_sched_barrier(0); } \
+    PP_FRAGS_KS(1, ao_, bo_);                                                                      \
+    if (DPL == 1) { __builtin_amdgcn_sched_barrier(0); PP_ISSUE_RANGE(LOADS_ / 4, LOADS_ / 2); __builtin_amdgcn_sched_barrier(0); } \
+    PP_FRAGS_KS(2, ao_, bo_);                                                                      \
+    if (DPL == 1) { __builtin_amdgcn_sched_barrier(0); PP_ISSUE_RANGE(LOADS_ / 2, 3 * LOADS_ / 4); __builtin_amdgcn_sched_barrier(0); } \
+    PP_FRAGS_KS(3, ao_, bo_);                                                                      \
+    if (DPL == 1) { __builtin_amdgcn_sched_barrier(0); PP_ISSUE_RANGE(3 * LOADS_ / 4, LOADS_); __builtin_amdgcn_sched_barrier(0); } \
+    if (DPL == 2) { __builtin_amdgcn_sched_barrier(0); PP_ISSUE_RANGE(0, LOADS_); __builtin_amdgcn_sched_barrier(0); } \
+    wait_lgkm<0>();                                                                                \
+    PP_STAMP(1);                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    PP_STAMP(2);                                                                                   \
+    PP_MMA_ALL();                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    PP_STAMP(3);                                                                                   \
+    WAITVM_;                                                                                       \
+    PP_STAMP(4);                                                                                   \
+    if (LASTBAR_) __builtin_amdgcn_s_barrier();                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    PP_STAMP(5);                                                                                   \
+  } while (0)
+
+  if (grp == 0) {
+    // ---------------------------------------------------------------- group 0: loads B, computes rows [0, 32*MI)
+    uint32_t vo[BB::NPAR];
+    const int par0 = (wn * PPW_B) % BB::NPAR;
+#pragma unroll
+    for (int q = 0; q < BB::NPAR; ++q) vo[q] = BB::lane_off(lane, (q + par0) % BB::NPAR, p.ldb);
+    const uint32_t org0 = BB::piece_org(wn * PPW_B, n0, k0, p.ldb);
+    const uint32_t pstep = BB::piece_org(1, 0, 0, p.ldb);      // source distance between consecutive pieces
+    // pieces [lo_, hi_) of this wave's share of B[t_] -> B buffer buf_
+#define PP_ISSUE_B(t_, buf_, lo_, hi_)                                                                         \
+  do {                                                                                                         \
+    char* dst_ = smem + B_BASE + (buf_) * BSZ + wn * PPW_B * 1024;                                             \
+    const uint32_t so_ = org0 + (uint32_t)(t_) * kb;                                                           \
+    _Pragma("unroll") for (int j = (lo_); j < (hi_); ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(        \
+        rb, (lds_void*)(dst_ + j * 1024), 16, vo[j % BB::NPAR], so_ + (uint32_t)j * pstep, 0, 0);              \
+  } while (0)
+    PP_ISSUE_B(0, 0, 0, PPW_B);
+    if (NB == 3 && nkt > 1) PP_ISSUE_B(1, 1, 0, PPW_B);
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+#if GOAT_G5_TIMING
+    tm_c = g5_now();
+#endif
+    int bbuf = 0;                                   // B buffer of tile t
+    for (int t = 0; t < nkt; ++t) {
+      const int nbuf = bbuf + 1 == NB ? 0 : bbuf + 1;
+      const int n2 = nbuf + 1 == NB ? 0 : nbuf + 1;
+      const uint32_t ao = smem_base + (uint32_t)((t & 1) * AH), bo = smem_base + (uint32_t)(bbuf * BSZ);
+      // MEM phase in slot 2t (issues B[t+1], with three buffers B[t+2]), MFMA phase in slot 2t+1
+#define PP_ISSUE_RANGE(lo_, hi_)                                                                   \
+  do {                                                                                             \
+    if (NB == 2) { if (t + 1 < nkt) PP_ISSUE_B(t + 1, nbuf, lo_, hi_); }                           \
+    else { if (t + 2 < nkt) PP_ISSUE_B(t + 2, n2, lo_, hi_); }                                     \
+  } while (0)
+#define PP_WAITVM_G0                                                                               \
+  do {                                                                                             \
+    if (NB == 2 || t + 2 >= nkt) wait_vm<0>();                                                     \
+    else wait_vm<PPW_B>();       /* B[t+1] has landed, B[t+2] may stay in flight */                \
+  } while (0)
+      PP_PERIOD(PPW_B, ao, bo, PP_WAITVM_G0, true);
+#undef PP_ISSUE_RANGE
+#undef PP_WAITVM_G0
+      bbuf = nbuf;
+    }
+#undef PP_ISSUE_B
+  } else {
+    // ---------------------------------------------------------------- group 1: loads both A half-blocks, computes rows [32*MI, 64*MI)
+    uint32_t vo[BA::NPAR];
+    const int par0 = (wn * PPW_A) % BA::NPAR;
+#pragma unroll
+    for (int q = 0; q < BA::NPAR; ++q) vo[q] = BA::lane_off(lane, (q + par0) % BA::NPAR, p.lda);
+    const uint32_t org0 = BA::piece_org(wn * PPW_A, m0, k0, p.lda);
+    const uint32_t org1 = BA::piece_org(wn * PPW_A, m0 + WROWS, k0, p.lda);
+    const uint32_t pstep = BA::piece_org(1, 0, 0, p.lda);
+    // pieces [lo_, hi_) of this wave's share of half h_ (0/1) of K-tile t_ -> buffer buf_ of that half
+#define PP_ISSUE_A(h_, t_, buf_, lo_, hi_)                                                                     \
+  do {                                                                                                         \
+    char* dst_ = smem + ((h_) * 2 + (buf_)) * AH + wn * PPW_A * 1024;                                          \
+    const uint32_t so_ = ((h_) ? org1 : org0) + (uint32_t)(t_) * ka;                                           \
+    _Pragma("unroll") for (int j = (lo_); j < (hi_); ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(        \
+        ra, (lds_void*)(dst_ + j * 1024), 16, vo[j % BA::NPAR], so_ + (uint32_t)j * pstep, 0, 0);              \
+  } while (0)
+    PP_ISSUE_A(0, 0, 0, 0, PPW_A);
+    PP_ISSUE_A(1, 0, 0, 0, PPW_A);
+    if (nkt > 1) PP_ISSUE_A(0, 1, 1, 0, PPW_A);
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                   // slot 0: group 0 reads tile 0, nothing to compute here yet
+#if GOAT_G5_TIMING
+    tm_c = g5_now();
+#endif
+    int bbuf = 0;
+    for (int t = 0; t < nkt; ++t) {
+      const uint32_t ao = smem_base + (uint32_t)((t & 1) * AH), bo = smem_base + (uint32_t)(bbuf * BSZ);
+      // MEM phase in slot 2t+1: pieces [0, PPW_A) = A_1[t+1], [PPW_A, 2 PPW_A) = A_0[t+2]; MFMA phase in slot 2t+2
+#define PP_ISSUE_RANGE(lo_, hi_)                                                                   \
+  do {                                                                                             \
+    if ((lo_) < PPW_A && t + 1 < nkt) PP_ISSUE_A(1, t + 1, (t + 1) & 1, (lo_), ((hi_) < PPW_A ? (hi_) : PPW_A)); \
+    if ((hi_) > PPW_A && t + 2 < nkt) PP_ISSUE_A(0, t + 2, t & 1, ((lo_) > PPW_A ? (lo_) - PPW_A : 0), (hi_) - PPW_A); \
+  } while (0)
+      PP_PERIOD(2 * PPW_A, ao, bo, wait_vm<0>(), (t + 1 < nkt));   // (group 0 has left its loop after its last MFMA phase)
+#undef PP_ISSUE_RANGE
+      bbuf = bbuf + 1 == NB ? 0 : bbuf + 1;
+    }
+#undef PP_ISSUE_A
+  }
+#if GOAT_G5_TIMING
+  if (p.aux != nullptr && lane == 0 && EPI == GOAT_EPI_NONE) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(p.aux) + ((size_t)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = tms[i];
+    o[6] = g5_now() - tm_start;
+    o[7] = (uint32_t)nkt;
+  }
+#endif
+#undef PP_PERIOD
+#undef PP_STAMP
+#undef PP_FRAGS_KS
+#undef PP_MMA_ALL
+
+  // From here on the LDS ring is free: the last fragment reads of both groups completed before the barrier that ended the last
+  // MEM phase, and no LDS-DMA is in flight.  Group 0 starts its epilogue while group 1 is in its last MFMA phase.
+  const int wrow0 = grp * WROWS, wcol0 = wn * WCOLS;
+  if (TA && do_colsum) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      const int row = m0 + wrow0 + i * 32 + l31;
+      if (hi == 0 && row < p.M) atomicAdd(p.colsum + row, v);
+    }
+  }
+  if (SPLITK) {
+    float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int col = n0 + wcol0 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wrow0 + i * 32 + c_row(r, lane);
+          if (row < p.M && col < p.N) atomicAdd(C + (int64_t)row * p.ldc + col, acc[i][j][r]);
+        }
+      }
+    return;
+  }
+  if (sizeof(OutT) == 4) {
+    float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int col = n0 + wcol0 + j * 32 + l31;
+        const float bcol = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wrow0 + i * 32 + c_row(r, lane);
+          if (row < p.M && col < p.N) {
+            float* dst = C + (int64_t)row * p.ldc + col;
+            const float u = acc[i][j][r] + bcol;
+            if (p.accum) *dst = u + *dst;
+            else __builtin_nontemporal_store(u, dst);
+          }
+        }
+      }
+    return;
+  }
+  // bf16 output: as gemm2_tile.hpp — swapped MFMA operand roles (lane = row of C, 4 consecutive columns per register group),
+  // staged one 32-row block row at a time through the wave's own slice of the free LDS, written out as 16-byte row pieces.
+  typedef bf16_t T;
+  constexpr int EPC = 8;
+  constexpr int RBY = WCOLS * 2 + 16;
+  constexpr int WSLICE = 32 * RBY;
+  static_assert(8 * WSLICE <= CF::SMEM, "per-wave epilogue slices must fit the LDS ring");
+  constexpr int CPR = WCOLS / EPC;
+  constexpr int CHUNKS = 32 * CPR / 64;
+  static_assert(32 * CPR % 64 == 0, "a block row is a whole number of 16-byte chunks per lane");
+  constexpr bool DACT = (EPI == GOAT_EPI_MUL_DGELU || EPI == GOAT_EPI_MUL_DRELU);
+  constexpr bool ACT = (EPI == GOAT_EPI_GELU || EPI == GOAT_EPI_RELU);
+  T* aux = reinterpret_cast<T*>(p.aux);
+  T* C = reinterpret_cast<T*>(p.C);
+  const bool c_vec = (p.ldc % EPC) == 0 && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+  const bool aux_vec = aux != nullptr && (p.ldaux % EPC) == 0 && ((reinterpret_cast<uintptr_t>(aux) & 15) == 0);
+  char* wsp = smem + wave * WSLICE;
+  const int col_w = n0 + wcol0;
+  f32x4 bv[NI][4];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = col_w + j * 32 + 4 * hi + 8 * q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[j][q][e] = (p.bias != nullptr && col + e < p.N) ? p.bias[col + e] : 0.f;
+    }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row_w = m0 + wrow0 + i * 32;
+    if (DACT) {
+#pragma unroll
+      for (int c = 0; c < CHUNKS; ++c) {
+        const int idx = c * 64 + lane, r = idx / CPR, cc = idx % CPR;
+        uint4 now;
+        load_aux_rows<1, CPR>(p, row_w, col_w, idx, &now);
+        *reinterpret_cast<uint4*>(wsp + r * RBY + cc * 16) = now;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        char* slot = wsp + l31 * RBY + (j * 32 + 4 * hi + 8 * q) * 2;
+        float u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = acc[i][j][4 * q + e] + bv[j][q][e];
+        if (DACT) {
+          const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(slot);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float av = (float)a4[e];
+            u[e] = (EPI == GOAT_EPI_MUL_DGELU) ? u[e] * dgelu_fast(av) : (av > 0.f ? u[e] : 0.f);
+          }
+        }
+        bf16x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)u[e];
+        *reinterpret_cast<bf16x4*>(slot) = o4;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      const int idx = c * 64 + lane, r = idx / CPR, cc = idx % CPR;
+      const int row = row_w + r, col = col_w + cc * EPC;
+      uint4 raw = *reinterpret_cast<const uint4*>(wsp + r * RBY + cc * 16);
+      if (row >= p.M || col >= p.N) continue;
+      if (ACT) {
+        if (aux != nullptr) {
+          if (col + EPC <= p.N && aux_vec) {
+            store16(aux + (int64_t)row * p.ldaux + col, raw);
+          } else {
+            const T* rv = reinterpret_cast<const T*>(&raw);
+            for (int e = 0; e < EPC; ++e)
+              if (col + e < p.N) aux[(int64_t)row * p.ldaux + col + e] = rv[e];
+          }
+        }
+        bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float u = (float)v[e];
+          const float h = (EPI == GOAT_EPI_GELU) ? gelu_fast(u) : fmaxf(u, 0.f);
+          v[e] = (bf16_t)h;
+        }
+        raw = *reinterpret_cast<uint4*>(&v);
+      }
+      if (col + EPC <= p.N && c_vec) {
+        store16(C + (int64_t)row * p.ldc + col, raw);
+      } else {
+        const T* rv = reinterpret_cast<const T*>(&raw);
+        for (int e = 0; e < EPC; ++e)
+          if (col + e < p.N) C[(int64_t)row * p.ldc + col + e] = rv[e];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <class CF, bool TA, bool TB, typename OutT, int EPI, bool SPLITK>
+__global__ __launch_bounds__(512) void pp_kernel(G2Args p) {
+  pp_tile<CF, TA, TB, OutT, EPI, SPLITK>(p, xcd_chunk_position(blockIdx.x, gridDim.x), blockIdx.y);
+}
+
+template <class CF>
+__global__ __launch_bounds__(512) void pp_group_kernel(GroupArgs g) {
+  const int pos = xcd_chunk_position(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i)
+    if (i < g.n && pos >= g.tile_start[i]) pi = i;
+  const G2Args p = g.prob[pi];
+  pp_tile<CF, true, true, float, GOAT_EPI_NONE, false>(p, pos - g.tile_start[pi], 0);
+}
+
+template <class CF, bool TA, bool TB, typename OutT, int EPI, bool SPLITK>
+int pp_launch(hipStream_t st, const G2Args& a, int split) {
+  static_assert(CF::SMEM <= 160 * 1024, "LDS exceeds the CU's 160 KiB");
+  auto kern = pp_kernel<CF, TA, TB, OutT, EPI, SPLITK>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(a.tiles_m * a.tiles_n, SPLITK ? split : 1);
+  hipLaunchKernelGGL(kern, grid, dim3(512), CF::SMEM, st, a);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+template <class CF, bool TA, bool TB>
+int pp_dispatch2(hipStream_t st, const G2Args& a, int dtype_out, int epi, int split) {
+  if (split > 1) return pp_launch<CF, TA, TB, float, GOAT_EPI_NONE, true>(st, a, split);
+  if (dtype_out == GOAT_F32) {
+    if (epi != GOAT_EPI_NONE && epi != GOAT_EPI_ACCUM) return GOAT_E_ARG;
+    return pp_launch<CF, TA, TB, float, GOAT_EPI_NONE, false>(st, a, 1);
+  }
+  if constexpr (TA) {
+    if (epi != GOAT_EPI_NONE) return GOAT_E_ARG;
+    return pp_launch<CF, TA, TB, bf16_t, GOAT_EPI_NONE, false>(st, a, 1);
+  }
+  switch (epi) {
+    case GOAT_EPI_NONE: return pp_launch<CF, TA, TB, bf16_t, GOAT_EPI_NONE, false>(st, a, 1);
+    case GOAT_EPI_GELU: return pp_launch<CF, TA, TB, bf16_t, GOAT_EPI_GELU, false>(st, a, 1);
+    case GOAT_EPI_RELU: return pp_launch<CF, TA, TB, bf16_t, GOAT_EPI_RELU, false>(st, a, 1);
+    case GOAT_EPI_MUL_DGELU: return pp_launch<CF, TA, TB, bf16_t, GOAT_EPI_MUL_DGELU, false>(st, a, 1);
+    case GOAT_EPI_MUL_DRELU: return pp_launch<CF, TA, TB, bf16_t, GOAT_EPI_MUL_DRELU, false>(st, a, 1);
+  }
+  return GOAT_E_ARG;
+}
+
+template <class CF>
+int pp_dispatch_layout(hipStream_t st, const G2Args& a, int trans_a, int trans_b, int dtype_out, int epi, int split) {
+  if (!trans_a && !trans_b) return pp_dispatch2<CF, false, false>(st, a, dtype_out, epi, split);
+  if (!trans_a && trans_b) return pp_dispatch2<CF, false, true>(st, a, dtype_out, epi, split);
+  if constexpr ((CF::MI & (CF::MI - 1)) == 0) {      // a transposed A half-block needs a power-of-two width
+    if (trans_a && trans_b) return pp_dispatch2<CF, true, true>(st, a, dtype_out, epi, split);
+  }
+  return GOAT_E_ARG;
+}
+
+template <class CF>
+int pp_launch_group(hipStream_t st, const GroupArgs& g) {
+  auto kern = pp_group_kernel<CF>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(g.tile_start[g.n]), dim3(512), CF::SMEM, st, g);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace goat_g5
+
+// gemm5.hip
+int goat_g5_dispatch(hipStream_t st, const goat_g2::G2Args& a, int bm, int bn, int trans_a, int trans_b, int dtype_out, int epi,
+                     int split, int nstage);
+int goat_g5_group(hipStream_t st, const goat_g2::GroupArgs& g, int bm, int bn, int nstage);
