@@ -11,7 +11,8 @@ LAYER = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]          # (n_out, n
 GROUPS = {'text x4 layers (rows 3840)': [(3840, o, i) for _ in range(4) for (o, i) in LAYER],
           'pano x2 layers (rows 8640) + text x2': [(8640, o, i) for _ in range(2) for (o, i) in LAYER] + [(3840, o, i) for _ in range(2) for (o, i) in LAYER],
           'cross-modal (rows 1776 / 1056) x16': [(r, o, i) for r in (1776, 1056) for _ in range(2) for (o, i) in LAYER]}
-CFGS = [(64, 3), (128, 2), (128, 0x102), (128, 0x103), (128, 0x104), (256, 2), (256, 3), (T(128, 256), 2), (T(128, 256), 3), (T(256, 256), 2)]
+CFGS = [(64, 3), (128, 2), (128, 0x102), (128, 0x103), (128, 0x104), (256, 2), (256, 3), (T(128, 256), 2), (T(128, 256), 3), (T(256, 256), 2),
+        (256, 0x202), (T(128, 256), 0x202), (T(256, 256), 0x202)]          # 0x200: ping-pong main loop
 GROUPS['text x2 layers (rows 3840), 8 problems'] = [(3840, o, i) for _ in range(2) for (o, i) in LAYER]
 if os.environ.get('WG_GROUP'):        # (PMC passes: one group, one configuration)
     k = list(GROUPS)[int(os.environ['WG_GROUP'])]
@@ -65,4 +66,4 @@ for gname, probs in GROUPS.items():
         res.append((us, hipops.tile_name(bm), ns, tiles))
     print('%s: %.1f GFLOP' % (gname, fl / 1e9))
     for us, name, ns, tiles in sorted(res):
-        print('   %-8s s%d%s  tiles %4d  %7.1f us  %6.0f TF' % (name, ns & 0xFF, ' 8w' if ns & 0x100 else (' 4w' if ns & 0x200 else '   '), tiles, us, fl / us / 1e6))
+        print('   %-8s s%d%s  tiles %4d  %7.1f us  %6.0f TF' % (name, ns & 0xFF, ' 8w' if ns & 0x100 else (' pp' if ns & 0x200 else '   '), tiles, us, fl / us / 1e6))

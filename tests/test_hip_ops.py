@@ -688,7 +688,9 @@ def test_dict_weighted_sum(ops, dtype):
                                    (128, 0x102), (128, 0x103), (128, 0x104),      # 0x100: the 128-row tile on eight waves
                                    (96, 2), (96, 3), (96, 4),                      # 96 x 128 (non-transposed A only)
                                    (128 | 256 << 16, 2), (128 | 256 << 16, 3), (192 | 256 << 16, 2), (256 | 192 << 16, 2),
-                                   (256 | 256 << 16, 2), (192 | 192 << 16, 2), (192 | 192 << 16, 3)])                          # rows | columns << 16: the 8-wave wide tiles
+                                   (256 | 256 << 16, 2), (192 | 192 << 16, 2), (192 | 192 << 16, 3),                          # rows | columns << 16: the 8-wave wide tiles
+                                   (128, 0x202), (256, 0x202), (128 | 256 << 16, 0x202), (192 | 256 << 16, 0x202),
+                                   (256 | 256 << 16, 0x202)])                      # 0x200: the ping-pong main loop (csrc/gemm5_tile.hpp)
 def test_gemm_bf16_every_tile_configuration(ops, ta, tb, bm, ns):
     """Every (tile, ring depth) the autotuner may pick, on a ragged shape, incl. GELU / x GELU' / C += A·B / split-K epilogues."""
     from vln_goat_amd._lib import EPI_ACCUM, EPI_GELU, EPI_MUL_DGELU, EPI_NONE
@@ -733,8 +735,9 @@ def test_wgrad_grouped(ops):
     from vln_goat_amd import _lib
     g = torch.Generator().manual_seed(77)
     shapes = [(3840, 768, 768), (1000, 2304, 768), (333, 768, 3072), (3840, 3072, 768), (37, 8, 768), (576, 1001, 768)]
-    for bm, ns in ((64, 3), (128, 2), (128, 0x102), (128, 0x103), (256, 2), (128 | 256 << 16, 3), (256 | 256 << 16, 2)):
-        # 0x100: eight waves on the 128-row tile; rows | columns << 16
+    for bm, ns in ((64, 3), (128, 2), (128, 0x102), (128, 0x103), (256, 2), (128 | 256 << 16, 3), (256 | 256 << 16, 2),
+                   (256, 0x202), (128 | 256 << 16, 0x202), (256 | 256 << 16, 0x202)):
+        # 0x100: eight waves on the 128-row tile; rows | columns << 16; 0x200: ping-pong main loop
         arr = (_lib.WgradProblem * len(shapes))()
         keep, refs = [], []
         for i, (rows, n_out, n_in) in enumerate(shapes):

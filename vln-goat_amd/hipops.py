@@ -267,6 +267,8 @@ def save_tuned(path):
 
 
 EIGHT_WAVES = 0x100     # GOAT_GEMM_8WAVES (include/goat_hip.h): flag in the nstage argument of goat_gemm_bf16
+PINGPONG = 0x200        # GOAT_GEMM_PP: the ping-pong main loop (csrc/gemm5_tile.hpp); tiles 256x256, 192x256, 128x256, 256x128, 128x128
+USE_PP = os.environ.get('GOAT_GEMM_NO_PP', '0') == '0'
 
 
 def tile(bm, bn=128):
@@ -276,6 +278,10 @@ def tile(bm, bn=128):
 
 def tile_name(t):
     return '%dx%d' % (t & 0xFFFF, (t >> 16) or 128)
+
+
+def stage_name(ns):
+    return ('pp' if ns & PINGPONG else 's%d' % (ns & 0xFF)) + ('8w' if ns & EIGHT_WAVES else '')
 
 
 def _tile_candidates(ta, tb, M, N):
@@ -294,6 +300,12 @@ def _tile_candidates(ta, tb, M, N):
                 c += [(tile(192, 256), 2)]
     if N >= 384 and M >= 1024 and not ta and not tb:
         c += [(tile(256, 192), 2), (tile(192, 192), 2), (tile(192, 192), 3)]
+    if USE_PP and M >= 512 and N >= 256:          # ping-pong main loop (eight waves, >= 128 x 128 tiles)
+        c += [(128, PINGPONG | 2), (tile(128, 256), PINGPONG | 2), (256, PINGPONG | 2)]
+        if M >= 1024:
+            c += [(tile(256, 256), PINGPONG | 2)]
+            if not ta:
+                c += [(tile(192, 256), PINGPONG | 2)]
     return c
 
 
@@ -439,7 +451,7 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
                  out.stride(0), M, N, Kc, _ptr(bias) if bias is not None else None, epi,
                  _ptr(aux) if aux is not None else None, aux.stride(0) if aux is not None else 0,
                  split_k, bm, nstage, _ptr(colsum_out) if colsum_out is not None else None)
-        PROFILE.append((e0, e1, 2.0 * M * N * Kc, (M, N, Kc, epi, split_k, 'v2 t%d%d %s s%d' % (ta, tb, tile_name(bm), nstage)),
+        PROFILE.append((e0, e1, 2.0 * M * N * Kc, (M, N, Kc, epi, split_k, 'v2 t%d%d %s %s' % (ta, tb, tile_name(bm), stage_name(nstage))),
                         ('goat_gemm_bf16', cargs, (a, b, out, bias, aux, colsum_out))))
     return out
 
@@ -628,7 +640,8 @@ class WgradQueue:
             with torch.cuda.stream(st):
                 cls._launch(q)
 
-    CANDIDATES = ((256, 3), (128, EIGHT_WAVES | 2), (tile(256, 256), 2))      # tile configurations a group may run on
+    CANDIDATES = ((256, 3), (128, EIGHT_WAVES | 2), (tile(256, 256), 2)) + (      # tile configurations a group may run on
+        ((tile(256, 256), PINGPONG | 2), (tile(128, 256), PINGPONG | 2), (256, PINGPONG | 2)) if USE_PP else ())
     tuned = {}              # group signature (rows, n_out, n_in per problem) -> configuration, timed on first sight (AUTOTUNE)
     TUNE = os.environ.get('GOAT_WGRAD_GROUP_TUNE', '1') != '0'
 
@@ -732,7 +745,7 @@ class WgradQueue:
                 e1.record()
                 fl = sum(2.0 * t[0].shape[0] * t[0].shape[1] * t[1].shape[1] for t in items)
                 by = sum((t[0].shape[0] * t[0].shape[1] + t[1].shape[0] * t[1].shape[1]) * 2 + t[0].shape[1] * t[1].shape[1] * 4 for t in items)
-                PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 %s s%d' % (tile_name(cfg[0]), cfg[1] & 0xFF)),
+                PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 %s %s' % (tile_name(cfg[0]), stage_name(cfg[1]))),
                                 ('goat_wgrad_grouped', (ctypes.addressof(arr), n, cfg[0], cfg[1]), (arr, items))))
             _lib.check(st, 'goat_wgrad_grouped(n=%d)' % n)
 
