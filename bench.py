@@ -58,7 +58,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--batch', type=int, default=None, help='per-rank batch (default: 48 = train_batch_size of r2r_GOAT_pretrain.json; 32 for config5)')
     ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS), help='BASELINE.json configuration timed as the headline')
-    ap.add_argument('--leg', default=None, choices=['config5', 'config4'], help='(internal) run one extra leg alone and print its JSON')
+    ap.add_argument('--leg', default=None, choices=['config5', 'config4', 'large_batch'], help='(internal) run one extra leg alone and print its JSON')
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the config 4 / config 5 / fresh-batch / optimizer legs (extra keys of the JSON line, N = 1 only)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
@@ -816,6 +816,36 @@ def config5_leg(args):
     return out
 
 
+def large_batch_leg(args):
+    """The headline workload (configs[1]: same model, tasks and shapes) at per-rank batch 192 and 256: where the MFMA fraction of the
+    GEMM family and of the whole step are no longer set by B = 48's 12-K-tile, one-tile-per-CU launches (2.4 TFLOP per
+    step at B = 48).  Each batch size: captured steps timed as the headline is, its own roofline block, peak HBM footprint."""
+    import gc
+    out = {'what': 'BASELINE.json configs[1] at larger per-rank batches (same model / tasks / shapes, hipGraph replay, dropout on, fwd+bwd); '
+                   'step_mfma_frac = algorithmic FLOPs of the step / time / dense bf16 MFMA peak'}
+    algo = sum(ALGO_GFLOP_PER_TRAJ_STEP.values()) / 3.0
+    for B in [int(x) for x in os.environ.get('GOAT_BENCH_LARGE_BATCHES', '192,256').split(',')]:
+        args.batch = B
+        torch.cuda.reset_peak_memory_stats()
+        n = max(9, min(args.steps, 15)) // 3 * 3
+        m = measure_pretrain(args, 1, 0, 'config2', n, 3)
+        value = m['n_traj'] * n / m['dt']
+        rec = {'per_rank_batch': B, 'value': round(value, 1), 'unit': 'trajectory-steps/s', 'ms_per_step': round(m['dt'] / n * 1e3, 3), 'steps': n,
+               'step_mfma_frac': round(value * algo * 1e9 / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4)}
+        if not args.no_roofline:
+            r = gemm_roofline(args, m['model'], m['gb'], m['wrapper'].arena, tasks=m['tasks'])
+            rec['roofline'] = {k: r[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'launches_per_cycle', 'avg_launch_us',
+                                                 'algorithmic_gflop_per_launch', 'algorithmic_bytes_per_launch', 'gemm_ms_per_cycle', 'method')}
+            rec['roofline']['traffic'] = None
+        rec['peak_hbm_gib'] = round(torch.cuda.max_memory_allocated() / 2**30, 2)
+        out['B%d' % B] = rec
+        m.clear()
+        del m
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def config4_leg(args):
     """BASELINE.json configs[3] per rank: the fine-tuning model's calls of one rollout (text once, then panorama + navigation
     per step with the [MEM] token carried: back-propagation through time) with BACL + FACL on, at the shapes of
@@ -1046,7 +1076,7 @@ def main():
         return launch_check(args)
     if args.leg:
         torch.cuda.set_device(0)
-        print(json.dumps(config5_leg(args) if args.leg == 'config5' else config4_leg(args)))
+        print(json.dumps({'config5': config5_leg, 'config4': config4_leg, 'large_batch': large_batch_leg}[args.leg](args)))
         if os.environ.get('GOAT_SAVE_TUNED'):
             from vln_goat_amd import hipops
             hipops.save_tuned(os.environ['GOAT_SAVE_TUNED'] + '.' + args.leg)
@@ -1102,6 +1132,8 @@ def main():
             m.clear()
             out['config5_reverie'] = leg_process(args, 'config5')
             out['config4_nav'] = leg_process(args, 'config4')
+            if not os.environ.get('GOAT_BENCH_NO_LARGE_BATCH'):
+                out['large_batch'] = leg_process(args, 'large_batch')
         if world == 1 and headline and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, cfg)
         print(json.dumps(out))

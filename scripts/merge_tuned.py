@@ -7,7 +7,7 @@ dst = os.path.join(ROOT, 'vln-goat_amd', 'tuned_gfx950.json')
 base = sys.argv[1]
 tab = {} if '--fresh' in sys.argv else json.load(open(dst))
 n_old = len(tab)
-for suf in ('', '.config5', '.config4'):
+for suf in ('', '.config5', '.config4', '.large_batch'):
     p = base + suf
     if os.path.exists(p):
         new = json.load(open(p))
