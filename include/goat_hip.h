@@ -67,7 +67,7 @@ int goat_gemm_nt(void* stream, int dtype_in, int dtype_out,
  *   trans_a=0: A is [M,Kc] (Kc contiguous) ; trans_a=1: A is [Kc,M] (M contiguous)   (same for B with N)
  *   (0,0) forward y = x·Wᵀ  (F.linear) ; (0,1) dgrad dx = dy·W ; (1,1) wgrad dW = dyᵀ·x  — the autograd of
  *   every nn.Linear on the path (P/model/Bert_backbone.py:170-172,302,348,362; P/model/transformer.py:137-140).
- * bf16 inputs; dtype_out GOAT_BF16 or GOAT_F32 (F32 only with GOAT_EPI_NONE).  K-contiguous operands need
+ * bf16 inputs; dtype_out GOAT_BF16 or GOAT_F32 (F32 only with GOAT_EPI_NONE); the activation-derivative epilogues take no bias.  K-contiguous operands need
  * Kc % 64 == 0 (transposed operands: any Kc, the tail is zero-filled by the buffer bounds check); lda/ldb
  * multiples of 8, bases 16-B aligned, each operand < 2 GiB.  split_k>1: f32 atomic accumulation into C.
  * bm: 64, 128 (four waves) or 256 (eight waves sharing one B tile: 25 % fewer L2->LDS bytes per flop, nstage <= 3; for

@@ -239,7 +239,7 @@ int main(int argc, char** argv) {
     float* bias;
     CK(hipMalloc(&bias, c.N * 4));
     CK(hipMemcpy(bias, hb.data(), c.N * 4, hipMemcpyHostToDevice));
-    const float* use_bias = (c.ta || c.split > 1) ? nullptr : bias;
+    const float* use_bias = (c.ta || c.split > 1 || c.epi == GOAT_EPI_MUL_DGELU || c.epi == GOAT_EPI_MUL_DRELU) ? nullptr : bias;
     float *cs0, *cs1;
     CK(hipMalloc(&cs0, c.M * 4));
     CK(hipMalloc(&cs1, c.M * 4));

@@ -83,7 +83,7 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   // whole 64-wide tiles (callers route other shapes to goat_gemm_nt)
   if ((!trans_a || !trans_b) && (Kc % BK)) return GOAT_E_SHAPE;
   if (trans_a && !trans_b) return GOAT_E_ARG;
-  if ((epilogue == GOAT_EPI_MUL_DGELU || epilogue == GOAT_EPI_MUL_DRELU) && !aux) return GOAT_E_ARG;
+  if ((epilogue == GOAT_EPI_MUL_DGELU || epilogue == GOAT_EPI_MUL_DRELU) && (!aux || bias)) return GOAT_E_ARG;   // C = (A·B) * act'(aux): no bias
   if (epilogue == GOAT_EPI_ACCUM && (dtype_out != GOAT_F32 || bias)) return GOAT_E_ARG;
   if (split_k > 1 && (dtype_out != GOAT_F32 || (epilogue != GOAT_EPI_NONE && epilogue != GOAT_EPI_ACCUM) || bias)) return GOAT_E_ARG;
   if (pp ? (eight || !pp_tile_ok(bm, bn, nstage)) : !tile_ok(bm, bn, eight)) return GOAT_E_ARG;
