@@ -57,7 +57,13 @@ def parse():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--batch', type=int, default=None, help='per-rank batch (default: 48 = train_batch_size of r2r_GOAT_pretrain.json; 32 for config5)')
-    ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS), help='BASELINE.json configuration timed as the headline')
+    ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS) + ['config4'], help='BASELINE.json configuration timed as the headline '
+                    '(config4: the fine-tuning iteration of map_nav_src, data-parallel over --gpus ranks)')
+    ap.add_argument('--wire', default='f32', choices=['f32', 'bf16'], help='gradient exchange format at N > 1: float32 as the reference DDP, or bf16 '
+                    'shards with float32 accumulation on receipt (dp.GradArena._reduce_mean_wire)')
+    ap.add_argument('--in-graph-comm', action='store_true', help='capture the gradient exchange INSIDE the step hipGraph (one graph per step: '
+                    'phased backward with each phase\'s all-reduce as a parallel branch); falls back to collectives between graphs on any capture error. '
+                    'At N = 1 a one-rank RCCL group is created so that the capture path runs')
     ap.add_argument('--leg', default=None, choices=['config5', 'config4', 'large_batch'], help='(internal) run one extra leg alone and print its JSON')
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the config 4 / config 5 / fresh-batch / optimizer legs (extra keys of the JSON line, N = 1 only)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
@@ -117,9 +123,19 @@ def setup_dist(args):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.in_graph_comm:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:                      # a one-rank RCCL group: the collectives are identities, their launch / capture path is real
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
+            from vln_goat_amd import dp
+            dp.FORCE_COLLECTIVES[0] = True
         backend = os.environ.get('GOAT_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm; 'gloo' only for single-GPU self-tests
+        if args.in_graph_comm:
+            # ProcessGroupNCCL recycles work events; one that was recorded inside a capture fails the watchdog's query when a later
+            # eager collective reuses it (hipErrorCapturedEvent on this runtime): no recycling when collectives are captured
+            os.environ.setdefault('TORCH_NCCL_CUDA_EVENT_CACHE', '0')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
@@ -246,7 +262,8 @@ def make_steps(args, model, gb, world, wrapper, tasks=None):
     hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')
     params = list(model.parameters())
     arena = [None]
-    phased = world > 1 or bool(os.environ.get('GOAT_BENCH_PHASED'))
+    in_graph = bool(getattr(args, 'in_graph_comm', False))
+    phased = world > 1 or bool(os.environ.get('GOAT_BENCH_PHASED')) or in_graph
     plan = PhasePlan(model, int(args.layers.split(',')[0])) if phased else None
 
     def prologue(task):
@@ -272,6 +289,7 @@ def make_steps(args, model, gb, world, wrapper, tasks=None):
             wrapper.reduce_gradients(task, phase=k, wait=(k == last))
 
     use_graph = not args.no_graph and not (args.no_arena and world > 1)     # (graphs at N > 1 need the arena's static gradient storage)
+    in_graph_ok = set()
     force_eager = {'cfp'} if os.environ.get('GOAT_BENCH_EAGER_CFP') else set()
     steps = {}
     side = torch.cuda.Stream()
@@ -370,8 +388,26 @@ def make_steps(args, model, gb, world, wrapper, tasks=None):
             if world > 1:
                 torch.cuda.synchronize()
                 dist.barrier()
-            mode = 'thread_local' if world > 1 else 'global'   # thread_local: the RCCL watchdog thread may touch the HIP runtime
-            if phased:
+            mode = 'thread_local' if (world > 1 or in_graph) else 'global'   # thread_local: the RCCL watchdog thread may touch the HIP runtime
+            if phased and in_graph:
+                # ONE graph per step: prologue, forward, every backward phase, and each phase's gradient exchange forked onto the
+                # communication stream right behind the phase that completes its gradients (parallel branches of the graph, joined
+                # by the last exchange).  No host work between the phases; the cfp all-gather is a graph node too.
+                try:
+                    gi = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gi, capture_error_mode=mode):
+                        eager_phased(task)
+                    steps[task] = (lambda gi=gi: gi.replay())
+                    in_graph_ok.add(task)
+                except Exception as e:      # noqa: BLE001
+                    print('[bench] in-graph communication: capture of %s failed (%s: %s); collectives between phase graphs instead'
+                          % (task, type(e).__name__, e), file=sys.stderr)
+                    torch.cuda.set_stream(launch_stream)
+                    hipops.Branch.used, hipops.Branch._armed = set(), False
+                    hipops.WgradQueue.reset()
+                    torch.cuda.synchronize()
+                    steps[task] = capture_phased(task, mode)
+            elif phased:
                 steps[task] = capture_phased(task, mode)
             else:
                 ga = torch.cuda.CUDAGraph()
@@ -385,7 +421,8 @@ def make_steps(args, model, gb, world, wrapper, tasks=None):
             hipops.WgradQueue.reset()
             torch.cuda.synchronize()
             steps[task] = eager
-    wrapper.launch_mode = 'phased' if phased else 'plain'
+    wrapper.launch_mode = ('in-graph' if in_graph_ok and len(in_graph_ok) == len([t for t in TASKS if t not in force_eager]) else 'phased') if phased else 'plain'
+    wrapper.in_graph_tasks = sorted(in_graph_ok)
     return steps
 
 
@@ -549,7 +586,7 @@ def measure_pretrain(args, world, rank, workload, n_steps, n_warmup):
     wl = WORKLOADS[workload]
     tasks = tuple(wl['tasks'])
     cfg, model, batch, gb, static = build(args, rank, workload)
-    wrapper = dp.GoatDataParallel(model, share_cfp_negatives=True)
+    wrapper = dp.GoatDataParallel(model, share_cfp_negatives=True, wire_dtype=torch.bfloat16 if args.wire == 'bf16' else None)
     wrapper.sparse_uniform_rows = True       # every rank's synthetic batch has B*L token rows (no count exchange / host sync)
     steps = make_steps(args, model, gb, world, wrapper, tasks)
 
@@ -846,7 +883,7 @@ def large_batch_leg(args):
     return out
 
 
-def config4_leg(args):
+def config4_leg(args, rank=0, world=1):
     """BASELINE.json configs[3] per rank: the fine-tuning model's calls of one rollout (text once, then panorama + navigation
     per step with the [MEM] token carried: back-propagation through time) with BACL + FACL on, at the shapes of
     M/scripts/run_r2r_goat.sh (batch 12 per rank, max_instr_len 200, dictionaries 35/39/50/24, G = 60 map nodes): forward,
@@ -861,7 +898,7 @@ def config4_leg(args):
     model = nav_model.GlocalTextPathNavCMT(nav_model.nav_config_from_args(a)).cuda().train()
     vln_goat_amd.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
     B, T = 12, 3
-    ep = synth.make_nav_episode(B=B, L=200, n_steps=T, seed=21, vocab_size=50265, extra_nodes=51)
+    ep = synth.make_nav_episode(B=B, L=200, n_steps=T, seed=21 + rank, vocab_size=50265, extra_nodes=51)      # every rank rolls out its own shard
     mv = lambda x: x.cuda() if torch.is_tensor(x) else x
     for st in ep['steps']:            # the agent's collate: logit-fusion matrix of the step from the id strings (host)
         st['nav_fusion'] = nav_model.nav_fusion_matrix(st['vp_cand_vpids'], st['gmap_vpids'], st['gmap_visited_masks'],
@@ -873,6 +910,11 @@ def config4_leg(args):
     hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')       # per-replay dropout counter
 
     arena = [None]
+    from vln_goat_amd import dp
+    # M/r2r/agent_base.py:100-102: vln_bert and critic both under data parallelism (rank 0's weights broadcast at construction)
+    critic = nav_model.Critic(a).cuda() if hasattr(nav_model, 'Critic') else None
+    wrapper, wcritic = dp.wrap_finetune_models(model, critic, wire_dtype=torch.bfloat16 if getattr(args, 'wire', 'f32') == 'bf16' else None)
+    in_graph = bool(getattr(args, 'in_graph_comm', False))
 
     def episode():
         if arena[0] is not None:
@@ -893,46 +935,88 @@ def config4_leg(args):
         for _ in range(2):
             episode()
         if not args.no_arena:
-            from vln_goat_amd import dp
-            wrapper = dp.GoatDataParallel(model)
             wrapper.record_usage('nav')
             for p in params:
                 p.grad = None
             arena[0] = wrapper.build_arena()
         for _ in range(2):
             episode()
+            dp.reduce_finetune_gradients((wrapper, wcritic))
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    run, launch = (lambda i: episode()), 'eager'
+    exchange = lambda: dp.reduce_finetune_gradients((wrapper, wcritic))      # no-op at N = 1 (unless --in-graph-comm forces the one-rank group)
+    run, launch = (lambda i: (episode(), exchange())), 'eager'
     if not args.no_graph:
         launch_stream = torch.cuda.current_stream()
-        try:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                episode()
-            run, launch = (lambda i: g.replay()), 'hipGraph replay'
-        except Exception as e:      # noqa: BLE001
-            print('[bench] hipGraph capture of the navigation episode failed (%s: %s); running it eagerly' % (type(e).__name__, e), file=sys.stderr)
+        mode = 'thread_local' if (world > 1 or in_graph) else 'global'
+
+        def reset_capture(e, what):
+            print('[bench] hipGraph capture of %s failed (%s: %s)' % (what, type(e).__name__, e), file=sys.stderr)
             torch.cuda.set_stream(launch_stream)
             hipops.Branch.used, hipops.Branch._armed = set(), False
             hipops.WgradQueue.reset()
             torch.cuda.synchronize()
-    n = max(6, min(args.steps, 20))
-    dt = timed(run, n, 2, 1)
+        done = False
+        if in_graph and arena[0] is not None:
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode=mode):
+                    episode()
+                    exchange()
+                run, launch, done = (lambda i: g.replay()), 'hipGraph replay, gradient exchange inside the graph', True
+            except Exception as e:      # noqa: BLE001
+                reset_capture(e, 'the navigation episode with its gradient exchange')
+        if not done:
+            try:
+                if world > 1:
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode=mode):
+                    episode()
+                run, launch = (lambda i: (g.replay(), exchange())), 'hipGraph replay' + (', then the gradient exchange' if world > 1 else '')
+            except Exception as e:      # noqa: BLE001
+                reset_capture(e, 'the navigation episode')
+    n = max(6, min(args.steps, 20)) if world == 1 and args.leg else args.steps
+    dt = timed(run, n, 2 if world == 1 and args.leg else args.warmup, world)
+    dp_diag = None
+    if world > 1 or in_graph:
+        # the diagnostics block of the pre-training workload, for the fine-tuning iteration: ranks seen, compute-only time, exchange alone
+        try:
+            info = [None] * world
+            if world > 1:
+                dist.all_gather_object(info, {'rank': rank, 'device': torch.cuda.current_device(), 'name': torch.cuda.get_device_name(), 'pid': os.getpid()})
+            nn_ = max(6, min(n, 12))
+            dt_c = timed((lambda i: g.replay()) if (not args.no_graph and not in_graph) else (lambda i: episode()), nn_, 2, world)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                exchange()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 3 * 1e3
+            nbytes = int(sum((b_ - a_) * 4 for a_, b_ in arena[0].ranges('nav', None, frozenset()))) if arena[0] is not None else None
+            dp_diag = {'ranks_seen_by_rccl': dist.get_world_size(), 'backend': dist.get_backend(), 'ranks': info if world > 1 else None,
+                       'launch_mode': launch, 'wire': getattr(args, 'wire', 'f32'), 'ms_per_episode': round(dt / n * 1e3, 3),
+                       'compute_only_ms_per_episode': round(dt_c / nn_ * 1e3, 3) if not in_graph else None,
+                       'exposed_comm_ms_per_episode': round(dt / n * 1e3 - dt_c / nn_ * 1e3, 3) if not in_graph else None,
+                       'exchange_alone': {'ms': round(ms, 3), 'bytes': nbytes,
+                                          'bus_GBps': round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1) if nbytes and world > 1 else None}}
+        except Exception as e:      # noqa: BLE001
+            dp_diag = {'error': '%s: %s' % (type(e).__name__, e)}
     roof = None
-    if not args.no_roofline:
+    if not args.no_roofline and world == 1:
         r = gemm_roofline(args, model, None, None, cycle=episode)
         roof = {k: r[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'launches_per_cycle', 'avg_launch_us',
                                   'algorithmic_gflop_per_launch', 'algorithmic_bytes_per_launch', 'gemm_ms_per_cycle', 'method')}
         roof['traffic'], roof['traffic_source'] = committed_traffic('_config4')
     nav = None
-    if not args.no_graph and not os.environ.get('GOAT_BENCH_NO_NAVIGATOR'):
+    if not args.no_graph and not os.environ.get('GOAT_BENCH_NO_NAVIGATOR') and world == 1 and not in_graph:
         try:
             nav = navigator_leg(args, model, ep, arena[0], B, T, dt / n)
         except Exception as e:      # noqa: BLE001
             nav = {'error': '%s: %s' % (type(e).__name__, e)}
-    return {'value': round(B * T * n / dt, 1), 'unit': 'trajectory-steps/s', 'ms_per_episode': round(dt / n * 1e3, 3), 'episodes': n,
-            'launch': launch, 'roofline': roof, 'navigator': nav,
+    return {'value': round(B * T * world * n / dt, 1), 'unit': 'trajectory-steps/s', 'ms_per_episode': round(dt / n * 1e3, 3), 'episodes': n,
+            'launch': launch, 'roofline': roof, 'navigator': nav, 'dp': dp_diag, 'per_rank_batch': B, 'steps_per_episode': T,
             'workload': 'map_nav_src fine-tune model calls of one rollout (run_r2r_goat.sh shapes): 6,3,2 layers, batch 12, L=200, 3 steps x '
                         '(panorama 36x768 + navigation, G=60), BACL+FACL on (type_2 / type_1 / door), dictionaries 35/39/50/24, dropout '
                         '0.1 / feat 0.5, BPTT through the [MEM] token, fwd+bwd, synthetic per-step inputs (no simulator)'}
@@ -1082,6 +1166,21 @@ def main():
             hipops.save_tuned(os.environ['GOAT_SAVE_TUNED'] + '.' + args.leg)
         return
     world, rank, local = setup_dist(args)
+    if args.workload == 'config4':
+        # BASELINE.json configs[3]: the fine-tuning iteration, data-parallel (vln_bert + critic wrapped as M/r2r/agent_base.py:100-102)
+        r = config4_leg(args, rank, world)
+        if rank == 0:
+            print(json.dumps({
+                'metric': 'trajectory-steps/sec fwd+bwd (GOAT fine-tune rollout, 36 views x 768, 200 tok)', 'value': r['value'], 'unit': r['unit'],
+                'n_gpus': world, 'steps': r['episodes'], 'warmup': args.warmup, 'ms_per_step': r['ms_per_episode'], 'higher_is_better': True,
+                'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+                'config': {'workload': r['workload'], 'name': 'BASELINE.json configs[3]', 'global_batch': r['per_rank_batch'] * world,
+                           'parallelism': 'dp%d' % world, 'launch': r['launch'], 'wire': args.wire},
+                'roofline': r['roofline'], 'dp': r['dp']}))
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     wl = WORKLOADS[args.workload]
     per_rank = args.batch or wl['per_rank']
     m = measure_pretrain(args, world, rank, args.workload, args.steps, args.warmup)
@@ -1104,10 +1203,12 @@ def main():
             'config': {'workload': wl['text'] % {'layers': args.layers, 'batch': per_rank}
                                    + ', fwd+bwd%s, random-init' % (' + grad all-reduce' if world > 1 else ''),
                        'name': 'BASELINE.json configs[%d]' % {'config2': 1, 'config5': 4}[args.workload],
-                       'global_batch': per_rank * world, 'parallelism': 'dp%d' % world,
+                       'global_batch': per_rank * world, 'parallelism': 'dp%d' % world, 'wire': args.wire,
                        'launch': 'eager' if args.no_graph else ('hipGraph replay' if world == 1 else
                                                                       'hipGraph replay, backward cut into %d phases whose gradient all-reduces overlap the later phases (cfp: one more cut around the eager all-gather + loss)' % wrapper.n_phases
-                                                                      if wrapper.launch_mode == 'phased' else 'hipGraph replay of forward + backward, then one gradient all-reduce (fallback path)')},
+                                                                      if wrapper.launch_mode == 'phased' else
+                                                                      'ONE hipGraph per step: %d backward phases, each gradient exchange a parallel branch of the graph' % wrapper.n_phases
+                                                                      if wrapper.launch_mode == 'in-graph' else 'hipGraph replay of forward + backward, then one gradient all-reduce (fallback path)')},
             'samples_per_s': round(value / 5.0, 1),
         }
         if dp_diag is not None:
@@ -1137,7 +1238,7 @@ def main():
         if world == 1 and headline and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, cfg)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

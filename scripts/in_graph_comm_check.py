@@ -1,0 +1,89 @@
+"""Gradient exchange INSIDE the captured step (VERDICT r3 #4c), exercised on ONE GPU: a one-rank RCCL process group with
+dp.FORCE_COLLECTIVES — the all-reduces / all-to-alls are identities, their launch and hipGraph-capture path is the real one.
+    python scripts/in_graph_comm_check.py
+For mlm / sap / cfp of a small pre-training model and for the fine-tuning episode: (a) phased backward with the exchange launched from
+the host between the phases (the tested path), (b) the same step captured as ONE graph with each phase's exchange forked onto the
+communication stream inside the capture, replayed twice.  Dropout off: the gradient arenas must agree (split-K atomics aside), with the
+float32 and with the bf16 wire format."""
+import os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT)
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+os.environ.setdefault('MASTER_PORT', '29534')
+os.environ.setdefault('RANK', '0')
+os.environ.setdefault('WORLD_SIZE', '1')
+# ProcessGroupNCCL recycles its work events; an event once recorded inside a capture makes a LATER eager collective's watchdog query fail on
+# this HIP runtime (hipErrorCapturedEvent): no recycling in processes that capture collectives
+os.environ.setdefault('TORCH_NCCL_CUDA_EVENT_CACHE', '0')
+import torch
+import torch.distributed as dist
+import vln_goat_amd
+from vln_goat_amd import config as gcfg, dp, pretrain_model, synth, hipops
+import bench
+
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+dp.FORCE_COLLECTIVES[0] = True
+cfg = gcfg.make_config(num_l_layers=4, num_top_layer=2, num_pano_layers=1, vocab_size=1000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+ok = True
+WIRES = {'f32': None, 'bf16': torch.bfloat16}
+for wire in [WIRES[x] for x in os.environ.get('CHK_WIRES', 'f32,bf16').split(',')]:
+    torch.manual_seed(0)
+    model = pretrain_model.GlocalTextPathCMTPreTraining(cfg).cuda().eval()
+    if os.environ.get('CHK_TRAIN'):
+        model.train()
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    gb = synth.batch_to(synth.make_pretrain_batch(B=4, T=[2, 3, 1, 2], L=[30, 22, 16, 25], seed=50, vocab_size=1000, style='rich'), 'cuda')
+    w = dp.GoatDataParallel(model, wire_dtype=wire)
+    tasks = tuple(os.environ.get('CHK_TASKS', 'mlm,sap,cfp').split(','))
+    plan = bench.PhasePlan(model, 4)
+    hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for t in tasks:
+            for p in model.parameters():
+                p.grad = None
+            model(gb, t, True).mean().backward()
+            w.record_usage(t)
+        for p in model.parameters():
+            p.grad = None
+        arena = w.build_arena(phase_prefixes=plan.prefixes)
+        last = w.n_phases - 1
+
+        def step(t):
+            arena.zero(t)
+            loss = model(gb, t, True).mean()
+            for k in plan.phases(w, loss):
+                w.reduce_gradients(t, phase=k, wait=(k == last) or bool(os.environ.get('CHK_WAIT_ALL')))
+        ref = {}
+        for t in tasks:
+            step(t)                                      # (first arena step of the task: learns which slices the kernels own)
+            step(t)
+            torch.cuda.synchronize()
+            ref[t] = arena.flat.clone()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for t in tasks:
+        g = torch.cuda.CUDAGraph()
+        print('capturing', t, flush=True)
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            step(t)
+        print('captured', t, flush=True)
+        for _ in range(2):
+            arena.flat.fill_(7.0)                        # stale values must not survive a replay
+            g.replay()
+        torch.cuda.synchronize()
+        worst = 0.0
+        for p in arena.params:
+            ts = arena.tasks_of[id(p)]
+            if ts is not None and t not in ts:
+                continue
+            a = arena.offsets[id(p)]
+            x, r = arena.flat[a:a + p.numel()].double(), ref[t][a:a + p.numel()].double()
+            worst = max(worst, float((x - r).abs().max()) / max(float(r.abs().max()), 1e-3 * float(ref[t].abs().max())))
+        print('wire %s task %s: in-graph vs host-launched exchange, worst deviation %.2e of the tensor scale' % ('f32' if wire is None else 'bf16', t, worst))
+        ok = ok and worst < (2e-3 if wire is None else 2e-2)
+    arena.detach()
+print('IN_GRAPH_COMM_OK' if ok else 'IN_GRAPH_COMM_FAILED')
+dist.barrier(); dist.destroy_process_group()

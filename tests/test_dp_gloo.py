@@ -172,3 +172,151 @@ def test_world_size_one_is_the_reference_formula():
     a = cfp_losses(x[0], x[1], x[2], x[3], 1.0, None)
     b = cfp_losses(x[0], x[1], x[2], x[3], 1.0, dp.CfpGather())
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------- bf16 wire format of the arena exchange
+def _worker_wire(rank, world, port, q):
+    _init(rank, world, port)
+    from vln_goat_amd import dp
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.Tanh(), torch.nn.Linear(40, 7))
+    torch.manual_seed(200 + rank)
+    x = torch.randn(9, 24)
+    out = {}
+    for name, wire in (('f32', None), ('bf16', torch.bfloat16)):
+        w = dp.GoatDataParallel(net, wire_dtype=wire)
+        arena = w.build_arena(bucket_bytes=1000)                 # chunks of 250 floats: not a multiple of the world size
+        arena.zero('nav')
+        net(x).pow(2).mean().backward()
+        w.reduce_gradients('nav')
+        out[name] = arena.flat.clone().numpy()
+        arena.detach()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_exchange_matches_the_float32_exchange():
+    """GradArena(wire_dtype=bfloat16): all-to-all of bf16 shards, float32 accumulation on receipt, all-gather of the averaged shards —
+    within bf16 rounding (2e-2 of the tensor's scale, north_star's bf16 bound) of the float32 all-reduce, and BIT-identical on both ranks."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_wire, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    import numpy as np
+    a0, a1 = res[0][1], res[1][1]
+    assert np.array_equal(a0['bf16'], a1['bf16'])                # ranks stay in lockstep
+    assert np.allclose(a0['f32'], a1['f32'], atol=1e-7)
+    scale = np.abs(a0['f32']).max()
+    assert scale > 0
+    err = np.abs(a0['bf16'] - a0['f32']).max()
+    assert err <= 2e-2 * scale, (err, scale)
+    assert err > 0                                               # (the reduced-precision path did run)
+    rel = np.abs(a0['bf16'] - a0['f32'])[np.abs(a0['f32']) > 0.05 * scale] / np.abs(a0['f32'])[np.abs(a0['f32']) > 0.05 * scale]
+    assert rel.max() < 2 ** -7                                   # two roundings to 8 mantissa bits
+
+
+# ---------------------------------------------------------------------------------------------- fine-tuning iteration (BASELINE configs[3])
+class _ToyVLNBert(torch.nn.Module):
+    """the VLNBert call contract of M/models/model.py:12-50: forward(mode, batch), several calls per rollout, BPTT through a carried state"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.txt = torch.nn.Linear(6, 8)
+        self.pano = torch.nn.Linear(5, 8)
+        self.nav = torch.nn.Linear(16, 4)
+        self.mem = torch.nn.Linear(4, 8)
+        self.never = torch.nn.Linear(2, 2)          # a parameter no mode uses (find_unused_parameters=True upstream)
+
+    def forward(self, mode, batch):
+        if mode == 'language':
+            return torch.tanh(self.txt(batch['txt']))
+        if mode == 'panorama':
+            return torch.tanh(self.pano(batch['views']))
+        h = torch.cat([batch['txt_embeds'], batch['pano'] + (0 if batch['mem'] is None else self.mem(batch['mem']))], 1)
+        return self.nav(h)
+
+
+def _toy_iteration(model, data, ml_weight=0.2):
+    """M/r2r/agent.py:414-437 (dagger): a teacher rollout weighted ml_weight and a second rollout weighted 1, losses summed over samples
+    and steps, divided by the batch size (agent.py:708), ONE backward."""
+    B = data['txt'].shape[0]
+    total = 0.0
+    for wgt, tgt in ((ml_weight, data['tgt_a']), (1.0, data['tgt_b'])):
+        txt = model('language', {'txt': data['txt']})
+        mem, loss = None, 0.0
+        for t in range(data['views'].shape[1]):
+            pano = model('panorama', {'views': data['views'][:, t]})
+            logits = model('navigation', {'txt_embeds': txt, 'pano': pano, 'mem': mem})
+            mem = logits
+            loss = loss + torch.nn.functional.cross_entropy(logits, tgt[:, t], reduction='sum')
+        total = total + loss * wgt / B
+    return total
+
+
+def _toy_data(seed, n):
+    g = torch.Generator().manual_seed(seed)
+    return {'txt': torch.randn(n, 6, generator=g), 'views': torch.randn(n, 3, 5, generator=g),
+            'tgt_a': torch.randint(0, 4, (n, 3), generator=g), 'tgt_b': torch.randint(0, 4, (n, 3), generator=g)}
+
+
+def _worker_finetune(rank, world, port, q):
+    _init(rank, world, port)
+    from vln_goat_amd import dp
+    model = _ToyVLNBert()
+    if rank == 1:                                    # rank 1 starts from other weights: the wrapper must broadcast rank 0's
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    critic = torch.nn.Linear(8, 1)
+    w, wc = dp.wrap_finetune_models(model, critic)
+    data = _toy_data(300 + rank, 3)
+    loss = _toy_iteration(w, data)
+    loss.backward()
+    w.record_usage('nav')
+    for p in model.parameters():
+        p.grad = None
+    arena = w.build_arena()
+    losses = []
+    for _ in range(2):                               # two iterations on the arena: the second must not see the first's gradients
+        arena.zero('nav')
+        loss = _toy_iteration(w, data)
+        loss.backward()
+        dp.reduce_finetune_gradients((w, wc))
+        losses.append(float(loss))
+    q.put((rank, losses, {n: (None if p.grad is None else p.grad.clone().numpy()) for n, p in model.named_parameters()},
+           [p.grad is None for p in critic.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_finetune_iteration_two_ranks_equals_single_process_on_the_concatenated_batch():
+    """dp.wrap_finetune_models / reduce_finetune_gradients: vln_bert + critic as M/r2r/agent_base.py:100-102 wraps them; the iteration of
+    M/r2r/agent.py:414-445 (two rollouts, one backward) on 2 ranks x 3 samples gives the gradients of one process on the 6 samples."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_finetune, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    import numpy as np
+    model = _ToyVLNBert()
+    d0, d1 = _toy_data(300, 3), _toy_data(301, 3)
+    cat = {k: torch.cat([d0[k], d1[k]]) for k in d0}
+    loss = _toy_iteration(model, cat)
+    loss.backward()
+    assert abs((res[0][1][1] + res[1][1][1]) / 2 - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    assert res[0][1][0] == res[0][1][1]
+    for n, p in model.named_parameters():
+        g0, g1 = res[0][2][n], res[1][2][n]
+        if p.grad is None:
+            assert g0 is None and g1 is None, n
+            continue
+        assert np.allclose(g0, p.grad.numpy(), rtol=1e-5, atol=1e-6), n
+        assert np.array_equal(g0, g1), n
+    assert all(res[0][3]) and all(res[1][3])         # the critic took no part: no gradient, no exchange

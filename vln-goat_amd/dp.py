@@ -24,12 +24,37 @@ import torch
 import torch.distributed as dist
 
 
+# Run the collectives even when the process group has ONE rank (they are identities there): the only way to exercise the RCCL
+# launch / hipGraph-capture path of the gradient exchange on a single-GPU box (RCCL refuses two ranks per device).  Set by the
+# in-graph communication tests and by `bench.py --in-graph-comm` at N = 1; never needed at N > 1.
+FORCE_COLLECTIVES = [False]
+
+
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _comm_on():
+    """is there a gradient exchange to run?  (more than one rank, or one rank with FORCE_COLLECTIVES)"""
+    return _world() > 1 or (FORCE_COLLECTIVES[0] and dist.is_available() and dist.is_initialized())
+
+
 def _rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _gloo_gather_rows(x):
+    """[W, n] = the vector x of every rank (gloo, tests only): all_gather on CPU tensors, a zero-padded float32 all-reduce on GPU tensors
+    (gloo has no GPU all-gather; adding zeros is exact, so the values are the senders' bits)."""
+    W = _world()
+    if x.is_cuda:
+        allv = torch.zeros((W, x.numel()), dtype=torch.float32, device=x.device)
+        allv[_rank()] = x.float()
+        dist.all_reduce(allv)
+        return allv.to(x.dtype)
+    parts = [torch.empty_like(x) for _ in range(W)]
+    dist.all_gather(parts, x)
+    return torch.stack(parts, 0)
 
 
 class _AllGatherCat(torch.autograd.Function):
@@ -159,8 +184,10 @@ class GradArena:
                         # group and are cleared by ONE fill per group in zero(); the large matrices are cleared / overwritten
                         # by their first writer (cache-warm for the split-K atomics)
 
-    def __init__(self, params, usage=None, bucket_bytes=128 << 20, phase_of=None):
-        """phase_of: optional {id(param): 0 | 1} — backward phase in which the parameter's gradient becomes final (0: the part of
+    def __init__(self, params, usage=None, bucket_bytes=128 << 20, phase_of=None, wire_dtype=None):
+        """wire_dtype: None — float32 on the wire, as the reference's DDP — or torch.bfloat16: half the bytes per step over xGMI
+        (the 8-GPU target needs it), accumulated in float32 on receipt (_reduce_mean_wire).
+        phase_of: optional {id(param): 0 | 1} — backward phase in which the parameter's gradient becomes final (0: the part of
         the backward pass that runs first, e.g. heads / cross-modal / panorama encoders; 1: the rest, e.g. text encoder and
         embeddings).  Phases are kept contiguous inside every usage group so that the phase-0 ranges can be all-reduced
         while the later phases are still computing (GoatDataParallel.backward_phase)."""
@@ -205,6 +232,8 @@ class GradArena:
         self._ranges, self._owned, self._fills, self._cur = {}, {}, {}, None
         self.no_zero = {}       # task -> ids of parameters whose slice zero() leaves alone (written wholesale elsewhere)
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        self.wire_dtype = wire_dtype
+        self._wire = {}         # staging buffers of the reduced-precision exchange, by chunk length (fixed addresses: capturable)
 
     # -- binding ---------------------------------------------------------------------------------
     def attach(self):
@@ -325,13 +354,54 @@ class GradArena:
             dist.all_reduce(c)
             c.div_(W)
 
+    def _reduce_mean_wire(self, c, W):
+        """Mean over ranks of the float32 chunk `c` with `wire_dtype` (bfloat16) on the wire and float32 accumulation:
+            1. every rank rounds its chunk to the wire dtype and sends shard j of it to rank j      (all-to-all, (W-1)/W of the chunk)
+            2. rank j adds the W shards it received in float32, divides by W, rounds the mean ONCE
+            3. the W averaged shards are all-gathered and widened back into the arena            (all-gather, (W-1)/W of the chunk)
+        Same bytes per rank as a ring all-reduce in the wire dtype, but one rounding of the inputs and one of the result instead
+        of one per ring hop, every rank ends with bit-identical gradients (they all widen the same gathered shards), and on the
+        xGMI full mesh both collectives use all links at once.  gloo (CPU tests) lacks all-to-all: all-gather + local sum, same
+        arithmetic.  Inside a hipGraph capture step 1-2 is a reduce-scatter in the wire dtype instead (RCCL's all-to-all does not
+        survive capture on this stack — scripts/rccl_capture_probe.py: it crashes hipStreamEndCapture; all-reduce, reduce-scatter,
+        all-gather and broadcast capture fine): one rounding per ring hop rather than one per input, same bytes, same 2e-2 bound."""
+        n = c.numel()
+        per = (n + W - 1) // W
+        buf = self._wire.get(n)
+        if buf is None:
+            wd = self.wire_dtype
+            buf = self._wire[n] = (torch.zeros(W * per, dtype=wd, device=c.device), torch.empty(W * per, dtype=wd, device=c.device),
+                                   torch.empty(per, dtype=wd, device=c.device), torch.empty(W * per, dtype=wd, device=c.device))
+        send, recv, shard, out = buf
+        send[:n].copy_(c)
+        gloo = dist.get_backend() == 'gloo'
+        if gloo:
+            r = _rank()
+            recv.copy_(_gloo_gather_rows(send)[:, r * per:(r + 1) * per].reshape(-1))
+            shard.copy_(recv.view(W, per).float().sum(0).div_(W))
+        elif c.is_cuda and torch.cuda.is_current_stream_capturing():
+            dist.reduce_scatter_tensor(shard, send)
+            if W > 1:
+                shard.copy_(shard.float().div_(W))
+        else:
+            dist.all_to_all_single(recv, send)
+            shard.copy_(recv.view(W, per).float().sum(0).div_(W))
+        if gloo:
+            out.copy_(_gloo_gather_rows(shard).reshape(-1))
+        else:
+            dist.all_gather_into_tensor(out, shard)
+        c.copy_(out[:n])
+
     def all_reduce_mean(self, task=None, phase=None, wait=True, exclude=frozenset(), extra=()):
         """Average the task's gradient ranges (of one backward phase, or all) over ranks, in place, on the communication
         stream.  wait=False: return without making the caller's stream wait (call wait_comm() before the gradients are
-        read) — this is how the phase-0 all-reduce overlaps the phase-1 backward computation."""
+        read) — this is how the phase-0 all-reduce overlaps the phase-1 backward computation.  Capturable: inside a
+        torch.cuda.graph() the communication stream joins the capture as a parallel branch (wait=False branches must be joined
+        by wait_comm() before the capture ends)."""
         W = _world()
-        if W == 1:
+        if not _comm_on():
             return
+        reduce = self._reduce_mean if self.wire_dtype is None else self._reduce_mean_wire
         chunks = []
         for a, b in tuple(self.ranges(task, phase, exclude)) + tuple(extra):        # extra: explicit (begin, end) element ranges
             while a < b:
@@ -342,12 +412,12 @@ class GradArena:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 for c in chunks:
-                    self._reduce_mean(c, W)
+                    reduce(c, W)
             if wait:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
             for c in chunks:
-                self._reduce_mean(c, W)
+                reduce(c, W)
 
     def wait_comm(self):
         if self.comm_stream is not None:
@@ -403,7 +473,7 @@ class GoatDataParallel(torch.nn.Module):
         self.n_phases = len(phase_prefixes) + 1
         self._phase_params = [[p for p in self.module.parameters() if phase_of[id(p)] == k and p.requires_grad]
                               for k in range(self.n_phases)]
-        self.arena = GradArena(self.module.parameters(), self._usage or None, bucket_bytes, phase_of).attach()
+        self.arena = GradArena(self.module.parameters(), self._usage or None, bucket_bytes, phase_of, wire_dtype=self.wire_dtype).attach()
         return self.arena
 
     # Phased backward: the gradient all-reduce of the parameters that finish first runs on the communication stream while the
@@ -535,7 +605,34 @@ class GoatDataParallel(torch.nn.Module):
             self._buckets[key] = gb
         if grads is not None:
             grads = [g for g in grads if g is not None]
-        gb.all_reduce_mean(grads)
+        if gb.params:                      # (a model that took no part in the loss — the critic outside RL training — has nothing to exchange)
+            gb.all_reduce_mean(grads)
+
+
+def wrap_finetune_models(vln_bert, critic=None, **kw):
+    """The fine-tuning agent's two models under data parallelism, as M/r2r/agent_base.py:100-102 (and M/reverie/agent_base.py:114-115)
+    wraps them in DDP(find_unused_parameters=True): rank 0's parameters and buffers broadcast at construction, one process per GPU,
+    every rank rolls out its own shard of the batch (M/r2r/env.py shards the instruction list by rank), the losses of the iteration's
+    rollouts (teacher + sampled, M/r2r/agent.py:414-437) are summed, ONE backward, gradients averaged over ranks.  The wrappers pass
+    `w(mode, batch)` through to the models; the gradient usage key of the whole iteration is 'nav':
+        w, wc = dp.wrap_finetune_models(vln_bert, critic)
+        ... first iteration: loss.backward(); w.record_usage('nav'); arena = w.build_arena() ...
+        arena.zero('nav'); loss = rollouts(w); loss.backward(); dp.reduce_finetune_gradients((w, wc))
+    The critic receives no gradient outside RL training (train_rl is commented out upstream): its exchange is empty, which is what
+    find_unused_parameters=True makes of it in the reference."""
+    w = GoatDataParallel(vln_bert, share_cfp_negatives=False, **kw)
+    wc = GoatDataParallel(critic, share_cfp_negatives=False, **kw) if critic is not None else None
+    return w, wc
+
+
+def reduce_finetune_gradients(wrappers, key='nav', wait=True):
+    """gradient average of one fine-tuning iteration over ranks, for every wrapped model that produced gradients."""
+    for w in wrappers:
+        if w is not None:
+            if w.arena is not None:
+                w.arena.all_reduce_mean(key, None, wait)
+            else:
+                w.reduce_gradients(key)
 
 
 def broadcast_task(task_names, chosen_index, device):

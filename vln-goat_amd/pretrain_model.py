@@ -659,7 +659,7 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
             to = attn_pool(txt, self.tim_txt_attn, cache.get('cfp_txt_mask'))
         if batch['extra_heads']:
             vp = self.tim_local_head(vp)
-        vo = attn_pool(vp, self.tim_local_attn)
+        vo = attn_pool(vp, self.tim_local_attn, cache.get('cfp_vp_mask'))
         bg.join(gmap, go)
         bt.join(txt, to)
         fw = self._fuse_weights(gmap, vp)

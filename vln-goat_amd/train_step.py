@@ -177,7 +177,8 @@ def pad_batch(batch, L=None, N=None, G=None, W=None, shape_only=()):
     grow('gmap_pair_dists', [(1, G), (2, G)])
     grow('vp_pos_fts', [(1, W)])
     # the batch's own padded widths: the reference's un-masked CFP pooling runs over exactly these (collate_indices -> cfp_*_mask)
-    out['_own'] = batch.get('_own') or {'L': int(batch['txt_ids'].shape[1]), 'G': int(batch['gmap_step_ids'].shape[1])}
+    out['_own'] = batch.get('_own') or {'L': int(batch['txt_ids'].shape[1]), 'G': int(batch['gmap_step_ids'].shape[1]),
+                                        'W': int(batch['vp_pos_fts'].shape[1])}
     return out
 
 
@@ -186,7 +187,10 @@ def index_capacities(batch, tasks, mlm_rate=0.25):
     Nn, V = batch['traj_view_img_fts'].shape[:2]
     B, Lb = batch['txt_ids'].shape
     W = batch['vp_pos_fts'].shape[1]
-    return {'nnz_gmap': Nn * V + Nn, 'nnz_vp': B * W, 'mlm': max(8, int(mlm_rate * B * Lb))}
+    O = batch['traj_obj_img_fts'].shape[1] if torch.is_tensor(batch.get('traj_obj_img_fts')) else 0
+    # the MRC selections draw from the B last panoramas' views / objects, not from the text: capacities of their own
+    return {'nnz_gmap': Nn * V + Nn, 'nnz_vp': B * W, 'mlm': max(8, int(mlm_rate * B * Lb)),
+            'mrc_view': max(8, B * V), 'mrc_obj': max(8, B * O)}
 
 
 def _pad1(t, n, fill):
@@ -280,7 +284,7 @@ def collate_indices(config, batch, tasks=('mlm', 'sap', 'cfp'), caps=None, vp_wi
         for which in ('view', 'obj'):
             if 'mrc_' + which in out:
                 rows, sel = out['mrc_' + which]
-                n, cap = int(rows.shape[0]), c['mlm']
+                n, cap = int(rows.shape[0]), c.get('mrc_' + which, c['mlm'])
                 if n == 0:
                     raise ValueError('collate_indices: a bucketed batch needs at least one masked %s region' % which)
                 w = torch.zeros(cap, dtype=torch.float32)
@@ -302,7 +306,9 @@ def collate_indices(config, batch, tasks=('mlm', 'sap', 'cfp'), caps=None, vp_wi
             tm[:, own['L']:] = float('-inf')
             gm = torch.zeros(B, G, dtype=torch.float32)
             gm[:, own['G']:] = float('-inf')
-            out['cfp_txt_mask'], out['cfp_gmap_mask'] = tm, gm
+            vm = torch.zeros(B, W, dtype=torch.float32)
+            vm[:, own.get('W', W):] = float('-inf')
+            out['cfp_txt_mask'], out['cfp_gmap_mask'], out['cfp_vp_mask'] = tm, gm, vm
         if 'mlm' in tasks:
             n = int(out['mlm_idx'].shape[0])
             if n == 0:
@@ -437,7 +443,7 @@ class StaticBatch:
         for k, d in parts.items():
             if k == 'vp':
                 cache[k] = (d[0], d[1], d[2], self.vp_width)
-            elif k in ('mlm_idx', 'mlm_tgt', 'mlm_scale', 'view_lens_cpu', 'obj_lens_cpu', 'mrc_view_w', 'mrc_obj_w', 'cfp_txt_mask', 'cfp_gmap_mask'):
+            elif k in ('mlm_idx', 'mlm_tgt', 'mlm_scale', 'view_lens_cpu', 'obj_lens_cpu', 'mrc_view_w', 'mrc_obj_w', 'cfp_txt_mask', 'cfp_gmap_mask', 'cfp_vp_mask'):
                 cache[k] = d[0]
             else:
                 cache[k] = tuple(d[i] for i in sorted(d))
