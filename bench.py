@@ -54,7 +54,7 @@ ALGO_GFLOP_PER_TRAJ_STEP = {'mlm': 12.98, 'sap': 9.83, 'cfp': 7.6}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--steps', type=int, default=96, help='timed steps (default 96: a timed region of ~0.55 s, 32 of each task)')
     ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--batch', type=int, default=None, help='per-rank batch (default: 48 = train_batch_size of r2r_GOAT_pretrain.json; 32 for config5)')
     ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS) + ['config4'], help='BASELINE.json configuration timed as the headline '
@@ -168,7 +168,8 @@ def build(args, rank, workload='config2'):
         static = train_step.StaticBatch(cfg, batch, [t for t in wl['tasks'] if t in ('mlm', 'sap', 'cfp')])
         gb = static.gb
     else:
-        gb = synth.batch_to(batch, 'cuda')
+        from vln_goat_amd import train_step
+        gb = synth.batch_to(train_step.prepare_position_features(batch), 'cuda')      # (position features cast + K-padded once, on the host)
     return cfg, model, batch, gb, static
 
 
@@ -897,12 +898,16 @@ def config4_leg(args, rank=0, world=1):
     torch.manual_seed(0)
     model = nav_model.GlocalTextPathNavCMT(nav_model.nav_config_from_args(a)).cuda().train()
     vln_goat_amd.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
-    B, T = 12, 3
-    ep = synth.make_nav_episode(B=B, L=200, n_steps=T, seed=21 + rank, vocab_size=50265, extra_nodes=51)      # every rank rolls out its own shard
+    # T = 6: the length of an R2R ground-truth path (5-7 viewpoints; the teacher-forced rollout of M/r2r/agent.py stops at its end; the
+    # reference caps rollouts at max_action_len 15, scripts/run_r2r_goat.sh:35 — GOAT_NAV_T=15 runs that as a stress case).  Round 3 timed T = 3.
+    B, T = 12, int(os.environ.get('GOAT_NAV_T', '6'))
+    ep = synth.make_nav_episode(B=B, L=200, n_steps=T, seed=21 + rank, vocab_size=50265, extra_nodes=54 - T)      # G = 60 map nodes at the last step; every rank rolls out its own shard
     mv = lambda x: x.cuda() if torch.is_tensor(x) else x
     for st in ep['steps']:            # the agent's collate: logit-fusion matrix of the step from the id strings (host)
         st['nav_fusion'] = nav_model.nav_fusion_matrix(st['vp_cand_vpids'], st['gmap_vpids'], st['gmap_visited_masks'],
                                                        st['gmap_step_ids'].shape[1], st['vp_masks'].shape[1])
+    from vln_goat_amd import train_step
+    ep['steps'] = [train_step.prepare_position_features(st) for st in ep['steps']]      # (cast + K-pad of the 7- / 14-wide features: once, on the host)
     ep = {k: ([{kk: mv(vv) for kk, vv in st.items()} for st in v] if k == 'steps' else mv(v)) for k, v in ep.items()}
     params = list(model.parameters())
     hipops.manual_seed(4321)
@@ -1017,7 +1022,7 @@ def config4_leg(args, rank=0, world=1):
             nav = {'error': '%s: %s' % (type(e).__name__, e)}
     return {'value': round(B * T * world * n / dt, 1), 'unit': 'trajectory-steps/s', 'ms_per_episode': round(dt / n * 1e3, 3), 'episodes': n,
             'launch': launch, 'roofline': roof, 'navigator': nav, 'dp': dp_diag, 'per_rank_batch': B, 'steps_per_episode': T,
-            'workload': 'map_nav_src fine-tune model calls of one rollout (run_r2r_goat.sh shapes): 6,3,2 layers, batch 12, L=200, 3 steps x '
+            'workload': 'map_nav_src fine-tune model calls of one rollout (run_r2r_goat.sh shapes): 6,3,2 layers, batch 12, L=200, %d steps x ' % T +
                         '(panorama 36x768 + navigation, G=60), BACL+FACL on (type_2 / type_1 / door), dictionaries 35/39/50/24, dropout '
                         '0.1 / feat 0.5, BPTT through the [MEM] token, fwd+bwd, synthetic per-step inputs (no simulator)'}
 
@@ -1066,6 +1071,60 @@ def dp_diagnostics(args, m, world, rank, dt_step):
             'exposed_comm_ms_per_step': round(step_ms - comp_ms, 3), 'allreduce_alone': alone}
 
 
+def dagger_iteration(model, te, bufs, batches, extras, arena, sim, store, B, T, ml_weight=0.2, max_action_len=15):
+    """The reference's training iteration (train_alg=dagger, M/r2r/agent.py:414-445 with scripts/run_r2r_goat.sh:35,41-42): a TEACHER rollout
+    weighted ml_weight = 0.2 and a SAMPLE rollout (the policy's own sampled actions, up to max_action_len = 15 steps, loss against the
+    teacher action of every visited state), the two losses summed, ONE backward.  Here: the sampled rollout is host-driven (the next
+    observation depends on the sampled action: one B-element device -> host copy per step, eager launches; rollout.NavRollout) and
+    back-propagates first; the teacher rollout is the captured episode graph, captured in ACCUMULATE form (no arena clear: every gradient
+    slice was already written in this step, so every kernel of the replay adds) with its loss scaled by ml_weight — together
+    d(L_sample + 0.2 L_teacher), what the reference's single backward produces."""
+    from vln_goat_amd import hipops, rollout
+    call = lambda mode, batch: model(mode, batch)
+    ro = rollout.NavRollout(call, sim, store, max_action_len=max_action_len, pano_width=38, gmap_buckets=[64, 96, 128])
+
+    def sample_part(i):
+        arena.zero('nav')
+        hipops.RngState.dev.add_(0x9E3779B1)
+        loss, _ = ro.run(batches[i % len(batches)], feedback='sample', extras=extras, train_ml=1.0)
+        loss.backward()
+        return ro.steps, ro.host_s
+
+    def teacher_part():
+        (te.body(call, bufs, extras) * ml_weight).backward()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(2):                         # warm-up: tunes the GEMM shapes of the longer sampled rollouts, then the accumulate path
+            sample_part(i)
+            teacher_part()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    sample_part(0)                                 # the capture below must see every slice already written in this step
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        teacher_part()
+    torch.cuda.synchronize()
+    n, t_s, steps, host = 4, [], [], []
+    t_all = time.perf_counter()
+    for i in range(n):
+        t0 = time.perf_counter()
+        st, hs = sample_part(i)
+        torch.cuda.synchronize()
+        t_s.append(time.perf_counter() - t0)
+        steps.append(st)
+        host.append(hs)
+        bufs.load(te.plan(batches[i % len(batches)]))
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t_all) / n
+    return {'ms_per_iteration': round(dt * 1e3, 2), 'sample_rollout_ms': round(sum(t_s) / n * 1e3, 2), 'sample_steps': round(sum(steps) / n, 1),
+            'sample_host_builder_ms': round(sum(host) / n * 1e3, 2), 'teacher_part_ms': round((dt - sum(t_s) / n) * 1e3, 2),
+            'ml_weight': ml_weight, 'max_action_len': max_action_len,
+            'what': 'teacher rollout (captured graph incl. its host plan, loss x %.1f, accumulate form) + sampled rollout (eager, one read-back per step) '
+                    '+ their backward passes into one gradient arena: the reference iteration of train_alg=dagger' % ml_weight}
+
+
 def navigator_leg(args, model, ep, arena, B, T, frozen_s):
     """The same rollout driven by the graph-only navigator: NEW episodes every iteration — start viewpoints, paths,
     instructions, panoramas, growing maps — on synthetic scans.  Per iteration, inside the timed region: the host walks the B
@@ -1107,12 +1166,8 @@ def navigator_leg(args, model, ep, arena, B, T, frozen_s):
                              'front_gmap_feats': ep['front_gmap_feats']}}
     import time
     plans = [te.plan(batches[0])]              # (cold: shortest-path tables of the scans are built on first use)
-    ts = []
     for k in (1, 2, 3):
-        t0 = time.perf_counter()
         te.plan(batches[k])
-        ts.append((time.perf_counter() - t0) * 1e3)
-    plan_ms = sorted(ts)[1]                     # steady-state host work per batch of episodes (hidden under the previous replay)
     bufs = rollout.EpisodeBuffers(plans[0])
     call = lambda mode, batch: model(mode, batch)
     params = list(model.parameters())
@@ -1135,18 +1190,28 @@ def navigator_leg(args, model, ep, arena, B, T, frozen_s):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         episode()
-    state = {'plan': None}
+    state = {'plan': None, 'plan_s': []}
 
     def run(i):
         plan = state['plan'] if state['plan'] is not None else te.plan(batches[i % len(batches)])
         bufs.load(plan)                      # pinned H2D, enqueued behind the previous replay
         g.replay()
+        t0 = time.perf_counter()
         state['plan'] = te.plan(batches[(i + 1) % len(batches)])       # host work of the next episode, under the replay just launched
+        state['plan_s'].append(time.perf_counter() - t0)
     n = 12
     dt = timed(run, n, 3, 1)
+    in_loop = state['plan_s'][-n:]
+    plan_ms = sum(in_loop) / len(in_loop) * 1e3          # the IN-LOOP host plan time (mean over the timed iterations), not a separate measurement
     n_traj = sum(te.plan(batches[i % len(batches)])['_n_traj'] for i in range(n))
-    return {'ms_per_episode': round(dt / n * 1e3, 3), 'value': round(n_traj / dt, 1), 'unit': 'trajectory-steps/s', 'episodes': n,
-            'vs_frozen_episode': round((dt / n) / frozen_s, 3), 'host_plan_ms': round(plan_ms, 2), 'h2d_bytes_per_episode': bufs.nbytes,
+    dagger = None
+    if arena is not None and not os.environ.get('GOAT_BENCH_NO_DAGGER'):
+        try:
+            dagger = dagger_iteration(model, te, bufs, batches, extras, arena, sim, store, B, T)
+        except Exception as e:      # noqa: BLE001
+            dagger = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    return {'dagger_iteration': dagger, 'ms_per_episode': round(dt / n * 1e3, 3), 'value': round(n_traj / dt, 1), 'unit': 'trajectory-steps/s', 'episodes': n,
+            'vs_frozen_episode': round((dt / n) / frozen_s, 3), 'host_plan_ms': round(plan_ms, 2), 'host_plan_ms_max': round(max(in_loop) * 1e3, 2), 'h2d_bytes_per_episode': bufs.nbytes,
             'what': 'graph-only navigator on 4 synthetic scans (60 viewpoints each), %d new episodes per iteration, teacher forcing, '
                     'pano width 38, map width 64, text bucket %d; host plan + one pinned H2D + replay of the captured episode graph' % (B, L)}
 
@@ -1186,6 +1251,12 @@ def main():
     m = measure_pretrain(args, world, rank, args.workload, args.steps, args.warmup)
     dt, n_traj, wrapper = m['dt'], m['n_traj'], m['wrapper']
 
+    # each task's step alone (same graphs, 12 replays each, all ranks take part: the steps hold collectives at N > 1)
+    per_task = {}
+    for t in m['tasks']:
+        n_t = 12
+        dt_t = timed(lambda i, t=t: m['steps'][t](), n_t, 2, world)
+        per_task[t] = round(dt_t / n_t * 1e3, 3)
     dp_diag = None
     if world > 1 and not os.environ.get('GOAT_BENCH_NO_DP_DIAG'):
         try:
@@ -1216,6 +1287,7 @@ def main():
         headline = args.workload == 'config2' and TASKS == ('mlm', 'sap', 'cfp')
         if headline:
             out['step_mfma_frac'] = round(value / world * algo * 1e9 / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4)
+            out['ms_per_task_step'] = per_task
         if world == 1 and headline and not args.no_roofline:
             out['roofline'] = gemm_roofline(args, m['model'], m['gb'], wrapper.arena)
         if world == 1 and headline and not args.no_extra_configs and not args.no_graph and not args.no_arena:

@@ -376,6 +376,16 @@ int goat_infonce_bwd(void* stream, const float* const* x_loc, const float* const
  * ds_read_b64_tr_b16 when lane l points at elements 4l..4l+3 of an LDS array holding 0,1,2,... */
 int goat_probe_tr16(void* stream, uint16_t* out);
 
+/* ---- glue of the captured steps (csrc/glue.hip) -------------------------------------------------------------------------
+ * out[numel] = sum_i srcs[i][numel] (n <= 8 tensors of `dtype`, float32 accumulation, ONE rounding): the gradient of a tensor with
+ * several consumers — replaces the k - 1 pairwise `add` launches of torch's autograd engine (AccumulateGrad-free fan-in: the text
+ * states read by every cross-modal layer, P/model/vilmodel_goat.py:163-199; LayerNorm outputs with two consumers,
+ * P/model/Bert_backbone.py:304-310).  srcs is a HOST array of device pointers (16-B aligned); out may alias srcs[0]. */
+int goat_add_n(void* stream, int dtype, const void* const* srcs, int n, void* out, int64_t numel);
+/* n <= 16 byte ranges (16-B aligned, multiples of 16 bytes) cleared by one launch — optimizer.zero_grad() of the reference
+ * (P/train_r2r_goat.py:301-363) over the gradient arena's per-task ranges.  ptrs / nbytes are HOST arrays. */
+int goat_zero_ranges(void* stream, void* const* ptrs, const int64_t* nbytes, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,6 +154,27 @@ int main(int argc, char** argv) {
       });
       printf("  gemm K=%-15d %7.2f us   (%.0f TFLOP/s)%s\n", K, t, 2.0 * s.M * s.N * K / t / 1e6, rc ? "  [launch error]" : "");
     }
+    // epilogues of the FFN pair (cold operands): bias, bias + GELU with the pre-activation saved (aux store), x GELU'(aux) (aux load)
+    if (s.N == 3072 || s.N == 2304) {
+      float* bias;
+      CK(hipMalloc(&bias, s.N * 4));
+      CK(hipMemset(bias, 0, s.N * 4));
+      std::vector<uint16_t*> X(ROT);
+      for (int i = 0; i < ROT; ++i) { CK(hipMalloc(&X[i], (size_t)s.M * s.N * 2)); CK(hipMemset(X[i], 0x11, (size_t)s.M * s.N * 2)); }
+      struct E { int epi; bool bias, aux; const char* name; };
+      const E es[] = {{GOAT_EPI_NONE, true, false, "bias"}, {GOAT_EPI_GELU, true, true, "bias+GELU, aux store"}, {GOAT_EPI_GELU, true, false, "bias+GELU, no aux"},
+                      {GOAT_EPI_MUL_DGELU, false, true, "x GELU'(aux)"}};
+      for (const E& e : es) {
+        int rc = 0;
+        t = graph_time(st, NL, [&](int i) {
+          rc |= goat_gemm_bf16(st, 0, 0, GOAT_BF16, A[i % ROT], s.K, B[i % ROT], s.K, C[i % ROT], s.N, s.M, s.N, s.K, e.bias ? bias : nullptr, e.epi,
+                               e.aux ? X[i % ROT] : nullptr, s.N, 1, s.bm | (s.bn << 16), s.ns, nullptr);
+        });
+        printf("  gemm K=%d %-22s %7.2f us   (%.0f TFLOP/s)%s\n", s.K, e.name, t, 2.0 * s.M * s.N * s.K / t / 1e6, rc ? "  [launch error]" : "");
+      }
+      for (int i = 0; i < ROT; ++i) CK(hipFree(X[i]));
+      CK(hipFree(bias));
+    }
     // the same GEMM with warm operands (one buffer set)
     {
       int rc = 0;

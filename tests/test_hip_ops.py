@@ -1009,3 +1009,75 @@ def test_layer_norm_output_dropout_in_the_same_launch(ops, dtype):
             pairs.append((post.grad.float(), pr.grad, 'dpost'))
         for a, b, what in pairs:
             assert float((a - b).abs().max()) <= 2 * tol * max(1.0, float(b.abs().max())), (what, with_post)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,numel', [(2, 4096), (6, 48 * 80 * 768), (8, 1003), (3, 7)])
+def test_add_n_and_fanout(ops, dtype, n, numel):
+    """goat_add_n: the gradient fan-in of a tensor with n consumers in one launch (float32 accumulation) == the sum of the parts;
+    hipops.fanout: n handles on one buffer whose gradients meet in that launch == plain autograd with n uses of the tensor."""
+    torch.manual_seed(n * 1000 + numel % 97)
+    parts = [torch.randn(numel, device=DEV).to(dtype) for _ in range(n)]
+    ref = torch.stack([p.float() for p in parts]).sum(0)
+    got = ops.add_n(parts)
+    assert got.dtype == dtype
+    _close(got, ref, dtype, 'add_n')
+    if dtype == torch.float32:
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # in place on the first summand
+    first = parts[0].clone()
+    ops.add_n([first] + parts[1:], out=first)
+    assert torch.equal(first, got)
+    # fanout vs. n plain uses
+    x = torch.randn(5, 13, device=DEV).to(dtype).requires_grad_(True)
+    ws = [torch.randn(5, 13, device=DEV).to(dtype) for _ in range(n)]
+    hs = ops.fanout(x, n)
+    assert len(hs) == n and all(h.data_ptr() == x.data_ptr() for h in hs)
+    sum((h * w).sum() for h, w in zip(hs[:-1], ws[:-1])).backward()          # the last handle stays unused: its gradient is None
+    g_fan = x.grad.clone()
+    x.grad = None
+    sum((x * w).sum() for w in ws[:-1]).backward()
+    _close(g_fan, x.grad, dtype, 'fanout gradient')
+
+
+def test_zero_ranges_clears_exactly_the_ranges(ops):
+    """goat_zero_ranges: the arena's per-step fills as one launch; neighbours of the ranges keep their contents."""
+    buf = torch.full((1 << 16,), 3.0, device=DEV)
+    views = [buf[64:192], buf[1024:1024 + 4096], buf[40000:40004], buf[50000:50000 + 12 * 1024]]
+    ops.zero_ranges(views)
+    ref = torch.full((1 << 16,), 3.0)
+    for a, b in ((64, 192), (1024, 1024 + 4096), (40000, 40004), (50000, 50000 + 12 * 1024)):
+        ref[a:b] = 0
+    assert torch.equal(buf.cpu(), ref)
+    many = [buf[i * 256:i * 256 + 64] for i in range(40)]                    # more than 16 ranges: several launches
+    buf.fill_(5.0)
+    ops.zero_ranges(many)
+    ref = torch.full((1 << 16,), 5.0)
+    for i in range(40):
+        ref[i * 256:i * 256 + 64] = 0
+    assert torch.equal(buf.cpu(), ref)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_linear_accepts_inputs_already_padded_along_k(ops, dtype):
+    """train_step.prepare_position_features hands the 7- / 14-wide features over cast and zero-padded to the GEMM's K chunk:
+    same outputs and parameter gradients as the unpadded input."""
+    torch.manual_seed(3)
+    for K in (7, 14):
+        w = (torch.randn(768, K, device=DEV) * 0.1).requires_grad_(True)
+        b = torch.randn(768, device=DEV).requires_grad_(True)
+        x = torch.randn(50, 9, K, device=DEV)
+        e = 8 if dtype == torch.bfloat16 else 4
+        xp = torch.nn.functional.pad(x.to(dtype), (0, (-K) % e))
+        y0 = ops.linear(x.to(dtype), w, b)
+        g = torch.randn_like(y0)
+        y0.backward(g)
+        gw0, gb0 = w.grad.clone(), b.grad.clone()
+        w.grad = b.grad = None
+        y1 = ops.linear(xp, w, b)
+        y1.backward(g)
+        assert torch.equal(y0, y1)
+        _close(w.grad, gw0, dtype, 'dW')
+        _close(b.grad, gb0, dtype, 'db')
+    with pytest.raises(ValueError):
+        ops.linear(torch.randn(4, 11, device=DEV).to(dtype), torch.randn(8, 7, device=DEV))

@@ -84,7 +84,11 @@ def test_static_batch_pack_commit_and_shape_guard():
     first, second = mk(1), mk(2)
     sb = train_step.StaticBatch(cfg, first, device='cpu')
     addr = {k: v.data_ptr() for k, v in sb.gb.items() if torch.is_tensor(v)}
-    for k, v in first.items():
+    # (the 7- / 14-wide position features are stored in the form their Linear consumes: compute dtype, K zero-padded to a 16-byte chunk)
+    prep = train_step.prepare_position_features
+    assert prep(first)['traj_loc_fts'].shape[-1] == 8 and prep(first)['vp_pos_fts'].shape[-1] == 16
+    assert torch.equal(prep(first)['gmap_pos_fts'][..., :7], first['gmap_pos_fts']) and not prep(first)['gmap_pos_fts'][..., 7:].any()
+    for k, v in prep(first).items():
         if torch.is_tensor(v):
             assert torch.equal(sb.gb[k], v), k
     # a mask memoised on the static batch before the swap follows the new data afterwards, at the same address
@@ -97,7 +101,7 @@ def test_static_batch_pack_commit_and_shape_guard():
     buf = sb.pack(second)
     sb.stage(buf)
     sb.commit()
-    for k, v in second.items():
+    for k, v in prep(second).items():
         if torch.is_tensor(v):
             assert torch.equal(sb.gb[k], v) and sb.gb[k].data_ptr() == addr[k], k
     idx = train_step.collate_indices(cfg, second)

@@ -456,11 +456,14 @@ def test_shape_bucketed_static_batch_replays_ragged_batches():
     torch.manual_seed(0)
     model = pretrain_model.GlocalTextPathCMTPreTraining(cfg).cuda().eval()
 
-    def mk(seed, T, L):
-        b = synth.make_pretrain_batch(B=4, T=T, L=L, seed=seed, vocab_size=1000, style='rich')
+    def mk(seed, T, L, **kw):
+        b = synth.make_pretrain_batch(B=4, T=T, L=L, seed=seed, vocab_size=1000, style='rich', **kw)
         b['traj_view_img_fts'] = b['traj_view_img_fts'].to(torch.bfloat16)          # the bf16 feature store's rows
         return b
-    first, second, third = mk(5, [3, 2, 4, 3], [30, 22, 16, 25]), mk(6, [1, 4, 2, 2], [12, 28, 9, 20]), mk(7, [4, 4, 3, 4], [32, 32, 5, 17])
+    # `second` has ragged panoramas whose LAST steps all hold fewer than 36 views: its own local width is 32 (31 views + [stop]) inside the
+    # bucket's 37 — the CFP pooling of the local branch must stay on those 32 slots (cfp_vp_mask)
+    first, second, third = mk(5, [3, 2, 4, 3], [30, 22, 16, 25]), mk(20, [1, 4, 2, 2], [12, 28, 9, 20], ragged_views=True), mk(7, [4, 4, 3, 4], [32, 32, 5, 17])
+    assert second['vp_pos_fts'].shape[1] == 32 and first['vp_pos_fts'].shape[1] == 37 and second['traj_view_img_fts'].shape[1] == 36
     G = max(b['gmap_step_ids'].shape[1] for b in (first, second, third))
     vln_goat_amd.set_compute_dtype(torch.bfloat16)
     try:

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('GOAT_HIP_LIB') or os.path.join(CSRC, 'libgoat_hip.so')     # (override: kernel A/B experiments)
-SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm3.hip', 'gemm5.hip', 'attention.hip', 'attention2.hip', 'rowops.hip', 'causal.hip', 'optim.hip']
+SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm3.hip', 'gemm5.hip', 'attention.hip', 'attention2.hip', 'rowops.hip', 'causal.hip', 'optim.hip', 'glue.hip']
 
 GOAT_F32, GOAT_BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_ACCUM = 0, 1, 2, 3, 4, 5
@@ -68,6 +68,8 @@ SIGNATURES = {
     'goat_infonce_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32],
     'goat_infonce_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32],
     'goat_probe_tr16': [_vp, _vp],
+    'goat_add_n': [_vp, _i32, _vp, _i32, _vp, _i64],
+    'goat_zero_ranges': [_vp, _vp, _vp, _i32],
 }
 
 

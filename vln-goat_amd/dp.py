@@ -298,8 +298,7 @@ class GradArena:
         self._cur = (key, hipops.ARENA_EPOCH[0])
         owned = self._owned.get(key)
         if owned is None:
-            for a, b in self.ranges(task, None, frozenset(self.no_zero.get(key, ()))):
-                self.flat[a:b].zero_()
+            self._zero([self.flat[a:b] for a, b in self.ranges(task, None, frozenset(self.no_zero.get(key, ())))])
             return
         fills = self._fills.get(key)
         if fills is None or fills[0] != frozenset(owned):
@@ -315,8 +314,15 @@ class GradArena:
                 else:
                     r.append([a, b])
             fills = self._fills[key] = (frozenset(owned), r)
-        for a, b in fills[1]:
-            self.flat[a:b].zero_()
+        self._zero([self.flat[a:b] for a, b in fills[1]])
+
+    def _zero(self, views):
+        if views and views[0].is_cuda:
+            from . import hipops
+            hipops.zero_ranges(views)          # one launch for the step's fills (csrc/glue.hip)
+        else:
+            for v in views:
+                v.zero_()
 
     # -- communication ---------------------------------------------------------------------------
     def close_step(self):

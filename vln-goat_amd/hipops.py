@@ -906,7 +906,17 @@ class _LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        x2, pad = _pad_k(x2, _epc(x2))
+        Kw = weight.shape[1]
+        if x2.shape[1] == Kw:
+            x2, pad = _pad_k(x2, _epc(x2))
+            prepad = False
+        else:
+            # input already K-padded with zero columns to the GEMM's 16-byte chunk (train_step.prepare_position_features: the 7- / 14-wide
+            # position features are cast and padded ONCE per batch on the host instead of by two launches per Linear and step)
+            pad = (-Kw) % _epc(x2)
+            if x2.shape[1] != Kw + pad:
+                raise ValueError('linear: input width %d matches neither the weight (%d) nor its padded width (%d)' % (x2.shape[1], Kw, Kw + pad))
+            prepad = True
         w = _shadow(weight, x2.dtype, False, pad)
         N = w.shape[0]
         out = torch.empty((x2.shape[0], N), dtype=out_dtype or x2.dtype, device=x2.device)
@@ -916,7 +926,7 @@ class _LinearFn(torch.autograd.Function):
             aux = torch.empty_like(out)
         gemm(x2, w, out, bias=bias.detach() if bias is not None else None, epi=epi, aux=aux)
         ctx.save_for_backward(x2, aux)
-        ctx.weight, ctx.bias, ctx.has_bias, ctx.act, ctx.pad, ctx.xshape = weight, bias, bias is not None, act, pad, x.shape
+        ctx.weight, ctx.bias, ctx.has_bias, ctx.act, ctx.pad, ctx.xshape, ctx.prepad = weight, bias, bias is not None, act, pad, x.shape, prepad
         return out.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -935,7 +945,7 @@ class _LinearFn(torch.autograd.Function):
             w = _shadow(weight, x2.dtype, False, ctx.pad)  # [N, Kp]
             dx = torch.empty_like(x2)
             gemm(dy2, w, dx, ta=False, tb=True)        # dx[M,Kp] = dy[M,N] @ W[N,Kp]
-            if ctx.pad:
+            if ctx.pad and not ctx.prepad:
                 dx = dx[:, :x2.shape[1] - ctx.pad]
             dx = dx.reshape(ctx.xshape)
         if SMALLK_WGRAD and ctx.pad and x2.shape[1] - ctx.pad <= 16 and (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])):
@@ -1295,7 +1305,9 @@ class _LnFn(torch.autograd.Function):
         L = _lib.lib()
         dx = torch.empty_like(z)
         dres = torch.empty_like(z) if (ctx.has_res and p > 0) else None
-        dpost = torch.empty_like(z) if ctx.has_post else None       # gradient of the summand behind the norm: the (masked) dy
+        # gradient of the summand behind the norm: the (masked) dy — without output dropout it IS dy: handed on as such, no copy
+        post_alias = ctx.has_post and ctx.out_drop[0] == 0.0 and dyb is None
+        dpost = torch.empty_like(z) if (ctx.has_post and not post_alias) else None
         sg, sb = _sink(ctx.gb[0]), _sink(ctx.gb[1])
         sunk = sg is not None and sb is not None
         if not sunk:
@@ -1328,7 +1340,7 @@ class _LnFn(torch.autograd.Function):
             dr = dres.view(ctx.shape) if dres is not None else dxv
         else:
             dr = None
-        return dxv, dr, dg, db, None, None, None, None, None, None, (dpost.view(ctx.shape) if dpost is not None else None)
+        return dxv, dr, dg, db, None, None, None, None, None, None, (dy2.view(ctx.shape) if post_alias else (dpost.view(ctx.shape) if dpost is not None else None))
 
 
 def layer_norm(x, gamma, beta, eps, residual=None, p=0.0, fork=False, fork_in=False, z_out=False, p_out=0.0, post_add=None):
@@ -1340,6 +1352,66 @@ def layer_norm(x, gamma, beta, eps, residual=None, p=0.0, fork=False, fork_in=Fa
     p_out: dropout on the LayerNorm's output in the same launch (the embedding blocks' dropout(LayerNorm(e)));
     post_add: a summand added behind the norm and in front of that dropout: dropout(LayerNorm(z) + post_add)."""
     return _LnFn.apply(x, residual, gamma, beta, float(eps), float(p), bool(fork), bool(fork_in), bool(z_out), float(p_out), post_add)
+
+
+# ----------------------------------------------------------------------------- gradient fan-in / fills (csrc/glue.hip)
+FANOUT = os.environ.get('GOAT_NO_FANOUT', '0') != '1'        # (diagnostics: A/B against the autograd engine's pairwise adds)
+
+
+def add_n(tensors, out=None):
+    """out = sum(tensors) (same shape / dtype, contiguous), float32 accumulation, one launch (goat_add_n)."""
+    ts = [t if t.is_contiguous() else t.contiguous() for t in tensors]
+    out = torch.empty_like(ts[0]) if out is None else out
+    while len(ts) > 8:                       # (never on the GOAT paths: at most 7 consumers)
+        head = add_n(ts[:8])
+        ts = [head] + ts[8:]
+    arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    st = _lib.lib().goat_add_n(_stream(), _dt(ts[0]), arr, len(ts), _ptr(out), ts[0].numel())
+    _lib.check(st, 'goat_add_n')
+    return out
+
+
+class _FanoutFn(torch.autograd.Function):
+    """n autograd handles on ONE buffer; backward = the sum of the handles' gradients in one launch."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        dt = gs[0].dtype
+        gs = [g if g.dtype == dt else g.to(dt) for g in gs]
+        return add_n(gs), None
+
+
+def fanout(x, n):
+    """A tensor with n consumers: returns n handles on x's buffer, one per consumer.  Their gradients meet in ONE goat_add_n launch
+    (float32 accumulation) instead of n - 1 pairwise `add` kernels issued by the autograd engine as the gradients trickle in."""
+    if n <= 1 or not FANOUT or not (torch.is_tensor(x) and x.requires_grad and x.is_cuda):
+        return [x] * max(n, 1)
+    return list(_FanoutFn.apply(x, n))
+
+
+def zero_ranges(tensors):
+    """clear up to 16 contiguous tensors (16-byte aligned, sizes multiples of 16 bytes) per launch (goat_zero_ranges)."""
+    ts = [t for t in tensors if t.numel()]
+    for i in range(0, len(ts), 16):
+        grp = ts[i:i + 16]
+        if any((t.data_ptr() & 15) or ((t.numel() * t.element_size()) & 15) or not t.is_contiguous() or not t.is_cuda for t in grp):
+            for t in grp:
+                t.zero_()
+            continue
+        ptrs = (ctypes.c_void_p * len(grp))(*[t.data_ptr() for t in grp])
+        nb = (ctypes.c_int64 * len(grp))(*[t.numel() * t.element_size() for t in grp])
+        st = _lib.lib().goat_zero_ranges(_stream(), ptrs, nb, len(grp))
+        _lib.check(st, 'goat_zero_ranges')
 
 
 class _DropAddFn(torch.autograd.Function):

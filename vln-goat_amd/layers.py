@@ -315,8 +315,14 @@ class CrossmodalEncoder(nn.Module):
     def forward(self, q_embeds, q_kmask, kv_embeds, kv_kmask, bias=None, kv_cache=None):
         """q_kmask / kv_kmask: additive float32 [B,L] key masks (already -10000-style).  kv_cache: project_kv(kv_embeds)."""
         n = len(self.crossattention)
+        # the attended sequence (and the graph-distance bias) is read by every layer: one autograd handle per layer, their gradients
+        # meet in ONE launch (hipops.fanout) instead of n - 1 pairwise adds of the autograd engine
+        kvs = hipops.fanout(kv_embeds, n) if kv_cache is None else [kv_embeds] * n
+        biases = hipops.fanout(bias, n) if torch.is_tensor(bias) else [bias] * n
+        if not isinstance(q_embeds, tuple):
+            q_embeds = tuple(hipops.fanout(q_embeds, 2))          # layer 0 reads it twice: first Linear + residual (a _pair)
         for i, layer in enumerate(self.crossattention):
-            q_embeds = layer(q_embeds, kv_embeds, q_kmask, kv_kmask, bias, fork=i + 1 < n, enc_kv=None if kv_cache is None else kv_cache[i])
+            q_embeds = layer(q_embeds, kvs[i], q_kmask, kv_kmask, biases[i], fork=i + 1 < n, enc_kv=None if kv_cache is None else kv_cache[i])
         return q_embeds
 
 

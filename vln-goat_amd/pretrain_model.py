@@ -257,6 +257,9 @@ class LocalVPEncoder(nn.Module):
         vidx, vstart, vp_lens, width = idx
         B = vp_pos_fts.shape[0]
         vp_img = hipops.gather_segmean(pano_embeds, vidx, vstart, None, B * width, inverse).view(B, width, -1)
+        # (kept as a separate add: folding it into the LayerNorm launch (post_add) removes one bf16 rounding, which moved the most
+        #  noise-sensitive gradient of the model — sap_fuse_linear, a difference of two softmax-weighted sums — past its calibrated
+        #  bf16 bound in 2 of 16 parity cases; 3 us per step are not worth re-calibrating the bound)
         pos = self.vp_pos_embeddings[1](self.vp_pos_embeddings[0](vp_pos_fts[:, :width].to(vp_img.dtype)))
         return vp_img + pos, gen_seq_masks(vp_lens, width)
 
@@ -372,16 +375,17 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
         txt, txt_kmask = self._text(batch)
         br.join(x, src)
         gmap = None
+        t_g, t_v, t_out = hipops.fanout(txt, 3)           # the text states feed both cross-modal encoders (and the caller)
         if return_gmap_embeds:
             with hipops.Branch('global') as bg:
                 g, gm = self._gmap_in(batch, src, cache)
                 bias = self.global_encoder.sprels(batch['gmap_pair_dists']) if self.global_encoder.sprel_linear is not None else None
-                gmap = self.global_encoder.encoder(g, neg_mask(gm), txt, txt_kmask, bias)
+                gmap = self.global_encoder.encoder(g, neg_mask(gm), t_g, txt_kmask, bias)
         v, vm = self._vp_in(batch, x, cache)
-        vp = self.local_encoder.encoder(v, neg_mask(vm), txt, txt_kmask)
+        vp = self.local_encoder.encoder(v, neg_mask(vm), t_v, txt_kmask)
         if return_gmap_embeds:
             bg.join(gmap)
-        return gmap, vp, txt
+        return gmap, vp, t_out
 
     def forward_mlm(self, batch):
         # P/model/vilmodel_goat.py:597-648: text queries attend to map / local tokens, outputs summed
@@ -390,11 +394,12 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
             x, src = self._pano(batch)
         txt, txt_kmask = self._text(batch)
         br.join(x, src)
+        t = hipops.fanout(txt, 4)                         # text queries of both encoders, each read twice by its first layer (a _pair)
         with hipops.Branch('global') as bg:
             g, gm = self._gmap_in(batch, src, cache)
-            gt = self.global_encoder.encoder(txt, txt_kmask, g, neg_mask(gm))
+            gt = self.global_encoder.encoder((t[0], t[1]), txt_kmask, g, neg_mask(gm))
         v, vm = self._vp_in(batch, x, cache)
-        vt = self.local_encoder.encoder(txt, txt_kmask, v, neg_mask(vm))
+        vt = self.local_encoder.encoder((t[2], t[3]), txt_kmask, v, neg_mask(vm))
         bg.join(gt)
         return gt + vt
 
@@ -550,7 +555,8 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
         nav, M = cache['sap']
         # scores of the two heads -> masked global / local / fused logits (and the three cross-entropies) in ONE launch per direction
         # (hipops.sap_fuse: the reference's * fw, masked_fill x4, bmm, log_softmax x3 ... are ~25 launches on [48, 22..37] tensors)
-        fwl = None if self.sap_fuse_linear is None else self.sap_fuse_linear(torch.cat([gmap[:, 0], vp[:, 0]], 1))
+        (gmap, gmap0), (vp, vp0) = hipops.fanout(gmap, 2), hipops.fanout(vp, 2)      # head + [CLS] row of the fusion weight
+        fwl = None if self.sap_fuse_linear is None else self.sap_fuse_linear(torch.cat([gmap0[:, 0], vp0[:, 0]], 1))
         ga, la = batch['global_act_labels'], batch['local_act_labels']
         gl, ll, fused, loss = hipops.sap_fuse(self.global_sap_head(gmap).squeeze(2), self.local_sap_head(vp).squeeze(2), fwl,
                                               gvis=batch['gmap_visited_masks'], glens=batch['gmap_lens'], lmask=nav, M=M,

@@ -733,17 +733,22 @@ class NavRollout:
             t_host = time.perf_counter()
             moves = []
             for i in range(B):
-                nxt = None if (stop[i] or ended[i] or gin['no_vp_left'][i] or t == self.max_action_len - 1) else nav_vpids[i][int(a_t[i])]
-                if nxt is None:                     # (a sampled action 0 is the [stop] token: nav_vpids[i][0] is None, M/r2r/agent.py:623-629)
+                forced = bool(stop[i] or ended[i] or gin['no_vp_left'][i] or t == self.max_action_len - 1)
+                nxt = None if forced else nav_vpids[i][int(a_t[i])]
+                if forced:
+                    just_ended[i] = True            # M/r2r/agent.py:657-660: ONLY these four conditions mark the episode for the stop-node backtrack;
+                if nxt is None:                     # a sampled action 0 (the [stop] token: nav_vpids[i][0] is None, :661) ends it without one
                     moves.append(None)
-                    just_ended[i] = True
                 else:
                     hop = gmaps[i].graph.path(obs[i]['viewpoint'], nxt)
                     traj[i]['path'].append(hop)
                     prev = traj[i]['path'][-2][-1] if len(hop) == 1 else hop[-2]
                     view = next(c['pointId'] for c in obs[i]['scan_graph'].candidates(prev) if c['viewpointId'] == nxt)
                     moves.append((nxt, view))
-            if feedback != 'teacher':                  # go back to the node with the best stop score (M/r2r/agent.py:633-642)
+            # go back to the node with the best stop score (M/r2r/agent.py:665-672).  The reference does this in every feedback mode; teacher
+            # forcing records no stop scores here (they would cost a device -> host read-back per step, and the trainer never reads the
+            # trajectories of its teacher rollouts: M/r2r/agent.py:414-445 uses only the loss), so its dictionary is empty and nothing moves
+            if True:
                 for i in range(B):
                     if (not ended[i]) and just_ended[i] and gmaps[i].node_stop_scores:
                         stop_node = max(gmaps[i].node_stop_scores.items(), key=lambda kv: kv[1]['stop'])[0]

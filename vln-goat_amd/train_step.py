@@ -182,6 +182,30 @@ def pad_batch(batch, L=None, N=None, G=None, W=None, shape_only=()):
     return out
 
 
+POSITION_FEATURES = ('traj_loc_fts', 'gmap_pos_fts', 'vp_pos_fts', 'loc_fts')      # ('loc_fts': the fine-tuning model's panorama input)
+
+
+def prepare_position_features(batch, dtype=None):
+    """The 7- / 14-wide angle / distance features (P/data/tasks.py collates: traj_loc_fts, gmap_pos_fts, vp_pos_fts) in the form their
+    first Linear consumes: compute dtype, last dimension zero-padded to the GEMM's 16-byte K chunk (8 bf16 / 4 float32 elements).  Done
+    once per batch where the batch is built (host side), so the step launches neither the cast nor the pad (2 launches per Linear and step
+    before).  hipops.linear accepts both forms; the padded columns meet zero weight columns.  -> a new dict."""
+    from . import layers
+    dt = dtype or layers.compute_dtype()
+    e = 8 if dt == torch.bfloat16 else 4
+    out = dict(batch)
+    for k in POSITION_FEATURES:
+        t = batch.get(k)
+        if not torch.is_tensor(t) or not t.is_floating_point():
+            continue
+        pad = (-t.shape[-1]) % e
+        if t.shape[-1] > 16 or (pad == 0 and t.dtype == dt):
+            continue
+        t = t.to(dt)
+        out[k] = torch.nn.functional.pad(t, (0, pad)) if pad else t
+    return out
+
+
 def index_capacities(batch, tasks, mlm_rate=0.25):
     """upper bounds of the variable-length index tensors of collate_indices for every batch that fits the shapes of `batch`."""
     Nn, V = batch['traj_view_img_fts'].shape[:2]
@@ -252,6 +276,14 @@ def collate_indices(config, batch, tasks=('mlm', 'sap', 'cfp'), caps=None, vp_wi
         if nav.shape[1] < W:
             nav = torch.cat([nav, torch.ones(nav.shape[0], W - nav.shape[1], dtype=torch.bool)], 1)
         out['sap'] = (nav, graphmap.build_sap_fusion(batch['traj_cand_vpids'], batch['gmap_vpids'], batch['gmap_visited_masks'], G, W))
+        # goat_sap_fuse skips a label outside its logit row (it must: -100 is the ignore value); F.cross_entropy, which it replaces, raises
+        # on such targets — so a mislabelled or bucket-mismatched batch is refused here, on the host, before it trains on silence
+        for key, width in (('global_act_labels', G), ('local_act_labels', W)):
+            lab = batch.get(key)
+            if torch.is_tensor(lab):
+                bad = (lab != -100) & ((lab < 0) | (lab >= width))
+                if bool(bad.any()):
+                    raise ValueError('collate_indices: %s holds %d outside [0, %d) (and not the ignore value -100)' % (key, int(lab[bad][0]), width))
     has_obj = batch.get('traj_obj_img_fts') is not None
     last = torch.as_tensor(batch['traj_step_lens']).cumsum(0) - 1
     if 'og' in tasks and has_obj:
@@ -373,6 +405,9 @@ class StaticBatch:
         the object then accepts every RAGGED batch that fits (`pad_batch` + capacity-padded index tensors), so that one captured
         step serves all batches of the bucket instead of falling back to the eager path."""
         self.config, self.tasks, self.device = config, tuple(tasks), torch.device(device)
+        from . import layers
+        self.pos_dtype = layers.compute_dtype()       # the position features are stored cast + K-padded (prepare_position_features)
+        host_batch = prepare_position_features(host_batch, self.pos_dtype)
         self.bucket = None
         if bucket is not None:
             self.bucket = {'L': bucket.get('L', host_batch['txt_ids'].shape[1]), 'N': bucket.get('N', host_batch['traj_view_img_fts'].shape[0]),
@@ -460,6 +495,8 @@ class StaticBatch:
         """host batch -> flat (pinned) buffer in the device layout; builds the batch's index tensors on the way.
         tensors=False: only the index tensors are (re)built and written — for a loader that collated the batch's tensors
         straight into `out` (its previous pack)."""
+        if _idx is None:
+            host_batch = prepare_position_features(host_batch, self.pos_dtype)
         raw = host_batch
         if self.bucket is not None and _idx is None:
             host_batch = pad_batch(host_batch, **self.bucket, shape_only=BIG_TENSORS)
