@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc counter_collection CSVs: per kernel family, launches / total / average per launch."""
 import csv, glob, re, sys, collections
 d = sys.argv[1]
-fam = lambda n: ('gemm2_kernel' if 'gemm2_' in n else 'gemm_nt_kernel' if 'gemm_nt_kernel' in n else
+fam = lambda n: ('gemm2_kernel' if 'gemm2_' in n else 'pp_kernel (ping-pong GEMM)' if ('pp_kernel' in n or 'pp_group_kernel' in n) else 'gemm_nt_kernel' if 'gemm_nt_kernel' in n else
                  re.sub(r'<.*', '', re.sub(r'^void ', '', n)).replace('(anonymous namespace)::', '')[:60])
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):

@@ -10,7 +10,7 @@ def gemm_rows(d, counter):
     rows = []
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            if ('gemm2_' in r['Kernel_Name'] or 'gemm_nt_kernel' in r['Kernel_Name']) and r['Counter_Name'] == counter:
+            if any(k in r['Kernel_Name'] for k in ('gemm2_', 'gemm_nt_kernel', 'pp_kernel', 'pp_group_kernel')) and r['Counter_Name'] == counter:
                 rows.append((int(r['Dispatch_Id']), r['Kernel_Name'], float(r['Counter_Value'])))
     rows.sort()
     return rows
@@ -40,7 +40,7 @@ nf, f = fam_avg(RF, LAST)
 nw, w = fam_avg(RW, LAST)
 nf_all, f_all = fam_avg(RF, 0)
 nw_all, w_all = fam_avg(RW, 0)
-print(json.dumps({'kernel': 'gemm2_kernel + gemm2_group_kernel + gemm_nt_kernel', 'launches_counted': nf, 'selection': ('the last %d GEMM dispatches = the repeating tail of the dispatch sequence (one task cycle / episode; warm-up excluded)' % LAST) if LAST else 'every GEMM dispatch of the run',
+print(json.dumps({'kernel': 'gemm2_kernel + gemm2_group_kernel + pp_kernel + pp_group_kernel + gemm_nt_kernel', 'launches_counted': nf, 'selection': ('the last %d GEMM dispatches = the repeating tail of the dispatch sequence (one task cycle / episode; warm-up excluded)' % LAST) if LAST else 'every GEMM dispatch of the run',
                   'all_dispatches': {'launches': nf_all, 'traffic_bytes_per_launch': f_all * 1024 * 2 + w_all * 1024},
                   'fetch_kb_per_launch_reported': f, 'write_kb_per_launch_reported': w,
                   'read_bytes_per_launch': f * 1024 * 2, 'write_bytes_per_launch': w * 1024,

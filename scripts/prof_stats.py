@@ -15,7 +15,7 @@ for r in rows[: int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
 fam = {}
 for r in rows:
     n = r["Name"]
-    k = "GEMM family (gemm2_kernel* + gemm_nt_kernel*)" if ("gemm2_" in n or "gemm_nt_kernel" in n) else None
+    k = "GEMM family (gemm2_kernel* + pp_kernel* + gemm_nt_kernel*)" if any(x in n for x in ("gemm2_", "gemm_nt_kernel", "pp_kernel", "pp_group_kernel")) else None
     if k:
         a = fam.setdefault(k, [0, 0.0])
         a[0] += int(r["Calls"]); a[1] += float(r["TotalDurationNs"])

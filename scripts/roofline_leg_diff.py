@@ -19,7 +19,7 @@ def load(p):
 full, nrl = load(sys.argv[1]), load(sys.argv[2])
 rows, tc, tt = [], 0, 0.0
 for k, (c, t) in full.items():
-    if ('gemm2_' in k or 'gemm_nt_kernel' in k) and not k.startswith('GEMM family'):      # (prof_stats' own family row is a sum of these)
+    if any(x in k for x in ('gemm2_', 'gemm_nt_kernel', 'pp_kernel', 'pp_group_kernel')) and not k.startswith('GEMM family'):      # (prof_stats' own family row is a sum of these)
         c0, t0 = nrl.get(k, (0, 0.0))
         if c - c0 > 0:
             rows.append((t - t0, c - c0, k))

@@ -13,6 +13,10 @@ ev = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name
 t_end = max(e for _, e, _ in ev)
 ev = [x for x in ev if x[0] >= t_end - win * 1e6]
 nsteps = win / msps
+# one goat_zero_ranges launch opens every captured step (the gradient arena's fills): count the steps of the window from it when present
+marks = sum(1 for _, _, n in ev if 'zero_ranges_kernel' in n)
+if marks >= 3:
+    nsteps, msps = float(marks), win / marks
 
 
 def fam(n):

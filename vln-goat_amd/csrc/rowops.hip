@@ -1099,7 +1099,12 @@ extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* r
 
 #define GOAT_LN_BWD_PARTS 512
 #ifndef GOAT_LN_BWD_WAVES
-#define GOAT_LN_BWD_WAVES 8    // waves per block of the atomic-mode LayerNorm backward (scripts/ln_bench.py: 4 -> 20.4 us, 8 -> 15.8, 16 -> 42 at 3840 rows)
+// waves per block of the LayerNorm backward.  Isolated (scripts/ln_bench.py, atomic mode, 3840 rows): 4 -> 20.4 us, 8 -> 15.8, 16 -> 42.  Inside
+// the step the kernel runs with deferred column partials (no atomics) and usually NEXT TO a GEMM of the other graph branch whose
+// workgroups hold 96-112 KiB of a CU's 160 KiB LDS: an 8-wave block needs 48 KiB for its column reduction and fits beside such a
+// workgroup only just or not at all, a 4-wave block (24 KiB) always does.  Same-box A/B of the whole step, three alternations (round 4):
+// 8 waves 5.647 / 5.672 / 5.662 ms, 4 waves 5.579 / 5.598 / 5.614 ms; 2 waves (12 KiB, twice the partial rows) is slower again (+0.06 ms).
+#define GOAT_LN_BWD_WAVES 4
 #endif
 #ifndef GOAT_LN_RIF
 #define GOAT_LN_RIF 2      // rows in flight per wave (bf16); measured: 4 rows / fewer partial blocks are slower (8.52-8.80 vs 8.45 ms/step)

@@ -576,9 +576,15 @@ class WgradQueue:
     never in the same group as an earlier write of that slice (hipops._sink flushes first)."""
     enabled = os.environ.get('GOAT_WGRAD_GROUP', '1') != '0'
     cfg = tuple(int(v) for v in os.environ.get('GOAT_WGRAD_GROUP_CFG', '256,3').split(','))   # (tile = rows | cols << 16, ring stages | 0x100 = eight waves on 128x128): scripts/wgrad_group_bench.py, profiles/round2_wgrad_grouped.txt
-    MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '16'))      # problems per launch (measured 8 / 12 / 16: 7.12 / 7.09 / 7.06 ms per step)
+    MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '24'))      # problems per launch = the kernel's GROUP_MAX (round 1: 8 / 12 / 16 -> 7.12 / 7.09 /
+                                                                 # 7.06 ms per step; round 4, same box, three alternations: 16 -> 5.80 / 5.81 / 5.80, 24 -> 5.75 / 5.76 / 5.76)
     # (round 2 also had a mode that ran the grouped launches on a stream of their own, off the dgrad chain: 6.52 vs 6.28 ms per step — the
     #  kernels contend, they do not fill idle CUs: removed in round 3)
+    # (diagnostics; measured and NOT adopted) every queued problem waits for the end of the backward pass (or for a re-write of its slice)
+    # and the launches then run back to back, MAX problems each — instead of interleaving with the dgrad chains, whose short kernels on
+    # the OTHER graph branch starve behind a chip-filling grouped launch (profiles/round4_step_ln_attention_by_shape.txt: 10 us kernels
+    # stretched to 200 us).  Same step time (5.80 / 5.80 / 5.82 vs 5.80 / 5.81 / 5.80 ms): what the chains gain, the lost overlap costs.
+    DEFER_ALL = os.environ.get('GOAT_WGRAD_DEFER_ALL', '0') == '1'
     queues = {}             # HIP stream handle -> (torch stream, [(dy, x, w_sink, b_sink, accumulate)]): tensors are kept alive until
     pending_ids = {}        # the launch, which happens on the stream the problems were produced on;  id(param) -> stream handle
     _callback_armed = False
@@ -591,7 +597,7 @@ class WgradQueue:
         for i in param_ids:
             cls.pending_ids[i] = st.cuda_stream
         cls.arm()
-        if len(q) >= cls.MAX:
+        if len(q) >= cls.MAX and not cls.DEFER_ALL:
             cls.flush(st.cuda_stream)
 
     @classmethod
@@ -638,7 +644,8 @@ class WgradQueue:
             for pid in [k for k, v in cls.pending_ids.items() if v == h]:
                 del cls.pending_ids[pid]
             with torch.cuda.stream(st):
-                cls._launch(q)
+                for i in range(0, len(q), cls.MAX):
+                    cls._launch(q[i:i + cls.MAX])
 
     CANDIDATES = ((256, 3), (128, EIGHT_WAVES | 2), (tile(256, 256), 2)) + (      # tile configurations a group may run on
         ((tile(256, 256), PINGPONG | 2), (tile(128, 256), PINGPONG | 2), (256, PINGPONG | 2)) if USE_PP else ())

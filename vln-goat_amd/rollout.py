@@ -720,9 +720,9 @@ class NavRollout:
                 stop = [ob['viewpoint'] == ob['gt_path'][-1] for ob in obs]
             elif feedback in ('argmax', 'sample'):
                 # ONE device -> host copy per step: the chosen actions and the stop probabilities (M/r2r/agent.py:575-580,601-607)
-                probs = torch.softmax(logits.float(), 1)
+                probs = torch.softmax(logits.detach().float(), 1)
                 act = probs.argmax(1) if feedback == 'argmax' else torch.distributions.Categorical(probs).sample()
-                back = torch.stack([act.to(torch.float32), probs[:, 0]], 0).cpu().numpy()
+                back = torch.stack([act.to(torch.float32), probs[:, 0].detach()], 0).cpu().numpy()
                 a_t = back[0].astype(np.int64)
                 stop = (a_t == 0) if feedback == 'argmax' else [ob['viewpoint'] == ob['gt_path'][-1] for ob in obs]
                 for i, g in enumerate(gmaps):
