@@ -61,7 +61,7 @@ struct PCfg {
   static constexpr int BSZ = NI * 16384;   // bytes of one B block (128*NI columns x 64 k)
   static constexpr int SMEM = 4 * AH + NB * BSZ;
 };
-// Product tiles (DMA placement 1: measured equal to or ahead of the other two, profiles/round4_gemm_pp_cycle_stamps.txt; a third B
+// Product tiles (DMA placement 1: measured equal to or ahead of the other two with the cycle-stamp harness scripts/gemm_pp_stamps.cpp; a third B
 // buffer — PCfg<4, 2, 3>, 160 KiB — buys nothing: the pieces already have a whole MFMA phase to land).
 typedef PCfg<4, 2, 2, 1> P256x256;   // 128 KiB
 typedef PCfg<3, 2, 2, 1> P192x256;   // 112 KiB  (M = 3840 = 20 x 192: 240 tiles at N = 3072; K-contiguous A only)
