@@ -270,10 +270,155 @@ def episode_case():
     print('wrote', path, os.path.getsize(path) // 1024, 'KiB  loss', float(loss), 'steps', t + 1)
 
 
+def scripted_actions(t, nav, ended, rs):
+    """The FIXED 'sample' sequence of the sampled-rollout golden: per sample a valid map slot drawn by a seeded numpy generator —
+    [stop] (slot 0) with probability 0.12 from step 2 on, else uniform over the unvisited, unmasked nodes (what a sampled policy can
+    pick: M/r2r/agent.py masks visited nodes out of the logits).  The test replays this sequence through NavRollout's `sampler` hook."""
+    masks = (nav['gmap_masks'] & ~nav['gmap_visited_masks']).numpy()
+    acts = np.zeros(len(ended), np.int64)
+    for i in range(len(ended)):
+        cand = [j for j in np.nonzero(masks[i])[0] if j >= 2]
+        u = rs.uniform()
+        acts[i] = 0 if (not cand or (t >= 2 and u < 0.12)) else cand[int(rs.randint(len(cand)))]
+    return acts
+
+
+def sample_episode_case():
+    """The SAMPLED rollout of the DAgger iteration (feedback = 'sample', M/r2r/agent.py:436-437,629-631,650-672) on the REFERENCE model with a
+    FIXED action sequence in place of Categorical.sample(): the policy walks off the ground-truth path, the loss is the cross-entropy
+    against `_teacher_action(imitation_learning=False)` (the shortest-path expert of the CURRENT state) at every visited state, a sampled
+    [stop] ends an episode without the stop-node backtrack, the forced ends (goal reached / no viewpoint left / last step) go back to the
+    node with the best recorded stop probability.  -> rollout_episode_sample.npz (+ .json: the id strings)"""
+    agent, gu = import_agent()
+    import models.vilmodel_GOAT as vg
+    from collections import defaultdict
+    from vln_goat_amd import nav_model, rollout, synth
+    dd = lambda d: defaultdict(lambda: None, d)
+    args = SimpleNamespace(**EP_ARGS)
+    cfg = nav_model.nav_config_from_args(args)
+    torch.manual_seed(0)
+    ref = vg.GlocalTextPathNavCMT(cfg)
+    ours = nav_model.GlocalTextPathNavCMT(cfg)
+    ref.load_state_dict(synth.seeded_state_dict(ours, seed=EP_WEIGHT_SEED))
+    ref.eval()
+    scan, feats, eps, dicts = synth.make_rollout_case()
+
+    class Rows:
+        def row(self, s, vp):
+            return scan.index[vp]
+    sim = rollout.GraphSim(Rows())
+    obs = sim.reset(eps)
+    Bn = len(obs)
+    dist = scan.shortest()[0]
+    me = SimpleNamespace(args=SimpleNamespace(image_feat_size=768, act_visited_nodes=False, enc_full_graph=True, ignoreid=-100, expert_policy='spl'),
+                         env=SimpleNamespace(shortest_distances={scan.name: {a: {b: float(dist[i, j]) for j, b in enumerate(scan.vpids)}
+                                                                             for i, a in enumerate(scan.vpids)}}))
+    A = agent.GMapNavAgent
+    robs = ref_obs(obs, feats)
+    gmaps = [gu.GraphMap(ob['viewpoint']) for ob in robs]
+    for g, ob in zip(gmaps, robs):
+        g.update_graph(ob)
+    instr_zdict = {k: dicts[k] for k in ('instr_direction_features', 'instr_direction_pzs', 'instr_landmark_features', 'instr_landmark_pzs')}
+    img_zdict = {'img_features': dicts['img_features'], 'img_pzs': dicts['img_pzs']}
+    front = {k: torch.from_numpy(np.array([dicts[k]] * Bn)) for k in ('txt_feats', 'vp_feats', 'gmap_feats')}
+    lang = A._language_variable(me, robs, instr_zdict, front['txt_feats'])
+    txt_embeds = ref('language', dd(lang))
+    ended = np.zeros(Bn, bool)
+    just_ended = np.zeros(Bn, bool)
+    traj = [{'instr_id': ob['instr_id'], 'path': [[ob['viewpoint']]]} for ob in robs]
+    last = None
+    ml_loss = 0.0
+    store, ids = {}, {'actions': [], 'viewpoints': []}
+    max_len = 7
+    rs = np.random.RandomState(23)
+    for t in range(max_len):
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.node_step_ids[robs[i]['viewpoint']] = t + 1
+        pano = A._panorama_feature_variable_do(me, robs, img_zdict, noise=None)
+        pano_embeds, pano_masks, fused = ref('panorama', dd(pano))
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.update_node_embed(robs[i]['viewpoint'], fused[i], rewrite=True)
+                for j, cvp in enumerate(pano['cand_vpids'][i]):
+                    if not g.graph.visited(cvp):
+                        g.update_node_embed(cvp, pano_embeds[i, j])
+        nav = A._nav_gmap_variable(me, robs, gmaps, last)
+        nav.update(A._nav_vp_variable_mem(me, robs, gmaps, pano_embeds, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], last))
+        nav.update({'txt_embeds': txt_embeds, 'txt_masks': lang['txt_masks'], 'front_txt_feats': front['txt_feats'],
+                    'front_vp_feats': front['vp_feats'], 'front_gmap_feats': front['gmap_feats']})
+        out = ref('navigation', dd(nav))
+        last = out['cls_embeds']
+        logits = out['fused_logits']
+        probs = torch.softmax(logits, 1)
+        for i, g in enumerate(gmaps):                        # M/r2r/agent.py:605-611
+            if not ended[i]:
+                g.node_stop_scores[robs[i]['viewpoint']] = {'stop': probs[i, 0].data.item()}
+        tgt = A._teacher_action(me, robs, nav['gmap_vpids'], ended, visited_masks=nav['gmap_visited_masks'], imitation_learning=False, t=t, traj=traj)
+        ml_loss = ml_loss + torch.nn.functional.cross_entropy(logits, tgt, reduction='sum', ignore_index=-100)
+        a_t = scripted_actions(t, nav, ended, rs)
+        store['s%d_fused_logits' % t] = logits.detach().numpy()
+        store['s%d_cls_embeds' % t] = out['cls_embeds'].detach().numpy()
+        store['s%d_target' % t] = tgt.numpy()
+        store['s%d_action' % t] = a_t
+        ids['viewpoints'].append([ob['viewpoint'] for ob in robs])
+        a_t_stop = [ob['viewpoint'] == ob['gt_path'][-1] for ob in robs]           # :650-651 (training feedback)
+        cpu_a_t = []
+        for i in range(Bn):                                                          # :656-662
+            if a_t_stop[i] or ended[i] or nav['no_vp_left'][i] or (t == max_len - 1):
+                cpu_a_t.append(None)
+                just_ended[i] = True
+            else:
+                cpu_a_t.append(nav['gmap_vpids'][i][int(a_t[i])])
+        moves = []
+        for i, vp in enumerate(cpu_a_t):                                             # make_equiv_action (:349-384) on the graph-only navigator
+            if vp is None:
+                moves.append(None)
+                continue
+            hop = gmaps[i].graph.path(robs[i]['viewpoint'], vp)
+            traj[i]['path'].append(hop)
+            prev = traj[i]['path'][-2][-1] if len(hop) == 1 else hop[-2]
+            view = next(c['pointId'] for c in scan.candidates(prev) if c['viewpointId'] == vp)
+            moves.append((vp, view))
+        for i in range(Bn):                                                          # :665-672
+            if (not ended[i]) and just_ended[i]:
+                stop_node, stop_score = None, {'stop': -float('inf')}
+                for k, v in gmaps[i].node_stop_scores.items():
+                    if v['stop'] > stop_score['stop']:
+                        stop_score, stop_node = v, k
+                if stop_node is not None and robs[i]['viewpoint'] != stop_node:
+                    traj[i]['path'].append(gmaps[i].graph.path(robs[i]['viewpoint'], stop_node))
+        obs = sim.step(moves)
+        robs = ref_obs(obs, feats)
+        for i, ob in enumerate(robs):
+            if not ended[i]:
+                gmaps[i].update_graph(ob)
+        ended = np.logical_or(ended, np.array([x is None for x in cpu_a_t]))
+        if ended.all():
+            break
+    loss = ml_loss * 1.0 / Bn
+    loss.backward()
+    store['n_steps'] = np.array([t + 1])
+    store['loss'] = np.array([float(loss)], np.float32)
+    store['param_names'] = np.array([n for n, _ in ref.named_parameters()])
+    store['grad_fp'] = np.stack([fingerprint(p.grad) for _, p in ref.named_parameters()])
+    ids['traj'] = [tr['path'] for tr in traj]
+    path = os.path.join(HERE, 'rollout_episode_sample.npz')
+    np.savez_compressed(path, **store)
+    with open(os.path.join(HERE, 'rollout_episode_sample.json'), 'w') as f:
+        json.dump(ids, f)
+    off_path = sum(1 for tr, ep in zip(traj, eps) if [h[-1] for h in tr['path']][:len(ep['path'])] != ep['path'])
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB  loss', float(loss), 'steps', t + 1, ' episodes off the ground-truth path:', off_path,
+          ' actions', [store['s%d_action' % k].tolist() for k in range(t + 1)])
+
+
 if __name__ == '__main__':
-    if sys.argv[1:] == ['episode']:
+    if sys.argv[1:] == ['sample']:
+        sample_episode_case()
+    elif sys.argv[1:] == ['episode']:
         episode_case()
     else:
         main()
         if not sys.argv[1:]:
             episode_case()
+            sample_episode_case()

@@ -79,6 +79,61 @@ def test_nav_rollout_matches_the_reference_rollout():
         assert [h[-1] for h in tr['path']] == ep['path']
 
 
+def test_sampled_rollout_with_a_fixed_action_sequence_matches_the_reference():
+    """The SAMPLED half of the DAgger iteration (M/r2r/agent.py:436-437,629-672) pinned to the imported reference: its model, builders and
+    GraphMap rolled out with a FIXED action sequence in place of Categorical.sample() (tests/golden/make_golden_rollout.py sample) — all
+    three episodes leave their ground-truth path, two end on a sampled [stop].  NavRollout(feedback='sample', sampler=...) must reproduce
+    every step's logits and [MEM] state, the DAgger labels (`teacher_action(imitation_learning=False)`: the shortest-path expert of the
+    CURRENT state), the loss, the gradient fingerprint of every parameter, and the trajectories incl. the stop-node backtrack."""
+    import json
+    from vln_goat_amd import rollout, synth
+    z = np.load(os.path.join(HERE, 'golden', 'rollout_episode_sample.npz'))
+    ids = json.load(open(os.path.join(HERE, 'golden', 'rollout_episode_sample.json')))
+    scan, feats, eps, dicts = synth.make_rollout_case()
+    model = _model()
+    store = _store(scan, feats, torch.float32)
+    sim = rollout.GraphSim(store)
+    ro = rollout.NavRollout(lambda mode, batch: model(mode, batch), sim, store, max_action_len=7)
+    rec = []
+    inner = ro.model
+
+    def spy(mode, batch):
+        out = inner(mode, batch)
+        if mode == 'navigation':
+            rec.append(out)
+        return out
+    ro.model = spy
+    n_steps = int(z['n_steps'][0])
+    loss, traj = ro.run(eps, feedback='sample', extras=synth.rollout_extras(dicts, len(eps), 'cuda'),
+                        sampler=lambda t, probs: z['s%d_action' % t])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert ro.steps == n_steps == len(rec)
+    for t, out in enumerate(rec):
+        ref = z['s%d_fused_logits' % t]
+        got = out['fused_logits'].detach().float().cpu().numpy()
+        fin = np.isfinite(ref)
+        assert np.array_equal(fin, np.isfinite(got)), t
+        assert np.abs(got[fin] - ref[fin]).max() <= 1e-3 * max(1.0, np.abs(ref[fin]).max()), t
+        assert np.abs(out['cls_embeds'].detach().float().cpu().numpy() - z['s%d_cls_embeds' % t]).max() <= 1e-3, t
+    assert abs(float(loss) - float(z['loss'][0])) <= 1e-3 * float(z['loss'][0])
+    names = [str(n) for n in z['param_names']]
+    params = dict(model.named_parameters())
+    top = float(z['grad_fp'][:, 0].max())
+    checked = 0
+    for n, fp in zip(names, z['grad_fp']):
+        g = params[n].grad
+        norm = 0.0 if g is None else float(g.double().norm())
+        assert abs(norm - float(fp[0])) <= 2e-3 * max(float(fp[0]), 1e-3 * top), (n, norm, float(fp[0]))
+        if g is not None and fp[0] > 1e-3 * top:
+            lead = g.detach().float().reshape(-1)[:8].cpu().numpy()
+            assert np.abs(lead - fp[1:1 + lead.size]).max() <= 2e-3 * max(float(np.abs(fp[1:]).max()), 1e-2 * float(fp[0])), n
+            checked += 1
+    assert checked > 100
+    assert [tr['path'] for tr in traj] == ids['traj']                 # hops, sampled stops without and forced ends with the stop-node backtrack
+    assert any([h[-1] for h in tr['path']][:len(ep['path'])] != ep['path'] for tr, ep in zip(traj, eps))      # (the walk did leave the gt paths)
+
+
 def test_nav_rollout_bf16_store_and_sampled_feedback():
     """bf16 feature table + bf16 compute: same rollout within the bf16 tolerance of north_star (2e-2 on the logits); argmax /
     sample feedback run to completion with one action read-back per step and valid trajectories."""

@@ -235,3 +235,40 @@ def test_collate_indices_covers_object_batches():
     oi, om = idx['og_idx']
     for b, (v, o) in enumerate(zip(vl, ol)):
         assert oi[b, :o].tolist() == list(range(1 + v, 1 + v + o)) and om[b].tolist() == [True] * o + [False] * (om.shape[1] - o)
+
+
+def test_collate_refuses_action_labels_outside_their_logit_row():
+    """goat_sap_fuse treats a label outside its row like the ignore value (loss 0, no gradient); F.cross_entropy, which it replaces, raises.
+    collate_indices therefore validates the labels on the host."""
+    from vln_goat_amd import config as gcfg, synth, train_step
+    cfg = gcfg.make_config(num_l_layers=1, num_top_layer=1, num_pano_layers=1, vocab_size=300)
+    b = synth.make_pretrain_batch(B=3, T=2, L=12, seed=4, vocab_size=300, style='survey')
+    train_step.collate_indices(cfg, b, ('sap',))                      # valid labels pass
+    G, W = b['gmap_step_ids'].shape[1], b['vp_pos_fts'].shape[1]
+    ok = dict(b)
+    ok['global_act_labels'] = b['global_act_labels'].clone()
+    ok['global_act_labels'][0] = -100                                  # the ignore value stays legal
+    train_step.collate_indices(cfg, ok, ('sap',))
+    for key, width in (('global_act_labels', G), ('local_act_labels', W)):
+        bad = dict(b)
+        bad[key] = b[key].clone()
+        bad[key][1] = width
+        with pytest.raises(ValueError):
+            train_step.collate_indices(cfg, bad, ('sap',))
+        bad[key][1] = -3
+        with pytest.raises(ValueError):
+            train_step.collate_indices(cfg, bad, ('sap',))
+
+
+def test_position_features_are_prepared_once_for_every_dtype():
+    from vln_goat_amd import synth, train_step
+    b = synth.make_pretrain_batch(B=2, T=2, L=10, seed=2, vocab_size=300, style='survey')
+    for dt, e in ((torch.bfloat16, 8), (torch.float32, 4)):
+        p = train_step.prepare_position_features(b, dt)
+        for k in ('traj_loc_fts', 'gmap_pos_fts', 'vp_pos_fts'):
+            assert p[k].dtype == dt and p[k].shape[-1] % e == 0 and p[k].shape[:-1] == b[k].shape[:-1]
+            n = b[k].shape[-1]
+            assert torch.equal(p[k][..., :n], b[k].to(dt)) and not p[k][..., n:].any()
+        assert p['txt_ids'] is b['txt_ids']                            # everything else untouched
+        again = train_step.prepare_position_features(p, dt)            # idempotent
+        assert all(again[k] is p[k] for k in ('traj_loc_fts', 'gmap_pos_fts', 'vp_pos_fts'))

@@ -415,6 +415,8 @@ class GradArena:
                 chunks.append(self.flat[a:e])
                 a = e
         if self.comm_stream is not None:
+            from . import hipops
+            hipops.note_parallel_branch()          # (a capture in progress gets a parallel branch: see hipops' hipGraph lifetime note)
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 for c in chunks:

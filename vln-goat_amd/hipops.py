@@ -458,24 +458,50 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
 
 # ----------------------------------------------------------------------------- hipGraph lifetime (runtime workaround)
 # ROCm 7.2 (libamdhip64 of this torch build): destroying a hipGraphExec whose graph had parallel branches (the side streams of
-# `Branch` below) leaves dangling entries in the runtime's pool of parallel launch streams; after two such graphs have been
-# destroyed, the launch of a LATER graph crashes on the host in hip::Graph::UpdateStreams (found by the test suite: capture A,
-# destroy; capture B, destroy; capture C -> segfault in hipGraphLaunch; scripts/dbg_graph_lifetime.py reproduces it).  Every
-# torch.cuda.CUDAGraph created after this package is imported is therefore kept alive for the life of the process — what a
-# trainer does anyway (its step graphs live as long as it does); the cost is the graphs' private memory pools.
+# `Branch` below, the communication stream of dp.GradArena) leaves dangling entries in the runtime's pool of parallel launch streams;
+# after two such graphs have been destroyed, the launch of a LATER graph crashes on the host in hip::Graph::UpdateStreams (found by the
+# test suite: capture A, destroy; capture B, destroy; capture C -> segfault in hipGraphLaunch; scripts/dbg_graph_lifetime.py
+# reproduces it).  The graphs that forked a side stream of THIS package during their capture are therefore kept alive for the life of
+# the process — what a trainer does anyway (its step graphs live as long as it does).  Graphs of other code in the process, and graphs of
+# this package without parallel branches, are created and destroyed as torch would (the first version retained every
+# torch.cuda.CUDAGraph of the process).  GOAT_NO_GRAPH_RETAIN=1 switches the workaround off, GOAT_GRAPH_RETAIN_ALL=1 restores the old rule.
 _RETAINED_GRAPHS = []
+_CAPTURING = []             # graphs between capture_begin and capture_end (innermost last)
+_FORKED = [False]           # a side stream of this package joined the capture in progress
+
+
+def note_parallel_branch():
+    """called where this package forks a side stream (Branch, the arena's communication stream): marks the graph being captured."""
+    if _CAPTURING:
+        _FORKED[0] = True
 
 
 def _retain_cuda_graphs():
     if getattr(torch.cuda.CUDAGraph, '_goat_retained', False) or os.environ.get('GOAT_NO_GRAPH_RETAIN'):
         return
-    orig_new = torch.cuda.CUDAGraph.__new__
+    keep_all = bool(os.environ.get('GOAT_GRAPH_RETAIN_ALL'))
+    orig_begin, orig_end = torch.cuda.CUDAGraph.capture_begin, torch.cuda.CUDAGraph.capture_end
 
-    def __new__(cls, *a, **k):
-        g = orig_new(cls, *a, **k)
-        _RETAINED_GRAPHS.append(g)
-        return g
-    torch.cuda.CUDAGraph.__new__ = __new__
+    def capture_begin(self, *a, **k):
+        _CAPTURING.append(self)
+        _FORKED[0] = False
+        try:
+            return orig_begin(self, *a, **k)
+        except BaseException:
+            _CAPTURING.pop()
+            raise
+
+    def capture_end(self, *a, **k):
+        try:
+            return orig_end(self, *a, **k)
+        finally:
+            if _CAPTURING and _CAPTURING[-1] is self:
+                _CAPTURING.pop()
+            if (_FORKED[0] or keep_all) and not any(g is self for g in _RETAINED_GRAPHS):
+                _RETAINED_GRAPHS.append(self)
+            _FORKED[0] = False
+    torch.cuda.CUDAGraph.capture_begin = capture_begin
+    torch.cuda.CUDAGraph.capture_end = capture_end
     torch.cuda.CUDAGraph._goat_retained = True
 
 
@@ -517,6 +543,7 @@ class Branch:
         if Branch._stale:               # first fork of a new step: forget the streams of the previous one
             Branch.used, Branch._stale = set(), False
         Branch.used.add(self.side)
+        note_parallel_branch()
         self._ctx = torch.cuda.stream(self.side)
         self._ctx.__enter__()
         return self
@@ -543,6 +570,7 @@ class Branch:
 
     @staticmethod
     def _arm(grad):
+        note_parallel_branch()        # (a graph that captures only this backward pass has the side streams as parallel branches too)
         if not Branch._armed:
             Branch._armed = True
             torch.autograd.Variable._execution_engine.queue_callback(Branch._end_of_backward)

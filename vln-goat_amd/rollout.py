@@ -644,7 +644,7 @@ class NavRollout:
         pano = panorama_inputs(obs, self.sim.angle_feat_size, self.pano_width)
         return pano
 
-    def run(self, episodes, feedback='teacher', extras=None, train_ml=1.0, compute_loss=True):
+    def run(self, episodes, feedback='teacher', extras=None, train_ml=1.0, compute_loss=True, sampler=None):
         import time
         from collections import defaultdict
         dd = lambda d: defaultdict(lambda: None, d)
@@ -721,7 +721,12 @@ class NavRollout:
             elif feedback in ('argmax', 'sample'):
                 # ONE device -> host copy per step: the chosen actions and the stop probabilities (M/r2r/agent.py:575-580,601-607)
                 probs = torch.softmax(logits.detach().float(), 1)
-                act = probs.argmax(1) if feedback == 'argmax' else torch.distributions.Categorical(probs).sample()
+                if feedback == 'argmax':
+                    act = probs.argmax(1)
+                elif sampler is not None:           # (a fixed action sequence in place of Categorical.sample(): the sampled-rollout golden)
+                    act = torch.as_tensor(sampler(t, probs), dtype=torch.int64, device=probs.device)
+                else:
+                    act = torch.distributions.Categorical(probs).sample()
                 back = torch.stack([act.to(torch.float32), probs[:, 0].detach()], 0).cpu().numpy()
                 a_t = back[0].astype(np.int64)
                 stop = (a_t == 0) if feedback == 'argmax' else [ob['viewpoint'] == ob['gt_path'][-1] for ob in obs]
