@@ -395,6 +395,8 @@ def make_steps(args, model, gb, world, wrapper, tasks=None):
                 # communication stream right behind the phase that completes its gradients (parallel branches of the graph, joined
                 # by the last exchange).  No host work between the phases; the cfp all-gather is a graph node too.
                 try:
+                    from vln_goat_amd import dp as _dp
+                    _dp.quiesce_collectives()        # (the watchdog must have retired every eager collective before the streams capture)
                     gi = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gi, capture_error_mode=mode):
                         eager_phased(task)
@@ -964,6 +966,7 @@ def config4_leg(args, rank=0, world=1):
         done = False
         if in_graph and arena[0] is not None:
             try:
+                dp.quiesce_collectives()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode=mode):
                     episode()

@@ -376,6 +376,15 @@ int goat_infonce_bwd(void* stream, const float* const* x_loc, const float* const
  * ds_read_b64_tr_b16 when lane l points at elements 4l..4l+3 of an LDS array holding 0,1,2,... */
 int goat_probe_tr16(void* stream, uint16_t* out);
 
+/* CFP fused vector (P/model/pretrain_goat.py:486-499 with the glocal fusion weight of :393-399): w = sigmoid(fwl[b]) (fwl: the
+ * output of sap_fuse_linear, [B] in dtype_fwl); fo[b,:] = go[b,:] * w + vo[b,:] * (1 - w) (float32 [B,H]); fw[b] = w saved for backward.
+ * Replaces sigmoid, two muls, rsub, add (and their ~10 backward launches) on [B,768] tensors. */
+int goat_cfp_mix_fwd(void* stream, int dtype_fwl, const float* go, const float* vo, const void* fwl, float* fo, float* fw, int B, int H);
+/* backward: dgo = dfo * w, dvo = dfo * (1 - w) (accumulate != 0: ADDED to what dgo / dvo hold — the InfoNCE gradients of the same vectors),
+ * dfwl[b] = w (1 - w) sum_h dfo (go - vo) in dtype_fwl. */
+int goat_cfp_mix_bwd(void* stream, int dtype_fwl, const float* go, const float* vo, const float* fw, const float* dfo, float* dgo,
+                     float* dvo, void* dfwl, int B, int H, int accumulate);
+
 /* ---- glue of the captured steps (csrc/glue.hip) -------------------------------------------------------------------------
  * out[numel] = sum_i srcs[i][numel] (n <= 8 tensors of `dtype`, float32 accumulation, ONE rounding): the gradient of a tensor with
  * several consumers — replaces the k - 1 pairwise `add` launches of torch's autograd engine (AccumulateGrad-free fan-in: the text

@@ -66,6 +66,7 @@ for wire in [WIRES[x] for x in os.environ.get('CHK_WIRES', 'f32,bf16').split(','
     torch.cuda.synchronize()
     for t in tasks:
         g = torch.cuda.CUDAGraph()
+        dp.quiesce_collectives()                         # (no eager collective may still sit with the watchdog when the capture starts)
         print('capturing', t, flush=True)
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
             step(t)

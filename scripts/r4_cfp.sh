@@ -1,0 +1,10 @@
+#!/bin/bash
+OUT=/root/repo/gpurun_out/r4cfp; mkdir -p $OUT; cd /root/repo
+for i in 1 2 3; do timeout 300 python scripts/in_graph_comm_check.py > $OUT/ig_$i.txt 2>&1; echo "in-graph check $i: rc=$? $(grep -c IN_GRAPH_COMM_OK $OUT/ig_$i.txt)"; done
+timeout 900 python -m pytest tests/test_hip_ops.py -x -q -m gpu -k "cfp or infonce or add_n" > $OUT/pytest_ops.txt 2>&1; tail -n 2 $OUT/pytest_ops.txt
+timeout 1500 python -m pytest tests/test_model_parity_gpu.py tests/test_train_step_gpu.py tests/test_dp_two_rank_gpu.py -q -m gpu > $OUT/pytest_model.txt 2>&1; tail -n 3 $OUT/pytest_model.txt | cut -c1-200
+timeout 600 python scripts/aten_sites.py > $OUT/aten_sites.txt 2>&1; grep "==" $OUT/aten_sites.txt
+for i in 1 2; do
+python bench.py --no-cpu-baseline --no-extra-configs --no-roofline --steps 60 > $OUT/b_$i.json 2> $OUT/err.txt; python -c "import json; d=json.loads([l for l in open('$OUT/b_$i.json') if l.startswith('{')][-1]); print('new', d['ms_per_step'], d['ms_per_task_step'])"
+GOAT_NO_FANOUT=1 python bench.py --no-cpu-baseline --no-extra-configs --no-roofline --steps 60 > $OUT/n_$i.json 2>> $OUT/err.txt; python -c "import json; d=json.loads([l for l in open('$OUT/n_$i.json') if l.startswith('{')][-1]); print('nofanout', d['ms_per_step'], d['ms_per_task_step'])"
+done

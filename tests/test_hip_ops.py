@@ -1081,3 +1081,47 @@ def test_linear_accepts_inputs_already_padded_along_k(ops, dtype):
         _close(b.grad, gb0, dtype, 'db')
     with pytest.raises(ValueError):
         ops.linear(torch.randn(4, 11, device=DEV).to(dtype), torch.randn(8, 7, device=DEV))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_cfp_mix_and_tail_match_the_torch_chain(ops, dtype):
+    """goat_cfp_mix_fwd/_bwd (fo = go w + vo (1 - w), w = sigmoid(fusion logit)) and hipops.cfp_tail (mix + the three symmetric InfoNCE losses
+    as one autograd node) against the reference's spelling, P/model/pretrain_goat.py:486-499,519-534."""
+    torch.manual_seed(11)
+    B, H, tau = 12, 768, 0.07
+    mk = lambda: torch.nn.functional.normalize(torch.randn(B, H, device=DEV), dim=1).requires_grad_(True)
+    go, vo, to = mk(), mk(), mk()
+    fwl = torch.randn(B, 1, device=DEV).to(dtype).requires_grad_(True)
+
+    def ref_chain():
+        fw = torch.sigmoid(fwl.float())
+        fo = go * fw + vo * (1 - fw)
+        tgt = torch.arange(B, device=DEV)
+        sym = lambda x: (torch.nn.functional.cross_entropy(x @ to.T / tau, tgt, reduction='none')
+                         + torch.nn.functional.cross_entropy(to @ x.T / tau, tgt, reduction='none')) / 2
+        return fo, sym(go) + sym(vo) + sym(fo)
+    fo_ref, loss_ref = ref_chain()
+    w = torch.randn(B, device=DEV)
+    (loss_ref * w).sum().backward()
+    g_ref = [t.grad.clone() for t in (go, vo, fwl, to)]
+    for t in (go, vo, fwl, to):
+        t.grad = None
+    fo = ops.cfp_mix(go, vo, fwl)
+    _close(fo, fo_ref, torch.float32, 'fo')
+    loss = ops.cfp_tail(go, vo, fwl, to, tau)
+    _close(loss, loss_ref, torch.float32, 'loss')
+    (loss * w).sum().backward()
+    for name, t, r in zip(('dgo', 'dvo', 'dfwl', 'dto'), (go, vo, fwl, to), g_ref):
+        _close(t.grad, r, dtype if name == 'dfwl' else torch.float32, name)
+    # the mix alone, with its own backward
+    for t in (go, vo, fwl):
+        t.grad = None
+    gsel = torch.randn(B, H, device=DEV)
+    (ops.cfp_mix(go, vo, fwl) * gsel).sum().backward()
+    got = [t.grad.clone() for t in (go, vo, fwl)]
+    for t in (go, vo, fwl):
+        t.grad = None
+    fw = torch.sigmoid(fwl.float())
+    ((go * fw + vo * (1 - fw)) * gsel).sum().backward()
+    for name, a, t in zip(('dgo', 'dvo', 'dfwl'), got, (go, vo, fwl)):
+        _close(a, t.grad, dtype if name == 'dfwl' else torch.float32, 'mix ' + name)

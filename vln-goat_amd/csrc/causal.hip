@@ -479,6 +479,41 @@ __global__ __launch_bounds__(64) void sap_bwd_kernel(SapArgs p) {
   acc_fw = wave_sum(acc_fw);
   if (lane == 0 && p.dfwl) reinterpret_cast<T*>(p.dfwl)[b] = (T)(p.fw_sigmoid ? acc_fw * fw * (1.f - fw) : acc_fw);
 }
+
+// ---- CFP fused vector: fo = go * w + vo * (1 - w), w = sigmoid(fwl)   (P/model/pretrain_goat.py:486-499: the glocal fusion weight on the
+// pooled map / local vectors).  One block per sample; float32 vectors, the fusion logit in the compute dtype.
+template <typename T>
+__global__ __launch_bounds__(256) void cfp_mix_fwd_kernel(const float* __restrict__ go, const float* __restrict__ vo, const T* __restrict__ fwl,
+                                                          float* __restrict__ fo, float* __restrict__ fw, int H) {
+  const int b = blockIdx.x;
+  const float w = 1.f / (1.f + __expf(-to_f(fwl[b])));
+  if (threadIdx.x == 0) fw[b] = w;
+  for (int h = threadIdx.x; h < H; h += 256) {
+    const int64_t i = (int64_t)b * H + h;
+    fo[i] = go[i] * w + vo[i] * (1.f - w);
+  }
+}
+// dgo += dfo * w ; dvo += dfo * (1 - w) ; dfwl = w (1 - w) sum_h dfo (go - vo)
+template <typename T>
+__global__ __launch_bounds__(256) void cfp_mix_bwd_kernel(const float* __restrict__ go, const float* __restrict__ vo, const float* __restrict__ fw,
+                                                          const float* __restrict__ dfo, float* __restrict__ dgo, float* __restrict__ dvo,
+                                                          T* __restrict__ dfwl, int H, int accumulate) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float w = fw[b];
+  float s = 0.f;
+  for (int h = threadIdx.x; h < H; h += 256) {
+    const int64_t i = (int64_t)b * H + h;
+    const float d = dfo[i];
+    s += d * (go[i] - vo[i]);
+    dgo[i] = accumulate ? dgo[i] + d * w : d * w;
+    dvo[i] = accumulate ? dvo[i] + d * (1.f - w) : d * (1.f - w);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dfwl[b] = from_f<T>((red[0] + red[1] + red[2] + red[3]) * w * (1.f - w));
+}
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -645,6 +680,33 @@ extern "C" int goat_infonce_bwd(void* stream, const float* const* x_loc, const f
   q.row_groups = (Ba + 3) / 4;
   hipLaunchKernelGGL(infonce_bwd_kernel, dim3(q.nroles * q.row_groups, (H + 63) / 64), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), q);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_cfp_mix_fwd(void* stream, int dtype_fwl, const float* go, const float* vo, const void* fwl, float* fo, float* fw, int B, int H) {
+  if (!go || !vo || !fwl || !fo || !fw) return GOAT_E_ARG;
+  if (B <= 0 || H <= 0) return GOAT_E_SHAPE;
+  if (dtype_fwl == GOAT_BF16)
+    hipLaunchKernelGGL(cfp_mix_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, ST(stream), go, vo, (const bf16_t*)fwl, fo, fw, H);
+  else if (dtype_fwl == GOAT_F32)
+    hipLaunchKernelGGL(cfp_mix_fwd_kernel<float>, dim3(B), dim3(256), 0, ST(stream), go, vo, (const float*)fwl, fo, fw, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_cfp_mix_bwd(void* stream, int dtype_fwl, const float* go, const float* vo, const float* fw, const float* dfo, float* dgo,
+                                float* dvo, void* dfwl, int B, int H, int accumulate) {
+  if (!go || !vo || !fw || !dfo || !dgo || !dvo || !dfwl) return GOAT_E_ARG;
+  if (B <= 0 || H <= 0) return GOAT_E_SHAPE;
+  if (dtype_fwl == GOAT_BF16)
+    hipLaunchKernelGGL(cfp_mix_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, ST(stream), go, vo, fw, dfo, dgo, dvo, (bf16_t*)dfwl, H, accumulate);
+  else if (dtype_fwl == GOAT_F32)
+    hipLaunchKernelGGL(cfp_mix_bwd_kernel<float>, dim3(B), dim3(256), 0, ST(stream), go, vo, fw, dfo, dgo, dvo, (float*)dfwl, H, accumulate);
+  else
+    return GOAT_E_ARG;
   GOAT_LAUNCH_CHECK();
   return 0;
 }

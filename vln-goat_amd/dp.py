@@ -617,6 +617,19 @@ class GoatDataParallel(torch.nn.Module):
             gb.all_reduce_mean(grads)
 
 
+def quiesce_collectives(seconds=0.3):
+    """Call right before a hipGraph capture that will contain collectives.  ProcessGroupNCCL's watchdog thread polls the end events of the
+    eager collectives issued so far (every 100 ms); on this HIP runtime `hipEventQuery` fails with hipErrorCapturedEvent once the STREAM an
+    event was recorded on has entered capture mode — even though the event itself was recorded before — and the watchdog then takes the
+    process down.  After a device synchronise every earlier collective is complete, and one watchdog period later it has retired them all:
+    nothing is left to poll while the communication stream is capturing.  (Found as a 1-in-3 flake of scripts/in_graph_comm_check.py.)"""
+    import time
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if dist.is_available() and dist.is_initialized():
+        time.sleep(seconds)
+
+
 def wrap_finetune_models(vln_bert, critic=None, **kw):
     """The fine-tuning agent's two models under data parallelism, as M/r2r/agent_base.py:100-102 (and M/reverie/agent_base.py:114-115)
     wraps them in DDP(find_unused_parameters=True): rank 0's parameters and buffers broadcast at construction, one process per GPU,

@@ -2029,5 +2029,86 @@ class _InfoNceFn(torch.autograd.Function):
         return tuple(gl) + tuple((ga[k] if need_all[k] else None) for k in range(4)) + (None, None)
 
 
+def _cfp_mix_fwd(go, vo, fwl):
+    B, H = go.shape
+    fo = torch.empty_like(go)
+    fw = torch.empty(B, dtype=torch.float32, device=go.device)
+    st = _lib.lib().goat_cfp_mix_fwd(_stream(), _dt(fwl), _ptr(go), _ptr(vo), _ptr(fwl), _ptr(fo), _ptr(fw), B, H)
+    _lib.check(st, 'goat_cfp_mix_fwd')
+    return fo, fw
+
+
+def _cfp_mix_bwd(go, vo, fw, dfo, dgo, dvo, fwl_dtype, accumulate):
+    B, H = go.shape
+    dfwl = torch.empty(B, dtype=fwl_dtype, device=go.device)
+    st = _lib.lib().goat_cfp_mix_bwd(_stream(), GOAT_BF16 if fwl_dtype == torch.bfloat16 else GOAT_F32, _ptr(go), _ptr(vo), _ptr(fw), _ptr(dfo),
+                                     _ptr(dgo), _ptr(dvo), _ptr(dfwl), B, H, int(accumulate))
+    _lib.check(st, 'goat_cfp_mix_bwd')
+    return dfwl
+
+
+class _CfpMixFn(torch.autograd.Function):
+    """fo = go * sigmoid(fwl) + vo * (1 - sigmoid(fwl))  (float32 [B,H] pooled vectors, fusion logit [B] / [B,1] in the compute dtype):
+    the fused CFP vector of P/model/pretrain_goat.py:486-499 in one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, go, vo, fwl):
+        go, vo = go.float().contiguous(), vo.float().contiguous()
+        f1 = fwl.reshape(-1).contiguous()
+        fo, fw = _cfp_mix_fwd(go, vo, f1)
+        ctx.save_for_backward(go, vo, fw)
+        ctx.fshape, ctx.fdtype = fwl.shape, f1.dtype
+        return fo
+
+    @staticmethod
+    def backward(ctx, dfo):
+        go, vo, fw = ctx.saved_tensors
+        dgo, dvo = torch.empty_like(go), torch.empty_like(vo)
+        dfwl = _cfp_mix_bwd(go, vo, fw, dfo.float().contiguous(), dgo, dvo, ctx.fdtype, False)
+        return dgo, dvo, dfwl.view(ctx.fshape)
+
+
+def cfp_mix(go, vo, fwl):
+    return _CfpMixFn.apply(go, vo, fwl)
+
+
+class _CfpTailFn(torch.autograd.Function):
+    """loss = InfoNCE(go, vo, fo, to) with fo = mix(go, vo, fwl) — the whole CFP tail behind the three pooled vectors as ONE autograd node
+    (single rank: candidates = the batch's own vectors): two launches per direction, and the gradients of go / vo from the loss and from
+    the fused vector meet inside the backward kernels instead of in autograd-engine adds."""
+
+    @staticmethod
+    def forward(ctx, go, vo, fwl, to, temperature):
+        go, vo, to = go.float().contiguous(), vo.float().contiguous(), to.float().contiguous()
+        f1 = fwl.reshape(-1).contiguous()
+        fo, fw = _cfp_mix_fwd(go, vo, f1)
+        Bl, H = go.shape
+        loss = torch.zeros(Bl, dtype=torch.float32, device=go.device)
+        prob = torch.empty((6, Bl, Bl), dtype=torch.float32, device=go.device)
+        xs = (ctypes.c_void_p * 3)(_ptr(go), _ptr(vo), _ptr(fo))
+        st = _lib.lib().goat_infonce_fwd(_stream(), xs, xs, _ptr(to), _ptr(to), _ptr(loss), _ptr(prob), Bl, Bl, H, 0, float(temperature))
+        _lib.check(st, 'goat_infonce_fwd')
+        ctx.save_for_backward(go, vo, fo, to, fw, prob)
+        ctx.fshape, ctx.fdtype, ctx.temperature = fwl.shape, f1.dtype, float(temperature)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        go, vo, fo, to, fw, prob = ctx.saved_tensors
+        Bl, H = go.shape
+        d = torch.zeros((4, Bl, H), dtype=torch.float32, device=go.device)          # dgo | dvo | dfo | dto, accumulated by the kernels
+        xs = (ctypes.c_void_p * 3)(_ptr(go), _ptr(vo), _ptr(fo))
+        dx = (ctypes.c_void_p * 3)(_ptr(d[0]), _ptr(d[1]), _ptr(d[2]))
+        st = _lib.lib().goat_infonce_bwd(_stream(), xs, xs, _ptr(to), _ptr(to), _ptr(dloss.float().contiguous()), _ptr(prob), dx, dx, _ptr(d[3]), _ptr(d[3]),
+                                         Bl, Bl, H, 0, ctx.temperature)
+        _lib.check(st, 'goat_infonce_bwd')
+        dfwl = _cfp_mix_bwd(go, vo, fw, d[2], d[0], d[1], ctx.fdtype, True)
+        return d[0], d[1], dfwl.view(ctx.fshape), d[3], None
+
+
+def cfp_tail(go, vo, fwl, to, temperature):
+    return _CfpTailFn.apply(go, vo, fwl, to, temperature)
+
+
 def infonce(g_loc, v_loc, f_loc, t_loc, g_all, v_all, f_all, t_all, target0, temperature):
     return _InfoNceFn.apply(g_loc, v_loc, f_loc, t_loc, g_all, v_all, f_all, t_all, target0, temperature)

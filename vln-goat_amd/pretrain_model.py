@@ -668,8 +668,18 @@ class GlocalTextPathCMTPreTraining(GoatPreTrainedModel):
         vo = attn_pool(vp, self.tim_local_attn, cache.get('cfp_vp_mask'))
         bg.join(gmap, go)
         bt.join(txt, to)
-        fw = self._fuse_weights(gmap, vp)
-        fo = go * fw + vo * (1 - fw)
+        if self.sap_fuse_linear is not None and go.is_cuda and hipops.FANOUT:
+            # fusion logit -> sigmoid -> fused vector in one launch per direction (hipops.cfp_mix); on a single rank the three InfoNCE losses
+            # behind it join the same autograd node (hipops.cfp_tail: no engine adds for the gradients of the pooled vectors)
+            fwl = self.sap_fuse_linear(torch.cat([gmap[:, 0], vp[:, 0]], 1))
+            single = self.cfp_gather is None or not (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                                     and torch.distributed.get_world_size() > 1)
+            if compute_loss and single:
+                return hipops.cfp_tail(go, vo, fwl, to, self.temperature)
+            fo = hipops.cfp_mix(go, vo, fwl)
+        else:
+            fw = self._fuse_weights(gmap, vp)
+            fo = go * fw + vo * (1 - fw)
         if compute_loss:
             return cfp_losses(go, vo, fo, to, self.temperature, self.cfp_gather)
         return go, vo, fo, to
