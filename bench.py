@@ -279,7 +279,7 @@ def make_steps(args, model, gb, world, wrapper, tasks=None):
     def step_body(task):                        # single-graph step (N = 1, warm-up)
         prologue(task)
         loss = model(gb, task, compute_loss=True)
-        loss.mean().backward()
+        hipops.backward_mean(loss)              # loss.mean().backward(): the mean for the log + a cached 1/n seed (no ones_like / div launches)
         return loss
 
     def eager_phased(task):

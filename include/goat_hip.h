@@ -376,6 +376,14 @@ int goat_infonce_bwd(void* stream, const float* const* x_loc, const float* const
  * ds_read_b64_tr_b16 when lane l points at elements 4l..4l+3 of an LDS array holding 0,1,2,... */
 int goat_probe_tr16(void* stream, uint16_t* out);
 
+/* Linear(H, 1) — the last layer of ClsPrediction (P/model/pretrain_goat.py:27-38: the global / local action scores, the fusion logit, the
+ * object scores): y[m] = x[m,:] . w + b (w: float32 [H], rounded to the activation dtype as the GEMM path's shadow weight; b: float32 [1] or
+ * NULL; float32 accumulation; y in `dtype`).  H a multiple of 8, <= 1024. */
+int goat_rowdot_fwd(void* stream, int dtype, const void* x, const float* w, const float* b, void* y, int M, int H);
+/* backward: dx[m,:] = dy[m] w (NULL: skipped); dw[H] += sum_m dy[m] x[m,:], db[1] += sum_m dy[m] (float32 atomics: the caller clears or
+ * accumulates; NULL dw: both skipped). */
+int goat_rowdot_bwd(void* stream, int dtype, const void* x, const float* w, const void* dy, void* dx, float* dw, float* db, int M, int H);
+
 /* CFP fused vector (P/model/pretrain_goat.py:486-499 with the glocal fusion weight of :393-399): w = sigmoid(fwl[b]) (fwl: the
  * output of sap_fuse_linear, [B] in dtype_fwl); fo[b,:] = go[b,:] * w + vo[b,:] * (1 - w) (float32 [B,H]); fw[b] = w saved for backward.
  * Replaces sigmoid, two muls, rsub, add (and their ~10 backward launches) on [B,768] tensors. */

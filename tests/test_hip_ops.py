@@ -1125,3 +1125,27 @@ def test_cfp_mix_and_tail_match_the_torch_chain(ops, dtype):
     ((go * fw + vo * (1 - fw)) * gsel).sum().backward()
     for name, a, t in zip(('dgo', 'dvo', 'dfwl'), got, (go, vo, fwl)):
         _close(a, t.grad, dtype if name == 'dfwl' else torch.float32, 'mix ' + name)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(48, 22, 768), (48, 768), (1776, 768), (5, 256)])
+def test_linear_with_one_output_column_through_the_rowdot_kernels(ops, dtype, shape):
+    """Linear(H, 1) (last layer of ClsPrediction): goat_rowdot_fwd/_bwd == F.linear on the same (dtype-rounded) operands, gradients of x, W, b."""
+    torch.manual_seed(5)
+    H = shape[-1]
+    w = (torch.randn(1, H, device=DEV) * 0.05).requires_grad_(True)
+    b = torch.randn(1, device=DEV).requires_grad_(True)
+    x = torch.randn(*shape, device=DEV).to(dtype).requires_grad_(True)
+    y = ops.linear(x, w, b)
+    assert y.shape == shape[:-1] + (1,) and y.dtype == dtype
+    g = torch.randn_like(y)
+    y.backward(g)
+    got = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    wq = w.to(dtype).float()
+    ref = torch.nn.functional.linear(x.float(), wq, b)
+    ref.backward(g.float())
+    _close(got[0], ref, dtype, 'y')
+    _close(got[1], x.grad, dtype, 'dx')
+    _close(got[2], w.grad, dtype, 'dW')
+    _close(got[3], b.grad, dtype, 'db')

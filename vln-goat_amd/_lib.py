@@ -69,6 +69,8 @@ SIGNATURES = {
     'goat_infonce_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32],
     'goat_probe_tr16': [_vp, _vp],
     'goat_add_n': [_vp, _i32, _vp, _i32, _vp, _i64],
+    'goat_rowdot_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32],
+    'goat_rowdot_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
     'goat_cfp_mix_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
     'goat_cfp_mix_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_zero_ranges': [_vp, _vp, _vp, _i32],

@@ -514,6 +514,80 @@ __global__ __launch_bounds__(256) void cfp_mix_bwd_kernel(const float* __restric
   __syncthreads();
   if (threadIdx.x == 0) dfwl[b] = from_f<T>((red[0] + red[1] + red[2] + red[3]) * w * (1.f - w));
 }
+
+// ---- Linear(H, 1): the last layer of ClsPrediction (P/model/pretrain_goat.py:27-38: global / local action scores, fusion logit, object scores).
+// As a GEMM it is one output column: a 64 x 128 tile computing 1/128 of itself, a split-K weight gradient, and torch glue for the odd shapes
+// around it.  Here: y[m] = x[m,:] . w + b with one wave per row; backward dx[m,:] = dy[m] w and per-block partials of dw / db added
+// atomically (float32; the caller's arena slice or a zeroed temporary).  The weight is rounded to the activation dtype first, as the GEMM
+// path's bf16 shadow was: same products, float32 accumulation.
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                         T* __restrict__ y, int M, int H) {
+  constexpr int EPC = DT<T>::EPC;
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float s = 0.f;
+  for (int c = lane; c < H / EPC; c += 64) {
+    Chunk<T> v;
+    v.load(x + (int64_t)row * H + c * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s += v.v[e] * to_f(from_f<T>(w[c * EPC + e]));
+  }
+  s = wave_sum(s);
+  if (lane == 0) y[row] = from_f<T>(s + (b ? b[0] : 0.f));
+}
+
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const T* __restrict__ dy,
+                                                         T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int M, int H) {
+  constexpr int EPC = DT<T>::EPC;
+  extern __shared__ float part[];          // [4][H]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[MAXC][EPC], wv[MAXC][EPC];
+  float dbs = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      acc[i][e] = 0.f;
+      const int c = lane + 64 * i;
+      wv[i][e] = (c < H / EPC) ? to_f(from_f<T>(w[c * EPC + e])) : 0.f;
+    }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float d = to_f(dy[row]);
+    if (lane == 0) dbs += d;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < H / EPC) {
+        const int64_t base = (int64_t)row * H + c * EPC;
+        if (dw) {
+          Chunk<T> v;
+          v.load(x + base);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) acc[i][e] += d * v.v[e];
+        }
+        if (dx) {
+          Chunk<T> o;
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) o.v[e] = d * wv[i][e];
+          o.store(dx + base);
+        }
+      }
+    }
+  }
+  if (!dw) return;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < H / EPC)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) part[wave * H + c * EPC + e] = acc[i][e];
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < H; h += 256) atomicAdd(dw + h, part[h] + part[H + h] + part[2 * H + h] + part[3 * H + h]);
+  if (db && lane == 0) atomicAdd(db, dbs);
+}
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -680,6 +754,43 @@ extern "C" int goat_infonce_bwd(void* stream, const float* const* x_loc, const f
   q.row_groups = (Ba + 3) / 4;
   hipLaunchKernelGGL(infonce_bwd_kernel, dim3(q.nroles * q.row_groups, (H + 63) / 64), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), q);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_rowdot_fwd(void* stream, int dtype, const void* x, const float* w, const float* b, void* y, int M, int H) {
+  if (!x || !w || !y) return GOAT_E_ARG;
+  if (M <= 0 || H <= 0 || (H % 8)) return GOAT_E_SHAPE;
+  const int blocks = (M + 3) / 4;
+  if (dtype == GOAT_BF16)
+    hipLaunchKernelGGL(rowdot_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST(stream), (const bf16_t*)x, w, b, (bf16_t*)y, M, H);
+  else if (dtype == GOAT_F32)
+    hipLaunchKernelGGL(rowdot_fwd_kernel<float>, dim3(blocks), dim3(256), 0, ST(stream), (const float*)x, w, b, (float*)y, M, H);
+  else
+    return GOAT_E_ARG;
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int goat_rowdot_bwd(void* stream, int dtype, const void* x, const float* w, const void* dy, void* dx, float* dw, float* db, int M,
+                               int H) {
+  if (!x || !w || !dy) return GOAT_E_ARG;
+  if (M <= 0 || H <= 0 || (H % 8)) return GOAT_E_SHAPE;
+  if (!dx && !dw) return 0;
+  int blocks = (M + 3) / 4;
+  if (blocks > 128) blocks = 128;          // (each block adds H + 1 partials atomically)
+  const size_t sm = (size_t)4 * H * sizeof(float);
+  if (dtype == GOAT_BF16) {
+    if (H > 64 * 8 * 2) return GOAT_E_SHAPE;
+    hipLaunchKernelGGL((rowdot_bwd_kernel<bf16_t, 2>), dim3(blocks), dim3(256), sm, ST(stream), (const bf16_t*)x, w, (const bf16_t*)dy, (bf16_t*)dx,
+                       dw, db, M, H);
+  } else if (dtype == GOAT_F32) {
+    if (H > 64 * 4 * 4) return GOAT_E_SHAPE;
+    hipLaunchKernelGGL((rowdot_bwd_kernel<float, 4>), dim3(blocks), dim3(256), sm, ST(stream), (const float*)x, w, (const float*)dy, (float*)dx, dw,
+                       db, M, H);
+  } else {
+    return GOAT_E_ARG;
+  }
   GOAT_LAUNCH_CHECK();
   return 0;
 }

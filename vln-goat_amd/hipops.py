@@ -1017,7 +1017,65 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class _RowDotFn(torch.autograd.Function):
+    """y[..., 0] = x[..., :] . w + b for a Linear(H, 1) (the last layer of ClsPrediction, P/model/pretrain_goat.py:27-38) without the GEMM
+    machinery: goat_rowdot_fwd / _bwd (one wave per row; dW / db by block partials + atomics straight into the arena slices)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x)
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M, H = x2.shape
+        y = torch.empty(M, dtype=x2.dtype, device=x2.device)
+        st = _lib.lib().goat_rowdot_fwd(_stream(), _dt(x2), _ptr(x2), _ptr(weight), _ptr(bias) if bias is not None else None, _ptr(y), M, H)
+        _lib.check(st, 'goat_rowdot_fwd')
+        ctx.save_for_backward(x2)
+        ctx.weight, ctx.bias, ctx.xshape = weight, bias, x.shape
+        return y.view(*x.shape[:-1], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        M, H = x2.shape
+        dy2 = dy.reshape(-1)
+        if dy2.dtype != x2.dtype:
+            dy2 = dy2.to(x2.dtype)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        need_w = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])
+        dw = db = dwt = dbt = None
+        if need_w:
+            w_sink = _sink(weight)
+            b_sink = _sink(bias) if (bias is not None and w_sink is not None) else None
+            if w_sink is not None and (b_sink is not None or bias is None):
+                if _first_touch(weight):
+                    w_sink.zero_()
+                if b_sink is not None and _first_touch(bias):
+                    b_sink.zero_()
+                dwt, dbt = w_sink, b_sink
+            else:
+                _prep_fallback(weight, *([bias] if bias is not None else []))
+                buf = torch.zeros(H + 1, dtype=torch.float32, device=x2.device)
+                dwt, dbt = buf[:H], (buf[H:] if bias is not None else None)
+                dw, db = dwt.view(weight.shape), (dbt.view(bias.shape) if bias is not None else None)
+        st = _lib.lib().goat_rowdot_bwd(_stream(), _dt(x2), _ptr(x2), _ptr(weight), _ptr(dy2), _ptr(dx) if dx is not None else None,
+                                        _ptr(dwt) if dwt is not None else None, _ptr(dbt) if dbt is not None else None, M, H)
+        _lib.check(st, 'goat_rowdot_bwd')
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, db
+
+
+ROWDOT = os.environ.get('GOAT_NO_ROWDOT', '0') != '1'        # (diagnostics: Linear(H, 1) through the GEMM path again)
+
+
 def linear(x, weight, bias=None, act=None, out_dtype=None):
+    if (ROWDOT and weight.shape[0] == 1 and act in (None, 'none') and out_dtype is None and x.is_cuda and x.shape[-1] == weight.shape[1]
+            and weight.shape[1] % 8 == 0 and weight.shape[1] <= 1024 and weight.dtype == torch.float32 and weight.is_contiguous()
+            and (bias is None or bias.dtype == torch.float32) and x.dtype in (torch.float32, torch.bfloat16)):
+        return _RowDotFn.apply(x, weight, bias)
     return _LinearFn.apply(x, weight, bias, act, out_dtype)
 
 
@@ -2066,6 +2124,23 @@ class _CfpMixFn(torch.autograd.Function):
         dgo, dvo = torch.empty_like(go), torch.empty_like(vo)
         dfwl = _cfp_mix_bwd(go, vo, fw, dfo.float().contiguous(), dgo, dvo, ctx.fdtype, False)
         return dgo, dvo, dfwl.view(ctx.fshape)
+
+
+_MEAN_SEED = {}
+
+
+def backward_mean(loss_vec, scale=1.0):
+    """`(loss_vec.mean() * scale).backward()` as the trainer spells it (P/train_r2r_goat.py:333-338), minus the autograd engine's seed
+    launches: the mean is still computed (one launch: trainers log it; returned detached), the backward pass starts from a cached
+    constant vector scale / n instead of ones_like + div (+ mul) kernels."""
+    n = loss_vec.numel()
+    key = (n, float(scale), loss_vec.device, loss_vec.dtype)
+    g = _MEAN_SEED.get(key)
+    if g is None:
+        g = _MEAN_SEED[key] = torch.full((n,), float(scale) / n, dtype=loss_vec.dtype, device=loss_vec.device)
+    m = loss_vec.detach().mean()
+    torch.autograd.backward(loss_vec, grad_tensors=g.view_as(loss_vec))
+    return m
 
 
 def cfp_mix(go, vo, fwl):
