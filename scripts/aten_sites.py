@@ -50,7 +50,7 @@ wrapper = dp.GoatDataParallel(model)
 for task in bench.TASKS:
     for p in model.parameters():
         p.grad = None
-    model(gb, task, compute_loss=True).mean().backward()
+    hipops.backward_mean(model(gb, task, compute_loss=True))
     wrapper.record_usage(task)
 for p in model.parameters():
     p.grad = None
@@ -58,12 +58,12 @@ arena = wrapper.build_arena()
 for rep in range(2):
     for task in bench.TASKS:
         arena.zero(task)
-        model(gb, task, compute_loss=True).mean().backward()
+        hipops.backward_mean(model(gb, task, compute_loss=True))          # (the step of bench.py)
 torch.cuda.synchronize()
 for task in (sys.argv[1:] or bench.TASKS):
     with Sites() as s:
         arena.zero(task)
-        model(gb, task, compute_loss=True).mean().backward()
+        hipops.backward_mean(model(gb, task, compute_loss=True))          # (the step of bench.py)
     torch.cuda.synchronize()
     print('== %s: %d non-view aten calls on device tensors' % (task, sum(s.count.values())))
     for (name, where), c in sorted(s.count.items(), key=lambda kv: -kv[1]):

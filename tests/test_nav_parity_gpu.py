@@ -309,6 +309,8 @@ def test_nav_episode_gradient_arena_equals_autograd(dtype):
                     continue
                 assert p.grad is arena.views[id(p)], n
                 d = float((p.grad.float() - ref[n]).abs().max())
-                assert d <= tol * max(float(ref[n].abs().max()), 1e-3 * gmax) + 1e-9, (rep, n, d, float(ref[n].abs().max()))
+                # (+ 3e-7: the bias of a Linear(H, 1) in front of a softmax cross-entropy receives sum(p - onehot) = 0 — O(1) terms that cancel;
+                #  goat_rowdot_bwd adds its block partials atomically, so that zero carries float32 rounding noise of a run-dependent order)
+                assert d <= tol * max(float(ref[n].abs().max()), 1e-3 * gmax) + 3e-7, (rep, n, d, float(ref[n].abs().max()))
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)

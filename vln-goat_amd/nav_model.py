@@ -358,9 +358,15 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
         bias = None
         if ge.sprel_linear is not None:
             bias = gmap_pair_dists.float() * ge.sprel_linear.weight.view(()) + ge.sprel_linear.bias.view(())
-        if front_gmap_feats is not None:
-            gmap = self.front_global_encoder(gmap, front_gmap_feats, gmap_masks)
-        gmap = ge.encoder(gmap, neg_mask(gmap_masks), txt_embeds, txt_km, bias, kv_cache=None if txt_kv is None else txt_kv['global'])
+        # the global-map branch (FACL front-door block, cross-modal encoder, its action head and pooler) is independent of the local
+        # one until the logit fusion: a parallel branch of the captured step / episode graph, as in the pre-training model
+        # (hipops.Branch; both chains are launch-latency-bound at 12 x 60 / 12 x 38 rows)
+        with hipops.Branch('global', 'nav_step') as bg:
+            if front_gmap_feats is not None:
+                gmap = self.front_global_encoder(gmap, front_gmap_feats, gmap_masks)
+            gmap = ge.encoder(gmap, neg_mask(gmap_masks), txt_embeds, txt_km, bias, kv_cache=None if txt_kv is None else txt_kv['global'])
+            g_scores = self.global_sap_head(gmap).squeeze(2)
+            g_pool = self.gmap_pooler(gmap)
 
         le = self.local_encoder
         vp = vp_img_embeds.to(dt) + le.vp_pos_embeddings[1](le.vp_pos_embeddings[0](vp_pos_fts.to(dt)))
@@ -370,18 +376,20 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
 
         # scores of the two heads -> masked global / local / fused logits in one launch per direction (hipops.sap_fuse; the
         # reference's chain: M/models/vilmodel_GOAT.py:803-839).  The stop column of the fused logits takes the local stop logit.
+        l_scores = self.local_sap_head(vp).squeeze(2)
+        bg.join(gmap, g_scores, g_pool)
         fwl = None if self.sap_fuse_linear is None else self.sap_fuse_linear(torch.cat([gmap[:, 0], vp[:, 0]], 1))
         M = None
         if not flops_count:
             M = nav_fusion if nav_fusion is not None else \
                 nav_fusion_matrix(vp_cand_vpids, gmap_vpids, gmap_visited_masks, G, vp.shape[1]).to(gmap.device)
-        gl, ll, fused, _ = hipops.sap_fuse(self.global_sap_head(gmap).squeeze(2), self.local_sap_head(vp).squeeze(2), fwl,
+        gl, ll, fused, _ = hipops.sap_fuse(g_scores, l_scores, fwl,
                                            gvis=gmap_visited_masks, gvalid=gmap_masks, lmask=vp_nav_masks, lmask_is_valid=True, M=M,
                                            add_stop=True)
         obj_logits = None
         if vp_obj_masks is not None and getattr(self.config, 'dataset', 'r2r') in ('reverie', 'soon'):
             obj_logits = torch.where(vp_obj_masks, self.og_head(vp).squeeze(2).float(), -float('inf'))      # (no clone: see pretrain_model.forward_og)
-        cls = torch.cat((self.gmap_pooler(gmap), self.vp_pooler(vp), self.txt_pooler(txt_embeds)), dim=-1)
+        cls = torch.cat((g_pool, self.vp_pooler(vp), self.txt_pooler(txt_embeds)), dim=-1)
         cls_embeds = self.local_his_ln(self.local_his_map(cls))
         return {'gmap_embeds': gmap, 'vp_embeds': vp, 'global_logits': gl, 'local_logits': ll, 'fused_logits': fused,
                 'obj_logits': obj_logits, 'txt_embeds': txt_embeds, 'cls_embeds': cls_embeds}

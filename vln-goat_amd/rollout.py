@@ -905,8 +905,6 @@ class TeacherEpisode:
         B = t_['txt_ids'].shape[0]
         lang = {'txt_ids': t_['txt_ids'], 'txt_masks': t_['txt_masks']}
         lang.update(extras.get('language', {}))
-        txt = model('language', dd(lang))
-        txt_kv = model('text_kv', {'txt_embeds': txt}) if hoist_text_kv else None
         pool, last, loss = [], None, 0.0
 
         def panoramas(k, n):
@@ -917,7 +915,13 @@ class TeacherEpisode:
                 pin[name] = z.repeat(n // B, *([1] * (z.dim() - 1))) if (torch.is_tensor(z) and n != B and z.dim() > 1 and z.shape[0] == B) else z
             return model('panorama', dd(pin))
 
-        whole = panoramas('all_', self.T * B) if hoist_pano else None
+        # (the hoisted panorama pass depends on the observations only: a parallel branch of the instruction encoder in the captured graph)
+        with hipops.Branch('pano', 'nav_pano') as bp:
+            whole = panoramas('all_', self.T * B) if hoist_pano else None
+        txt = model('language', dd(lang))
+        txt_kv = model('text_kv', {'txt_embeds': txt}) if hoist_text_kv else None
+        if whole is not None:
+            bp.join(*whole)
         for s in range(self.T):
             k = 's%d_' % s
             if whole is not None:
@@ -946,6 +950,103 @@ class TeacherEpisode:
             logits = {'local': out['local_logits'], 'global': out['global_logits']}.get(self.fusion, out['fused_logits'])
             loss = loss + torch.nn.functional.cross_entropy(logits.float(), t_[k + 'target'], reduction='sum', ignore_index=self.ignoreid)
         return loss / B
+
+
+class _RowIndex:
+    """key -> row lookup of a feature store without its table (what GraphSim needs of it on the host)."""
+
+    def __init__(self, keys):
+        self.index = {k: i for i, k in enumerate(keys)}
+
+    def row(self, scan, vp):
+        return self.index['%s_%s' % (scan, vp)]
+
+
+def _plan_worker_main(conn, spec):
+    import os
+    import time
+    os.environ.setdefault('HIP_VISIBLE_DEVICES', '-1')        # host work only: the worker never touches the GPU
+    torch.set_num_threads(1)          # small host tensors only: the default intra-op pool (one thread per core: 128-256 on the GPU boxes) costs
+                                      # tens of ms in wake-ups per plan (measured: 60 ms per plan with the pool, 13 ms without)
+    scans = spec['scans']
+    te = TeacherEpisode(GraphSim(_RowIndex(spec['keys']), spec['angle_feat_size']), None, spec['n_steps'], spec['text_len'],
+                        pano_width=spec['pano_width'], gmap_width=lambda t, w=spec['gmap_widths']: w[min(t, len(w) - 1)],
+                        fusion=spec['fusion'], ignoreid=spec['ignoreid'])
+    while True:
+        try:
+            episodes = conn.recv()
+        except EOFError:
+            break
+        if episodes is None:
+            break
+        try:
+            t0 = time.perf_counter()
+            plan = te.plan([dict(e, scan=scans[e['scan']]) for e in episodes])
+            plan['_plan_s'] = time.perf_counter() - t0
+            plan.pop('_traj', None)
+            # numpy through the pipe: torch tensors would travel as one shared-memory segment + file descriptor EACH (~150 per plan: 10 ms)
+            conn.send({k: (('__t', v.numpy()) if torch.is_tensor(v) else v) for k, v in plan.items()})
+        except Exception as e:      # noqa: BLE001  (reported to the caller, the worker stays alive)
+            conn.send(e)
+
+
+class PlanWorker:
+    """TeacherEpisode.plan in a worker PROCESS.  The plan of a batch of episodes is 10-15 ms of pure-Python table building; next to it the
+    training process copies the previous plan into the pinned buffer and launches a ~3 000-node episode graph (several ms of host time in
+    hipGraphLaunch).  A thread does not help (the builders hold the GIL: 21-24 ms per episode against 19 ms of GPU work); a process does.
+    submit(episodes) returns at once (the episodes travel with their scan NAMES; the worker holds the ScanGraphs, its own GraphSim over the
+    store's key -> row map, and never initialises the GPU — spawn context, safe beside an initialised HIP runtime); a reader thread of this
+    process drains the worker's pipe (plans are ~3 MB: a worker blocked in send while this process blocks in submit would deadlock);
+    result() hands back the next plan dict (CPU tensors) in submission order.
+
+        pw = PlanWorker(te, store.keys, scans);  pw.submit(eps_0); pw.submit(eps_1)          # two in flight
+        for k in ...:  plan = pw.result(); pw.submit(eps_k2); bufs.load(plan); graph.replay()"""
+
+    def __init__(self, te, keys, scans):
+        import multiprocessing as mp
+        import queue
+        import threading
+        ctx = mp.get_context('spawn')
+        self.conn, child = ctx.Pipe()
+        scans = {sc.name: sc for sc in (scans.values() if isinstance(scans, dict) else scans)}
+        spec = {'keys': list(keys), 'scans': scans, 'angle_feat_size': te.sim.angle_feat_size, 'n_steps': te.T, 'text_len': te.L,
+                'pano_width': te.W, 'gmap_widths': [int(te.gw(t)) for t in range(max(te.T, 1))], 'fusion': te.fusion, 'ignoreid': te.ignoreid}
+        self.proc = ctx.Process(target=_plan_worker_main, args=(child, spec), daemon=True)
+        self.proc.start()
+        child.close()
+        self.pending = 0
+        self._q = queue.Queue()
+
+        def drain():
+            while True:
+                try:
+                    self._q.put(self.conn.recv())
+                except (EOFError, OSError):
+                    self._q.put(EOFError('plan worker exited'))
+                    return
+        self._reader = threading.Thread(target=drain, daemon=True)
+        self._reader.start()
+
+    def submit(self, episodes):
+        self.conn.send([dict(e, scan=e['scan'].name if not isinstance(e['scan'], str) else e['scan']) for e in episodes])
+        self.pending += 1
+
+    def result(self, timeout=120.0):
+        plan = self._q.get(timeout=timeout)
+        self.pending -= 1
+        if isinstance(plan, Exception):
+            raise plan
+        return {k: (torch.from_numpy(v[1]) if (isinstance(v, tuple) and len(v) == 2 and isinstance(v[0], str) and v[0] == '__t') else v)
+                for k, v in plan.items()}
+
+    def close(self):
+        try:
+            self.conn.send(None)
+        except (OSError, BrokenPipeError):
+            pass
+        self.proc.join(5)
+        if self.proc.is_alive():
+            self.proc.terminate()
 
 
 def _pad1np(a, n, fill, dtype):

@@ -380,13 +380,10 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
             lang[k] = mv(ep[k])
     if use_facl:
         lang['front_txt_feats'] = mv(ep['front_txt_feats'])
-    txt = model('language', dd(lang))
-    txt_kv = model('text_kv', {'txt_embeds': txt}) if hoist_text_kv else None      # (HIP model only: the instruction's K|V once per episode)
-    B = txt.shape[0]
-    mem = None
-    loss = 0.0
-    rec = {'txt_embeds': txt, 'steps': []}
-    fused_hist = []
+    from . import hipops
+    B = lang['txt_ids'].shape[0]
+    do_hoist = hoist_pano and len({tuple(st['view_img_fts'].shape) for st in ep['steps']}) == 1
+    hoisted = None
     def pano_inputs(sts):
         cat = lambda k: mv(sts[0][k]) if len(sts) == 1 else torch.cat([mv(st[k]) for st in sts], 0)
         pin = {'view_img_fts': cat('view_img_fts'), 'loc_fts': cat('loc_fts'), 'nav_types': cat('nav_types'),
@@ -398,11 +395,19 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
             for k in ('reverie_obj_img_fts', 'reverie_obj_lens', 'reverie_obj_names'):
                 pin[k] = cat(k) if torch.is_tensor(sts[0][k]) else sum((list(st[k]) for st in sts), [])
         return pin
-
-    hoisted = None
-    if hoist_pano and len({tuple(st['view_img_fts'].shape) for st in ep['steps']}) == 1:
-        pa, pm, fu = model('panorama', dd(pano_inputs(ep['steps'])))
+    # the hoisted panorama pass sees the observations only: a parallel branch of the instruction encoder when the episode is captured
+    with hipops.Branch('pano', 'nav_pano') as bp:
+        if do_hoist:
+            pa, pm, fu = model('panorama', dd(pano_inputs(ep['steps'])))
+    txt = model('language', dd(lang))
+    txt_kv = model('text_kv', {'txt_embeds': txt}) if hoist_text_kv else None      # (HIP model only: the instruction's K|V once per episode)
+    if do_hoist:
+        bp.join(pa, pm, fu)
         hoisted = [(pa[i * B:(i + 1) * B], pm[i * B:(i + 1) * B], None if fu is None else fu[i * B:(i + 1) * B]) for i in range(len(ep['steps']))]
+    mem = None
+    loss = 0.0
+    rec = {'txt_embeds': txt, 'steps': []}
+    fused_hist = []
     for t, st in enumerate(ep['steps']):
         has_obj = 'reverie_obj_img_fts' in st
         pano, pmask, fused = hoisted[t] if hoisted is not None else model('panorama', dd(pano_inputs([st])))
