@@ -35,19 +35,20 @@ GOAT_BENCH_NO_PER_TASK=1 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --
 rm -rf $OUT/pmc_mfma
 cd /root/repo
 unset GOAT_BENCH_NO_PER_TASK
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-python scripts/vendor_gemm_compare.py > $OUT/vendor_gemm_compare.txt 2>&1
-python scripts/wgrad_group_bench.py > $OUT/wgrad_grouped.txt 2>&1
-python scripts/gemm_table.py > $OUT/gemm_shape_table.txt 2>&1
-python scripts/attn_kernel_bench.py > $OUT/attention_kernels.txt 2>&1
+timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout 600 python scripts/vendor_gemm_compare.py > $OUT/vendor_gemm_compare.txt 2>&1
+timeout 600 python scripts/wgrad_group_bench.py > $OUT/wgrad_grouped.txt 2>&1
+timeout 600 python scripts/gemm_table.py > $OUT/gemm_shape_table.txt 2>&1
+timeout 600 python scripts/attn_kernel_bench.py > $OUT/attention_kernels.txt 2>&1
 LD_LIBRARY_PATH=vln-goat_amd/csrc timeout 300 scripts/launch_floor.bin > $OUT/gemm_launch_floor.txt 2>&1
-python scripts/aten_sites.py > $OUT/aten_sites.txt 2>&1
-python bench.py --in-graph-comm --no-cpu-baseline --no-extra-configs --no-roofline > $OUT/bench_in_graph_comm.json 2> $OUT/bench_in_graph_comm.err
-python bench.py --workload config4 --no-roofline --steps 20 > $OUT/bench_config4_workload.json 2> $OUT/bench_config4_workload.err
+timeout 600 python scripts/aten_sites.py > $OUT/aten_sites.txt 2>&1
+timeout 600 python bench.py --in-graph-comm --no-cpu-baseline --no-extra-configs --no-roofline > $OUT/bench_in_graph_comm.json 2> $OUT/bench_in_graph_comm.err
+timeout 600 python bench.py --workload config4 --no-roofline --steps 20 > $OUT/bench_config4_workload.json 2> $OUT/bench_config4_workload.err
+rm -f $OUT/rccl_capture_probe.txt
 for n in all_reduce all_to_all_single all_gather_into_tensor reduce_scatter_tensor broadcast; do
   timeout 120 python scripts/rccl_capture_probe.py $n > $OUT/_probe.txt 2>&1; echo "$n: exit code $? $(grep -c CAPTURE_OK $OUT/_probe.txt) capture(s) replayed" >> $OUT/rccl_capture_probe.txt
 done
 rm -f $OUT/_probe.txt
 python scripts/roofline_leg_diff.py $OUT/kernel_stats.txt $OUT/kernel_stats_no_roofline_leg.txt $OUT/bench_line_under_rocprof.json > $OUT/roofline_leg_kernel_durations.txt 2>&1
-python scripts/ln_bench.py > $OUT/ln_bench.txt 2>&1
+timeout 600 python scripts/ln_bench.py > $OUT/ln_bench.txt 2>&1
 ls -la $OUT
