@@ -201,9 +201,31 @@ def prepare_position_features(batch, dtype=None):
         pad = (-t.shape[-1]) % e
         if t.shape[-1] > 16 or (pad == 0 and t.dtype == dt):
             continue
-        t = t.to(dt)
-        out[k] = torch.nn.functional.pad(t, (0, pad)) if pad else t
+        out[k] = _cast_pad_host(t, dt, pad)
     return out
+
+
+def _cast_pad_host(t, dt, pad):
+    """float32 host tensor -> `dt` with `pad` zero columns appended, through numpy: torch's own cast / pad of a few hundred KB wakes the
+    intra-op thread pool of the GPU boxes' 128-256-core hosts (measured on the fresh-batch leg: 6.1 -> 16.9 ms per step with torch ops
+    here).  bfloat16 = round-to-nearest-even of the float32 bits, as torch's .to(torch.bfloat16)."""
+    if t.is_cuda or t.dtype != torch.float32 or dt not in (torch.float32, torch.bfloat16):
+        t = t.to(dt)
+        return torch.nn.functional.pad(t, (0, pad)) if pad else t
+    src = np.ascontiguousarray(t.numpy())
+    shape = src.shape[:-1] + (src.shape[-1] + pad,)
+    if dt == torch.float32:
+        arr = np.zeros(shape, np.float32)
+        arr[..., :src.shape[-1]] = src
+        return torch.from_numpy(arr)
+    u = src.view(np.uint32)
+    nan = np.isnan(src)
+    r = ((u + (np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1)))) >> np.uint32(16)).astype(np.uint16)
+    if nan.any():
+        r[nan] = 0x7FC0
+    arr = np.zeros(shape, np.uint16)
+    arr[..., :src.shape[-1]] = r
+    return torch.from_numpy(arr.view(np.int16)).view(torch.bfloat16)
 
 
 def index_capacities(batch, tasks, mlm_rate=0.25):
