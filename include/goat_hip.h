@@ -296,10 +296,10 @@ int goat_attn_pool_bwd(void* stream, int dtype, const void* x, const float* w, c
 int goat_door_gate_fwd(void* stream, int dtype, const void* aug, const void* ori, const float* wa, const float* wo,
                        const float* ba, const float* bo, void* out, float* gate, int rows, int H);
 /* backward: daug/dori overwritten; dwa/dwo float32 [H] and dbias float32 [1] accumulated (caller zero-fills);
- * dbias is the gradient of BOTH biases.  H <= 1024. */
+ * dbias is the gradient of BOTH biases; dbias2 (may be NULL) receives the same sum — the second bias' own gradient slice.  H <= 1024. */
 int goat_door_gate_bwd(void* stream, int dtype, const void* aug, const void* ori, const float* wa, const float* wo,
                        const float* gate, const void* dout, void* daug, void* dori, float* dwa, float* dwo, float* dbias,
-                       int rows, int H);
+                       int rows, int H, float* dbias2);
 
 /* probability-weighted dictionary sum of BACL type_1: out[b,:] = sum_k p[b,k] z[b,k,:]
  * (P/model/vilmodel_goat.py:115-118; M/models/vilmodel_GOAT.py:246-249).  z float32 [B,K,H], p float32 [B,K];

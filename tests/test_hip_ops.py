@@ -1149,3 +1149,29 @@ def test_linear_with_one_output_column_through_the_rowdot_kernels(ops, dtype, sh
     _close(got[1], x.grad, dtype, 'dx')
     _close(got[2], w.grad, dtype, 'dW')
     _close(got[3], b.grad, dtype, 'db')
+
+
+@pytest.mark.parametrize('N', [64, 60, 37])
+def test_cross_entropy_rows_with_masked_actions_and_ignored_rows(ops, N):
+    """hipops.cross_entropy_rows (the navigation step's action loss): == F.cross_entropy(reduction='none', ignore_index=-100) on logits with
+    -inf entries (masked actions) and ignored rows; gradient included.  Widths that are no multiple of 4 take the torch path."""
+    torch.manual_seed(N)
+    B = 12
+    lg = torch.randn(B, N, device=DEV) * 3
+    lg[:, N - 5:] = float('-inf')
+    lg[3, 1:7] = float('-inf')
+    lg.requires_grad_(True)
+    tg = torch.randint(0, N - 5, (B,), device=DEV)
+    tg[3] = 0
+    tg[5] = -100
+    w = torch.randn(B, device=DEV)
+    got = ops.cross_entropy_rows(lg, tg)
+    (got * w).sum().backward()
+    g_got = lg.grad.clone()
+    lg.grad = None
+    ref = torch.nn.functional.cross_entropy(lg, tg, reduction='none', ignore_index=-100)
+    (ref * w).sum().backward()
+    assert float(got[5]) == 0.0
+    _close(got, ref, torch.float32, 'loss')
+    assert torch.equal(torch.isfinite(g_got), torch.isfinite(lg.grad))
+    _close(torch.nan_to_num(g_got), torch.nan_to_num(lg.grad), torch.float32, 'dlogits')

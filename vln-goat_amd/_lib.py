@@ -57,7 +57,7 @@ SIGNATURES = {
     'goat_attn_pool_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     'goat_attn_pool_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_door_gate_fwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
-    'goat_door_gate_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32],
+    'goat_door_gate_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
     'goat_dict_wsum_fwd': [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_dict_wsum_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_wgrad_grouped': [_vp, _vp, _i32, _i32, _i32],

@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void door_bwd_kernel(const T* __restrict__ aug
                                                        const float* __restrict__ wa, const float* __restrict__ wo,
                                                        const float* __restrict__ gate, const T* __restrict__ dout,
                                                        T* __restrict__ daug, T* __restrict__ dori, float* __restrict__ dwa,
-                                                       float* __restrict__ dwo, float* __restrict__ dbias, int rows, int H) {
+                                                       float* __restrict__ dwo, float* __restrict__ dbias, float* __restrict__ dbias2,
+                                                       int rows, int H) {
   extern __shared__ float sm[];   // [4 waves][2][H]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float pa[DOOR_MAXC], po[DOOR_MAXC], pb = 0.f;
@@ -204,7 +205,10 @@ __global__ __launch_bounds__(256) void door_bwd_kernel(const T* __restrict__ aug
                     sm[(3 * 2 + which) * H + col];
     atomicAdd((which ? dwo : dwa) + col, v);
   }
-  if (lane == 0) atomicAdd(dbias, pb);   // (each wave's rows; lanes hold the same value after wave_sum)
+  if (lane == 0) {                       // (each wave's rows; lanes hold the same value after wave_sum)
+    atomicAdd(dbias, pb);
+    if (dbias2) atomicAdd(dbias2, pb);   // the second gate bias receives the same gradient (its own arena slice)
+  }
 }
 
 // ------------------------------------------------------------------------------------ weighted dictionary sum
@@ -649,7 +653,7 @@ extern "C" int goat_door_gate_fwd(void* stream, int dtype, const void* aug, cons
 
 extern "C" int goat_door_gate_bwd(void* stream, int dtype, const void* aug, const void* ori, const float* wa,
                                   const float* wo, const float* gate, const void* dout, void* daug, void* dori, float* dwa,
-                                  float* dwo, float* dbias, int rows, int H) {
+                                  float* dwo, float* dbias, int rows, int H, float* dbias2) {
   if (!aug || !ori || !wa || !wo || !gate || !dout || !daug || !dori || !dwa || !dwo || !dbias) return GOAT_E_ARG;
   if (rows <= 0 || H <= 0 || H > 64 * DOOR_MAXC) return GOAT_E_SHAPE;
   int blocks = (rows + 3) / 4;
@@ -657,10 +661,10 @@ extern "C" int goat_door_gate_bwd(void* stream, int dtype, const void* aug, cons
   const size_t sm = (size_t)8 * H * sizeof(float);
   if (dtype == GOAT_BF16)
     hipLaunchKernelGGL(door_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), sm, ST(stream), (const bf16_t*)aug, (const bf16_t*)ori,
-                       wa, wo, gate, (const bf16_t*)dout, (bf16_t*)daug, (bf16_t*)dori, dwa, dwo, dbias, rows, H);
+                       wa, wo, gate, (const bf16_t*)dout, (bf16_t*)daug, (bf16_t*)dori, dwa, dwo, dbias, dbias2, rows, H);
   else if (dtype == GOAT_F32)
     hipLaunchKernelGGL(door_bwd_kernel<float>, dim3(blocks), dim3(256), sm, ST(stream), (const float*)aug, (const float*)ori,
-                       wa, wo, gate, (const float*)dout, (float*)daug, (float*)dori, dwa, dwo, dbias, rows, H);
+                       wa, wo, gate, (const float*)dout, (float*)daug, (float*)dori, dwa, dwo, dbias, dbias2, rows, H);
   else
     return GOAT_E_ARG;
   GOAT_LAUNCH_CHECK();

@@ -939,8 +939,9 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, act, out_dtype):
         _need_gpu(x)
         x2 = x.reshape(-1, x.shape[-1])
-        if not x2.is_contiguous():
-            x2 = x2.contiguous()
+        if not x2.is_contiguous() and not (x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0
+                                           and x2.dtype == torch.bfloat16 and x2.shape[1] % 64 == 0):
+            x2 = x2.contiguous()          # (a row-strided view — the [CLS] rows hidden[:, 0] of a pooler — goes to the GEMM as it is: lda = its row stride)
         Kw = weight.shape[1]
         if x2.shape[1] == Kw:
             x2, pad = _pad_k(x2, _epc(x2))
@@ -1492,6 +1493,54 @@ def fanout(x, n):
     return list(_FanoutFn.apply(x, n))
 
 
+def fanout_tree(obj, n):
+    """fanout() over every tensor of a nested list / tuple / dict: -> list of n objects of the same structure (the K|V projections of an
+    instruction, read by every step of a navigation episode: their gradients meet in one launch per tensor instead of T - 1 adds)."""
+    if torch.is_tensor(obj):
+        return fanout(obj, n)
+    if isinstance(obj, dict):
+        parts = {k: fanout_tree(v, n) for k, v in obj.items()}
+        return [{k: parts[k][i] for k in obj} for i in range(n)]
+    if isinstance(obj, (list, tuple)):
+        parts = [fanout_tree(v, n) for v in obj]
+        return [type(obj)(p[i] for p in parts) for i in range(n)]
+    return [obj] * n
+
+
+class _CeRowsFn(torch.autograd.Function):
+    """loss[m] = logsumexp(logits[m, :]) - logits[m, target[m]] (float32; a negative target = ignored row, loss 0): F.cross_entropy(reduction=
+    'none', ignore_index=-100) on the action logits of a navigation step (M/r2r/agent.py:614-616) as one launch per direction
+    (goat_ce_fwd / _bwd) instead of log_softmax + nll_loss and their two backward kernels.  Masked actions carry -inf logits."""
+
+    @staticmethod
+    def forward(ctx, logits, targets):
+        lg = logits.float().contiguous()
+        M, N = lg.shape
+        tg = targets.to(torch.int64).contiguous()
+        loss = torch.empty(M, dtype=torch.float32, device=lg.device)
+        lse = torch.empty(M, dtype=torch.float32, device=lg.device)
+        st = _lib.lib().goat_ce_fwd(_stream(), _ptr(lg), N, M, N, _ptr(tg), _ptr(loss), _ptr(lse))
+        _lib.check(st, 'goat_ce_fwd')
+        ctx.save_for_backward(lg, tg, lse)
+        ctx.in_dtype = logits.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lg, tg, lse = ctx.saved_tensors
+        M, N = lg.shape
+        dl = torch.empty_like(lg)
+        st = _lib.lib().goat_ce_bwd(_stream(), GOAT_F32, _ptr(lg), N, M, N, _ptr(tg), _ptr(lse), _ptr(dloss.float().contiguous()), _ptr(dl), N)
+        _lib.check(st, 'goat_ce_bwd')
+        return (dl if ctx.in_dtype == torch.float32 else dl.to(ctx.in_dtype)), None
+
+
+def cross_entropy_rows(logits, targets):
+    if logits.shape[1] % 4 or not logits.is_cuda:      # (goat_ce_* reads 16-byte pieces of a row: widths that are no multiple of 4 stay with torch)
+        return torch.nn.functional.cross_entropy(logits.float(), targets, reduction='none', ignore_index=-100)
+    return _CeRowsFn.apply(logits, targets)
+
+
 def zero_ranges(tensors):
     """clear up to 16 contiguous tensors (16-byte aligned, sizes multiples of 16 bytes) per launch (goat_zero_ranges)."""
     ts = [t for t in tensors if t.numel()]
@@ -1909,6 +1958,7 @@ class _DoorGateFn(torch.autograd.Function):
         _lib.check(st, 'goat_door_gate_fwd')
         ctx.save_for_backward(a2, o2, wav, wov, gate)
         ctx.shapes = (aug.shape, ori.shape, ori.dtype, wa.shape, wo.shape)
+        ctx.params = (wa, ba, wo, bo)
         return out.view(aug.shape)
 
     @staticmethod
@@ -1919,9 +1969,22 @@ class _DoorGateFn(torch.autograd.Function):
         d2 = dout.reshape(rows, H).to(a2.dtype)
         d2 = d2 if d2.is_contiguous() else d2.contiguous()
         daug, dori = torch.empty_like(a2), torch.empty_like(a2)
+        sinks = [_sink(p_) for p_ in ctx.params]
+        if all(t is not None for t in sinks):
+            # gradient arena: the four gate parameters are small (cleared by GradArena.zero at the start of the step, never a first touch) —
+            # the kernel's atomics add straight into their slices; a gate used in every step of an episode would otherwise cost a zero fill,
+            # a clone and four AccumulateGrad adds per use
+            for p_ in ctx.params:
+                if _first_touch(p_):
+                    _sink(p_).zero_()
+            st = _lib.lib().goat_door_gate_bwd(_stream(), _dt(a2), _ptr(a2), _ptr(o2), _ptr(wav), _ptr(wov), _ptr(gate), _ptr(d2),
+                                               _ptr(daug), _ptr(dori), _ptr(sinks[0]), _ptr(sinks[2]), _ptr(sinks[1]), rows, H, _ptr(sinks[3]))
+            _lib.check(st, 'goat_door_gate_bwd')
+            return daug.view(ashape), dori.view(oshape).to(odtype), None, None, None, None
+        _prep_fallback(*ctx.params)
         buf = torch.zeros(2 * H + 1, dtype=torch.float32, device=a2.device)
         st = _lib.lib().goat_door_gate_bwd(_stream(), _dt(a2), _ptr(a2), _ptr(o2), _ptr(wav), _ptr(wov), _ptr(gate), _ptr(d2),
-                                           _ptr(daug), _ptr(dori), _ptr(buf), _ptr(buf, H), _ptr(buf, 2 * H), rows, H)
+                                           _ptr(daug), _ptr(dori), _ptr(buf), _ptr(buf, H), _ptr(buf, 2 * H), rows, H, None)
         _lib.check(st, 'goat_door_gate_bwd')
         db = buf[2 * H:]          # both biases receive the same gradient (distinct tensors: autograd may keep them as .grad)
         return daug.view(ashape), dori.view(oshape).to(odtype), buf[:H].view(washape), db, buf[H:2 * H].view(woshape), db.clone()

@@ -310,7 +310,8 @@ class CrossmodalEncoder(nn.Module):
 
     def project_kv(self, kv_embeds):
         """the K|V projections of every layer's cross-attention for one attended sequence (see BertSelfAttention.project_kv)."""
-        return [layer.crossattention.self.project_kv(kv_embeds) for layer in self.crossattention]
+        kvs = hipops.fanout(kv_embeds, len(self.crossattention))
+        return [layer.crossattention.self.project_kv(kv) for layer, kv in zip(self.crossattention, kvs)]
 
     def forward(self, q_embeds, q_kmask, kv_embeds, kv_kmask, bias=None, kv_cache=None):
         """q_kmask / kv_kmask: additive float32 [B,L] key masks (already -10000-style).  kv_cache: project_kv(kv_embeds)."""
@@ -333,7 +334,7 @@ class BertPooler(nn.Module):
         self.activation = nn.Tanh()
 
     def forward(self, hidden, location=0):
-        return torch.tanh(self.dense(hidden[:, location].contiguous()))
+        return torch.tanh(self.dense(hidden[:, location]))          # (the row-strided [CLS] view goes to the GEMM as it is: hipops.linear)
 
 
 class BertPredictionHeadTransform(nn.Module):

@@ -397,7 +397,8 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
     def text_kv(self, txt_embeds):
         """per-episode K|V projections of the instruction for the cross-modal layers of the global and the local branch."""
         t = txt_embeds.to(compute_dtype())
-        return {'global': self.global_encoder.encoder.project_kv(t), 'local': self.local_encoder.encoder.project_kv(t)}
+        tg, tl = hipops.fanout(t, 2)
+        return {'global': self.global_encoder.encoder.project_kv(tg), 'local': self.local_encoder.encoder.project_kv(tl)}
 
     # ---- CFP feature extraction (builds the FACL dictionaries) -------------------------------------------------
     def extract_cfp_features(self, batch):

@@ -919,13 +919,22 @@ class TeacherEpisode:
         with hipops.Branch('pano', 'nav_pano') as bp:
             whole = panoramas('all_', self.T * B) if hoist_pano else None
         txt = model('language', dd(lang))
-        txt_kv = model('text_kv', {'txt_embeds': txt}) if hoist_text_kv else None
+        # (one autograd handle per step on the instruction states and their hoisted K|V projections: hipops.fanout)
+        txt_h = hipops.fanout(txt, self.T + 1)
+        txt_kv = model('text_kv', {'txt_embeds': txt_h[self.T]}) if hoist_text_kv else None
+        kv_h = hipops.fanout_tree(txt_kv, self.T) if txt_kv is not None else [None] * self.T
         if whole is not None:
             bp.join(*whole)
+            # (unbind: ONE backward node stacks the per-step gradients — not T zero-filled slice_backward tensors and T - 1 adds)
+            whole_s = [None if x is None else x.view(self.T, B, *x.shape[1:]).unbind(0) for x in whole]
+        nav_extras = dict(extras.get('navigation', {}))
+        for name in ('front_vp_feats', 'front_gmap_feats', 'front_txt_feats'):      # constant over the episode: cast once, not per step
+            if torch.is_tensor(nav_extras.get(name)) and nav_extras[name].is_floating_point():
+                nav_extras[name] = nav_extras[name].to(txt.dtype)
         for s in range(self.T):
             k = 's%d_' % s
             if whole is not None:
-                pano, pmask, fused = (None if x is None else x[s * B:(s + 1) * B] for x in whole)
+                pano, pmask, fused = (None if x is None else x[s] for x in whole_s)
             else:
                 pano, pmask, fused = panoramas(k, B)
             if fused is None:
@@ -938,17 +947,20 @@ class TeacherEpisode:
                                          (t_[k + 'inv_idx'], t_[k + 'inv_start'], t_[k + 'inv_w'])).view(B, G, H)
             zero = pano.new_zeros(B, 1, H)
             memtok = zero if last is None else last.unsqueeze(1).to(pano.dtype)
-            nin = {'txt_embeds': txt, 'txt_masks': t_['txt_masks'], 'gmap_img_embeds': gimg,
-                   'vp_img_embeds': torch.cat([zero, memtok, pano], 1), 'vp_obj_masks': None, 'flops_count': False, 'txt_kv': txt_kv,
+            nin = {'txt_embeds': txt_h[s], 'txt_masks': t_['txt_masks'], 'gmap_img_embeds': gimg,
+                   'vp_img_embeds': torch.cat([zero, memtok, pano], 1), 'vp_obj_masks': None, 'flops_count': False, 'txt_kv': kv_h[s],
                    'nav_fusion': t_[k + 'nav_fusion']}
             for name in ('gmap_step_ids', 'gmap_pos_fts', 'gmap_pair_dists', 'gmap_visited_masks', 'gmap_masks', 'vp_pos_fts', 'vp_masks',
                          'vp_nav_masks'):
                 nin[name] = t_[k + name]
-            nin.update(extras.get('navigation', {}))
+            nin.update(nav_extras)
             out = model('navigation', dd(nin))
             last = out['cls_embeds']
             logits = {'local': out['local_logits'], 'global': out['global_logits']}.get(self.fusion, out['fused_logits'])
-            loss = loss + torch.nn.functional.cross_entropy(logits.float(), t_[k + 'target'], reduction='sum', ignore_index=self.ignoreid)
+            if self.ignoreid < 0:
+                loss = loss + hipops.cross_entropy_rows(logits, t_[k + 'target']).sum()
+            else:
+                loss = loss + torch.nn.functional.cross_entropy(logits.float(), t_[k + 'target'], reduction='sum', ignore_index=self.ignoreid)
         return loss / B
 
 

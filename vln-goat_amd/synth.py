@@ -400,13 +400,27 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
         if do_hoist:
             pa, pm, fu = model('panorama', dd(pano_inputs(ep['steps'])))
     txt = model('language', dd(lang))
-    txt_kv = model('text_kv', {'txt_embeds': txt}) if hoist_text_kv else None      # (HIP model only: the instruction's K|V once per episode)
+    T_ = len(ep['steps'])
+    on_gpu = torch.is_tensor(txt) and txt.is_cuda
+    # the instruction states (and their hoisted K|V projections) are read by every step: one autograd handle per step, so that the T
+    # gradients of each tensor meet in ONE launch (hipops.fanout) instead of T - 1 engine adds of [B, L, 768] / [B, L, 1536] tensors
+    txt_h = hipops.fanout(txt, T_ + 1) if on_gpu else [txt] * (T_ + 1)
+    txt_kv = model('text_kv', {'txt_embeds': txt_h[T_]}) if hoist_text_kv else None      # (HIP model only: the instruction's K|V once per episode)
+    kv_h = hipops.fanout_tree(txt_kv, T_) if (txt_kv is not None and on_gpu) else [txt_kv] * T_
     if do_hoist:
         bp.join(pa, pm, fu)
-        hoisted = [(pa[i * B:(i + 1) * B], pm[i * B:(i + 1) * B], None if fu is None else fu[i * B:(i + 1) * B]) for i in range(len(ep['steps']))]
+        # (unbind, not T slices: ONE backward node stacks the per-step gradients instead of T zero-filled slice_backward tensors + T - 1 adds)
+        pa_s, pm_s = pa.view(T_, B, *pa.shape[1:]).unbind(0), pm.view(T_, B, *pm.shape[1:]).unbind(0)
+        fu_s = [None] * T_ if fu is None else fu.view(T_, B, *fu.shape[1:]).unbind(0)
+        hoisted = [(pa_s[i], pm_s[i], fu_s[i]) for i in range(T_)]
     mem = None
     loss = 0.0
     rec = {'txt_embeds': txt, 'steps': []}
+    if use_facl and on_gpu:      # the FACL dictionaries are constant over the episode: cast to the compute dtype once, not in every step
+        from . import layers
+        front_vp, front_gmap = mv(ep['front_vp_feats']).to(layers.compute_dtype()), mv(ep['front_gmap_feats']).to(layers.compute_dtype())
+    elif use_facl:
+        front_vp, front_gmap = mv(ep['front_vp_feats']), mv(ep['front_gmap_feats'])
     fused_hist = []
     for t, st in enumerate(ep['steps']):
         has_obj = 'reverie_obj_img_fts' in st
@@ -421,7 +435,7 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
         gimg = torch.cat(parts, 1)
         gimg = gimg[:, :G] if gimg.shape[1] >= G else torch.cat([gimg, pano.new_zeros(B, G - gimg.shape[1], H)], 1)
         vimg = torch.cat([zero, memtok, pano], 1)
-        nin = {'txt_embeds': txt, 'txt_masks': mv(ep['txt_masks']), 'gmap_img_embeds': gimg,
+        nin = {'txt_embeds': txt_h[t], 'txt_masks': mv(ep['txt_masks']), 'gmap_img_embeds': gimg,
                'gmap_step_ids': mv(st['gmap_step_ids']), 'gmap_pos_fts': mv(st['gmap_pos_fts']), 'gmap_masks': mv(st['gmap_masks']),
                'gmap_pair_dists': mv(st['gmap_pair_dists']), 'gmap_visited_masks': mv(st['gmap_visited_masks']),
                'gmap_vpids': st['gmap_vpids'], 'vp_img_embeds': vimg, 'vp_pos_fts': mv(st['vp_pos_fts']),
@@ -429,13 +443,16 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
                'vp_obj_masks': mv(st['vp_obj_masks']) if has_obj else None,
                'vp_cand_vpids': st['vp_cand_vpids'], 'flops_count': False, 'nav_fusion': st.get('nav_fusion')}
         if txt_kv is not None:
-            nin['txt_kv'] = txt_kv
+            nin['txt_kv'] = kv_h[t]
         if use_facl:
-            nin['front_vp_feats'], nin['front_gmap_feats'] = mv(ep['front_vp_feats']), mv(ep['front_gmap_feats'])
+            nin['front_vp_feats'], nin['front_gmap_feats'] = front_vp, front_gmap
         out = model('navigation', dd(nin))
         mem = out['cls_embeds']
         logits = out['fused_logits'].float() if to_float else out['fused_logits']
-        loss = loss + torch.nn.functional.cross_entropy(logits, mv(st['target']), reduction='sum', ignore_index=-100)
+        if logits.is_cuda:      # (one launch per direction; targets of -100 are ignored rows)
+            loss = loss + hipops.cross_entropy_rows(logits, mv(st['target'])).sum()
+        else:
+            loss = loss + torch.nn.functional.cross_entropy(logits, mv(st['target']), reduction='sum', ignore_index=-100)
         if has_obj and t + 1 == len(ep['steps']):        # object grounding at the stop step (M/reverie/agent_obj.py)
             ol = out['obj_logits'].float() if to_float else out['obj_logits']
             loss = loss + torch.nn.functional.cross_entropy(ol, mv(st['obj_target']), reduction='sum', ignore_index=-100)
