@@ -353,8 +353,9 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
         txt_km = neg_mask(txt_masks)
         B, G = gmap_step_ids.shape
         ge = self.global_encoder
-        pos = ge.gmap_pos_embeddings[1](ge.gmap_pos_embeddings[0](gmap_pos_fts.to(dt)))
-        gmap = gmap_img_embeds.to(dt) + hipops.embedding(gmap_step_ids, ge.gmap_step_embeddings.weight, out_dtype=dt) + pos
+        # (image embedding + step embedding) + LayerNorm(Linear(position features)): the second sum rides in the LayerNorm launch (post_add)
+        ie = gmap_img_embeds.to(dt) + hipops.embedding(gmap_step_ids, ge.gmap_step_embeddings.weight, out_dtype=dt)
+        gmap = ge.gmap_pos_embeddings[1](ge.gmap_pos_embeddings[0](gmap_pos_fts.to(dt)), post_add=ie)
         bias = None
         if ge.sprel_linear is not None:
             bias = gmap_pair_dists.float() * ge.sprel_linear.weight.view(()) + ge.sprel_linear.bias.view(())
@@ -365,20 +366,27 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
             if front_gmap_feats is not None:
                 gmap = self.front_global_encoder(gmap, front_gmap_feats, gmap_masks)
             gmap = ge.encoder(gmap, neg_mask(gmap_masks), txt_embeds, txt_km, bias, kv_cache=None if txt_kv is None else txt_kv['global'])
-            g_scores = self.global_sap_head(gmap).squeeze(2)
-            g_pool = self.gmap_pooler(gmap)
+            # the encoder output feeds the action head and — through its [CLS] row — the pooler and the fusion logit: two autograd handles
+            # (their gradients meet in one launch), the [CLS] row selected once for both of its readers
+            gmap_h, gmap_c = hipops.fanout(gmap, 2)
+            g_cls = gmap_c[:, 0]
+            g_scores = self.global_sap_head(gmap_h).squeeze(2)
+            g_pool = torch.tanh(self.gmap_pooler.dense(g_cls))
 
         le = self.local_encoder
-        vp = vp_img_embeds.to(dt) + le.vp_pos_embeddings[1](le.vp_pos_embeddings[0](vp_pos_fts.to(dt)))
+        vp = le.vp_pos_embeddings[1](le.vp_pos_embeddings[0](vp_pos_fts.to(dt)), post_add=vp_img_embeds.to(dt))
         if front_vp_feats is not None:
             vp = self.front_local_encoder(vp, front_vp_feats, vp_masks)
         vp = le.encoder(vp, neg_mask(vp_masks), txt_embeds, txt_km, kv_cache=None if txt_kv is None else txt_kv['local'])
 
         # scores of the two heads -> masked global / local / fused logits in one launch per direction (hipops.sap_fuse; the
         # reference's chain: M/models/vilmodel_GOAT.py:803-839).  The stop column of the fused logits takes the local stop logit.
-        l_scores = self.local_sap_head(vp).squeeze(2)
-        bg.join(gmap, g_scores, g_pool)
-        fwl = None if self.sap_fuse_linear is None else self.sap_fuse_linear(torch.cat([gmap[:, 0], vp[:, 0]], 1))
+        n_vp = 3 if (vp_obj_masks is not None and getattr(self.config, 'dataset', 'r2r') in ('reverie', 'soon')) else 2
+        vp_hs = hipops.fanout(vp, n_vp)
+        v_cls = vp_hs[1][:, 0]
+        l_scores = self.local_sap_head(vp_hs[0]).squeeze(2)
+        bg.join(gmap, g_scores, g_pool, g_cls)
+        fwl = None if self.sap_fuse_linear is None else self.sap_fuse_linear(torch.cat([g_cls, v_cls], 1))
         M = None
         if not flops_count:
             M = nav_fusion if nav_fusion is not None else \
@@ -388,8 +396,8 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
                                            add_stop=True)
         obj_logits = None
         if vp_obj_masks is not None and getattr(self.config, 'dataset', 'r2r') in ('reverie', 'soon'):
-            obj_logits = torch.where(vp_obj_masks, self.og_head(vp).squeeze(2).float(), -float('inf'))      # (no clone: see pretrain_model.forward_og)
-        cls = torch.cat((g_pool, self.vp_pooler(vp), self.txt_pooler(txt_embeds)), dim=-1)
+            obj_logits = torch.where(vp_obj_masks, self.og_head(vp_hs[2]).squeeze(2).float(), -float('inf'))      # (no clone: see pretrain_model.forward_og)
+        cls = torch.cat((g_pool, torch.tanh(self.vp_pooler.dense(v_cls)), self.txt_pooler(txt_embeds)), dim=-1)
         cls_embeds = self.local_his_ln(self.local_his_map(cls))
         return {'gmap_embeds': gmap, 'vp_embeds': vp, 'global_logits': gl, 'local_logits': ll, 'fused_logits': fused,
                 'obj_logits': obj_logits, 'txt_embeds': txt_embeds, 'cls_embeds': cls_embeds}

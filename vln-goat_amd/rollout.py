@@ -905,7 +905,7 @@ class TeacherEpisode:
         B = t_['txt_ids'].shape[0]
         lang = {'txt_ids': t_['txt_ids'], 'txt_masks': t_['txt_masks']}
         lang.update(extras.get('language', {}))
-        pool, last, loss = [], None, 0.0
+        pool, last, loss, ce_rows = [], None, 0.0, []
 
         def panoramas(k, n):
             fts = hipops.gather_segmean(self.features.dev, t_[k + 'feat_idx'], t_[k + 'feat_start'], None, n * self.W, None)
@@ -958,9 +958,11 @@ class TeacherEpisode:
             last = out['cls_embeds']
             logits = {'local': out['local_logits'], 'global': out['global_logits']}.get(self.fusion, out['fused_logits'])
             if self.ignoreid < 0:
-                loss = loss + hipops.cross_entropy_rows(logits, t_[k + 'target']).sum()
+                ce_rows.append(hipops.cross_entropy_rows(logits, t_[k + 'target']))          # (summed once behind the loop)
             else:
                 loss = loss + torch.nn.functional.cross_entropy(logits.float(), t_[k + 'target'], reduction='sum', ignore_index=self.ignoreid)
+        if ce_rows:
+            loss = loss + torch.stack(ce_rows, 0).sum()
         return loss / B
 
 

@@ -415,6 +415,7 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
         hoisted = [(pa_s[i], pm_s[i], fu_s[i]) for i in range(T_)]
     mem = None
     loss = 0.0
+    ce_rows = []
     rec = {'txt_embeds': txt, 'steps': []}
     if use_facl and on_gpu:      # the FACL dictionaries are constant over the episode: cast to the compute dtype once, not in every step
         from . import layers
@@ -449,14 +450,16 @@ def run_nav_episode(model, ep, device='cpu', use_bacl=True, use_facl=True, to_fl
         out = model('navigation', dd(nin))
         mem = out['cls_embeds']
         logits = out['fused_logits'].float() if to_float else out['fused_logits']
-        if logits.is_cuda:      # (one launch per direction; targets of -100 are ignored rows)
-            loss = loss + hipops.cross_entropy_rows(logits, mv(st['target'])).sum()
+        if logits.is_cuda:      # (one launch per direction; targets of -100 are ignored rows; the T loss vectors are summed once, below)
+            ce_rows.append(hipops.cross_entropy_rows(logits, mv(st['target'])))
         else:
             loss = loss + torch.nn.functional.cross_entropy(logits, mv(st['target']), reduction='sum', ignore_index=-100)
         if has_obj and t + 1 == len(ep['steps']):        # object grounding at the stop step (M/reverie/agent_obj.py)
             ol = out['obj_logits'].float() if to_float else out['obj_logits']
             loss = loss + torch.nn.functional.cross_entropy(ol, mv(st['obj_target']), reduction='sum', ignore_index=-100)
         rec['steps'].append({'pano_embeds': pano, 'pano_fused': fused, **out})
+    if ce_rows:
+        loss = loss + torch.stack(ce_rows, 0).sum()
     return loss, rec
 
 
