@@ -73,7 +73,7 @@ def _check_grads_f32(model, ref_grads, gmax):
         d = float((p.grad.double().cpu() - rg.double()).norm())
         num += d
         den += float(rg.double().norm())
-        if d / float(rg.double().norm()) > 1e-3:
+        if d > 1e-3 * float(rg.double().norm()) + 3e-7:          # (+ 3e-7: see the zero-sum biases in test_full_size_matches_reference_golden)
             bad.append((n, d / float(rg.double().norm())))
     assert not bad, bad[:10]
     assert num / den < 1e-4, num / den
@@ -327,7 +327,9 @@ def test_full_size_matches_reference_golden(case, task, dtype):
             assert gotp[0] <= (1e-4 if dtype == torch.float32 else 5e-3) * gmax, n
             continue
         if dtype == torch.float32:
-            if np.abs(gotp - refp).max() / refp[0] > rtol:
+            # (+ 3e-7: the bias of a Linear(H, 1) in front of a softmax cross-entropy receives sum(p - onehot) = 0 — O(1) terms that cancel to
+            #  float32 rounding noise; goat_rowdot_bwd adds its block partials atomically, so that noise has a run-dependent order)
+            if np.abs(gotp - refp).max() > rtol * refp[0] + 3e-7:
                 bad.append((n, gotp[0], refp[0]))
         else:
             # bf16: the norm of every gradient tensor (rounding noise moves a norm only to second order; a mis-scaled or
