@@ -92,7 +92,7 @@ def test_nav_episode_matches_reference_golden(case, dtype):
             if ref[0] <= 1e-6 * gmax:
                 assert got[0] <= 1e-4 * gmax, n
                 continue
-            assert np.abs(got - ref).max() / ref[0] < 2e-3, (n, got, ref)
+            assert np.abs(got - ref).max() < 2e-3 * ref[0] + 3e-7, (n, got, ref)      # (+ 3e-7: zero-sum head biases, see test_model_parity_gpu)
         for k in ('front_txt_feats', 'front_gmap_feats', 'z_img_features', 'instr_z_direction_features'):
             ref = gold['dinput_' + k]
             got = fingerprint(ep[k].grad)
