@@ -266,10 +266,13 @@ class FrontDoorEncoder(nn.Module):
 
     def forward(self, local_feats, global_feats, local_masks=None):
         km = neg_mask(local_masks) if local_masks is not None else None
-        ll = self.ll_self_attn(local_feats, km)
-        lg = self.lg_cross_attn(local_feats, None, global_feats.to(local_feats.dtype), None)
+        # the tokens are read five times (projection + residual of either attention block, the gate's pass-through input): one autograd
+        # handle each, their gradients meet in one launch (hipops.fanout)
+        h = hipops.fanout(local_feats, 5)
+        ll = self.ll_self_attn((h[0], h[1]), km)
+        lg = self.lg_cross_attn((h[2], h[3]), None, global_feats.to(local_feats.dtype), None)
         out = self.ln(ll, residual=lg)
-        return _door(self.aug_linear, self.ori_linear, out, local_feats)
+        return _door(self.aug_linear, self.ori_linear, out, h[4])
 
 
 class GlocalTextPathNavCMT(GoatPreTrainedModel):
