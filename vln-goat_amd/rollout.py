@@ -1046,7 +1046,14 @@ class PlanWorker:
         self.pending += 1
 
     def result(self, timeout=120.0):
-        plan = self._q.get(timeout=timeout)
+        import queue
+        if self.pending <= 0:
+            raise RuntimeError('PlanWorker.result() without a submitted batch of episodes')
+        try:
+            plan = self._q.get(timeout=timeout)
+        except queue.Empty:
+            raise TimeoutError('plan worker (pid %s, %s) returned no plan within %.0f s'
+                               % (self.proc.pid, 'alive' if self.proc.is_alive() else 'exited', timeout)) from None
         self.pending -= 1
         if isinstance(plan, Exception):
             raise plan
@@ -1054,6 +1061,9 @@ class PlanWorker:
                 for k, v in plan.items()}
 
     def close(self):
+        """stop the worker (idempotent); plans not yet fetched are dropped."""
+        if self.proc is None:
+            return
         try:
             self.conn.send(None)
         except (OSError, BrokenPipeError):
@@ -1061,6 +1071,16 @@ class PlanWorker:
         self.proc.join(5)
         if self.proc.is_alive():
             self.proc.terminate()
+            self.proc.join(5)
+        self.conn.close()
+        self.proc = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
 
 def _pad1np(a, n, fill, dtype):
