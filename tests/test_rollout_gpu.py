@@ -247,3 +247,63 @@ def test_teacher_episode_graph_replays_new_episodes():
             assert n > 100
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+def test_two_pass_sampled_rollout_matches_the_single_pass():
+    """The sampled half of the dagger iteration in two passes: (1) NavRollout(feedback='sample') under no_grad and without a loss fixes the
+    trajectory and records its actions; (2) TeacherEpisode.plan(actions=) re-walks them on the host and ONE pass of the shape-stable
+    episode body (the code the captured episode graph replays) gives the loss and the gradients.  The fixed action sequence, the
+    trajectories and the DAgger labels are those of the imported reference's sampled rollout (tests/golden/rollout_episode_sample.npz);
+    loss and every gradient equal the single-pass eager rollout — itself pinned to that fixture by the test above — run at the same
+    panorama width (float32, dropout off).  The width matters: the reference's adaptive panorama fusion is a softmax over ALL slots of
+    the padded panorama (M/models/vilmodel_GOAT.py:728-735, no mask), so its result depends on the width the batch was padded to; the
+    fixture holds the reference's per-step batch maxima, the episode body one fixed width."""
+    import json
+    from vln_goat_amd import rollout, synth
+    z = np.load(os.path.join(HERE, 'golden', 'rollout_episode_sample.npz'))
+    ids = json.load(open(os.path.join(HERE, 'golden', 'rollout_episode_sample.json')))
+    scan, feats, eps, dicts = synth.make_rollout_case()
+    model = _model()
+    store = _store(scan, feats, torch.float32)
+    sim = rollout.GraphSim(store)
+    call = lambda mode, batch: model(mode, batch)
+    ex = synth.rollout_extras(dicts, len(eps), 'cuda')
+    T = int(z['n_steps'][0])
+    fixed = lambda t, probs: z['s%d_action' % t]
+    params = [p for p in model.parameters()]
+    names = {id(p): n for n, p in model.named_parameters()}
+    # the single pass (eager autograd through the rollout loop) at panorama width 40
+    ro = rollout.NavRollout(call, sim, store, max_action_len=T, pano_width=40)
+    ref_loss, ref_traj = ro.run(eps, feedback='sample', extras=ex, sampler=fixed)
+    ref_loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(ref_loss.detach()) - float(z['loss'][0])) <= 1e-3 * float(z['loss'][0])        # (width 40 against the batch maxima)
+    ref = {id(p): (None if p.grad is None else p.grad.detach().clone()) for p in params}
+    for p in params:
+        p.grad = None
+    # pass 1: no autograd graph, no loss
+    with torch.no_grad():
+        none, traj = ro.run(eps, feedback='sample', extras=ex, compute_loss=False, sampler=fixed)
+    assert none is None and ro.steps == T and len(ro.actions) == T
+    assert [tr['path'] for tr in traj] == ids['traj'] == [tr['path'] for tr in ref_traj]
+    # pass 2: host plan along the recorded actions + the episode body
+    te = rollout.TeacherEpisode(sim, store, n_steps=T, text_len=32, pano_width=40)
+    plan = te.plan(eps, actions=ro.actions)
+    for t in range(T):
+        assert np.array_equal(plan['s%d_target' % t].numpy(), z['s%d_target' % t]), t
+    bufs = rollout.EpisodeBuffers(plan)
+    loss = te.body(call, bufs, ex)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-5 * float(ref_loss.detach()), (float(loss), float(ref_loss))
+    top = max(float(g.abs().max()) for g in ref.values() if g is not None)
+    n = 0
+    for p in params:
+        a, b = p.grad, ref[id(p)]
+        assert (a is None) == (b is None), names[id(p)]
+        if b is None:
+            continue
+        scale = max(float(b.abs().max()), 1e-3 * top)
+        assert float((a - b).abs().max()) <= 5e-4 * scale, (names[id(p)], float((a - b).abs().max()), scale)
+        n += 1
+    assert n > 100

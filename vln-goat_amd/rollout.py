@@ -670,6 +670,7 @@ class NavRollout:
         last_embeds = None
         ml_loss = 0.0
         steps = 0
+        self.actions = []           # the action index of every sample at every step taken (TeacherEpisode.plan(actions=) re-walks them)
         for t in range(self.max_action_len):
             t_host = time.perf_counter()
             pano = self.build_step(obs, gmaps, t, ended, feedback == 'teacher')
@@ -736,6 +737,7 @@ class NavRollout:
             else:
                 raise ValueError('invalid feedback option %r' % (feedback,))
             t_host = time.perf_counter()
+            self.actions.append(np.where(ended, 0, np.asarray(a_t, np.int64)))
             moves = []
             for i in range(B):
                 forced = bool(stop[i] or ended[i] or gin['no_vp_left'][i] or t == self.max_action_len - 1)
@@ -794,8 +796,20 @@ class TeacherEpisode:
         self.fusion, self.ignoreid = fusion, ignoreid
 
     # ---- host ---------------------------------------------------------------------------------------------------------------
-    def plan(self, episodes):
+    def plan(self, episodes, actions=None):
+        """host tables of all T steps.  actions=None: the teacher-forced walk along the ground-truth paths (imitation labels).
+        actions = [steps, B] action indices into the step's map nodes (0 = [stop]), e.g. NavRollout.actions of a sampled rollout run
+        under no_grad: the walk follows THEM — the policy's own path — and the targets are the DAgger labels of the states it visits
+        (`teacher_action(imitation_learning=False)`: M/r2r/agent.py:325-347), the episode ends as the sampled rollout does
+        (:601-607,657-663: at the goal, on a sampled [stop], with no node left, at the last step).  One replay of the captured body then
+        gives the loss and the gradients of the sampled half of the dagger iteration (:436-437) without an eager autograd pass."""
         from . import graphmap, nav_model
+        if actions is not None:
+            actions = [np.asarray(a, np.int64) for a in actions]
+            if len(actions) > self.T:
+                raise ValueError('%d recorded steps exceed the episode bucket T = %d' % (len(actions), self.T))
+            if any(a.shape != (len(episodes),) for a in actions):
+                raise ValueError('actions must hold one index per episode and step')
         afs = self.sim.angle_feat_size
         obs = self.sim.reset(episodes)
         B = len(obs)
@@ -829,7 +843,7 @@ class TeacherEpisode:
             G = self.gw(t)
             gin = gmap_inputs(obs, gmaps, G, afs)
             vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], self.W + 2, afs)
-            target = teacher_action(obs, gin['gmap_vpids'], ended, gin['gmap_visited_masks'].numpy(), True, t, self.ignoreid)
+            target = teacher_action(obs, gin['gmap_vpids'], ended, gin['gmap_visited_masks'].numpy(), actions is None, t, self.ignoreid)
             k = 's%d_' % t
             # feature gather of the panorama tokens: compact CSR (padding slots = empty segments)
             rows = pano['view_rows'].reshape(-1).numpy()
@@ -857,14 +871,23 @@ class TeacherEpisode:
             out[k + 'inv_idx'] = _pad1np(inv[0].numpy()[:n_tok], n_src, -1, np.int32)
             out[k + 'inv_start'] = inv[1]
             out[k + 'inv_w'] = _pad1np(inv[2].numpy()[:n_tok], n_src, 0.0, np.float32)
-            # the teacher-forced move
+            # the move: the teacher's, or the recorded one
             moves = []
             for i in range(B):
                 stop = obs[i]['viewpoint'] == obs[i]['gt_path'][-1]
                 if stop or ended[i] or gin['no_vp_left'][i] or t == self.T - 1:
                     moves.append(None)
+                    continue
+                if actions is None:
+                    a = int(target[i])
                 else:
-                    nxt = gin['gmap_vpids'][i][int(target[i])]
+                    a = int(actions[t][i]) if t < len(actions) else 0
+                    if not 0 <= a < len(gin['gmap_vpids'][i]) or (a > 0 and bool(gin['gmap_visited_masks'][i, a])):
+                        raise ValueError('step %d, episode %d: recorded action %d is not a navigable node of the map' % (t, i, a))
+                nxt = gin['gmap_vpids'][i][a]
+                if nxt is None:             # a recorded [stop] (node 0): the episode ends here (M/r2r/agent.py:661)
+                    moves.append(None)
+                else:
                     hop = gmaps[i].graph.path(obs[i]['viewpoint'], nxt)
                     traj[i]['path'].append(hop)
                     prev = traj[i]['path'][-2][-1] if len(hop) == 1 else hop[-2]
