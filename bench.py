@@ -1121,11 +1121,76 @@ def dagger_iteration(model, te, bufs, batches, extras, arena, sim, store, B, T, 
         g.replay()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t_all) / n
+    two = None
+    if not os.environ.get('GOAT_BENCH_NO_TWO_PASS'):
+        try:
+            two = two_pass_iteration(call, te, bufs, g, batches, extras, arena, sim, store, ro, max_action_len)
+        except Exception as e:      # noqa: BLE001
+            two = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     return {'ms_per_iteration': round(dt * 1e3, 2), 'sample_rollout_ms': round(sum(t_s) / n * 1e3, 2), 'sample_steps': round(sum(steps) / n, 1),
             'sample_host_builder_ms': round(sum(host) / n * 1e3, 2), 'teacher_part_ms': round((dt - sum(t_s) / n) * 1e3, 2),
-            'ml_weight': ml_weight, 'max_action_len': max_action_len,
+            'ml_weight': ml_weight, 'max_action_len': max_action_len, 'two_pass': two,
             'what': 'teacher rollout (captured graph incl. its host plan, loss x %.1f, accumulate form) + sampled rollout (eager, one read-back per step) '
                     '+ their backward passes into one gradient arena: the reference iteration of train_alg=dagger' % ml_weight}
+
+
+def two_pass_iteration(call, te, bufs, g_teacher, batches, extras, arena, sim, store, ro, max_action_len):
+    """The same iteration with the sampled half in TWO passes: (1) the sampled rollout under no_grad, no loss — it only fixes
+    the trajectory (rollout.NavRollout.actions; eager, one read-back per step); (2) TeacherEpisode.plan(actions=) re-walks it on the host
+    with the DAgger labels and the episode graph captured at T = max_action_len replays forward + backward (dropout masks drawn anew);
+    then the teacher graph in accumulate form as before.  The T = 15 graph runs the tuned GEMM configurations where the table has the
+    shape and the heuristic ones elsewhere (the 15-step panorama batch): tuning them on first sight would add minutes to this leg."""
+    from vln_goat_amd import hipops, rollout
+    te_s = rollout.TeacherEpisode(sim, store, n_steps=max_action_len, text_len=te.L, pano_width=38, gmap_width=lambda t: 64)
+
+    def pass1(i):
+        hipops.RngState.dev.add_(0x9E3779B1)
+        with torch.no_grad():
+            ro.run(batches[i % len(batches)], feedback='sample', extras=extras, compute_loss=False)
+        return ro.actions
+
+    bufs_s = rollout.EpisodeBuffers(te_s.plan(batches[0], actions=pass1(0)))
+
+    def sampled_body():
+        arena.zero('nav')
+        hipops.RngState.dev.add_(0x9E3779B1)
+        te_s.body(call, bufs_s, extras).backward()
+    auto, hipops.AUTOTUNE = hipops.AUTOTUNE, False
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                sampled_body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g_s = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_s):
+            sampled_body()
+        torch.cuda.synchronize()
+    finally:
+        hipops.AUTOTUNE = auto
+    n, t1, t2, t3, steps = 4, [], [], [], []
+    for it in range(n + 1):                        # (first iteration untimed)
+        batch = batches[it % len(batches)]
+        t0 = time.perf_counter()
+        acts = pass1(it)
+        ta = time.perf_counter()
+        plan = te_s.plan(batch, actions=acts)
+        tb = time.perf_counter()
+        bufs_s.load(plan)
+        g_s.replay()
+        bufs.load(te.plan(batch))
+        g_teacher.replay()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        if it:
+            t1.append(ta - t0), t2.append(tb - ta), t3.append(tc - tb), steps.append(ro.steps)
+    ms = lambda v: round(sum(v) / len(v) * 1e3, 2)
+    return {'ms_per_iteration': round(ms(t1) + ms(t2) + ms(t3), 2), 'pass1_no_grad_rollout_ms': ms(t1), 'plan_along_actions_ms': ms(t2),
+            'sampled_graph_plus_teacher_part_ms': ms(t3), 'sample_steps': round(sum(steps) / len(steps), 1), 'episode_bucket_T': max_action_len,
+            'what': 'sampled rollout under no_grad (eager, fixes the trajectory) + host plan along the recorded actions + replay of the episode '
+                    'graph captured at T = %d (forward + backward of the sampled half) + the teacher part as above' % max_action_len}
 
 
 def navigator_leg(args, model, ep, arena, B, T, frozen_s):
