@@ -1187,8 +1187,40 @@ def two_pass_iteration(call, te, bufs, g_teacher, batches, extras, arena, sim, s
         if it:
             t1.append(ta - t0), t2.append(tb - ta), t3.append(tc - tb), steps.append(ro.steps)
     ms = lambda v: round(sum(v) / len(v) * 1e3, 2)
+    graphs = None
+    try:
+        # pass 1 as captured forward graphs (rollout.SampledEpisode): the step tables go into the SAME episode buffers as the walk proceeds,
+        # the plan is finished by the time the last step has been sampled
+        auto, hipops.AUTOTUNE = hipops.AUTOTUNE, False
+        try:
+            se = rollout.SampledEpisode(te_s, call, bufs_s, extras)
+        finally:
+            hipops.AUTOTUNE = auto
+        import numpy as np
+        rng = np.random.RandomState(17)
+        u1, u2, usteps, uhost = [], [], [], []
+        for it in range(n + 1):
+            batch = batches[it % len(batches)]
+            t0 = time.perf_counter()
+            plan, _ = se.run(batch, rng)
+            ta = time.perf_counter()
+            bufs_s.load(plan)
+            g_s.replay()
+            bufs.load(te.plan(batch))
+            g_teacher.replay()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            if it:
+                u1.append(ta - t0), u2.append(tb - ta), usteps.append(se.steps), uhost.append(se.host_s)
+        graphs = {'ms_per_iteration': round(ms(u1) + ms(u2), 2), 'pass1_step_graphs_ms': ms(u1), 'pass1_host_builder_ms': ms(uhost),
+                  'sampled_graph_plus_teacher_part_ms': ms(u2), 'sample_steps': round(sum(usteps) / len(usteps), 1),
+                  'what': 'pass 1 as %d captured forward graphs (instruction + one per step) fed step by step by EpisodePlanner / '
+                          'EpisodeBuffers.load_part, one B x G read-back per step, sampling on the host; the finished plan feeds pass 2' % (max_action_len + 1)}
+    except Exception as e:      # noqa: BLE001
+        graphs = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     return {'ms_per_iteration': round(ms(t1) + ms(t2) + ms(t3), 2), 'pass1_no_grad_rollout_ms': ms(t1), 'plan_along_actions_ms': ms(t2),
             'sampled_graph_plus_teacher_part_ms': ms(t3), 'sample_steps': round(sum(steps) / len(steps), 1), 'episode_bucket_T': max_action_len,
+            'pass1_captured': graphs,
             'what': 'sampled rollout under no_grad (eager, fixes the trajectory) + host plan along the recorded actions + replay of the episode '
                     'graph captured at T = %d (forward + backward of the sampled half) + the teacher part as above' % max_action_len}
 

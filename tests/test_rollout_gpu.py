@@ -307,3 +307,61 @@ def test_two_pass_sampled_rollout_matches_the_single_pass():
         assert float((a - b).abs().max()) <= 5e-4 * scale, (names[id(p)], float((a - b).abs().max()), scale)
         n += 1
     assert n > 100
+
+
+def test_sampled_episode_step_graphs_match_the_eager_rollout():
+    """rollout.SampledEpisode: pass 1 of the two-pass sampled rollout as captured forward graphs (instruction graph + one graph per
+    step over the episode buffers, tables of a step copied in by EpisodeBuffers.load_part).  With the fixture's fixed action sequence
+    the action probabilities of every step equal the eager NavRollout's at the same panorama width (float32, dropout off), the
+    returned plan is TeacherEpisode.plan(actions=) with the reference's DAgger labels, and a second run on other episodes through
+    the SAME graphs matches its own eager rollout (nothing of the first run is left in the buffers)."""
+    from vln_goat_amd import rollout, synth
+    z = np.load(os.path.join(HERE, 'golden', 'rollout_episode_sample.npz'))
+    scan, feats, eps, dicts = synth.make_rollout_case()
+    model = _model()
+    store = _store(scan, feats, torch.float32)
+    sim = rollout.GraphSim(store)
+    call = lambda mode, batch: model(mode, batch)
+    ex = synth.rollout_extras(dicts, len(eps), 'cuda')
+    T = int(z['n_steps'][0])
+    te = rollout.TeacherEpisode(sim, store, n_steps=T, text_len=32, pano_width=40)
+    bufs = rollout.EpisodeBuffers(te.plan(eps))
+    se = rollout.SampledEpisode(te, call, bufs, ex)
+    other = synth.rollout_episodes(scan, np.random.RandomState(5), B=3, max_steps=4, starts=[3, 11, 16])
+
+    def eager(episodes, sampler):
+        rec = []
+
+        def spy(mode, batch):
+            out = call(mode, batch)
+            if mode == 'navigation':
+                rec.append(torch.softmax(out['fused_logits'].detach().float(), 1).cpu().numpy())
+            return out
+        ro = rollout.NavRollout(spy, sim, store, max_action_len=T, pano_width=40)
+        with torch.no_grad():
+            ro.run(episodes, feedback='sample', extras=ex, compute_loss=False, sampler=sampler)
+        return rec, ro.actions
+
+    for episodes, fixed in ((eps, lambda t, probs: z['s%d_action' % t]), (other, None), (eps, lambda t, probs: z['s%d_action' % t])):
+        got = []
+        if fixed is None:                       # a deterministic policy-dependent choice: the most probable node that is not [stop], while it can
+            fixed = lambda t, probs: np.where(np.asarray(probs)[:, 1:].max(1) > 0, np.asarray(probs)[:, 1:].argmax(1) + 1, 0)
+        as_np = lambda x: x.detach().float().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+        def sampler(t, probs):
+            got.append(np.array(probs))
+            return fixed(t, as_np(probs))
+        plan, actions = se.run(episodes, sampler=sampler)
+        ref, ref_actions = eager(episodes, lambda t, probs: fixed(t, as_np(probs)))
+        assert len(got) == len(ref) == se.steps
+        for t, (a, b) in enumerate(zip(got, ref)):
+            G = b.shape[1]
+            assert np.abs(a[:, :G] - b).max() <= 2e-4, (t, float(np.abs(a[:, :G] - b).max()))
+            assert np.abs(a[:, G:]).max(initial=0.0) == 0.0
+        assert all(np.array_equal(x, y) for x, y in zip(actions, ref_actions))
+        want = te.plan(episodes, actions=actions)
+        for k, v in want.items():
+            if torch.is_tensor(v):
+                assert torch.equal(plan[k], v), k
+    for t in range(T):
+        assert np.array_equal(plan['s%d_target' % t].numpy(), z['s%d_target' % t]), t

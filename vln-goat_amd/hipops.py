@@ -534,6 +534,12 @@ class Branch:
             return self
         if Branch.mode != 'always' and not torch.cuda.is_current_stream_capturing():
             return self
+        if not torch.is_grad_enabled():
+            # forward-only capture (rollout.SampledEpisode): nothing is saved for a backward pass, so a tensor made on the caller's stream
+            # and read by the branch is released as soon as Python drops it and its block is handed to the caller's next allocation while
+            # the branch may still read it (the allocator orders reuse per allocating stream) — measured: action probabilities that
+            # change from replay to replay.  The inference graphs are small and host-paced; they run on one stream.
+            return self
         dev = torch.cuda.current_device()
         self.side = Branch._streams.get((dev, self.name))
         if self.side is None:

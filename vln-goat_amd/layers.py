@@ -76,17 +76,22 @@ def _prune_memo():
             del _MASK_MEMO[key]
 
 
-def refresh_masks():
+def refresh_masks(only=None):
     """recompute, into the same storage, every memoised mask whose source tensor was edited in place (insertion order: a mask
-    derived from another memoised mask is refreshed after it).  Entries of dead tensors are dropped."""
+    derived from another memoised mask is refreshed after it).  Entries of dead tensors are dropped.
+    only: the edited source tensors (views of one buffer share a version counter: after a PARTIAL copy into an EpisodeBuffers every
+    view looks edited) — just their masks, and the masks derived from those, are recomputed."""
+    ids = None if only is None else {id(t) for t in only}
     for key in list(_MASK_MEMO):
         ent = _MASK_MEMO[key]
         t = ent[0]()
         if t is None:
             del _MASK_MEMO[key]
-        elif ent[1] != t._version:
+        elif ent[1] != t._version and (ids is None or id(t) in ids):
             ent[2].copy_(ent[3](t))
             ent[1] = t._version
+            if ids is not None:
+                ids.add(id(ent[2]))
 
 
 def neg_mask(masks, value=-10000.0):

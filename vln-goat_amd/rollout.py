@@ -803,116 +803,66 @@ class TeacherEpisode:
         (`teacher_action(imitation_learning=False)`: M/r2r/agent.py:325-347), the episode ends as the sampled rollout does
         (:601-607,657-663: at the goal, on a sampled [stop], with no node left, at the last step).  One replay of the captured body then
         gives the loss and the gradients of the sampled half of the dagger iteration (:436-437) without an eager autograd pass."""
-        from . import graphmap, nav_model
         if actions is not None:
             actions = [np.asarray(a, np.int64) for a in actions]
             if len(actions) > self.T:
                 raise ValueError('%d recorded steps exceed the episode bucket T = %d' % (len(actions), self.T))
             if any(a.shape != (len(episodes),) for a in actions):
                 raise ValueError('actions must hold one index per episode and step')
-        afs = self.sim.angle_feat_size
-        obs = self.sim.reset(episodes)
-        B = len(obs)
-        gmaps = [GraphMap(ob['viewpoint']) for ob in obs]
-        for g, ob in zip(gmaps, obs):
-            g.update_graph(ob)
-        lang = language_inputs(obs)
-        if lang['txt_ids'].shape[1] > self.L:
-            raise ValueError('instruction of %d tokens exceeds the text bucket %d' % (lang['txt_ids'].shape[1], self.L))
-        ids = torch.zeros(B, self.L, dtype=torch.int64)
-        msk = torch.zeros(B, self.L, dtype=torch.bool)
-        ids[:, :lang['txt_ids'].shape[1]], msk[:, :lang['txt_masks'].shape[1]] = lang['txt_ids'], lang['txt_masks']
-        out = {'txt_ids': ids, 'txt_masks': msk}
-        store = NodeEmbedStore(B)
-        ended = np.zeros(B, bool)
-        traj = [{'instr_id': ob['instr_id'], 'path': [[ob['viewpoint']]]} for ob in obs]
-        n_traj = 0
+        p = EpisodePlanner(self, episodes, imitation=actions is None)
         for t in range(self.T):
-            for i, g in enumerate(gmaps):
-                if not ended[i]:
-                    g.node_step_ids[obs[i]['viewpoint']] = t + 1
-            n_traj += int((~ended).sum())
-            pano = panorama_inputs(obs, afs, self.W)
-            store.advance(B, self.W)
-            for i, g in enumerate(gmaps):
-                if not ended[i]:
-                    store.rewrite(i, obs[i]['viewpoint'])
-                    for j, cvp in enumerate(pano['cand_vpids'][i]):
-                        if not g.graph.visited(cvp):
-                            store.accumulate(i, cvp, j)
-            G = self.gw(t)
-            gin = gmap_inputs(obs, gmaps, G, afs)
-            vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], self.W + 2, afs)
-            target = teacher_action(obs, gin['gmap_vpids'], ended, gin['gmap_visited_masks'].numpy(), actions is None, t, self.ignoreid)
-            k = 's%d_' % t
-            # feature gather of the panorama tokens: compact CSR (padding slots = empty segments)
-            rows = pano['view_rows'].reshape(-1).numpy()
-            valid = rows >= 0
-            fidx = np.full(rows.shape[0], -1, np.int32)
-            fidx[:int(valid.sum())] = rows[valid]
-            out[k + 'feat_idx'] = torch.from_numpy(fidx)
-            out[k + 'feat_start'] = torch.from_numpy(np.concatenate([[0], np.cumsum(valid)]).astype(np.int32))
-            for name in ('loc_fts', 'nav_types', 'view_lens'):
-                out[k + name] = pano[name]
-            for name in ('gmap_step_ids', 'gmap_pos_fts', 'gmap_pair_dists', 'gmap_visited_masks', 'gmap_masks'):
-                out[k + name] = gin[name]
-            for name in ('vp_pos_fts', 'vp_masks', 'vp_nav_masks'):
-                out[k + name] = vin[name]
-            out[k + 'nav_fusion'] = nav_model.nav_fusion_matrix(vin['vp_cand_vpids'], gin['gmap_vpids'], gin['gmap_visited_masks'], G, self.W + 2)
-            out[k + 'target'] = torch.from_numpy(target)
-            # node embeddings: CSR over the pool of this and all earlier steps (+ the previous [MEM] state behind it)
-            n_src = store.rows + (B if t > 0 else 0)
-            mem_rows = [store.rows + b for b in range(B)] if t > 0 else None
-            idx, start, scale = store.csr(gin['gmap_vpids'], G, mem_rows)
-            inv = graphmap.inverse_index(idx, start, scale, n_src)
-            n_tok = int(start[-1])
-            out[k + 'csr_idx'] = _pad1np(idx[:n_tok] if n_tok else idx[:0], n_src, -1, np.int32)
-            out[k + 'csr_start'], out[k + 'csr_scale'] = torch.from_numpy(start), torch.from_numpy(scale)
-            out[k + 'inv_idx'] = _pad1np(inv[0].numpy()[:n_tok], n_src, -1, np.int32)
-            out[k + 'inv_start'] = inv[1]
-            out[k + 'inv_w'] = _pad1np(inv[2].numpy()[:n_tok], n_src, 0.0, np.float32)
-            # the move: the teacher's, or the recorded one
-            moves = []
-            for i in range(B):
-                stop = obs[i]['viewpoint'] == obs[i]['gt_path'][-1]
-                if stop or ended[i] or gin['no_vp_left'][i] or t == self.T - 1:
-                    moves.append(None)
-                    continue
-                if actions is None:
-                    a = int(target[i])
-                else:
-                    a = int(actions[t][i]) if t < len(actions) else 0
-                    if not 0 <= a < len(gin['gmap_vpids'][i]) or (a > 0 and bool(gin['gmap_visited_masks'][i, a])):
-                        raise ValueError('step %d, episode %d: recorded action %d is not a navigable node of the map' % (t, i, a))
-                nxt = gin['gmap_vpids'][i][a]
-                if nxt is None:             # a recorded [stop] (node 0): the episode ends here (M/r2r/agent.py:661)
-                    moves.append(None)
-                else:
-                    hop = gmaps[i].graph.path(obs[i]['viewpoint'], nxt)
-                    traj[i]['path'].append(hop)
-                    prev = traj[i]['path'][-2][-1] if len(hop) == 1 else hop[-2]
-                    view = next(c['pointId'] for c in obs[i]['scan_graph'].candidates(prev) if c['viewpointId'] == nxt)
-                    moves.append((nxt, view))
-            obs = self.sim.step(moves)
-            for i, ob in enumerate(obs):
-                if not ended[i]:
-                    gmaps[i].update_graph(ob)
-            ended = np.logical_or(ended, np.array([m is None for m in moves]))
-        # the panoramas of all steps as ONE batch [T * B] (body(hoist_pano=True)): the compact feature-gather CSR of the steps joined
-        valid_rows, starts, off = [], [], 0
-        for t in range(self.T):
-            st = out['s%d_feat_start' % t].numpy()
-            valid_rows.append(out['s%d_feat_idx' % t].numpy()[:int(st[-1])])
-            starts.append(st[:-1] + off)
-            off += int(st[-1])
-        out['all_feat_idx'] = _pad1np(np.concatenate(valid_rows), self.T * B * self.W, -1, np.int32)
-        out['all_feat_start'] = torch.from_numpy(np.concatenate(starts + [[off]]).astype(np.int32))
-        for name in ('loc_fts', 'nav_types', 'view_lens'):
-            out['all_' + name] = torch.cat([out['s%d_%s' % (t, name)] for t in range(self.T)], 0)
-        out['_traj'], out['_n_traj'] = traj, n_traj
-        return out
+            p.build_step()
+            p.advance(None if actions is None else (actions[t] if t < len(actions) else np.zeros(len(episodes), np.int64)))
+        return p.finish()
 
     # ---- device -------------------------------------------------------------------------------------------------------------
+    def _panoramas(self, model, t_, extras, k, n, B):
+        """panorama encoder over the n panoramas of the tables with prefix k ('s<t>_': B of one step, 'all_': T * B)."""
+        from collections import defaultdict
+        from . import hipops
+        fts = hipops.gather_segmean(self.features.dev, t_[k + 'feat_idx'], t_[k + 'feat_start'], None, n * self.W, None)
+        pin = {'view_img_fts': fts.view(n, self.W, -1), 'loc_fts': t_[k + 'loc_fts'], 'nav_types': t_[k + 'nav_types'],
+               'view_lens': t_[k + 'view_lens'], 'already_dropout': False}
+        for name, z in (extras or {}).get('panorama', {}).items():      # per-sample dictionary copies ([B, K, ...]) follow the joint batch
+            pin[name] = z.repeat(n // B, *([1] * (z.dim() - 1))) if (torch.is_tensor(z) and n != B and z.dim() > 1 and z.shape[0] == B) else z
+        return model('panorama', defaultdict(lambda: None, pin))
+
+    @staticmethod
+    def _nav_extras(extras, dtype):
+        nav_extras = dict((extras or {}).get('navigation', {}))
+        for name in ('front_vp_feats', 'front_gmap_feats', 'front_txt_feats'):      # constant over the episode: cast once, not per step
+            if torch.is_tensor(nav_extras.get(name)) and nav_extras[name].is_floating_point():
+                nav_extras[name] = nav_extras[name].to(dtype)
+        return nav_extras
+
+    def _nav_step(self, model, t_, s, txt, txt_kv, pano, pmask, fused, pool, last, nav_extras):
+        """navigation step s over the tables 's<s>_*': node embeddings gathered from `pool` (the panoramas of this and all earlier steps,
+        appended to here) and the previous [MEM] state `last`.  -> (logits of the configured fusion, the new [MEM] state)"""
+        from collections import defaultdict
+        from . import hipops
+        k = 's%d_' % s
+        B = pano.shape[0]
+        if fused is None:
+            fused = torch.sum(pano * pmask.unsqueeze(2), 1) / torch.sum(pmask, 1, keepdim=True)
+        H = pano.shape[-1]
+        pool += [pano.reshape(B * self.W, H), fused.to(pano.dtype)]
+        src = torch.cat(pool + ([last.to(pano.dtype)] if last is not None else []), 0)
+        G = t_[k + 'gmap_step_ids'].shape[1]
+        gimg = hipops.gather_segmean(src, t_[k + 'csr_idx'], t_[k + 'csr_start'], t_[k + 'csr_scale'], B * G,
+                                     (t_[k + 'inv_idx'], t_[k + 'inv_start'], t_[k + 'inv_w'])).view(B, G, H)
+        zero = pano.new_zeros(B, 1, H)
+        memtok = zero if last is None else last.unsqueeze(1).to(pano.dtype)
+        nin = {'txt_embeds': txt, 'txt_masks': t_['txt_masks'], 'gmap_img_embeds': gimg,
+               'vp_img_embeds': torch.cat([zero, memtok, pano], 1), 'vp_obj_masks': None, 'flops_count': False, 'txt_kv': txt_kv,
+               'nav_fusion': t_[k + 'nav_fusion']}
+        for name in ('gmap_step_ids', 'gmap_pos_fts', 'gmap_pair_dists', 'gmap_visited_masks', 'gmap_masks', 'vp_pos_fts', 'vp_masks',
+                     'vp_nav_masks'):
+            nin[name] = t_[k + name]
+        nin.update(nav_extras)
+        out = model('navigation', defaultdict(lambda: None, nin))
+        logits = {'local': out['local_logits'], 'global': out['global_logits']}.get(self.fusion, out['fused_logits'])
+        return logits, out['cls_embeds']
+
     def body(self, model, bufs, extras=None, hoist_text_kv=True, hoist_pano=True):
         """forward + imitation loss of the planned episodes from the tensors of `bufs` (EpisodeBuffers.t): no host data, no
         device -> host copy.  -> loss (sum over steps and samples of the cross-entropy / B, M/r2r/agent.py:664-667).
@@ -929,14 +879,7 @@ class TeacherEpisode:
         lang = {'txt_ids': t_['txt_ids'], 'txt_masks': t_['txt_masks']}
         lang.update(extras.get('language', {}))
         pool, last, loss, ce_rows = [], None, 0.0, []
-
-        def panoramas(k, n):
-            fts = hipops.gather_segmean(self.features.dev, t_[k + 'feat_idx'], t_[k + 'feat_start'], None, n * self.W, None)
-            pin = {'view_img_fts': fts.view(n, self.W, -1), 'loc_fts': t_[k + 'loc_fts'], 'nav_types': t_[k + 'nav_types'],
-                   'view_lens': t_[k + 'view_lens'], 'already_dropout': False}
-            for name, z in extras.get('panorama', {}).items():      # per-sample dictionary copies ([B, K, ...]) follow the joint batch
-                pin[name] = z.repeat(n // B, *([1] * (z.dim() - 1))) if (torch.is_tensor(z) and n != B and z.dim() > 1 and z.shape[0] == B) else z
-            return model('panorama', dd(pin))
+        panoramas = lambda k, n: self._panoramas(model, t_, extras, k, n, B)
 
         # (the hoisted panorama pass depends on the observations only: a parallel branch of the instruction encoder in the captured graph)
         with hipops.Branch('pano', 'nav_pano') as bp:
@@ -950,36 +893,14 @@ class TeacherEpisode:
             bp.join(*whole)
             # (unbind: ONE backward node stacks the per-step gradients — not T zero-filled slice_backward tensors and T - 1 adds)
             whole_s = [None if x is None else x.view(self.T, B, *x.shape[1:]).unbind(0) for x in whole]
-        nav_extras = dict(extras.get('navigation', {}))
-        for name in ('front_vp_feats', 'front_gmap_feats', 'front_txt_feats'):      # constant over the episode: cast once, not per step
-            if torch.is_tensor(nav_extras.get(name)) and nav_extras[name].is_floating_point():
-                nav_extras[name] = nav_extras[name].to(txt.dtype)
+        nav_extras = self._nav_extras(extras, txt.dtype)
         for s in range(self.T):
             k = 's%d_' % s
             if whole is not None:
                 pano, pmask, fused = (None if x is None else x[s] for x in whole_s)
             else:
                 pano, pmask, fused = panoramas(k, B)
-            if fused is None:
-                fused = torch.sum(pano * pmask.unsqueeze(2), 1) / torch.sum(pmask, 1, keepdim=True)
-            H = pano.shape[-1]
-            pool += [pano.reshape(B * self.W, H), fused.to(pano.dtype)]
-            src = torch.cat(pool + ([last.to(pano.dtype)] if last is not None else []), 0)
-            G = t_[k + 'gmap_step_ids'].shape[1]
-            gimg = hipops.gather_segmean(src, t_[k + 'csr_idx'], t_[k + 'csr_start'], t_[k + 'csr_scale'], B * G,
-                                         (t_[k + 'inv_idx'], t_[k + 'inv_start'], t_[k + 'inv_w'])).view(B, G, H)
-            zero = pano.new_zeros(B, 1, H)
-            memtok = zero if last is None else last.unsqueeze(1).to(pano.dtype)
-            nin = {'txt_embeds': txt_h[s], 'txt_masks': t_['txt_masks'], 'gmap_img_embeds': gimg,
-                   'vp_img_embeds': torch.cat([zero, memtok, pano], 1), 'vp_obj_masks': None, 'flops_count': False, 'txt_kv': kv_h[s],
-                   'nav_fusion': t_[k + 'nav_fusion']}
-            for name in ('gmap_step_ids', 'gmap_pos_fts', 'gmap_pair_dists', 'gmap_visited_masks', 'gmap_masks', 'vp_pos_fts', 'vp_masks',
-                         'vp_nav_masks'):
-                nin[name] = t_[k + name]
-            nin.update(nav_extras)
-            out = model('navigation', dd(nin))
-            last = out['cls_embeds']
-            logits = {'local': out['local_logits'], 'global': out['global_logits']}.get(self.fusion, out['fused_logits'])
+            logits, last = self._nav_step(model, t_, s, txt_h[s], kv_h[s], pano, pmask, fused, pool, last, nav_extras)
             if self.ignoreid < 0:
                 ce_rows.append(hipops.cross_entropy_rows(logits, t_[k + 'target']))          # (summed once behind the loop)
             else:
@@ -987,6 +908,145 @@ class TeacherEpisode:
         if ce_rows:
             loss = loss + torch.stack(ce_rows, 0).sum()
         return loss / B
+
+
+class EpisodePlanner:
+    """TeacherEpisode.plan one step at a time: build_step() makes the host tables of step t from the navigator's current state,
+    advance(actions) moves it (the teacher's actions when `imitation`, else the given ones — a sampled rollout decides them from the
+    step's logits), finish() adds the joint panorama tables and returns the plan dict.  While a planner is alive it owns te.sim."""
+
+    def __init__(self, te, episodes, imitation=True):
+        self.te, self.imitation = te, imitation
+        obs = te.sim.reset(episodes)
+        self.B = B = len(obs)
+        self.gmaps = [GraphMap(ob['viewpoint']) for ob in obs]
+        for g, ob in zip(self.gmaps, obs):
+            g.update_graph(ob)
+        lang = language_inputs(obs)
+        if lang['txt_ids'].shape[1] > te.L:
+            raise ValueError('instruction of %d tokens exceeds the text bucket %d' % (lang['txt_ids'].shape[1], te.L))
+        ids = torch.zeros(B, te.L, dtype=torch.int64)
+        msk = torch.zeros(B, te.L, dtype=torch.bool)
+        ids[:, :lang['txt_ids'].shape[1]], msk[:, :lang['txt_masks'].shape[1]] = lang['txt_ids'], lang['txt_masks']
+        self.out = {'txt_ids': ids, 'txt_masks': msk}
+        self.obs = obs
+        self.store = NodeEmbedStore(B)
+        self.ended = np.zeros(B, bool)
+        self.traj = [{'instr_id': ob['instr_id'], 'path': [[ob['viewpoint']]]} for ob in obs]
+        self.n_traj = 0
+        self.t = 0
+        self._gin = self._target = None
+
+    def build_step(self):
+        """-> {key: tensor} of step t (also kept for finish())."""
+        from . import graphmap, nav_model
+        te, t, obs, gmaps, ended, store, B = self.te, self.t, self.obs, self.gmaps, self.ended, self.store, self.B
+        if t >= te.T:
+            raise ValueError('the episode bucket holds %d steps' % te.T)
+        afs = te.sim.angle_feat_size
+        out = {}
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.node_step_ids[obs[i]['viewpoint']] = t + 1
+        self.n_traj += int((~ended).sum())
+        pano = panorama_inputs(obs, afs, te.W)
+        store.advance(B, te.W)
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                store.rewrite(i, obs[i]['viewpoint'])
+                for j, cvp in enumerate(pano['cand_vpids'][i]):
+                    if not g.graph.visited(cvp):
+                        store.accumulate(i, cvp, j)
+        G = te.gw(t)
+        gin = gmap_inputs(obs, gmaps, G, afs)
+        vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], te.W + 2, afs)
+        target = teacher_action(obs, gin['gmap_vpids'], ended, gin['gmap_visited_masks'].numpy(), self.imitation, t, te.ignoreid)
+        k = 's%d_' % t
+        # feature gather of the panorama tokens: compact CSR (padding slots = empty segments)
+        rows = pano['view_rows'].reshape(-1).numpy()
+        valid = rows >= 0
+        fidx = np.full(rows.shape[0], -1, np.int32)
+        fidx[:int(valid.sum())] = rows[valid]
+        out[k + 'feat_idx'] = torch.from_numpy(fidx)
+        out[k + 'feat_start'] = torch.from_numpy(np.concatenate([[0], np.cumsum(valid)]).astype(np.int32))
+        for name in ('loc_fts', 'nav_types', 'view_lens'):
+            out[k + name] = pano[name]
+        for name in ('gmap_step_ids', 'gmap_pos_fts', 'gmap_pair_dists', 'gmap_visited_masks', 'gmap_masks'):
+            out[k + name] = gin[name]
+        for name in ('vp_pos_fts', 'vp_masks', 'vp_nav_masks'):
+            out[k + name] = vin[name]
+        out[k + 'nav_fusion'] = nav_model.nav_fusion_matrix(vin['vp_cand_vpids'], gin['gmap_vpids'], gin['gmap_visited_masks'], G, te.W + 2)
+        out[k + 'target'] = torch.from_numpy(target)
+        # node embeddings: CSR over the pool of this and all earlier steps (+ the previous [MEM] state behind it)
+        n_src = store.rows + (B if t > 0 else 0)
+        mem_rows = [store.rows + b for b in range(B)] if t > 0 else None
+        idx, start, scale = store.csr(gin['gmap_vpids'], G, mem_rows)
+        inv = graphmap.inverse_index(idx, start, scale, n_src)
+        n_tok = int(start[-1])
+        out[k + 'csr_idx'] = _pad1np(idx[:n_tok] if n_tok else idx[:0], n_src, -1, np.int32)
+        out[k + 'csr_start'], out[k + 'csr_scale'] = torch.from_numpy(start), torch.from_numpy(scale)
+        out[k + 'inv_idx'] = _pad1np(inv[0].numpy()[:n_tok], n_src, -1, np.int32)
+        out[k + 'inv_start'] = inv[1]
+        out[k + 'inv_w'] = _pad1np(inv[2].numpy()[:n_tok], n_src, 0.0, np.float32)
+        self._gin, self._target = gin, target
+        self.out.update(out)
+        return out
+
+    def advance(self, actions=None):
+        """the move of step t: the teacher's (imitation) or `actions` [B] (indices into the step's map nodes, 0 = [stop])."""
+        te, t, obs, gmaps, ended, B = self.te, self.t, self.obs, self.gmaps, self.ended, self.B
+        gin, target = self._gin, self._target
+        if gin is None:
+            raise RuntimeError('advance() before build_step()')
+        if not self.imitation and actions is None:
+            raise ValueError('a planner of a sampled walk needs the actions of every step')
+        moves = []
+        for i in range(B):
+            stop = obs[i]['viewpoint'] == obs[i]['gt_path'][-1]
+            if stop or ended[i] or gin['no_vp_left'][i] or t == te.T - 1:
+                moves.append(None)
+                continue
+            if self.imitation:
+                a = int(target[i])
+            else:
+                a = int(actions[i])
+                if not 0 <= a < len(gin['gmap_vpids'][i]) or (a > 0 and bool(gin['gmap_visited_masks'][i, a])):
+                    raise ValueError('step %d, episode %d: recorded action %d is not a navigable node of the map' % (t, i, a))
+            nxt = gin['gmap_vpids'][i][a]
+            if nxt is None:             # a recorded [stop] (node 0): the episode ends here (M/r2r/agent.py:661)
+                moves.append(None)
+            else:
+                hop = gmaps[i].graph.path(obs[i]['viewpoint'], nxt)
+                self.traj[i]['path'].append(hop)
+                prev = self.traj[i]['path'][-2][-1] if len(hop) == 1 else hop[-2]
+                view = next(c['pointId'] for c in obs[i]['scan_graph'].candidates(prev) if c['viewpointId'] == nxt)
+                moves.append((nxt, view))
+        self.obs = obs = te.sim.step(moves)
+        for i, ob in enumerate(obs):
+            if not ended[i]:
+                gmaps[i].update_graph(ob)
+        self.ended = np.logical_or(ended, np.array([m is None for m in moves]))
+        self._gin = self._target = None
+        self.t = t + 1
+
+    def finish(self):
+        """the plan of the whole episode (every step built and advanced)."""
+        te, out, B = self.te, self.out, self.B
+        if self.t != te.T:
+            raise RuntimeError('finish() after %d of %d steps' % (self.t, te.T))
+        # the panoramas of all steps as ONE batch [T * B] (body(hoist_pano=True)): the compact feature-gather CSR of the steps joined
+        valid_rows, starts, off = [], [], 0
+        for t in range(te.T):
+            st = out['s%d_feat_start' % t].numpy()
+            valid_rows.append(out['s%d_feat_idx' % t].numpy()[:int(st[-1])])
+            starts.append(st[:-1] + off)
+            off += int(st[-1])
+        out['all_feat_idx'] = _pad1np(np.concatenate(valid_rows), te.T * B * te.W, -1, np.int32)
+        out['all_feat_start'] = torch.from_numpy(np.concatenate(starts + [[off]]).astype(np.int32))
+        for name in ('loc_fts', 'nav_types', 'view_lens'):
+            out['all_' + name] = torch.cat([out['s%d_%s' % (t, name)] for t in range(te.T)], 0)
+        out['_traj'], out['_n_traj'] = self.traj, self.n_traj
+        return out
 
 
 class _RowIndex:
@@ -1138,6 +1198,34 @@ class EpisodeBuffers:
         self._copied = None
         self.load(plan)
 
+    def load_part(self, part):
+        """the tensors of `part` only (e.g. EpisodePlanner.build_step(): the tables of one step): packed into the pinned buffer, ONE H2D of
+        the byte range that covers them (the bytes between them are what the device already holds), their memoised masks refreshed."""
+        from . import layers
+        if self._copied is not None:
+            self._copied.synchronize()
+        where = getattr(self, '_where', None)
+        if where is None:
+            where = self._where = {k: (off, shape, dtype) for k, off, shape, dtype in self.layout}
+        dst = self.host.numpy()
+        lo, hi = self.nbytes, 0
+        for k, v in part.items():
+            if not torch.is_tensor(v):
+                continue
+            off, shape, dtype = where[k]
+            if tuple(v.shape) != shape or v.dtype != dtype:
+                raise ValueError('EpisodeBuffers: %s is %s %s, the captured layout has %s %s' % (k, tuple(v.shape), v.dtype, shape, dtype))
+            n = v.numel() * v.element_size()
+            if n:
+                dst[off:off + n] = v.contiguous().view(-1).view(torch.uint8).numpy()
+                lo, hi = min(lo, off), max(hi, off + n)
+        if hi > lo:
+            self.flat[lo:hi].copy_(self.host[lo:hi], non_blocking=True)
+            if self.device.type == 'cuda':
+                self._copied = torch.cuda.Event()
+                self._copied.record()
+        layers.refresh_masks(only=[self.t[k] for k in part if k in self.t])
+
     def load(self, plan, stream=None):
         """pack `plan` into the pinned buffer and copy it to the device (asynchronously on `stream` / the current stream)."""
         from . import layers
@@ -1161,3 +1249,109 @@ class EpisodeBuffers:
             self._copied = torch.cuda.Event()
             self._copied.record(stream)
         layers.refresh_masks()
+
+
+
+class SampledEpisode:
+    """Pass 1 of the two-pass sampled rollout (feedback = 'sample': M/r2r/agent.py:436-437,575-607) as captured FORWARD graphs over
+    the buffers of a TeacherEpisode: one graph for the instruction and its K|V projections, one per step t (feature gather, panorama
+    encoder, node-embedding gather over the panoramas of the steps <= t, navigation step, softmax).  Nothing is differentiated here:
+    the pass only decides the walk.  Per step the host builds the step's tables from the navigator's state (EpisodePlanner.build_step),
+    copies them into the episode buffers (one small pinned H2D), replays the step graph, reads the B x G action probabilities back — the
+    one device -> host copy of the step — and samples.  run() returns the finished plan (== TeacherEpisode.plan(episodes, actions):
+    the walk the policy took, the DAgger labels of its states), ready for `bufs.load(plan)` + the captured forward + backward body.
+
+        se = SampledEpisode(te, model, bufs, extras)              # captures T + 1 small graphs (bufs holds any valid plan)
+        plan, actions = se.run(episodes, rng);  bufs.load(plan);  episode_graph.replay()"""
+
+    def __init__(self, te, model, bufs, extras=None):
+        from collections import defaultdict
+        from . import hipops
+        self.te, self.bufs = te, bufs
+        extras = extras or {}
+        t_ = bufs.t
+        B = t_['txt_ids'].shape[0]
+        dd = lambda d: defaultdict(lambda: None, d)
+
+        def fresh_masks():                  # (a replay draws new dropout masks: the in-graph bump of the device-side counter, if one is in use)
+            if hipops.RngState.dev is not None:
+                hipops.RngState.dev.add_(0x9E3779B1)
+
+        def language():
+            fresh_masks()
+            lang = {'txt_ids': t_['txt_ids'], 'txt_masks': t_['txt_masks']}
+            lang.update(extras.get('language', {}))
+            txt = model('language', dd(lang))
+            return txt, model('text_kv', {'txt_embeds': txt})
+        self.g_lang, (self.txt, self.txt_kv) = self._capture(language)
+        nav_extras = te._nav_extras(extras, self.txt.dtype)
+        self.g_step, self.probs = [], []
+        pool, last = [], None
+        for s in range(te.T):
+            def step(s=s, pool=pool, last=last):
+                fresh_masks()
+                mine = list(pool)
+                pano, pmask, fused = te._panoramas(model, t_, extras, 's%d_' % s, B, B)
+                logits, new_last = te._nav_step(model, t_, s, self.txt, self.txt_kv, pano, pmask, fused, mine, last, nav_extras)
+                return torch.softmax(logits.float(), 1), mine, new_last
+            g, (probs, pool, last) = self._capture(step)
+            self.g_step.append(g)
+            self.probs.append(probs)
+        self._keep = (pool, last)               # (the static outputs the later step graphs read)
+        self.host_s = 0.0
+
+    @staticmethod
+    def _capture(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(g):
+            out = fn()
+        return g, out
+
+    @staticmethod
+    def sample(probs, rng):
+        """Categorical(probs).sample() on the host: inverse CDF per row (rows are the B episodes; never a zero-probability node)."""
+        c = np.cumsum(probs.astype(np.float64), 1)
+        u = rng.random_sample(probs.shape[0]) * c[:, -1]
+        return np.array([min(int(np.searchsorted(c[i], u[i], side='right')), probs.shape[1] - 1) for i in range(probs.shape[0])], np.int64)
+
+    def run(self, episodes, rng=None, sampler=None):
+        """-> (plan, actions).  sampler(t, probs [B, G] numpy) -> actions [B] overrides the random draw (tests: a fixed action sequence)."""
+        import time
+        te, bufs = self.te, self.bufs
+        rng = rng if rng is not None else np.random.RandomState(0)
+        t0 = time.perf_counter()
+        p = EpisodePlanner(te, episodes, imitation=False)
+        self.host_s = time.perf_counter() - t0
+        bufs.load_part({'txt_ids': p.out['txt_ids'], 'txt_masks': p.out['txt_masks']})
+        self.g_lang.replay()
+        actions = []
+        zeros = np.zeros(len(episodes), np.int64)
+        for t in range(te.T):
+            t0 = time.perf_counter()
+            part = p.build_step()
+            self.host_s += time.perf_counter() - t0
+            bufs.load_part(part)
+            self.g_step[t].replay()
+            probs = self.probs[t].cpu().numpy()             # (synchronises: the step's one read-back)
+            a = np.asarray(sampler(t, probs), np.int64) if sampler is not None else self.sample(probs, rng)
+            a = np.where(p.ended, 0, a)
+            actions.append(a)
+            t0 = time.perf_counter()
+            p.advance(a)
+            self.host_s += time.perf_counter() - t0
+            if p.ended.all():
+                break
+        self.steps = len(actions)
+        t0 = time.perf_counter()
+        while p.t < te.T:                                     # every episode has ended: the remaining steps carry no label
+            p.build_step()
+            p.advance(zeros)
+        plan = p.finish()
+        self.host_s += time.perf_counter() - t0
+        return plan, actions
