@@ -54,7 +54,9 @@ def angle_feature(heading, elevation, angle_feat_size=4):
 
 def get_angle_fts(headings, elevations, angle_feat_size=4):
     # M/utils/data.py:177-183 (sin / cos of the float32 angles)
-    ang = np.vstack([np.sin(headings), np.cos(headings), np.sin(elevations), np.cos(elevations)]).transpose().astype(np.float32)
+    headings, elevations = np.asarray(headings), np.asarray(elevations)
+    ang = np.empty((headings.shape[0], 4), np.float32)
+    ang[:, 0], ang[:, 1], ang[:, 2], ang[:, 3] = np.sin(headings), np.cos(headings), np.sin(elevations), np.cos(elevations)
     reps = angle_feat_size // 4
     return np.concatenate([ang] * reps, 1) if reps > 1 else ang
 
@@ -102,6 +104,7 @@ class FloydGraph:
         self.D = np.full((cap, cap), float(FLOYD_INF))
         self.P = np.full((cap, cap), -1, np.int32)
         self._visited = set()
+        self._hop_memo = {}         # (i, j) -> hops under the CURRENT _point matrix (cleared whenever an entry of P changes)
 
     def _ix(self, vp):
         i = self.ids.get(vp)
@@ -126,6 +129,7 @@ class FloydGraph:
         if dis < self.D[i, j]:
             self.D[i, j] = self.D[j, i] = dis
             self.P[i, j] = self.P[j, i] = -1
+            self._hop_memo.clear()
 
     def update(self, k):
         kk, n = self._ix(k), len(self.names)
@@ -135,6 +139,7 @@ class FloydGraph:
         np.fill_diagonal(better, False)
         D[better] = cand[better]
         P[better] = kk
+        self._hop_memo.clear()
         self._visited.add(k)
 
     def visited(self, k):
@@ -151,7 +156,11 @@ class FloydGraph:
         return self._hops(i, k, depth + 1) + self._hops(k, j, depth + 1)
 
     def path_len(self, x, y):
-        return self._hops(self._ix(x), self._ix(y))
+        key = (self._ix(x), self._ix(y))
+        n = self._hop_memo.get(key)
+        if n is None:               # (every step asks for the same pairs three times: map, candidates, start node)
+            n = self._hop_memo[key] = self._hops(*key)
+        return n
 
     def path(self, x, y):
         if x == y:
@@ -196,19 +205,30 @@ class GraphMap:
         """[n, angle_feat_size + 3]: sin / cos of the relative heading and elevation, line distance, map distance, map path length
         (graph_utils.py:127-149); None entries ([stop] / [MEM]) give the angle features of (0, 0) and zero distances."""
         n = len(gmap_vpids)
-        real = [i for i, vp in enumerate(gmap_vpids) if vp is not None]
+        first = 0
+        while first < n and gmap_vpids[first] is None:
+            first += 1
+        vps = gmap_vpids[first:]
+        if None in vps:             # (None entries between real nodes: not what the builders make, kept general)
+            real = [i for i, vp in enumerate(gmap_vpids) if vp is not None]
+            vps = [gmap_vpids[i] for i in real]
+        else:
+            real = slice(first, n)
         ang = np.zeros((n, 2), np.float64)
         dist = np.zeros((n, 3), np.float64)
-        if real:
-            vps = [gmap_vpids[i] for i in real]
+        if vps:
+            graph = self.graph
             pos = np.array([self.node_positions[vp] for vp in vps], np.float64)
             h, e, d = rel_pos(self.node_positions[cur_vp], pos)
             ang[real, 0], ang[real, 1] = h - cur_heading, e - cur_elevation
             dist[real, 0] = d / MAX_DIST
-            dist[real, 1] = self.graph.dist_rows(cur_vp, vps) / MAX_DIST
-            dist[real, 2] = np.array([self.graph.path_len(cur_vp, vp) for vp in vps], np.float64) / MAX_STEP
+            dist[real, 1] = graph.dist_rows(cur_vp, vps) / MAX_DIST
+            dist[real, 2] = np.array([graph.path_len(cur_vp, vp) for vp in vps], np.float64) / MAX_STEP
         ang = ang.astype(np.float32)
-        return np.concatenate([get_angle_fts(ang[:, 0], ang[:, 1], angle_feat_size), dist.astype(np.float32)], 1)
+        out = np.empty((n, angle_feat_size + 3), np.float32)
+        out[:, :angle_feat_size] = get_angle_fts(ang[:, 0], ang[:, 1], angle_feat_size)
+        out[:, angle_feat_size:] = dist          # (float64 -> float32 on assignment, as .astype did)
+        return out
 
     def pair_dists(self, gmap_vpids, first=2):
         """symmetric [G, G] float32 of map distances between the real nodes gmap_vpids[first:] (M/r2r/agent.py:191-195)."""
@@ -271,13 +291,14 @@ class NodeEmbedStore:
         empty (zeros); slot 1 ([MEM]) reads pool row mem_rows[b] if given; slots >= 2 the node's rows."""
         idx, start, scale = [], [0], []
         for b in range(self.B):
-            vps = gmap_vpids[b]
-            for g in range(G):
+            vps, state = gmap_vpids[b], self.state[b]
+            n = min(max(len(vps), 2), G)
+            for g in range(n):
                 rows, sc = (), 1.0
                 if g == 1 and mem_rows is not None:
                     rows = (mem_rows[b],)
                 elif g >= 2 and g < len(vps) and vps[g] is not None:
-                    kind, r = self.state[b][vps[g]]
+                    kind, r = state[vps[g]]
                     if kind == 'set':
                         rows = (r,)
                     else:
@@ -285,6 +306,9 @@ class NodeEmbedStore:
                 idx.extend(rows)
                 scale.append(sc)
                 start.append(len(idx))
+            if G > n:                           # the padding slots of the bucket: empty segments
+                scale.extend([1.0] * (G - n))
+                start.extend([len(idx)] * (G - n))
         if not idx:
             idx = [-1]
         return np.asarray(idx, np.int32), np.asarray(start, np.int32), np.asarray(scale, np.float32)
@@ -497,13 +521,15 @@ def panorama_inputs(obs, angle_feat_size=4, width=None):
             ty.append(1)
             cv.append(cc['viewpointId'])
             used.add(cc['pointId'])
-        for k in range(36):
-            if k not in used:
-                r.append(ob['feature_row'] * 36 + k)
-                ang.append(ob['view_angle_fts'][k])
-                ty.append(0)
-        ang = np.stack(ang, 0).astype(np.float32)
-        locs.append(np.concatenate([ang, np.ones((len(r), 3), np.float32)], 1))
+        rest = [k for k in range(36) if k not in used]
+        base = ob['feature_row'] * 36
+        r.extend(base + k for k in rest)
+        ty.extend([0] * len(rest))
+        loc = np.ones((len(r), angle_feat_size + 3), np.float32)
+        if ang:
+            loc[:len(ang), :angle_feat_size] = np.stack(ang, 0)
+        loc[len(ang):, :angle_feat_size] = np.asarray(ob['view_angle_fts'])[rest]
+        locs.append(loc)
         rows.append(r)
         types.append(ty)
         cand_vpids.append(cv)
@@ -556,17 +582,26 @@ def gmap_inputs(obs, gmaps, width=None, angle_feat_size=4):
             'gmap_lens': lens, 'no_vp_left': list(no_left)}
 
 
-def vp_inputs(obs, gmaps, cand_vpids, view_lens, nav_types, width, angle_feat_size=4):
+def vp_inputs(obs, gmaps, cand_vpids, view_lens, nav_types, width, angle_feat_size=4, gmap_pos=None):
     """_nav_vp_variable_mem (M/r2r/agent.py:271-304) without the embeddings: [stop], [MEM], then the panorama tokens.
-    width = panorama width + 2."""
+    width = panorama width + 2.  gmap_pos = (gmap_vpids, gmap_pos_fts [B, G, angle_feat_size + 3]) of gmap_inputs on the SAME
+    observations: the candidates and the start node are nodes of the map and their features are seen from the same viewpoint under
+    the same heading — the rows are taken from there instead of being computed a second and third time."""
     B = len(obs)
-    pos = np.zeros((B, width, 2 * (angle_feat_size + 3)), np.float32)
+    A = angle_feat_size + 3
+    pos = np.zeros((B, width, 2 * A), np.float32)
     for b, (ob, g) in enumerate(zip(obs, gmaps)):
-        cand = g.get_pos_fts(ob['viewpoint'], cand_vpids[b], ob['heading'], ob['elevation'], angle_feat_size) if cand_vpids[b] else \
-            np.zeros((0, angle_feat_size + 3), np.float32)
-        start = g.get_pos_fts(ob['viewpoint'], [g.start_vp], ob['heading'], ob['elevation'], angle_feat_size)
-        pos[b, :, :angle_feat_size + 3] = start
-        pos[b, 2:len(cand) + 2, angle_feat_size + 3:] = cand
+        if gmap_pos is not None:
+            where = {vp: j for j, vp in enumerate(gmap_pos[0][b]) if vp is not None}
+            rows = gmap_pos[1][b]
+            cand = rows[[where[vp] for vp in cand_vpids[b]]] if cand_vpids[b] else np.zeros((0, A), np.float32)
+            start = rows[where[g.start_vp]]
+        else:
+            cand = g.get_pos_fts(ob['viewpoint'], cand_vpids[b], ob['heading'], ob['elevation'], angle_feat_size) if cand_vpids[b] else \
+                np.zeros((0, A), np.float32)
+            start = g.get_pos_fts(ob['viewpoint'], [g.start_vp], ob['heading'], ob['elevation'], angle_feat_size)
+        pos[b, :, :A] = start
+        pos[b, 2:len(cand) + 2, A:] = cand
     nav_types = torch.as_tensor(nav_types)
     view_lens = torch.as_tensor(view_lens)
     nav = torch.cat([torch.ones(B, 1, dtype=torch.bool), torch.zeros(B, 1, dtype=torch.bool), nav_types == 1], 1)
@@ -693,7 +728,8 @@ class NavRollout:
             n_nodes = max(2 + len(g.node_positions) for g in gmaps)
             gin = gmap_inputs(obs, gmaps, self._bucket(n_nodes), self.sim.angle_feat_size)
             W = pano['view_rows'].shape[1]
-            vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], W + 2, self.sim.angle_feat_size)
+            vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], W + 2, self.sim.angle_feat_size,
+                            gmap_pos=(gin['gmap_vpids'], gin['gmap_pos_fts'].numpy()))
             G = gin['gmap_step_ids'].shape[1]
             nav_vpids = gin['gmap_vpids'] if self.fusion != 'local' else vin['vp_cand_vpids']
             target = None
@@ -959,7 +995,8 @@ class EpisodePlanner:
                         store.accumulate(i, cvp, j)
         G = te.gw(t)
         gin = gmap_inputs(obs, gmaps, G, afs)
-        vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], te.W + 2, afs)
+        vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], te.W + 2, afs,
+                        gmap_pos=(gin['gmap_vpids'], gin['gmap_pos_fts'].numpy()))
         target = teacher_action(obs, gin['gmap_vpids'], ended, gin['gmap_visited_masks'].numpy(), self.imitation, t, te.ignoreid)
         k = 's%d_' % t
         # feature gather of the panorama tokens: compact CSR (padding slots = empty segments)
