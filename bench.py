@@ -1127,7 +1127,14 @@ def dagger_iteration(model, te, bufs, batches, extras, arena, sim, store, B, T, 
             two = two_pass_iteration(call, te, bufs, g, batches, extras, arena, sim, store, ro, max_action_len)
         except Exception as e:      # noqa: BLE001
             two = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
-    return {'ms_per_iteration': round(dt * 1e3, 2), 'sample_rollout_ms': round(sum(t_s) / n * 1e3, 2), 'sample_steps': round(sum(steps) / n, 1),
+    forms = {'single_pass_eager': round(dt * 1e3, 2)}
+    if isinstance(two, dict) and 'ms_per_iteration' in two:
+        forms['two_pass'] = two['ms_per_iteration']
+        if isinstance(two.get('pass1_captured'), dict) and 'ms_per_iteration' in two['pass1_captured']:
+            forms['two_pass_pass1_captured'] = two['pass1_captured']['ms_per_iteration']
+    best = min(forms, key=forms.get)
+    return {'best_form': best, 'best_ms_per_iteration': forms[best], 'forms_ms': forms,
+            'ms_per_iteration': round(dt * 1e3, 2), 'sample_rollout_ms': round(sum(t_s) / n * 1e3, 2), 'sample_steps': round(sum(steps) / n, 1),
             'sample_host_builder_ms': round(sum(host) / n * 1e3, 2), 'teacher_part_ms': round((dt - sum(t_s) / n) * 1e3, 2),
             'ml_weight': ml_weight, 'max_action_len': max_action_len, 'two_pass': two,
             'what': 'teacher rollout (captured graph incl. its host plan, loss x %.1f, accumulate form) + sampled rollout (eager, one read-back per step) '
