@@ -148,19 +148,21 @@ class FloydGraph:
     def _hops(self, i, j, depth=0):
         if i == j:
             return 0
-        k = self.P[i, j]
-        if k < 0:
-            return 1
-        if depth > 4096:
-            raise RecursionError('FloydGraph: cyclic _point chain')
-        return self._hops(i, k, depth + 1) + self._hops(k, j, depth + 1)
+        memo = self._hop_memo
+        n = memo.get((i, j))
+        if n is None:               # (sub-paths are shared between the pairs a step asks for)
+            k = int(self.P[i, j])
+            if k < 0:
+                n = 1
+            else:
+                if depth > 4096:
+                    raise RecursionError('FloydGraph: cyclic _point chain')
+                n = self._hops(i, k, depth + 1) + self._hops(k, j, depth + 1)
+            memo[(i, j)] = n
+        return n
 
     def path_len(self, x, y):
-        key = (self._ix(x), self._ix(y))
-        n = self._hop_memo.get(key)
-        if n is None:               # (every step asks for the same pairs three times: map, candidates, start node)
-            n = self._hop_memo[key] = self._hops(*key)
-        return n
+        return self._hops(self._ix(x), self._ix(y))
 
     def path(self, x, y):
         if x == y:
