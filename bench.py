@@ -1162,7 +1162,8 @@ def two_pass_iteration(call, te, bufs, g_teacher, batches, extras, arena, sim, s
         arena.zero('nav')
         hipops.RngState.dev.add_(0x9E3779B1)
         te_s.body(call, bufs_s, extras).backward()
-    auto, hipops.AUTOTUNE = hipops.AUTOTUNE, False
+    tune = bool(os.environ.get('GOAT_BENCH_TUNE_TWO_PASS'))      # (one-off: measure the T = 15 shapes, then GOAT_SAVE_TUNED + scripts/merge_tuned.py)
+    auto, hipops.AUTOTUNE = hipops.AUTOTUNE, hipops.AUTOTUNE and tune
     try:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -1198,7 +1199,7 @@ def two_pass_iteration(call, te, bufs, g_teacher, batches, extras, arena, sim, s
     try:
         # pass 1 as captured forward graphs (rollout.SampledEpisode): the step tables go into the SAME episode buffers as the walk proceeds,
         # the plan is finished by the time the last step has been sampled
-        auto, hipops.AUTOTUNE = hipops.AUTOTUNE, False
+        auto, hipops.AUTOTUNE = hipops.AUTOTUNE, hipops.AUTOTUNE and tune
         try:
             se = rollout.SampledEpisode(te_s, call, bufs_s, extras)
         finally:
