@@ -38,8 +38,9 @@ def timeit(fn, n=48):
 
 
 for name, B, Lq, Lk, self_attn in (('text self', 48, 80, 80, True), ('pano self', 240, 36, 36, True), ('gmap<-text', 48, 22, 80, False),
-                                   ('vp<-text', 48, 37, 80, False), ('text<-gmap', 48, 80, 22, False), ('text<-vp', 48, 80, 37, False)):
-    for p, use_mask in ((0.1, True), (0.0, True), (0.0, False)):
+                                   ('vp<-text', 48, 37, 80, False), ('text<-gmap', 48, 80, 22, False), ('text<-vp', 48, 80, 37, False),
+                                   ('text160 self', 32, 160, 160, True)):
+    for p, use_mask in ((0.1, True), (0.0, True)):
         sets = []
         for _ in range(ROT):
             if self_attn:
@@ -80,5 +81,5 @@ for name, B, Lq, Lk, self_attn in (('text self', 48, 80, 80, True), ('pano self'
         tf, tb = timeit(fwd), timeit(bwd)
         mb_f = (B * (Lq + 2 * Lk) * H * 2 + B * Lq * H * 2) / 1e6
         mb_b = (B * (Lq + 2 * Lk) * H * 2 * 2 + 2 * B * Lq * H * 2) / 1e6
-        print('%-11s B=%3d Lq=%2d Lk=%2d p=%.1f mask=%d | fwd %5.1f us (%.1f MB -> %.2f TB/s) | bwd %5.1f us (%.1f MB -> %.2f TB/s)' % (
+        print('%-12s B=%3d Lq=%3d Lk=%3d p=%.1f mask=%d | fwd %5.1f us (%.1f MB -> %.2f TB/s) | bwd %5.1f us (%.1f MB -> %.2f TB/s)' % (
             name, B, Lq, Lk, p, use_mask, tf, mb_f, mb_f / tf, tb, mb_b, mb_b / tb), flush=True)

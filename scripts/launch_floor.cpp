@@ -98,7 +98,28 @@ static double graph_time(hipStream_t st, int NL, F&& launch) {
   return best;
 }
 
+// GOAT_FLOOR_RANDOM=1: operands are N(0,1)-like random bf16 instead of the constant 0x1111 (DVFS: constant operands draw less
+// power and clock higher -- MI355X_MICROARCH.md "DVFS give-back"; the random numbers are what a training step sees)
+static void fill(uint16_t* dst, size_t n, bool rnd) {
+  if (!rnd) { CK(hipMemset(dst, 0x11, n * 2)); return; }
+  static std::vector<uint16_t> host;
+  if (host.size() < n) {
+    size_t old = host.size();
+    host.resize(n);
+    uint32_t s = 12345u + (uint32_t)old;
+    for (size_t i = old; i < n; ++i) {
+      s = s * 1664525u + 1013904223u;
+      const float f = ((int)(s >> 8) - (1 << 23)) / (float)(1 << 22);      // uniform in [-2, 2)
+      uint32_t b; memcpy(&b, &f, 4);
+      host[i] = (uint16_t)(b >> 16);
+    }
+  }
+  CK(hipMemcpy(dst, host.data(), n * 2, hipMemcpyHostToDevice));
+}
+
 int main(int argc, char** argv) {
+  const bool rnd = getenv("GOAT_FLOOR_RANDOM") != nullptr;
+  printf("operands: %s\n", rnd ? "random bf16 in [-2, 2)" : "constant 0x1111");
   CK(hipSetDevice(0));
   hipStream_t st;
   CK(hipStreamCreate(&st));
@@ -120,8 +141,8 @@ int main(int argc, char** argv) {
       CK(hipMalloc(&A[i], (size_t)s.M * s.K * 2));
       CK(hipMalloc(&B[i], (size_t)s.N * s.K * 2));
       CK(hipMalloc(&C[i], (size_t)s.M * s.N * 2));
-      CK(hipMemset(A[i], 0x11, (size_t)s.M * s.K * 2));
-      CK(hipMemset(B[i], 0x11, (size_t)s.N * s.K * 2));
+      fill(A[i], (size_t)s.M * s.K, rnd);
+      fill(B[i], (size_t)s.N * s.K, rnd);
     }
     const int tiles_m = (s.M + s.bm - 1) / s.bm, tiles_n = (s.N + s.bn - 1) / s.bn, grid = tiles_m * tiles_n;
     const bool pp = (s.ns & GOAT_GEMM_PP) != 0;
@@ -160,7 +181,7 @@ int main(int argc, char** argv) {
       CK(hipMalloc(&bias, s.N * 4));
       CK(hipMemset(bias, 0, s.N * 4));
       std::vector<uint16_t*> X(ROT);
-      for (int i = 0; i < ROT; ++i) { CK(hipMalloc(&X[i], (size_t)s.M * s.N * 2)); CK(hipMemset(X[i], 0x11, (size_t)s.M * s.N * 2)); }
+      for (int i = 0; i < ROT; ++i) { CK(hipMalloc(&X[i], (size_t)s.M * s.N * 2)); fill(X[i], (size_t)s.M * s.N, rnd); }
       struct E { int epi; bool bias, aux; const char* name; };
       const E es[] = {{GOAT_EPI_NONE, true, false, "bias"}, {GOAT_EPI_GELU, true, true, "bias+GELU, aux store"}, {GOAT_EPI_GELU, true, false, "bias+GELU, no aux"},
                       {GOAT_EPI_MUL_DGELU, false, true, "x GELU'(aux)"}};

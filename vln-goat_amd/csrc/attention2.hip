@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(AttnArgs p) {
   GOAT_STAMP(0);
   {
     const StageOp ops[3] = {{Kb, kl, p.k_rs, p.Lk, NKT * 32}, {Vb, vl, p.v_rs, p.Lk, NKT * 32}, {Qb, ql, p.q_rs, p.Lq, nqt * 32}};
-    stage_ops<3, 8>(ops, tid, nth);
+    stage_ops<3, 12>(ops, tid, nth);      // (80 x 80 on three waves: 12 chunks per lane, one round trip)
   }
   for (int i = tid; i < NKT * 32; i += nth) kml[i] = i < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + i] : 0.f) : -INFINITY;
   GOAT_STAMP(1);
@@ -477,6 +477,265 @@ __global__ __launch_bounds__(512) void attn2_bwd_kernel(AttnArgs p) {
 #undef GOAT_DVB
 }
 
+
+// ======================================================================================== backward, shared dS (round 5)
+// The kernel above computes S, dP, the exponentials and the dropout bits of every (query tile, key tile) pair TWICE: once in the
+// query-major role that accumulates dQ and once in the key-major role that accumulates dK / dV (profiles/round4_step_breakdown.txt:
+// 42 us x 17 per step, VALU-bound).  Here every pair is visited once, in the key-major orientation (lane = key, registers = queries):
+//   phase 1: wave kt < nkt owns key tile kt, loops over the query tiles, accumulates dK^T and dV^T in registers as before and leaves
+//            dS (already scaled, bf16) in an LDS image ds[query][key]; the bias gradient (un-scaled dS) is added from here (lane = key:
+//            coalesced atomics);
+//   barrier;
+//   phase 2: the waves hand dK / dV out through the (dead) V tiles, then take the query tiles in turn: dQ^T[d, q] = sum_k K^T[d, k]
+//            dS^T[k, q] — K^T by transposed LDS reads of the staged K rows, dS rows straight from the image (lane = query, 8
+//            consecutive keys = one 16-byte read).  4 MFMAs per (query tile, key tile).
+// Workgroup = max(nkt, 2) waves (the old kernel: nqt + nkt waves of 245 registers — ONE workgroup per CU, 576 text heads in three
+// rounds over the 256 CUs; 3-wave workgroups fit twice).  LDS: the four operands as before + the dS image ((32 nqt) x (32 nkt + 8)
+// bf16): 76 KiB for 80 x 80, 46 KiB for 36 x 36, 146 KiB for 160 x 160 (the old kernel needed its multi-role form there).
+constexpr int DSP = 8;       // padding of a dS row in elements (16 bytes: row stride 16 mod 128 bytes -> conflict-free 16-byte row reads)
+// A fragment "fixed column, 8 consecutive rows": rows row_base + 16*step + 8*hi + {0..7} of column dt*32 + l31
+__device__ __forceinline__ bf16x8 bfrag_nrow(const bf16_t* lds, int row_base, int step, int dt, int lane) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+  const int g = lane >> 4, t15 = lane & 15;
+  const int col = dt * 32 + (g & 1) * 16 + (t15 & 3) * 4;
+  const int r0 = row_base + 16 * step + 8 * (g >> 1) + (t15 >> 2);
+  bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(lds + r0 * LSTR + col));
+  bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(lds + (r0 + 4) * LSTR + col));
+  bf16x8 f;
+  f[0] = v0[0]; f[1] = v0[1]; f[2] = v0[2]; f[3] = v0[3];
+  f[4] = v1[0]; f[5] = v1[1]; f[6] = v1[2]; f[7] = v1[3];
+  return f;
+}
+
+__global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+  const int nqt = (p.Lq + 31) / 32, nkt = (p.Lk + 31) / 32;
+  const int DSS = nkt * 32 + DSP;                               // dS row stride in elements
+  bf16_t* ql = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* dol = ql + nqt * TILE;
+  bf16_t* kl = dol + nqt * TILE;
+  bf16_t* vl = kl + nkt * TILE;
+  bf16_t* dsl = vl + nkt * TILE;
+  float* Dl = reinterpret_cast<float*>(dsl + nqt * 32 * DSS);   // D_q = sum_d dO[q,d] O[q,d]
+  float* lsel = Dl + nqt * 32;
+  float* kml = lsel + nqt * 32;
+
+  const bf16_t* Qb = reinterpret_cast<const bf16_t*>(p.Q) + b * p.q_bs + h * HD;
+  const bf16_t* Kb = reinterpret_cast<const bf16_t*>(p.K) + b * p.k_bs + h * HD;
+  const bf16_t* Vb = reinterpret_cast<const bf16_t*>(p.V) + b * p.v_bs + h * HD;
+  const bf16_t* Ob = reinterpret_cast<const bf16_t*>(p.O) + b * p.o_bs + h * HD;
+  const bf16_t* dOb = reinterpret_cast<const bf16_t*>(p.dO) + b * p.do_bs + h * HD;
+  // Staging: the first DD chunks per lane of dO and of O are requested BEFORE Q / K / V (registers are free here), so that a head's
+  // operands cost about one HBM round trip (80 x 80 on three waves: 4 + 4 + 12 16-byte loads per lane, all in flight together;
+  // the first version — Q / K / V in two rounds of 8, then dO / O — spent three dependent round trips, 6 of a workgroup's ~17 us).
+  constexpr int DD = 4;
+#define GOAT_DO_LOAD(c0_)                                                                          \
+  _Pragma("unroll") for (int d = 0; d < DD; ++d) {                                                 \
+    const int c = (c0_) + d * nth, r = c >> 3, cc = c & 7;                                         \
+    dv[d] = uint4{0u, 0u, 0u, 0u};                                                                 \
+    ov[d] = uint4{0u, 0u, 0u, 0u};                                                                 \
+    if (c < nqt * 32 * 8 && r < p.Lq) {                                                            \
+      dv[d] = *reinterpret_cast<const uint4*>(dOb + (int64_t)r * p.do_rs + cc * NE);               \
+      ov[d] = *reinterpret_cast<const uint4*>(Ob + (int64_t)r * p.o_rs + cc * NE);                 \
+    }                                                                                              \
+  }
+  // dO -> LDS, with D_q on the way: the 8 lanes that move a row's eight 16-byte chunks reduce their partial dot products
+#define GOAT_DO_PUT(c0_)                                                                           \
+  _Pragma("unroll") for (int d = 0; d < DD; ++d) {                                                 \
+    const int c = (c0_) + d * nth, r = c >> 3, cc = c & 7;                                         \
+    const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(&dv[d]), o8 = *reinterpret_cast<const bf16x8*>(&ov[d]); \
+    float part = 0.f;                                                                              \
+    _Pragma("unroll") for (int e = 0; e < NE; ++e) part += (float)d8[e] * (float)o8[e];            \
+    part += __shfl_xor(part, 1, 64);                                                               \
+    part += __shfl_xor(part, 2, 64);                                                               \
+    part += __shfl_xor(part, 4, 64);                                                               \
+    if (c < nqt * 32 * 8) {                                                                        \
+      *reinterpret_cast<uint4*>(dol + r * LSTR + cc * NE) = dv[d];                                 \
+      if (cc == 0) Dl[r] = part;                                                                   \
+    }                                                                                              \
+  }
+  {
+    uint4 dv[DD], ov[DD];
+    GOAT_DO_LOAD(tid);
+    {
+      // Q | K | V rows as one index space of 16-byte chunks, SD loads in flight per lane; the LDS destination is recomputed from the
+      // chunk index at the store (stage_ops keeps SD pointers alive beside the data: with SD = 12 it spilled 77 registers here)
+      constexpr int SD = 12;
+      const int nq8 = nqt * 32 * 8, nk8 = nkt * 32 * 8, total = nq8 + 2 * nk8;
+      for (int c0 = tid; c0 < total; c0 += nth * SD) {
+        uint4 v[SD];
+#pragma unroll
+        for (int d = 0; d < SD; ++d) {
+          const int c = c0 + d * nth;
+          const int w = c < nq8 ? 0 : (c < nq8 + nk8 ? 1 : 2);
+          const int cl = c - (w == 0 ? 0 : (w == 1 ? nq8 : nq8 + nk8)), r = cl >> 3, cc = cl & 7;
+          const bf16_t* src = (w == 0 ? Qb + (int64_t)r * p.q_rs : (w == 1 ? Kb + (int64_t)r * p.k_rs : Vb + (int64_t)r * p.v_rs)) + cc * NE;
+          v[d] = uint4{0u, 0u, 0u, 0u};
+          if (c < total && r < (w == 0 ? p.Lq : p.Lk)) v[d] = *reinterpret_cast<const uint4*>(src);
+        }
+#pragma unroll
+        for (int d = 0; d < SD; ++d) {
+          const int c = c0 + d * nth;
+          const int w = c < nq8 ? 0 : (c < nq8 + nk8 ? 1 : 2);
+          const int cl = c - (w == 0 ? 0 : (w == 1 ? nq8 : nq8 + nk8)), r = cl >> 3, cc = cl & 7;
+          bf16_t* dst = (w == 0 ? ql : (w == 1 ? kl : vl)) + r * LSTR + cc * NE;
+          if (c < total) *reinterpret_cast<uint4*>(dst) = v[d];
+        }
+      }
+    }
+    GOAT_DO_PUT(tid);
+  }
+  for (int c0 = tid + nth * DD; c0 < nqt * 32 * 8; c0 += nth * DD) {      // (longer sequences)
+    uint4 dv[DD], ov[DD];      // (arrays of their own: shared with the hoisted first pass they end up in scratch memory)
+    GOAT_DO_LOAD(c0);
+    GOAT_DO_PUT(c0);
+  }
+#undef GOAT_DO_LOAD
+#undef GOAT_DO_PUT
+  for (int i = tid; i < nqt * 32; i += nth) lsel[i] = i < p.Lq ? p.lse[((int64_t)b * p.nh + h) * p.Lq + i] : -INFINITY;
+  for (int i = tid; i < nkt * 32; i += nth) kml[i] = i < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + i] : 0.f) : -INFINITY;
+  __syncthreads();
+
+  const bool drop = p.p > 0.f;
+  const uint32_t thr = goat_thr16(p.p);
+  const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
+  const HeadRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull), p.offset, (uint32_t)blockIdx.x);
+  f32x16 ra[2], rb[2];           // phase 1: ra = dK^T, rb = dV^T; phase 2: ra = dQ^T
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ra[dt][r] = 0.f; rb[dt][r] = 0.f; }
+
+  if (wave < nkt) {
+    // ---- phase 1, key tile `wave`: lane = key.  S = Q·K^T, dP = dO·V^T per query tile; dV^T += dO^T·Pd, dK^T += Q^T·dS; dS -> LDS
+    const int k0 = wave * 32, key = k0 + l31;
+    const bool kv = key < p.Lk;
+    bf16x8 kf[KSTEPS], vf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      kf[ks] = lds_frag(kl + k0 * LSTR, l31, ks, hi);
+      vf[ks] = lds_frag(vl + k0 * LSTR, l31, ks, hi);
+    }
+    const float kmv = kml[key];
+    // (bias / its gradient: one 64-bit base per sample + 32-bit element offsets — with 64-bit addresses per register the compiler
+    // hoisted sixteen of them out of the query-tile loop and spilled them)
+    const float* bias_b = p.bias ? p.bias + (int64_t)b * p.Lq * p.Lk : nullptr;
+    float* dbias_b = p.dbias ? p.dbias + (int64_t)b * p.Lq * p.Lk : nullptr;
+    // dropout bits: the pair hash of (q * Lk + key) >> 1 serves this lane and its neighbour (key ^ 1) when q * Lk is even: with an even
+    // Lk every lane hashes half of its 16 queries and takes the other half from lane ^ 1 (one DPP move instead of a second hash)
+    const bool lk_even = (p.Lk & 1) == 0;
+    for (int it = 0; it < nqt; ++it) {
+      const int q0 = it * 32;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        mma32(s, lds_frag(ql + q0 * LSTR, l31, ks, hi), kf[ks]);
+        mma32(dp, lds_frag(dol + q0 * LSTR, l31, ks, hi), vf[ks]);
+      }
+      float lq[16], dq[16];                 // lse and D of this lane's 16 queries (q0 + 4*hi + 8*g + {0..3})
+      load_kmask(lsel, it, hi, lq);
+      load_kmask(Dl, it, hi, dq);
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int q = q0 + c_row(r, lane);
+          s[r] = s[r] * p.scale + ((q < p.Lq && kv) ? bias_b[(uint32_t)(q * p.Lk + key)] : 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] *= p.scale;
+      }
+      bf16x8 apf[TSTEPS], asf[TSTEPS];      // P (dropped) and dS as the MFMA fragments of k-step 0 / 1 (registers r8 / r8 + 8)
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+        // pair hashes of elements (query of register r8, key) and (query of register r8 + 8, key)
+        uint32_t h0 = 0, h1 = 0;
+        if (drop) {
+          if (lk_even) {
+            // even lanes hash register r8, odd lanes register r8 + 8 (lane and lane ^ 1 hold the same queries and share the pair index)
+            const int odd = lane & 1;
+            const uint32_t qh = (uint32_t)(q0 + (odd ? c_row(r8 + 8, lane) : c_row(r8, lane)));
+            const uint32_t mine = rng.pair((qh * (uint32_t)p.Lk + (uint32_t)key) >> 1);
+            const uint32_t theirs = (uint32_t)__shfl_xor((int)mine, 1, 64);
+            h0 = odd ? theirs : mine;
+            h1 = odd ? mine : theirs;
+          } else {
+            h0 = rng.pair(((uint32_t)(q0 + c_row(r8, lane)) * (uint32_t)p.Lk + (uint32_t)key) >> 1);
+            h1 = rng.pair(((uint32_t)(q0 + c_row(r8 + 8, lane)) * (uint32_t)p.Lk + (uint32_t)key) >> 1);
+          }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int r = r8 + 8 * half;
+          const int q = q0 + c_row(r, lane);
+          // (padded queries: lse = -inf -> exp(+inf) would be inf: guarded; masked keys: kmv = -inf -> 0)
+          const float pr = (lq[r] != -INFINITY && kv) ? __expf(s[r] + kmv - lq[r]) : 0.f;
+          float keep = 1.f;
+          if (drop) {
+            const uint32_t idx = (uint32_t)q * (uint32_t)p.Lk + (uint32_t)key, hh = half ? h1 : h0;
+            keep = (((idx & 1u) ? (hh >> 16) : (hh & 0xFFFFu)) >= thr) ? keep_scale : 0.f;
+          }
+          const float d = pr * (dp[r] * keep - dq[r]);
+          s[r] = d;
+          apf[half][r8] = (bf16_t)(pr * keep);
+          asf[half][r8] = (bf16_t)(d * p.scale);
+        }
+      }
+      if (p.dbias != nullptr && kv) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int q = q0 + c_row(r, lane);
+          if (q < p.Lq) atomicAdd(dbias_b + (uint32_t)(q * p.Lk + key), s[r]);
+        }
+      }
+      // dS image: element (query, key) as bf16; the 32 lanes of a half write 64 contiguous bytes of one row
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dsl[(q0 + c_row(r, lane)) * DSS + key] = asf[r >> 3][r & 7];
+#pragma unroll
+      for (int st = 0; st < TSTEPS; ++st) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          mma32(rb[dt], bfrag_crow(dol, q0, st, dt, lane), apf[st]);
+          mma32(ra[dt], bfrag_crow(ql, q0, st, dt, lane), asf[st]);
+        }
+      }
+    }
+  }
+  __syncthreads();      // the dS image is complete; Q, dO and V are dead from here on
+#define GOAT_DQB (reinterpret_cast<bf16_t*>(p.dQ) + b * p.dq_bs + h * HD)
+#define GOAT_DKB (reinterpret_cast<bf16_t*>(p.dK) + b * p.dk_bs + h * HD)
+#define GOAT_DVB (reinterpret_cast<bf16_t*>(p.dV) + b * p.dv_bs + h * HD)
+  if (wave < nkt) {
+    store_tile(vl + wave * TILE, ra, GOAT_DKB, p.dk_rs, wave * 32, p.Lk, lane);
+    store_tile(vl + wave * TILE, rb, GOAT_DVB, p.dv_rs, wave * 32, p.Lk, lane);
+  }
+  // ---- phase 2, query tiles wave, wave + #waves, ...: lane = query.  dQ^T += K^T · dS^T over all key tiles
+  for (int qt = wave; qt < nqt; qt += (nth >> 6)) {
+    const int q0 = qt * 32;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ra[dt][r] = 0.f;
+    for (int jt = 0; jt < nkt; ++jt) {
+#pragma unroll
+      for (int st = 0; st < TSTEPS; ++st) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dsl + (q0 + l31) * DSS + jt * 32 + st * 16 + hi * 8);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) mma32(ra[dt], bfrag_nrow(kl, jt * 32, st, dt, lane), a);
+      }
+    }
+    store_tile(ql + qt * TILE, ra, GOAT_DQB, p.dq_rs, q0, p.Lq, lane);
+  }
+#undef GOAT_DQB
+#undef GOAT_DKB
+#undef GOAT_DVB
+}
+
 template <typename K>
 int set_smem(K kern, size_t bytes, size_t& cur) {
   if (bytes > 64 * 1024 && bytes > cur) {
@@ -494,7 +753,7 @@ int launch_fwd(hipStream_t st, const AttnArgs& a) {
   static size_t cur = 0;
   if (int e = set_smem(attn2_fwd_kernel<NKT>, sm, cur)) return e;
   if (sm > 160 * 1024) return GOAT_E_SHAPE;
-  hipLaunchKernelGGL(attn2_fwd_kernel<NKT>, dim3(a.B * a.nh), dim3(64 * (nqt < 4 ? nqt : 4)), sm, st, a);
+  hipLaunchKernelGGL(attn2_fwd_kernel<NKT>, dim3(a.B * a.nh), dim3(64 * (nqt < 2 ? 2 : (nqt < 4 ? nqt : 4))), sm, st, a);   // (one query tile: a second wave helps staging K / V)
   GOAT_LAUNCH_CHECK();
   return 0;
 }
@@ -529,6 +788,18 @@ int goat_attn2_bwd(hipStream_t st, const AttnArgs& a) {
   if ((reinterpret_cast<uintptr_t>(a.O) & 15) || (reinterpret_cast<uintptr_t>(a.dO) & 15) || (reinterpret_cast<uintptr_t>(a.dQ) & 15) ||
       (reinterpret_cast<uintptr_t>(a.dK) & 15) || (reinterpret_cast<uintptr_t>(a.dV) & 15))
     return GOAT_E_SHAPE;
+  // GOAT_ATTN_BWD_DUP=1: the round-2 kernel (both roles recompute S / dP) for every problem (A/B experiments)
+  static const bool shared_ds = !(getenv("GOAT_ATTN_BWD_DUP") && getenv("GOAT_ATTN_BWD_DUP")[0] == '1');
+  if (shared_ds) {
+    const size_t sms = (size_t)(2 * nqt + 2 * nkt) * TILE * 2 + (size_t)nqt * 32 * (nkt * 32 + DSP) * 2 + (size_t)(2 * nqt + nkt) * 32 * 4;
+    if (sms <= 160 * 1024) {
+      static size_t cur_s = 0;
+      if (int e = set_smem(attn2_bwd_shared_kernel, sms, cur_s)) return e;
+      hipLaunchKernelGGL(attn2_bwd_shared_kernel, dim3(a.B * a.nh), dim3(64 * (nkt > 2 ? nkt : 2)), sms, st, a);
+      GOAT_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   const int nwv = nqt + nkt <= 8 ? nqt + nkt : 8;
   const size_t sm = (size_t)(2 * nqt + 2 * nkt) * TILE * 2 + (size_t)(2 * nqt + nkt) * 32 * 4 + (nqt + nkt > 8 ? (size_t)nwv * TILE * 2 : 0);
   if (sm > 160 * 1024) return GOAT_E_SHAPE;          // (e.g. 200 x 200: the caller falls back to the streaming kernels of attention.hip)
