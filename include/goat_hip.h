@@ -61,6 +61,9 @@ int goat_gemm_nt(void* stream, int dtype_in, int dtype_out,
 #define GOAT_GEMM_PP 0x200       /* flag in nstage: the "ping-pong" main loop (csrc/gemm5_tile.hpp) — two groups of four waves half a
                                     K-tile out of phase, one feeding the matrix pipe while the other loads; tiles 256x256, 192x256 (K-contiguous
                                     A only), 128x256, 256x128, 128x128, nstage 2; same operands, epilogues and (bit-identical) results */
+#define GOAT_GEMM_PERSIST 0x400  /* flag in nstage, with GOAT_GEMM_PP: one workgroup per CU walks the tiles of its XCD's chunk and requests the next
+                                    tile's first K-tile before the current tile's epilogue (bf16 results, unsplit, K-contiguous A; bit-identical
+                                    results; pays when the problem has more tiles than the chip has CUs, e.g. per-rank batch 256) */
 
 /* Pipelined bf16 GEMM with direct-to-LDS (LDS-DMA) operand staging, all operand layouts (csrc/gemm2.hip):
  *   C[M,N] = epilogue( op(A) · op(B)ᵀ + bias ),  contraction length Kc

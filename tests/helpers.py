@@ -80,6 +80,56 @@ def fingerprint(grad):
     return np.concatenate([[float(flat.double().norm())], first.numpy()]).astype(np.float32)
 
 
+# ---- seeded random projections of a gradient tensor (VERDICT r4 #5a) -------------------------------------------------------------
+# The fingerprint above pins the L2 norm and the first 8 elements: a wrong element past index 8 that preserves the norm to 2e-3 would
+# pass.  NPROJ inner products <g, r_j> with fixed pseudo-random vectors r_j in [-1, 1) cover EVERY element for 4 more numbers per
+# tensor.  r_j[i] is an integer hash of (i, j) — exact in numpy (uint64) and in torch (int64, on any device), so the generator (CPU,
+# imported reference) and the GPU tests build bit-identical vectors without storing or transferring them.
+NPROJ = 4
+
+
+def _proj_hash(idx, j, xp):
+    """idx: int64 / uint64 array of element indices -> values in [-1, 1) (float64).  32-bit multiply-xorshift, all arithmetic mod 2^32."""
+    m = 0xFFFFFFFF
+    x = (idx * 2654435761 + (j + 1) * 40503) & m
+    x = x ^ (x >> 15)
+    x = (x * 0x2C1B3C6D) & m
+    x = x ^ (x >> 12)
+    x = (x * 0x297A2D39) & m
+    x = x ^ (x >> 15)
+    return x
+
+
+def proj_vector_np(n, j):
+    x = _proj_hash(np.arange(n, dtype=np.uint64), j, np)
+    return (x & np.uint64(0xFFFF)).astype(np.float64) / 32768.0 - 1.0
+
+
+def projections(grad):
+    """[NPROJ] float64: <grad.flatten(), r_j> accumulated in float64 (zeros for a missing gradient).  Works for numpy arrays and for
+    torch tensors on any device (the hash runs where the tensor lives)."""
+    out = np.zeros(NPROJ, dtype=np.float64)
+    if grad is None:
+        return out
+    if torch.is_tensor(grad):
+        flat = grad.detach().reshape(-1).double()
+        idx = torch.arange(flat.numel(), dtype=torch.int64, device=flat.device)
+        for j in range(NPROJ):
+            r = (_proj_hash(idx, j, torch) & 0xFFFF).double() / 32768.0 - 1.0
+            out[j] = float((flat * r).sum())
+        return out
+    flat = np.asarray(grad, dtype=np.float64).reshape(-1)
+    for j in range(NPROJ):
+        out[j] = float(np.dot(flat, proj_vector_np(flat.size, j)))
+    return out
+
+
+def check_projections(got, ref, norm, tol, what=''):
+    """|<g, r_j> - reference| <= tol * ||g_ref|| for every j (an elementwise error e moves a projection by <e, r_j> ~ 0.58 ||e||)."""
+    err = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64)).max()
+    assert err <= tol * float(norm) + 1e-9, (what, err, float(norm), list(got), list(ref))
+
+
 def oracle_run(cfg, sd, batch, task, autocast_bf16=False):
     """Runs the oracle with autograd; returns (loss_vec, {name: grad}) for the parameter tensors in sd.
     autocast_bf16: the same restatement under stock torch.autocast(bfloat16) on the CPU — the yardstick the GPU tests use

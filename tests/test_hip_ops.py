@@ -728,6 +728,36 @@ def test_gemm_bf16_every_tile_configuration(ops, ta, tb, bm, ns):
     _close(acc + 1.0, ref, torch.bfloat16, 'split-K')
 
 
+@pytest.mark.parametrize('tb', [False, True])
+@pytest.mark.parametrize('bm', [128, 256, 128 | 256 << 16, 192 | 256 << 16, 256 | 256 << 16])
+def test_gemm_bf16_persistent_matches_one_workgroup_per_tile(ops, bm, tb):
+    """GOAT_GEMM_PERSIST (0x400, with the ping-pong loop): one workgroup per CU walks several tiles and requests the next tile's first
+    K-tile before the current epilogue.  Results must be BIT-identical to the one-workgroup-per-tile launch, with more tiles than CUs
+    (ragged edges included) and with fewer; bias, GELU (+ saved pre-activation) and x GELU' epilogues."""
+    from vln_goat_amd._lib import EPI_GELU, EPI_MUL_DGELU, EPI_NONE
+    rows, cols = bm & 0xFFFF, (bm >> 16) or 128
+    if tb and cols & (cols - 1):
+        pytest.skip('a transposed operand needs a power-of-two tile width on its side')
+    for M, N, Kc in ((rows * 37 + 5, cols * 9 - 24, 320), (rows * 3, cols * 2, 768), (rows * 23, cols * 12, 64)):
+        g = torch.Generator().manual_seed(bm + M)
+        a = torch.randn(M, Kc, generator=g).to(DEV, torch.bfloat16)
+        B = torch.randn(N, Kc, generator=g) * 0.1
+        b = (B.T.contiguous() if tb else B).to(DEV, torch.bfloat16)
+        bias = torch.randn(N, generator=g).to(DEV)
+
+        def run(ns, epi=EPI_NONE, aux=None, bias_=None):
+            out = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
+            ops._launch_gemm_bf16(a, b, out, False, tb, M, N, Kc, bias_, epi, aux, 1, bm, ns, None)
+            return out
+        ref = run(0x202, bias_=bias)
+        got = run(0x602, bias_=bias)
+        assert torch.equal(ref, got), ('plain', M, N, Kc, float((ref.float() - got.float()).abs().max()))
+        _close(got, a.float() @ (b.float() if tb else b.float().T) + bias, torch.bfloat16, 'persistent vs torch')
+        aux0, aux1 = (torch.zeros(M, N, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+        assert torch.equal(run(0x202, EPI_GELU, aux0, bias), run(0x602, EPI_GELU, aux1, bias)) and torch.equal(aux0, aux1)
+        assert torch.equal(run(0x202, EPI_MUL_DGELU, aux0), run(0x602, EPI_MUL_DGELU, aux0))
+
+
 def test_wgrad_grouped(ops):
     """goat_wgrad_grouped: several dW_i = dY_i^T · X_i problems of different shapes (ragged rows, row-strided dY) in one
     launch, with bias column sums; both tile heights."""

@@ -70,8 +70,10 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   if (!A || !B || !C) return GOAT_E_ARG;
   const bool eight = (nstage & GOAT_GEMM_8WAVES) != 0;
   const bool pp = (nstage & GOAT_GEMM_PP) != 0;               // the ping-pong main loop (gemm5_tile.hpp)
-  nstage &= ~(GOAT_GEMM_8WAVES | GOAT_GEMM_PP);
+  const bool persist = (nstage & GOAT_GEMM_PERSIST) != 0;     // ... as one workgroup per CU walking the tiles
+  nstage &= ~(GOAT_GEMM_8WAVES | GOAT_GEMM_PP | GOAT_GEMM_PERSIST);
   if (nstage < 2 || nstage > 4) return GOAT_E_ARG;
+  if (persist && !pp) return GOAT_E_ARG;
   int bn = (bm >> 16) & 0xFFFF;
   bm &= 0xFFFF;
   if (bn == 0) bn = 128;
@@ -106,7 +108,7 @@ extern "C" int goat_gemm_bf16(void* stream, int trans_a, int trans_b, int dtype_
   if (split_k > kt) split_k = kt;
   a.k_tiles_per_split = (kt + split_k - 1) / split_k;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (pp) return goat_g5_dispatch(st, a, bm, bn, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
+  if (pp) return goat_g5_dispatch(st, a, bm, bn, trans_a, trans_b, dtype_out, epilogue, split_k, nstage, persist);
   if (bn != 128 || bm == 96) return goat_g3_dispatch(st, a, bm, bn, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
   if (bm == 64) return dispatch_layout<T64>(st, a, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);
   if (bm == 256) return dispatch_layout<T256>(st, a, trans_a, trans_b, dtype_out, epilogue, split_k, nstage);

@@ -5,7 +5,15 @@
 using namespace goat_g5;
 
 int goat_g5_dispatch(hipStream_t st, const goat_g2::G2Args& a, int bm, int bn, int trans_a, int trans_b, int dtype_out, int epi,
-                     int split, int nstage) {
+                     int split, int nstage, bool persist) {
+  if (persist) {
+    if (bm == 256 && bn == 256 && nstage == 2) return pp_dispatch_persist<P256x256>(st, a, trans_a, trans_b, dtype_out, epi, split);
+    if (bm == 192 && bn == 256 && nstage == 2) return pp_dispatch_persist<P192x256>(st, a, trans_a, trans_b, dtype_out, epi, split);
+    if (bm == 128 && bn == 256 && nstage == 2) return pp_dispatch_persist<P128x256>(st, a, trans_a, trans_b, dtype_out, epi, split);
+    if (bm == 256 && bn == 128 && nstage == 2) return pp_dispatch_persist<P256x128>(st, a, trans_a, trans_b, dtype_out, epi, split);
+    if (bm == 128 && bn == 128 && nstage == 2) return pp_dispatch_persist<P128x128>(st, a, trans_a, trans_b, dtype_out, epi, split);
+    return GOAT_E_ARG;
+  }
   if (bm == 256 && bn == 256 && nstage == 2) return pp_dispatch_layout<P256x256>(st, a, trans_a, trans_b, dtype_out, epi, split);
   if (bm == 192 && bn == 256 && nstage == 2) return pp_dispatch_layout<P192x256>(st, a, trans_a, trans_b, dtype_out, epi, split);
   if (bm == 128 && bn == 256 && nstage == 2) return pp_dispatch_layout<P128x256>(st, a, trans_a, trans_b, dtype_out, epi, split);

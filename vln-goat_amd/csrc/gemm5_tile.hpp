@@ -608,9 +608,389 @@ int pp_launch_group(hipStream_t st, const GroupArgs& g) {
   return 0;
 }
 
+
+// ======================================================================================== persistent form (round 5)
+// pp_kernel gives every tile a workgroup of its own: a tile's first K-tile is requested when its workgroup starts (cold: ~1-2 us before
+// the first MFMA) and its epilogue (bias / activation, LDS transposition, 16-byte stores: a third of a K = 768 launch together with
+// the prologue) runs with the matrix pipe idle.  When a problem has more tiles than the chip has CUs (M = 20 480 at
+// per-rank batch 256: 1 284 tiles of 192 x 256) the grid here is ONE workgroup per CU and every workgroup walks its share of its XCD's
+// chunk of the tile order; the first K-tile of the NEXT tile (B[0] by group 0; A_0[0], A_1[0], A_0[1] by group 1 — what the prologue
+// issues) is requested BEFORE the epilogue of the current one, so the requests cross the fabric while the results are converted and
+// stored.  The epilogue's per-wave staging slices move out of the way of those DMA targets: into B buffer 1 (the first BSZ / WSLICE
+// waves) and A_1 buffer 1 (the rest), which receive nothing before the barrier that opens the next tile's main loop (every wave
+// passes it after its own epilogue).  bf16 results, unsplit, K-contiguous A (TA = false); same tile order inside an XCD chunk, same
+// arithmetic per tile: results are bit-identical to pp_kernel's.
+template <class CF, bool TB, int EPI>
+__device__ __forceinline__ void pp_tiles_persist(const G2Args& p, int pos0, int pos_step, int pos_end) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr bool TA = false;
+  constexpr int MI = CF::MI, NI = CF::NI, NB = CF::NB, BM = CF::BM, BN = CF::BN, AH = CF::AH, BSZ = CF::BSZ;
+  static_assert(NB == 2, "the persistent form is written for two B buffers");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef Blk<TA, 32 * MI> BA;
+  typedef Blk<TB, 128 * NI> BB;
+  constexpr int PPW_A = BA::NP / 4, PPW_B = BB::NP / 4;
+  constexpr int WROWS = 32 * MI, WCOLS = 32 * NI;
+  constexpr bool SWAP = true;
+  constexpr uint32_t B_BASE = 4 * AH;
+  if (pos0 >= pos_end) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int nkt = (p.Kc + BK - 1) / BK;
+
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)p.b_bytes, 0x00020000);
+
+  uint32_t va[4], vb[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    va[x] = BA::frag_lane(lane, x) + (uint32_t)(grp * 2 * AH);
+    if (!TB) vb[x] = BB::frag_lane(lane, x) + (uint32_t)(wn * WCOLS * 128) + B_BASE;
+    else vb[x] = BB::frag_lane(lane, wn * NI + (x < NI ? x : 0)) + B_BASE;
+  }
+  f32x16 acc[MI][NI];
+  bf16x8 fa[4][MI], fb[4][NI];
+  constexpr bool do_colsum = false;
+  float bsum[MI];
+  (void)bsum;
+
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_void*)smem;
+  const uint32_t ka = (uint32_t)(BK * 2);
+  const uint32_t kb = TB ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
+
+#define PP_FRAGS_KS(KS, ao_, bo_)                                                                  \
+  do {                                                                                             \
+    fa[KS][0] = pp_frag<TA, BA::W, KS, 0>(va, ao_);                                                \
+    if constexpr (MI > 1) fa[KS][1 < MI ? 1 : 0] = pp_frag<TA, BA::W, KS, 1>(va, ao_);             \
+    if constexpr (MI > 2) fa[KS][2 < MI ? 2 : 0] = pp_frag<TA, BA::W, KS, 2>(va, ao_);             \
+    if constexpr (MI > 3) fa[KS][3 < MI ? 3 : 0] = pp_frag<TA, BA::W, KS, 3>(va, ao_);             \
+    fb[KS][0] = pp_frag<TB, BB::W, KS, 0>(vb, bo_);                                                \
+    if constexpr (NI > 1) fb[KS][1 < NI ? 1 : 0] = pp_frag<TB, BB::W, KS, 1>(vb, bo_);             \
+  } while (0)
+#define PP_MMA_ALL()                                                                               \
+  do {                                                                                             \
+    if (GOAT_G5_SETPRIO) __builtin_amdgcn_s_setprio(1);                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                               \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                               \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j) mma32(acc[i][j], fb[ks][j], fa[ks][i]);     \
+    if (GOAT_G5_SETPRIO) __builtin_amdgcn_s_setprio(0);                                            \
+  } while (0)
+  static_assert(NI <= 2 && MI <= 4, "fragment macros are written for MI <= 4, NI <= 2");
+  static_assert((CF::VAR & 3) == 1, "the persistent form uses DMA placement 1");
+#define PP_PERIOD(LOADS_, ao_, bo_, WAITVM_, LASTBAR_)                                             \
+  do {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    PP_FRAGS_KS(0, ao_, bo_);                                                                      \
+    { __builtin_amdgcn_sched_barrier(0); PP_ISSUE_RANGE(0, LOADS_ / 4); __builtin_amdgcn_sched_barrier(0); } \
+    PP_FRAGS_KS(1, ao_, bo_);                                                                      \
+    { __builtin_amdgcn_sched_barrier(0); PP_ISSUE_RANGE(LOADS_ / 4, LOADS_ / 2); __builtin_amdgcn_sched_barrier(0); } \
+    PP_FRAGS_KS(2, ao_, bo_);                                                                      \
+    { __builtin_amdgcn_sched_barrier(0); PP_ISSUE_RANGE(LOADS_ / 2, 3 * LOADS_ / 4); __builtin_amdgcn_sched_barrier(0); } \
+    PP_FRAGS_KS(3, ao_, bo_);                                                                      \
+    { __builtin_amdgcn_sched_barrier(0); PP_ISSUE_RANGE(3 * LOADS_ / 4, LOADS_); __builtin_amdgcn_sched_barrier(0); } \
+    wait_lgkm<0>();                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    PP_MMA_ALL();                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    WAITVM_;                                                                                       \
+    if (LASTBAR_) __builtin_amdgcn_s_barrier();                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+
+  // tile position -> (first row, first column), pp_tile's order
+  const int gsz = p.group_m * p.tiles_n;
+#define PP_COORDS(pos_, m0_, n0_)                                                                  \
+  do {                                                                                             \
+    const int grpi_ = (pos_) / gsz, gi_ = (pos_) - grpi_ * gsz;                                    \
+    const int gm_ = min(p.tiles_m - grpi_ * p.group_m, p.group_m);                                 \
+    const int tn_ = gi_ / gm_, tm_ = grpi_ * p.group_m + (gi_ - tn_ * gm_);                        \
+    m0_ = tm_ * BM; n0_ = tn_ * BN;                                                                \
+  } while (0)
+
+  // lane parts of the DMA source addresses (tile-independent)
+  uint32_t vo[(BB::NPAR > BA::NPAR ? BB::NPAR : BA::NPAR)];
+  uint32_t pstep;
+  if (grp == 0) {
+    const int par0 = (wn * PPW_B) % BB::NPAR;
+#pragma unroll
+    for (int q = 0; q < BB::NPAR; ++q) vo[q] = BB::lane_off(lane, (q + par0) % BB::NPAR, p.ldb);
+    pstep = BB::piece_org(1, 0, 0, p.ldb);
+  } else {
+    const int par0 = (wn * PPW_A) % BA::NPAR;
+#pragma unroll
+    for (int q = 0; q < BA::NPAR; ++q) vo[q] = BA::lane_off(lane, (q + par0) % BA::NPAR, p.lda);
+    pstep = BA::piece_org(1, 0, 0, p.lda);
+  }
+  // pieces [lo_, hi_) of this wave's share of B[t_] of the tile whose B origin is org_ -> B buffer buf_
+#define PP_ISSUE_B(org_, t_, buf_, lo_, hi_)                                                                   \
+  do {                                                                                                         \
+    char* dst_ = smem + B_BASE + (buf_) * BSZ + wn * PPW_B * 1024;                                             \
+    const uint32_t so_ = (org_) + (uint32_t)(t_) * kb;                                                         \
+    _Pragma("unroll") for (int j = (lo_); j < (hi_); ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(        \
+        rb, (lds_void*)(dst_ + j * 1024), 16, vo[j % BB::NPAR], so_ + (uint32_t)j * pstep, 0, 0);              \
+  } while (0)
+  // pieces [lo_, hi_) of this wave's share of the A half-block with origin org_ of K-tile t_ -> buffer buf_ of half h_
+#define PP_ISSUE_A(org_, h_, t_, buf_, lo_, hi_)                                                               \
+  do {                                                                                                         \
+    char* dst_ = smem + ((h_) * 2 + (buf_)) * AH + wn * PPW_A * 1024;                                          \
+    const uint32_t so_ = (org_) + (uint32_t)(t_) * ka;                                                         \
+    _Pragma("unroll") for (int j = (lo_); j < (hi_); ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(        \
+        ra, (lds_void*)(dst_ + j * 1024), 16, vo[j % BA::NPAR], so_ + (uint32_t)j * pstep, 0, 0);              \
+  } while (0)
+
+  int m0, n0;
+  PP_COORDS(pos0, m0, n0);
+  // the first tile's first K-tile (pp_tile's prologue)
+  if (grp == 0) {
+    const uint32_t org0 = BB::piece_org(wn * PPW_B, n0, 0, p.ldb);
+    PP_ISSUE_B(org0, 0, 0, 0, PPW_B);
+  } else {
+    const uint32_t org0 = BA::piece_org(wn * PPW_A, m0, 0, p.lda), org1 = BA::piece_org(wn * PPW_A, m0 + WROWS, 0, p.lda);
+    PP_ISSUE_A(org0, 0, 0, 0, 0, PPW_A);
+    PP_ISSUE_A(org1, 1, 0, 0, 0, PPW_A);
+    if (nkt > 1) PP_ISSUE_A(org0, 0, 1, 1, 0, PPW_A);
+  }
+
+  // epilogue staging (see the header comment): wave-private slices outside the next tile's first DMA targets
+  typedef bf16_t T;
+  constexpr int EPC = 8;
+  constexpr int RBY = WCOLS * 2 + 16;
+  constexpr int WSLICE = 32 * RBY;
+  constexpr int NFIT = BSZ / WSLICE < 8 ? BSZ / WSLICE : 8;
+  static_assert((8 - NFIT) * WSLICE <= AH, "the staging slices that do not fit B buffer 1 must fit A_1 buffer 1");
+  char* wsp = wave < NFIT ? smem + B_BASE + BSZ + wave * WSLICE : smem + 3 * AH + (wave - NFIT) * WSLICE;
+  constexpr int CPR = WCOLS / EPC;
+  constexpr int CHUNKS = 32 * CPR / 64;
+  constexpr bool DACT = (EPI == GOAT_EPI_MUL_DGELU || EPI == GOAT_EPI_MUL_DRELU);
+  constexpr bool ACT = (EPI == GOAT_EPI_GELU || EPI == GOAT_EPI_RELU);
+  T* aux = reinterpret_cast<T*>(p.aux);
+  T* C = reinterpret_cast<T*>(p.C);
+  const bool c_vec = (p.ldc % EPC) == 0 && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+  const bool aux_vec = aux != nullptr && (p.ldaux % EPC) == 0 && ((reinterpret_cast<uintptr_t>(aux) & 15) == 0);
+  const int wrow0 = grp * WROWS, wcol0 = wn * WCOLS;
+
+  for (int pos = pos0; pos < pos_end; pos += pos_step) {
+    const int npos = pos + pos_step;
+    const bool has_next = npos < pos_end;
+    int nm0 = 0, nn0 = 0;
+    if (has_next) PP_COORDS(npos, nm0, nn0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (grp == 0) {
+      const uint32_t org0 = BB::piece_org(wn * PPW_B, n0, 0, p.ldb);
+      wait_vm<0>();                                 // this tile's B[0] (and the previous tile's result stores)
+      __builtin_amdgcn_s_barrier();
+      int bbuf = 0;
+      for (int t = 0; t < nkt; ++t) {
+        const int nbuf = bbuf ^ 1;
+        const uint32_t ao = smem_base + (uint32_t)((t & 1) * AH), bo = smem_base + (uint32_t)(bbuf * BSZ);
+#define PP_ISSUE_RANGE(lo_, hi_) do { if (t + 1 < nkt) PP_ISSUE_B(org0, t + 1, nbuf, lo_, hi_); } while (0)
+        PP_PERIOD(PPW_B, ao, bo, wait_vm<0>(), true);
+#undef PP_ISSUE_RANGE
+        bbuf = nbuf;
+      }
+      if (has_next) {
+        const uint32_t orgn = BB::piece_org(wn * PPW_B, nn0, 0, p.ldb);
+        PP_ISSUE_B(orgn, 0, 0, 0, PPW_B);
+      }
+    } else {
+      const uint32_t org0 = BA::piece_org(wn * PPW_A, m0, 0, p.lda), org1 = BA::piece_org(wn * PPW_A, m0 + WROWS, 0, p.lda);
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();                 // slot 0: group 0 reads tile 0, nothing to compute here yet
+      int bbuf = 0;
+      for (int t = 0; t < nkt; ++t) {
+        const uint32_t ao = smem_base + (uint32_t)((t & 1) * AH), bo = smem_base + (uint32_t)(bbuf * BSZ);
+#define PP_ISSUE_RANGE(lo_, hi_)                                                                   \
+  do {                                                                                             \
+    if ((lo_) < PPW_A && t + 1 < nkt) PP_ISSUE_A(org1, 1, t + 1, (t + 1) & 1, (lo_), ((hi_) < PPW_A ? (hi_) : PPW_A)); \
+    if ((hi_) > PPW_A && t + 2 < nkt) PP_ISSUE_A(org0, 0, t + 2, t & 1, ((lo_) > PPW_A ? (lo_) - PPW_A : 0), (hi_) - PPW_A); \
+  } while (0)
+        PP_PERIOD(2 * PPW_A, ao, bo, wait_vm<0>(), (t + 1 < nkt));
+#undef PP_ISSUE_RANGE
+        bbuf ^= 1;
+      }
+      if (has_next) {
+        const uint32_t orgn0 = BA::piece_org(wn * PPW_A, nm0, 0, p.lda), orgn1 = BA::piece_org(wn * PPW_A, nm0 + WROWS, 0, p.lda);
+        PP_ISSUE_A(orgn0, 0, 0, 0, 0, PPW_A);
+        PP_ISSUE_A(orgn1, 1, 0, 0, 0, PPW_A);
+        if (nkt > 1) PP_ISSUE_A(orgn0, 0, 1, 1, 0, PPW_A);
+      }
+    }
+
+    // ---- epilogue of tile (m0, n0): pp_tile's bf16 epilogue on the relocated staging slices
+    {
+      const int col_w = n0 + wcol0;
+      f32x4 bv[DACT ? 1 : NI][4];
+      if (!DACT) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = col_w + j * 32 + 4 * hi + 8 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[j][q][e] = (p.bias != nullptr && col + e < p.N) ? p.bias[col + e] : 0.f;
+          }
+      }
+      constexpr int AD = MI < 3 ? MI : (MI == 4 ? 2 : 3);      // (256 x 256: three rows ahead spill beside the persistent loop's extra state)
+      uint4 auxv[DACT ? AD : 1][CHUNKS];
+      if (DACT) {
+#pragma unroll
+        for (int i = 0; i < AD; ++i) load_aux_rows<CHUNKS, CPR>(p, m0 + wrow0 + i * 32, col_w, lane, auxv[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row_w = m0 + wrow0 + i * 32;
+        if (DACT) {
+#pragma unroll
+          for (int c = 0; c < CHUNKS; ++c) {
+            const int idx = c * 64 + lane, r = idx / CPR, cc = idx % CPR;
+            *reinterpret_cast<uint4*>(wsp + r * RBY + cc * 16) = auxv[DACT ? i % AD : 0][c];
+          }
+          if (i + AD < MI) load_aux_rows<CHUNKS, CPR>(p, row_w + AD * 32, col_w, lane, auxv[DACT ? i % AD : 0]);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            char* slot = wsp + l31 * RBY + (j * 32 + 4 * hi + 8 * q) * 2;
+            float u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = DACT ? acc[i][j][4 * q + e] : acc[i][j][4 * q + e] + bv[DACT ? 0 : j][q][e];
+            if (DACT) {
+              const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(slot);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float av = (float)a4[e];
+                u[e] = (EPI == GOAT_EPI_MUL_DGELU) ? u[e] * dgelu_fast(av) : (av > 0.f ? u[e] : 0.f);
+              }
+            }
+            bf16x4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)u[e];
+            *reinterpret_cast<bf16x4*>(slot) = o4;
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c) {
+          const int idx = c * 64 + lane, r = idx / CPR, cc = idx % CPR;
+          const int row = row_w + r, col = col_w + cc * EPC;
+          uint4 raw = *reinterpret_cast<const uint4*>(wsp + r * RBY + cc * 16);
+          if (row >= p.M || col >= p.N) continue;
+          if (ACT) {
+            if (aux != nullptr) {
+              if (col + EPC <= p.N && aux_vec) {
+                store16(aux + (int64_t)row * p.ldaux + col, raw);
+              } else {
+                const T* rv = reinterpret_cast<const T*>(&raw);
+                for (int e = 0; e < EPC; ++e)
+                  if (col + e < p.N) aux[(int64_t)row * p.ldaux + col + e] = rv[e];
+              }
+            }
+            bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+              const float u = (float)v[e];
+              const float h = (EPI == GOAT_EPI_GELU) ? gelu_fast(u) : fmaxf(u, 0.f);
+              v[e] = (bf16_t)h;
+            }
+            raw = *reinterpret_cast<uint4*>(&v);
+          }
+          if (col + EPC <= p.N && c_vec) {
+            store16(C + (int64_t)row * p.ldc + col, raw);
+          } else {
+            const T* rv = reinterpret_cast<const T*>(&raw);
+            for (int e = 0; e < EPC; ++e)
+              if (col + e < p.N) C[(int64_t)row * p.ldc + col + e] = rv[e];
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    m0 = nm0;
+    n0 = nn0;
+  }
+#undef PP_ISSUE_A
+#undef PP_ISSUE_B
+#undef PP_COORDS
+#undef PP_PERIOD
+#undef PP_FRAGS_KS
+#undef PP_MMA_ALL
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <class CF, bool TB, int EPI>
+__global__ __launch_bounds__(512) void pp_persist_kernel(G2Args p) {
+  // workgroup w runs on XCD w % 8 (observed placement; only locality depends on it) and walks that XCD's chunk of the tile order
+  const int nt = p.tiles_m * p.tiles_n, nwg = gridDim.x, w = blockIdx.x, x = w & 7, j = w >> 3;
+  const int q = nt >> 3, r = nt & 7;
+  const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = q + (x < r ? 1 : 0);
+  const int J = (nwg >> 3) + ((nwg & 7) > x ? 1 : 0);
+  pp_tiles_persist<CF, TB, EPI>(p, start + j, J, start + cnt);
+}
+
+inline int pp_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+template <class CF, bool TB, int EPI>
+int pp_launch_persist(hipStream_t st, const G2Args& a) {
+  static_assert(CF::SMEM <= 160 * 1024, "LDS exceeds the CU's 160 KiB");
+  auto kern = pp_persist_kernel<CF, TB, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int nt = a.tiles_m * a.tiles_n, slots = pp_cu_count() * (CF::SMEM <= 80 * 1024 ? 2 : 1);
+  hipLaunchKernelGGL(kern, dim3(nt < slots ? nt : slots), dim3(512), CF::SMEM, st, a);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+
+// persistent launches: bf16 results, unsplit, K-contiguous A; anything else -> GOAT_E_ARG
+template <class CF>
+int pp_dispatch_persist(hipStream_t st, const G2Args& a, int trans_a, int trans_b, int dtype_out, int epi, int split) {
+  if (trans_a || split > 1 || dtype_out != GOAT_BF16) return GOAT_E_ARG;
+  if (!trans_b) {
+    switch (epi) {
+      case GOAT_EPI_NONE: return pp_launch_persist<CF, false, GOAT_EPI_NONE>(st, a);
+      case GOAT_EPI_GELU: return pp_launch_persist<CF, false, GOAT_EPI_GELU>(st, a);
+      case GOAT_EPI_RELU: return pp_launch_persist<CF, false, GOAT_EPI_RELU>(st, a);
+      case GOAT_EPI_MUL_DGELU: return pp_launch_persist<CF, false, GOAT_EPI_MUL_DGELU>(st, a);
+      case GOAT_EPI_MUL_DRELU: return pp_launch_persist<CF, false, GOAT_EPI_MUL_DRELU>(st, a);
+    }
+  } else {
+    switch (epi) {
+      case GOAT_EPI_NONE: return pp_launch_persist<CF, true, GOAT_EPI_NONE>(st, a);
+      case GOAT_EPI_GELU: return pp_launch_persist<CF, true, GOAT_EPI_GELU>(st, a);
+      case GOAT_EPI_RELU: return pp_launch_persist<CF, true, GOAT_EPI_RELU>(st, a);
+      case GOAT_EPI_MUL_DGELU: return pp_launch_persist<CF, true, GOAT_EPI_MUL_DGELU>(st, a);
+      case GOAT_EPI_MUL_DRELU: return pp_launch_persist<CF, true, GOAT_EPI_MUL_DRELU>(st, a);
+    }
+  }
+  return GOAT_E_ARG;
+}
+
 }  // namespace goat_g5
 
 // gemm5.hip
 int goat_g5_dispatch(hipStream_t st, const goat_g2::G2Args& a, int bm, int bn, int trans_a, int trans_b, int dtype_out, int epi,
-                     int split, int nstage);
+                     int split, int nstage, bool persist);
 int goat_g5_group(hipStream_t st, const goat_g2::GroupArgs& g, int bm, int bn, int nstage);

@@ -268,7 +268,10 @@ def save_tuned(path):
 
 EIGHT_WAVES = 0x100     # GOAT_GEMM_8WAVES (include/goat_hip.h): flag in the nstage argument of goat_gemm_bf16
 PINGPONG = 0x200        # GOAT_GEMM_PP: the ping-pong main loop (csrc/gemm5_tile.hpp); tiles 256x256, 192x256, 128x256, 256x128, 128x128
+PERSIST = 0x400         # GOAT_GEMM_PERSIST (with PINGPONG): one workgroup per CU walks the tiles, next tile's first K-tile requested before the epilogue
 USE_PP = os.environ.get('GOAT_GEMM_NO_PP', '0') == '0'
+USE_PERSIST = os.environ.get('GOAT_GEMM_NO_PERSIST', '0') == '0'
+N_CU = 256              # (MI355X; only decides which shapes get the persistent candidates timed)
 
 
 def tile(bm, bn=128):
@@ -281,7 +284,7 @@ def tile_name(t):
 
 
 def stage_name(ns):
-    return ('pp' if ns & PINGPONG else 's%d' % (ns & 0xFF)) + ('8w' if ns & EIGHT_WAVES else '')
+    return ('pp' if ns & PINGPONG else 's%d' % (ns & 0xFF)) + ('8w' if ns & EIGHT_WAVES else '') + ('P' if ns & PERSIST else '')
 
 
 def _tile_candidates(ta, tb, M, N):
@@ -306,6 +309,12 @@ def _tile_candidates(ta, tb, M, N):
             c += [(tile(256, 256), PINGPONG | 2)]
             if not ta:
                 c += [(tile(192, 256), PINGPONG | 2)]
+        if USE_PERSIST and not ta:                # the persistent form of the same tiles where a problem has more tiles than workgroup slots
+            for t, ns in [x for x in c if x[1] & PINGPONG]:
+                rows, cols = t & 0xFFFF, (t >> 16) or 128
+                slots = N_CU * (2 if rows * cols <= 128 * 128 else 1)
+                if ((M + rows - 1) // rows) * ((N + cols - 1) // cols) > slots:
+                    c.append((t, ns | PERSIST))
     return c
 
 
