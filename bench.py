@@ -30,6 +30,13 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+
+def _goat_graph(g, **kw):
+    """torch.cuda.graph through vln_goat_amd.hipops.graph: a graph whose capture forked one of the package's parallel branches is kept
+    alive (ROCm 7.2 graph-destruction bug; see hipops.graph)."""
+    from vln_goat_amd import hipops
+    return hipops.graph(g, **kw)
+
 TASKS = tuple(os.environ.get('GOAT_BENCH_TASKS', 'mlm,sap,cfp').split(','))   # (diagnostics: time one task alone)
 # BASELINE.json configs -> (model-config overrides, synthetic batch shape, per-rank batch, task cycle, description)
 WORKLOADS = {
@@ -338,7 +345,7 @@ def make_steps(args, model, gb, world, wrapper, tasks=None):
 
         def cap(fn):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+            with _goat_graph(g, pool=pool, capture_error_mode=mode):
                 out = fn()
             graphs.append(g)
             return g.pool(), out
@@ -398,7 +405,7 @@ def make_steps(args, model, gb, world, wrapper, tasks=None):
                     from vln_goat_amd import dp as _dp
                     _dp.quiesce_collectives()        # (the watchdog must have retired every eager collective before the streams capture)
                     gi = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gi, capture_error_mode=mode):
+                    with _goat_graph(gi, capture_error_mode=mode):
                         eager_phased(task)
                     steps[task] = (lambda gi=gi: gi.replay())
                     in_graph_ok.add(task)
@@ -414,7 +421,7 @@ def make_steps(args, model, gb, world, wrapper, tasks=None):
                 steps[task] = capture_phased(task, mode)
             else:
                 ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, capture_error_mode=mode):
+                with _goat_graph(ga, capture_error_mode=mode):
                     step_body(task)
                 steps[task] = (lambda t=task, ga=ga: (ga.replay(), reduce_all(t)))
         except Exception as e:       # never lose the run to a capture problem: fall back to eager launches for this task
@@ -543,7 +550,7 @@ def gemm_roofline(args, model, gb, arena=None, tasks=None, cycle=None):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with _goat_graph(g):
         replay_all()
     for _ in range(2):
         g.replay()
@@ -769,7 +776,7 @@ def ragged_bucket_leg(args, m, B):
         torch.cuda.synchronize()
         for t in tasks:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _goat_graph(g):
                 body(t)
             graphs[(nb, t)] = g
     bufs = [sbs[w].pack(h) for w, h in zip(which, hosts)]
@@ -790,12 +797,16 @@ def ragged_bucket_leg(args, m, B):
         host_t[2] = max(host_t[2], time.perf_counter() - t0)
         done[k] = sbs[which[k]].stage(bufs[k])
 
+    opt = [None]
+
     def run(i):
         k = i % K
         if state['next'] != i:
             prefetch(i)
         sbs[which[k]].commit()
         graphs[(which[k], tasks[i % len(tasks)])].replay()
+        if opt[0] is not None:
+            opt[0].step(tasks[i % len(tasks)], max_norm=5.0)
         prefetch(i + 1)
         state['next'] = i + 1
     n = 36          # (a single host stall — 40-90 ms ones were seen on the pool's boxes — weighs 1-2 ms in the mean of 36 steps; the
@@ -803,6 +814,36 @@ def ragged_bucket_leg(args, m, B):
     for sb in sbs.values():
         if sb._pending is not None:
             sb.commit()
+    # ---- the whole training loop of P/train_r2r_goat.py:301-366: the same ragged-bucketed input path, the captured
+    # fwd+bwd AND the fused clip + AdamW update, in one timed loop; next to it the device side alone (replay + update, no new data)
+    train = None
+    if not os.environ.get('GOAT_BENCH_NO_TRAIN_LOOP'):
+        from vln_goat_amd import optim
+        opt[0] = optim.FusedAdamW(model.named_parameters(), arena, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01)
+        state['next'] = None
+        host_loop = list(host_t)
+        dt_t = timed(run, n, 4, 1)
+        for sb in sbs.values():
+            if sb._pending is not None:
+                sb.commit()
+        nb1 = which[0]
+        e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e2.record()
+        for r in range(6):
+            graphs[(nb1, tasks[r % len(tasks)])].replay()
+            opt[0].step(tasks[r % len(tasks)], max_norm=5.0)
+        e3.record()
+        torch.cuda.synchronize()
+        dev_ms = e2.elapsed_time(e3) / 6
+        traj_t = sum(synth.n_traj_steps(hosts[i % K]) for i in range(n))
+        train = {'ms_per_step': round(dt_t / n * 1e3, 3), 'value': round(traj_t / dt_t, 1), 'unit': 'trajectory-steps/s', 'steps': n,
+                 'replay_plus_optimizer_ms_per_step': round(dev_ms, 3), 'ratio_to_replay_plus_optimizer': round(dt_t / n * 1e3 / dev_ms, 3),
+                 'host_pack_ms': round((host_t[0] - host_loop[0]) / max(1, host_t[1] - host_loop[1]) * 1e3, 2),
+                 'what': 'the loop of pretrain_src/train_r2r_goat.py:301-366 per update: new ragged host batch (host padding + index build into '
+                         'its shape bucket, one pinned H2D on a side stream, one 27 MB D2D swap, mask refresh) + hipGraph replay of fwd+bwd + '
+                         'goat_grad_sqnorm + goat_adamw_step (clip 5.0), all inside the timed region; ratio = this / (replay + update with no new data)'}
+        opt[0] = None
     # the device side alone: replays of one bucket's three graphs (no new data)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     nb0 = which[0]
@@ -818,7 +859,7 @@ def ragged_bucket_leg(args, m, B):
     return {'ms_per_step': round(dt / n * 1e3, 3), 'value': round(traj / dt, 1), 'unit': 'trajectory-steps/s', 'steps': n,
             'buckets': {'L': wl['batch']['L'], 'N': list(sorted(set(which))), 'G': G}, 'mean_panoramas_per_batch': round(real, 1),
             'feature_dtype': str(feat_dt).replace('torch.', ''), 'host_pack_ms': round(host_t[0] / max(1, host_t[1]) * 1e3, 2), 'host_pack_ms_max': round(host_t[2] * 1e3, 2),
-            'replay_only_ms_per_step': round(replay_ms, 3),
+            'replay_only_ms_per_step': round(replay_ms, 3), 'train_loop': train,
             'what': 'B=%d, T ~ U{3..6}, L ~ U{40..80}: a new shape every step, padded into %d shape buckets; per step host padding + index '
                     'build, one pinned H2D, D2D swap, mask refresh, hipGraph replay of the bucket (all inside the timed region)' % (B, len(set(which)))}
 
@@ -968,7 +1009,7 @@ def config4_leg(args, rank=0, world=1):
             try:
                 dp.quiesce_collectives()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode=mode):
+                with _goat_graph(g, capture_error_mode=mode):
                     episode()
                     exchange()
                 run, launch, done = (lambda i: g.replay()), 'hipGraph replay, gradient exchange inside the graph', True
@@ -980,7 +1021,7 @@ def config4_leg(args, rank=0, world=1):
                     torch.cuda.synchronize()
                     dist.barrier()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode=mode):
+                with _goat_graph(g, capture_error_mode=mode):
                     episode()
                 run, launch = (lambda i: (g.replay(), exchange())), 'hipGraph replay' + (', then the gradient exchange' if world > 1 else '')
             except Exception as e:      # noqa: BLE001
@@ -1105,7 +1146,7 @@ def dagger_iteration(model, te, bufs, batches, extras, arena, sim, store, B, T, 
     torch.cuda.synchronize()
     sample_part(0)                                 # the capture below must see every slice already written in this step
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with _goat_graph(g):
         teacher_part()
     torch.cuda.synchronize()
     n, t_s, steps, host = 4, [], [], []
@@ -1173,7 +1214,7 @@ def two_pass_iteration(call, te, bufs, g_teacher, batches, extras, arena, sim, s
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g_s = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_s):
+        with _goat_graph(g_s):
             sampled_body()
         torch.cuda.synchronize()
     finally:
@@ -1296,7 +1337,7 @@ def navigator_leg(args, model, ep, arena, B, T, frozen_s):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with _goat_graph(g):
         episode()
     # the host plan of episode i + 1 is built by a WORKER PROCESS (rollout.PlanWorker) while this process copies plan i into the pinned
     # buffer and launches the episode graph (a ~3 000-node hipGraphLaunch holds the calling thread for several ms): with the navigation
@@ -1417,6 +1458,9 @@ def main():
             out['fresh_batch'] = leg('fresh_batch', lambda: fresh_batch_leg(args, m))
             if 'ms_per_step' in out['fresh_batch']:
                 out['fresh_batch_ms_per_step'] = out['fresh_batch']['ms_per_step']
+            tl = (out['fresh_batch'].get('ragged_bucketed') or {}).get('train_loop')
+            if tl:                                   # the whole training loop (new ragged batch + fwd/bwd + clip + AdamW), next to the headline
+                out['train_loop'] = tl
             out['with_optimizer'] = leg('with_optimizer', lambda: optimizer_leg(args, m))
         from vln_goat_amd import hipops as _h
         out['gemm_shapes_autotuned_in_this_run'] = _h.TUNE_EVENTS[0]      # 0: every shape came from vln-goat_amd/tuned_gfx950.json

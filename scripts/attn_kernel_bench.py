@@ -5,6 +5,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import torch
 from vln_goat_amd import _lib
 
+
+def _goat_graph(g, **kw):
+    """torch.cuda.graph through vln_goat_amd.hipops.graph: a graph whose capture forked one of the package's parallel branches is kept
+    alive (ROCm 7.2 graph-destruction bug; see hipops.graph)."""
+    from vln_goat_amd import hipops
+    return hipops.graph(g, **kw)
+
 torch.cuda.set_device(0)
 L = _lib.lib()
 ROT, NH, H = 4, 12, 768
@@ -21,7 +28,7 @@ def timeit(fn, n=48):
     global st
     keep = st
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with _goat_graph(g):
         st = torch.cuda.current_stream().cuda_stream
         for _ in range(n):
             fn()

@@ -7,6 +7,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import torch
 from vln_goat_amd import _lib, hipops
 
+
+def _goat_graph(g, **kw):
+    """torch.cuda.graph through vln_goat_amd.hipops.graph: a graph whose capture forked one of the package's parallel branches is kept
+    alive (ROCm 7.2 graph-destruction bug; see hipops.graph)."""
+    from vln_goat_amd import hipops
+    return hipops.graph(g, **kw)
+
 torch.cuda.set_device(0)
 L = _lib.lib()
 PP, PERSIST = 0x200, 0x400
@@ -22,7 +29,7 @@ def graph_time(fn, n=48):
         fn(i)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with _goat_graph(g):
         for i in range(n):
             fn(i)
     g.replay()

@@ -21,6 +21,13 @@ import vln_goat_amd
 from vln_goat_amd import config as gcfg, dp, pretrain_model, synth, hipops
 import bench
 
+
+def _goat_graph(g, **kw):
+    """torch.cuda.graph through vln_goat_amd.hipops.graph: a graph whose capture forked one of the package's parallel branches is kept
+    alive (ROCm 7.2 graph-destruction bug; see hipops.graph)."""
+    from vln_goat_amd import hipops
+    return hipops.graph(g, **kw)
+
 torch.cuda.set_device(0)
 dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
 dp.FORCE_COLLECTIVES[0] = True
@@ -68,7 +75,7 @@ for wire in [WIRES[x] for x in os.environ.get('CHK_WIRES', 'f32,bf16').split(','
         g = torch.cuda.CUDAGraph()
         dp.quiesce_collectives()                         # (no eager collective may still sit with the watchdog when the capture starts)
         print('capturing', t, flush=True)
-        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+        with _goat_graph(g, capture_error_mode='thread_local'):
             step(t)
         print('captured', t, flush=True)
         for _ in range(2):

@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 import ref_shim  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from helpers import projections  # noqa: E402
 
 CASES = {
     'nav_type2_door': dict(do_back_txt_type='type_2', do_back_img_type='type_1', do_add_method='door'),
@@ -75,6 +77,33 @@ def main(only=None):
                  'txt_embeds': rec['txt_embeds'][:, :, :16].detach().numpy()}
         for k in ('front_txt_feats', 'front_gmap_feats', 'z_img_features', 'instr_z_direction_features'):
             store['dinput_' + k] = fingerprint(ep[k].grad)
+            store['dproj_' + k] = projections(ep[k].grad)
+        # seeded random projections of every parameter gradient (helpers.projections: all elements covered)
+        store['grad_proj'] = np.stack([projections(p.grad) for _, p in ref.named_parameters()])
+        # What stock bf16 autocast does to THIS model's gradients (the yardstick of the bf16 GPU test, VERDICT r4 #5b): the same episode
+        # on the reference under torch.autocast('cpu', bfloat16); per parameter the relative L2 error and the norm ratio against the
+        # float32 gradients above, and the norm-weighted aggregate.
+        g32 = {n: (p.grad.detach().double().clone() if p.grad is not None else None) for n, p in ref.named_parameters()}
+        ref.zero_grad(set_to_none=True)
+        for k in ('front_txt_feats', 'front_vp_feats', 'front_gmap_feats', 'instr_z_direction_features', 'instr_z_landmark_features',
+                  'z_img_features'):
+            ep[k].grad = None
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            loss_ac, _ = synth.run_nav_episode(lambda m, b: ref(m, b), ep)
+        loss_ac.float().backward()
+        errs, ratios = [], []
+        for n, p in ref.named_parameters():
+            r = g32[n]
+            if r is None or p.grad is None or float(r.norm()) == 0.0:
+                errs.append(0.0)
+                ratios.append(0.0)
+                continue
+            g = p.grad.detach().double()
+            errs.append(float((g - r).norm() / r.norm()))
+            ratios.append(abs(float(g.norm() / r.norm()) - 1.0))
+        store['grad_err_autocast'] = np.array(errs, dtype=np.float32)
+        store['grad_norm_ratio_autocast'] = np.array(ratios, dtype=np.float32)
+        store['loss_autocast'] = np.array([float(loss_ac)], dtype=np.float32)
         for t, s in enumerate(rec['steps']):
             for k in ('global_logits', 'local_logits', 'fused_logits', 'cls_embeds'):
                 store['s%d_%s' % (t, k)] = s[k].detach().numpy()
@@ -84,8 +113,13 @@ def main(only=None):
             if s.get('obj_logits') is not None:
                 store['s%d_obj_logits' % t] = s['obj_logits'].detach().numpy()
         path = os.path.join(HERE, name + '.npz')
+        if os.path.exists(path):       # a regeneration must reproduce what is committed, bit for bit (new arrays may be added)
+            old = dict(np.load(path, allow_pickle=False))
+            for k, v in old.items():
+                assert k in store and np.array_equal(np.asarray(store[k]), v), 'regenerated %s differs from the committed %s' % (k, path)
         np.savez_compressed(path, **store)
-        print('wrote', path, os.path.getsize(path) // 1024, 'KiB', 'loss', float(loss))
+        print('wrote', path, os.path.getsize(path) // 1024, 'KiB', 'loss', float(loss), 'autocast loss', float(loss_ac),
+              'autocast grad error: median %.4f max %.4f' % (float(np.median(store['grad_err_autocast'])), float(store['grad_err_autocast'].max())))
 
 
 def extract_case():

@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import ref_shim  # noqa: E402
 
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from helpers import CASES, case_tasks  # noqa: E402  (single source of the case definitions)
+from helpers import CASES, case_tasks, projections  # noqa: E402  (single source of the case definitions)
 
 WEIGHT_SEED = 7
 REF_CFG_JSON = '/root/reference/pretrain_src/config/r2r_GOAT_model_config.json'
@@ -95,6 +95,9 @@ def main(only=None):
             store[task + '_loss_vec'] = loss_vec.detach().numpy()
             fp = grad_fingerprint(ref)
             store[task + '_grad_fp'] = np.stack([fp[n] for n in store['param_names']])
+            # NPROJ seeded random projections <grad, r_j> per parameter (helpers.projections): every element is covered, not only the first 8
+            pg_ = dict(ref.named_parameters())
+            store[task + '_grad_proj'] = np.stack([projections(pg_[str(n)].grad) for n in store['param_names']])
             with torch.no_grad():
                 if task == 'sap':
                     gl, ll, fl, _, _ = ref(batch, task, compute_loss=False)
@@ -124,6 +127,10 @@ def main(only=None):
             store['bert_vp_embeds'] = vp[:, :, :16].numpy()
             store['bert_txt_embeds'] = tx[:, :, :16].numpy()
         path = os.path.join(HERE, name + '.npz')
+        if os.path.exists(path):       # a regeneration must reproduce what is committed, bit for bit (new arrays may be added)
+            old = dict(np.load(path, allow_pickle=False))
+            for k, v in old.items():
+                assert k in store and np.array_equal(np.asarray(store[k]), v), 'regenerated %s differs from the committed %s' % (k, path)
         np.savez_compressed(path, **store)
         print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
 

@@ -504,6 +504,33 @@ def test_embedding_tables(ops, dtype, with_types):
         ops.check_embed_errors()
 
 
+@pytest.mark.parametrize('act', ['none', 'relu'])
+def test_linear_on_a_row_strided_view(ops, act):
+    """The pooler's input hidden[:, 0] ([B, H] view of [B, L, H]: row stride L * H) goes to goat_gemm_bf16 as it is (lda = L * H) and is
+    saved strided for the weight gradient (no op-level test covered forward / dW / dx on the strided operand)."""
+    B, L, H, N = 48, 80, 768, 768
+    g = torch.Generator().manual_seed(5)
+    hid = torch.randn(B, L, H, generator=g).to(DEV, torch.bfloat16).requires_grad_(True)
+    w = torch.nn.Parameter((torch.randn(N, H, generator=g) * 0.03).to(DEV))
+    b = torch.nn.Parameter((torch.randn(N, generator=g) * 0.1).to(DEV))
+    x = hid[:, 0]
+    assert not x.is_contiguous() and x.stride(0) == L * H
+    y = ops.linear(x, w, b, act=act) if act != 'none' else ops.linear(x, w, b)
+    dy = torch.randn(B, N, generator=g).to(DEV, torch.bfloat16)
+    y.backward(dy)
+    hr = hid.detach().float().requires_grad_(True)
+    wr, br = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yr = hr[:, 0] @ wr.to(torch.bfloat16).float().T + br
+    if act == 'relu':
+        yr = torch.relu(yr)
+    yr.backward(dy.float())
+    _close(y, yr, torch.bfloat16, 'strided linear y')
+    _close(w.grad, wr.grad, torch.bfloat16, 'strided linear dW')
+    _close(b.grad, br.grad, torch.bfloat16, 'strided linear db')
+    _close(hid.grad[:, 0], hr.grad[:, 0], torch.bfloat16, 'strided linear dx')
+    assert float(hid.grad[:, 1:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_linear_ffn_autograd(ops, dtype):
     M, H, F_ = 300, 768, 3072

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CASES, build_case, case_tasks, fingerprint, load_golden, oracle_run, ROOT
+from helpers import CASES, build_case, case_tasks, check_projections, fingerprint, load_golden, oracle_run, projections, ROOT
 
 SMALL = ['pretrain_small_fixed', 'pretrain_small_ragged']
 ALL = SMALL + (['pretrain_config1'] if os.path.exists(os.path.join(ROOT, 'tests/golden/pretrain_config1.npz')) else [])
@@ -36,6 +36,11 @@ def test_oracle_matches_reference_golden(case, task):
         worst = max(worst, err)
         assert err < 2e-4, (n, got, ref)
     assert worst < 2e-4
+    # seeded random projections of EVERY element of every gradient tensor (the fingerprint only sees the norm and 8 elements)
+    proj = gold[task + '_grad_proj']
+    gmax = float(fp[:, 0].max())
+    for i, n in enumerate(names):
+        check_projections(projections(grads.get(n)), proj[i], max(float(fp[i][0]), 1e-3 * gmax), 2e-4, n)
 
 
 @pytest.mark.parametrize('case', SMALL)

@@ -462,7 +462,9 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     const float l = mx + __logf(sum);
     lse[m] = l;
     const int64_t t = targets[m];
-    loss[m] = t < 0 ? 0.f : l - row[t];          // negative target: ignored row (F.cross_entropy's ignore_index), loss 0
+    // negative target: ignored row (F.cross_entropy's ignore_index), loss 0.  A target past the row (torch raises there; a kernel
+    // cannot) poisons the loss with NaN instead of reading out of bounds
+    loss[m] = t < 0 ? 0.f : (t < (int64_t)N ? l - row[t] : __builtin_nanf(""));
   }
 }
 
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
   const float* row = logits + (int64_t)m * ld;
   T* out = dlogits + (int64_t)m * ld_out;
   const int t = (int)targets[m];
-  const float l = lse[m], g = t < 0 ? 0.f : dloss[m];      // ignored row: zero gradient
+  const float l = lse[m], g = t < 0 ? 0.f : (t < N ? dloss[m] : __builtin_nanf(""));      // ignored row: zero gradient; out-of-range target: NaN (see ce_fwd_kernel)
   for (int c = threadIdx.x * 4; c < (int)ld_out; c += 256 * 4) {
     float v[4];
 #pragma unroll

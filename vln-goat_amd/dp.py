@@ -344,6 +344,7 @@ class GradArena:
     _avg_ok = None      # RCCL averages in the collective (ReduceOp.AVG); gloo and old stacks: sum, then one divide pass
 
     def _reduce_mean(self, c, W):
+        _note_collective(c)
         cls = type(self)
         if cls._avg_ok is None:
             cls._avg_ok = False
@@ -371,6 +372,7 @@ class GradArena:
         arithmetic.  Inside a hipGraph capture step 1-2 is a reduce-scatter in the wire dtype instead (RCCL's all-to-all does not
         survive capture on this stack — scripts/rccl_capture_probe.py: it crashes hipStreamEndCapture; all-reduce, reduce-scatter,
         all-gather and broadcast capture fine): one rounding per ring hop rather than one per input, same bytes, same 2e-2 bound."""
+        _note_collective(c)
         n = c.numel()
         per = (n + W - 1) // W
         buf = self._wire.get(n)
@@ -402,7 +404,7 @@ class GradArena:
         """Average the task's gradient ranges (of one backward phase, or all) over ranks, in place, on the communication
         stream.  wait=False: return without making the caller's stream wait (call wait_comm() before the gradients are
         read) — this is how the phase-0 all-reduce overlaps the phase-1 backward computation.  Capturable: inside a
-        torch.cuda.graph() the communication stream joins the capture as a parallel branch (wait=False branches must be joined
+        hipops.graph() the communication stream joins the capture as a parallel branch (wait=False branches must be joined
         by wait_comm() before the capture ends)."""
         W = _world()
         if not _comm_on():
@@ -617,6 +619,24 @@ class GoatDataParallel(torch.nn.Module):
             gb.all_reduce_mean(grads)
 
 
+_EAGER_SINCE_QUIESCE = [0]      # eager RCCL collectives of the gradient arena issued since the last quiesce_collectives()
+
+
+def _note_collective(t):
+    """Bookkeeping behind quiesce_collectives (nothing used to enforce the call).  An arena collective that is being CAPTURED while
+    eager RCCL collectives issued earlier may still sit with the process group's watchdog raises here, with the remedy in the message — instead
+    of the 1-in-3 process abort (hipErrorCapturedEvent in the watchdog thread) that the missing call used to produce."""
+    if not (t.is_cuda and dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'):
+        return
+    if torch.cuda.is_current_stream_capturing():
+        if _EAGER_SINCE_QUIESCE[0] > 0:
+            raise RuntimeError('a gradient collective is being captured into a hipGraph while %d eager collective(s) issued before the capture '
+                               'may still be polled by the RCCL watchdog: call vln_goat_amd.dp.quiesce_collectives() right before the capture '
+                               'begins' % _EAGER_SINCE_QUIESCE[0])
+    else:
+        _EAGER_SINCE_QUIESCE[0] += 1
+
+
 def quiesce_collectives(seconds=0.3):
     """Call right before a hipGraph capture that will contain collectives.  ProcessGroupNCCL's watchdog thread polls the end events of the
     eager collectives issued so far (every 100 ms); on this HIP runtime `hipEventQuery` fails with hipErrorCapturedEvent once the STREAM an
@@ -628,6 +648,7 @@ def quiesce_collectives(seconds=0.3):
         torch.cuda.synchronize()
     if dist.is_available() and dist.is_initialized():
         time.sleep(seconds)
+    _EAGER_SINCE_QUIESCE[0] = 0
 
 
 def wrap_finetune_models(vln_bert, critic=None, **kw):

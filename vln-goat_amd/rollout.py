@@ -940,7 +940,7 @@ class TeacherEpisode:
                 pano, pmask, fused = panoramas(k, B)
             logits, last = self._nav_step(model, t_, s, txt_h[s], kv_h[s], pano, pmask, fused, pool, last, nav_extras)
             if self.ignoreid < 0:
-                ce_rows.append(hipops.cross_entropy_rows(logits, t_[k + 'target']))          # (summed once behind the loop)
+                ce_rows.append(hipops.cross_entropy_rows(logits, t_[k + 'target'], self.ignoreid))          # (summed once behind the loop)
             else:
                 loss = loss + torch.nn.functional.cross_entropy(logits.float(), t_[k + 'target'], reduction='sum', ignore_index=self.ignoreid)
         if ce_rows:
@@ -1015,6 +1015,10 @@ class EpisodePlanner:
         for name in ('vp_pos_fts', 'vp_masks', 'vp_nav_masks'):
             out[k + name] = vin[name]
         out[k + 'nav_fusion'] = nav_model.nav_fusion_matrix(vin['vp_cand_vpids'], gin['gmap_vpids'], gin['gmap_visited_masks'], G, te.W + 2)
+        # host-side label validation, as train_step.collate_indices does for pre-training (goat_ce_fwd cannot raise; an
+        # out-of-range target would only show up as a NaN loss): a teacher action is a map slot of this step or the ignore value
+        if ((target >= G) | ((target < 0) & (target != te.ignoreid))).any():
+            raise ValueError('teacher action outside the %d map slots of step %d: %s' % (G, t, target.tolist()))
         out[k + 'target'] = torch.from_numpy(target)
         # node embeddings: CSR over the pool of this and all earlier steps (+ the previous [MEM] state behind it)
         n_src = store.rows + (B if t > 0 else 0)
@@ -1341,6 +1345,7 @@ class SampledEpisode:
 
     @staticmethod
     def _capture(fn):
+        from . import hipops
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
@@ -1348,7 +1353,7 @@ class SampledEpisode:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g):
+        with torch.no_grad(), hipops.graph(g):
             out = fn()
         return g, out
 
@@ -1356,8 +1361,10 @@ class SampledEpisode:
     def sample(probs, rng):
         """Categorical(probs).sample() on the host: inverse CDF per row (rows are the B episodes; never a zero-probability node)."""
         c = np.cumsum(probs.astype(np.float64), 1)
-        u = rng.random_sample(probs.shape[0]) * c[:, -1]
-        return np.array([min(int(np.searchsorted(c[i], u[i], side='right')), probs.shape[1] - 1) for i in range(probs.shape[0])], np.int64)
+        # u < c[-1] strictly (a product that rounds up to c[-1] would select the slot behind the last node with probability mass —
+        # a padding slot, which advance() rejects; ADVICE r4): the first index whose cumulative mass exceeds u always has probs > 0
+        u = np.minimum(rng.random_sample(probs.shape[0]) * c[:, -1], np.nextafter(c[:, -1], 0.0))
+        return np.array([int(np.searchsorted(c[i], u[i], side='right')) for i in range(probs.shape[0])], np.int64)
 
     def run(self, episodes, rng=None, sampler=None):
         """-> (plan, actions).  sampler(t, probs [B, G] numpy) -> actions [B] overrides the random draw (tests: a fixed action sequence)."""
