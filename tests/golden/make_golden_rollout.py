@@ -161,6 +161,115 @@ def main():
     print('wrote rollout_walk.npz (%d arrays), %d steps' % (len(out), len(ids['steps'])))
 
 
+def main_reverie():
+    """REVERIE builders (M/reverie/agent_obj_goat.py): `_panorama_feature_variable_do` (:180-271), `_nav_vp_variable_do` (:345-388),
+    `_teacher_action` (:390-417, the shortest-path expert), `_teacher_object` (:419-436) and `ObjectFeatureDB.get_object_feature`
+    (M/reverie/data_utils.py:80-99, fed through the class's own feature cache) over a teacher-forced walk with objects on the
+    viewpoints.  -> tests/golden/rollout_walk_reverie.npz / .json"""
+    import_agent()
+    import reverie.agent_obj_goat as ragent
+    import reverie.data_utils as rdu
+    import models.graph_utils as gu
+    from vln_goat_amd import rollout, synth
+    rs = np.random.RandomState(4)
+    scan = rollout.ScanGraph.synthetic('scanR', n=26, seed=6, degree=3)
+    feats = rs.standard_normal((len(scan.vpids), 36, D_FT)).astype(np.float32)
+    objects = rollout.ObjectStore.synthetic([scan], D=D_FT, max_objects=6, seed=8, dtype=torch.float32, p_empty=0.25)
+
+    class Rows:
+        def row(self, s, vp):
+            return scan.index[vp]
+    sim = rollout.GraphSim(Rows(), objects=objects)
+    eps = synth.reverie_episodes(scan, objects, rs, B, STEPS)
+    # the reference's object database with its cache pre-filled (the h5 reader is never reached)
+    db = rdu.ObjectFeatureDB.__new__(rdu.ObjectFeatureDB)
+    db.obj_feat_size, db._feature_store = D_FT, {}
+    otab = objects.table.numpy()
+    for key, n in objects.count.items():
+        a = objects.attrs[key]
+        attrs = {'directions': a['directions'], 'sizes': a['sizes'], 'obj_ids': a['obj_ids'], 'names': a['names']} if n else {}
+        db._feature_store[key] = (otab[objects.start[key]:objects.start[key] + n], attrs)
+
+    def ref_obs_reverie(obs):
+        out = ref_obs(obs, feats)
+        for ro, ob, ep in zip(out, obs, eps):
+            f, ang, box, ids, names = db.get_object_feature(ob['scan'], ob['viewpoint'], ob['heading'], ob['elevation'], 4, max_objects=None)
+            ro.update({'obj_img_fts': f, 'obj_ang_fts': ang, 'obj_box_fts': box, 'obj_ids': ids, 'obj_name': names,
+                       'gt_end_vps': ep['end_vps'], 'gt_obj_id': ep['obj_id']})
+        return out
+    me = SimpleNamespace(args=SimpleNamespace(image_feat_size=D_FT, act_visited_nodes=False, enc_full_graph=True, ignoreid=-100,
+                                              expert_policy='spl'),
+                         env=SimpleNamespace(shortest_distances={scan.name: {a: {b: float(scan.shortest()[0][i, j]) for j, b in enumerate(scan.vpids)}
+                                                                             for i, a in enumerate(scan.vpids)}}))
+    A = ragent.GMapObjectNavAgent
+    obs = sim.reset(eps)
+    gmaps = [gu.GraphMap(ob['viewpoint']) for ob in obs]
+    for g, ob in zip(gmaps, ref_obs_reverie(obs)):
+        g.update_graph(ob)
+    out = {'scan_pos': scan.pos, 'scan_edges': np.array([(i, j) for i in range(len(scan.vpids)) for j in scan.adj[i] if i < j], np.int64),
+           'feats': feats, 'obj_table': otab}
+    ids = {'scan_vpids': scan.vpids, 'paths': [e['path'] for e in eps], 'headings': [e['heading'] for e in eps],
+           'instr': [e['instr_encoding'] for e in eps], 'obj_id': [e['obj_id'] for e in eps], 'end_vps': [e['end_vps'] for e in eps],
+           'objects': {k: {'start': objects.start[k], 'count': objects.count[k], 'directions': objects.attrs[k]['directions'].tolist(),
+                           'sizes': objects.attrs[k]['sizes'].tolist(), 'obj_ids': [int(x) for x in objects.attrs[k]['obj_ids']],
+                           'names': [int(x) for x in objects.attrs[k]['names']]} for k in objects.count}, 'steps': []}
+    ended = np.zeros(B, bool)
+    last = None
+    H = 8
+    for t in range(STEPS):
+        robs = ref_obs_reverie(obs)
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.node_step_ids[robs[i]['viewpoint']] = t + 1
+        pano = A._panorama_feature_variable_do(me, robs, None, noise=None)
+        gen = torch.Generator().manual_seed(300 + t)
+        Wp = pano['loc_fts'].shape[1]
+        pano_embeds = torch.randn(B, Wp, H, generator=gen)
+        fused = torch.randn(B, H, generator=gen)
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.update_node_embed(robs[i]['viewpoint'], fused[i].clone(), rewrite=True)
+                for j, cvp in enumerate(pano['cand_vpids'][i]):
+                    if not g.graph.visited(cvp):
+                        g.update_node_embed(cvp, pano_embeds[i, j].clone())
+        nav = A._nav_gmap_variable(me, robs, gmaps, last)
+        nav.update(A._nav_vp_variable_do(me, robs, gmaps, pano_embeds, pano['cand_vpids'], pano['view_lens'], pano['reverie_obj_lens'],
+                                         pano['nav_types'], last))
+        tgt = A._teacher_action(me, robs, nav['gmap_vpids'], ended, visited_masks=nav['gmap_visited_masks'])
+        otgt = A._teacher_object(me, robs, ended, pano['view_lens'])
+        k = 't%d_' % t
+        for name in ('view_img_fts', 'loc_fts', 'nav_types', 'view_lens', 'reverie_obj_img_fts', 'reverie_obj_lens', 'reverie_obj_locs',
+                     'reverie_obj_nav_types', 'reverie_obj_names'):
+            out[k + name] = pano[name].numpy()
+        for name in ('vp_pos_fts', 'vp_masks', 'vp_nav_masks', 'vp_obj_masks', 'gmap_pos_fts', 'gmap_visited_masks'):
+            out[k + name] = nav[name].numpy()
+        out[k + 'target'], out[k + 'obj_target'] = tgt.numpy(), otgt.numpy()
+        ids['steps'].append({'cand_vpids': pano['cand_vpids'], 'obj_ids': [[int(x) for x in o] for o in pano['obj_ids']],
+                             'gmap_vpids': nav['gmap_vpids'], 'viewpoints': [ob['viewpoint'] for ob in obs]})
+        last = torch.randn(B, H, generator=gen)
+        moves = []
+        for i in range(B):
+            stop = obs[i]['viewpoint'] == obs[i]['gt_path'][-1]
+            if stop or ended[i] or nav['no_vp_left'][i] or t == STEPS - 1:
+                moves.append(None)
+            else:
+                nxt = nav['gmap_vpids'][i][int(tgt[i])]
+                hop = gmaps[i].graph.path(obs[i]['viewpoint'], nxt)
+                prev = obs[i]['viewpoint'] if len(hop) == 1 else hop[-2]
+                view = next(c['pointId'] for c in scan.candidates(prev) if c['viewpointId'] == nxt)
+                moves.append((nxt, view))
+        obs = sim.step(moves)
+        for i, ob in enumerate(ref_obs_reverie(obs)):
+            if not ended[i]:
+                gmaps[i].update_graph(ob)
+        ended = np.logical_or(ended, np.array([m is None for m in moves]))
+    np.savez_compressed(os.path.join(HERE, 'rollout_walk_reverie.npz'), **out)
+    with open(os.path.join(HERE, 'rollout_walk_reverie.json'), 'w') as f:
+        json.dump(ids, f)
+    print('wrote rollout_walk_reverie.npz (%d arrays), %d steps, object targets %s' % (
+        len(out), len(ids['steps']), [out['t%d_obj_target' % t].tolist() for t in range(STEPS)]))
+
+
 def fingerprint(g):
     if g is None:
         return np.zeros(9, dtype=np.float32)
@@ -417,8 +526,11 @@ if __name__ == '__main__':
         sample_episode_case()
     elif sys.argv[1:] == ['episode']:
         episode_case()
+    elif sys.argv[1:] == ['reverie']:
+        main_reverie()
     else:
         main()
         if not sys.argv[1:]:
             episode_case()
             sample_episode_case()
+            main_reverie()

@@ -38,6 +38,57 @@ def test_tsv_round_trip_and_bf16_table(tmp_path):
         features.FeatureStore.from_hdf5(str(tmp_path / 'x.hdf5'))        # no h5py in this image: said loudly
 
 
+def test_feature_store_hdf5_reader_runs_against_an_h5py_shaped_file_object(tmp_path, monkeypatch):
+    """FeatureStore.from_hdf5 (P/data/dataset.py:811-818: one dataset '<scan>_<viewpoint>' per panorama, read with ds[...]) had never
+    executed: the image has no h5py (exercise it or delete it).  The reader only uses h5py.File(path, 'r') as a context
+    manager, .keys() and ds[...]: a stand-in module with exactly that surface, backed by an .npz file, runs the real reader code —
+    key order, float32 conversion, bf16 rounding, the image_feat_size cut — against the TSV route on the same features."""
+    import sys
+    import types
+    from vln_goat_amd import features
+    rs = np.random.RandomState(3)
+    feats = {'scanA_vp%02d' % i: rs.standard_normal((36, 24)).astype(np.float64 if i % 2 else np.float32) for i in range(4)}
+    np.savez(str(tmp_path / 'store.npz'), **feats)
+
+    class _Dataset:
+        def __init__(self, arr):
+            self.arr = arr
+
+        def __getitem__(self, item):
+            assert item is Ellipsis
+            return self.arr
+
+    class _File:
+        def __init__(self, path, mode):
+            assert mode == 'r'
+            self.z = np.load(path.replace('.hdf5', '.npz'))
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            self.z.close()
+
+        def keys(self):
+            return list(self.z.keys())
+
+        def __getitem__(self, k):
+            return _Dataset(self.z[k])
+    fake = types.ModuleType('h5py')
+    fake.File = _File
+    monkeypatch.setitem(sys.modules, 'h5py', fake)
+    st = features.FeatureStore.from_hdf5(str(tmp_path / 'store.hdf5'))
+    assert st.keys == list(feats) and st.table.dtype == torch.bfloat16 and st.table.shape == (4 * 36, 24)
+    for k, v in feats.items():
+        scan, vp = k.split('_', 1)
+        assert torch.equal(st.view_block(scan, vp), torch.from_numpy(v.astype(np.float32)).to(torch.bfloat16))
+    cut = features.FeatureStore.from_hdf5(str(tmp_path / 'store.hdf5'), dtype=torch.float32, image_feat_size=8)
+    assert cut.table.shape == (4 * 36, 8) and np.array_equal(cut.view_block('scanA', 'vp01').numpy(), feats['scanA_vp01'][:, :8].astype(np.float32))
+    features.FeatureStore.write_tsv(str(tmp_path / 'store.tsv'), {k: v.astype(np.float32) for k, v in feats.items()})
+    tsv = features.FeatureStore.from_tsv(str(tmp_path / 'store.tsv'))
+    assert tsv.keys == st.keys and torch.equal(tsv.table, st.table)
+
+
 def test_zdict_tsv_readers(tmp_path):
     from vln_goat_amd import features
     rs = np.random.RandomState(1)

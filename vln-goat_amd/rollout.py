@@ -444,15 +444,91 @@ class ScanGraph:
         return out
 
 
+class ObjectStore:
+    """The object half of a REVERIE / SOON observation (M/reverie/data_utils.py:46-99 `ObjectFeatureDB`; M/reverie/env.py:451-479): per
+    (scan, viewpoint) up to `max_objects` detected objects with an image feature, a viewing direction (heading, elevation), a bounding
+    box size (w, h in pixels of the 640 x 480 frame), an object id and a category number (`obj_name` < 45).  The features of ALL objects
+    live in one [sum O, D] table that is moved to the device once (`to`); observations carry ROW numbers, and `gather` assembles a
+    batch's `reverie_obj_img_fts` with the kernel that gathers the view features (FeatureStore.gather) — the 768-wide rows are never
+    touched on the host.  `attributes` is `get_object_feature`: angle features relative to the agent's heading / elevation, box
+    features (h / 480, w / 640, their product)."""
+
+    def __init__(self, entries, D, dtype=torch.bfloat16, max_objects=None):
+        """entries: {'<scan>_<vp>': dict(fts float32 [O, >= D], directions [O, 2], sizes [O, 2] (w, h), obj_ids [O], names int [O])}"""
+        self.start, self.count, self.attrs = {}, {}, {}
+        blocks, n = [], 0
+        for k, e in entries.items():
+            o = len(e['obj_ids']) if max_objects is None else min(len(e['obj_ids']), max_objects)
+            self.start[k], self.count[k] = n, o
+            self.attrs[k] = {'directions': np.asarray(e['directions'], np.float64).reshape(-1, 2)[:o], 'sizes': np.asarray(e['sizes'], np.float64).reshape(-1, 2)[:o],
+                             'obj_ids': list(e['obj_ids'])[:o], 'names': np.asarray(e['names'], np.int64)[:o]}
+            blocks.append(np.asarray(e['fts'], np.float32).reshape(-1, np.asarray(e['fts']).shape[-1] if len(e['obj_ids']) else D)[:o, :D])
+            n += o
+        tab = np.concatenate(blocks, 0) if n else np.zeros((0, D), np.float32)
+        from .features import FeatureStore
+        self._fs = FeatureStore.__new__(FeatureStore)               # (row gather only: the table is [sum O, D], one row per object)
+        self._fs.keys, self._fs.index, self._fs.views = [], {}, 1
+        self._fs.table = torch.from_numpy(np.ascontiguousarray(tab)).to(dtype)
+        self._fs.dev = None
+        self.D = D
+
+    @classmethod
+    def synthetic(cls, scans, D=768, max_objects=20, seed=0, dtype=torch.bfloat16, p_empty=0.2):
+        """random objects on every viewpoint of the given ScanGraphs (object ids unique per scan; ~p_empty of the viewpoints see none)."""
+        rs = np.random.RandomState(seed)
+        entries = {}
+        for scan in scans:
+            next_id = 0
+            for vp in scan.vpids:
+                o = 0 if rs.uniform() < p_empty else int(rs.randint(1, max_objects + 1))
+                entries['%s_%s' % (scan.name, vp)] = {
+                    'fts': rs.standard_normal((o, D)).astype(np.float32), 'directions': np.stack([rs.uniform(0, 2 * np.pi, o), rs.uniform(-0.5, 0.5, o)], 1),
+                    'sizes': np.stack([rs.uniform(20, 640, o), rs.uniform(20, 480, o)], 1), 'obj_ids': list(range(next_id, next_id + o)),
+                    'names': rs.randint(0, 45, o)}
+                next_id += o
+        return cls(entries, D, dtype)
+
+    def to(self, device):
+        self._fs.to(device)
+        return self
+
+    @property
+    def table(self):
+        return self._fs.table
+
+    def attributes(self, scan, vp, base_heading, base_elevation, angle_feat_size=4):
+        """-> (rows int64 [O], obj_ang_fts [O, angle_feat_size], obj_box_fts [O, 3], obj_ids, obj_names) — get_object_feature (:80-99)."""
+        k = '%s_%s' % (scan, vp)
+        o, a = self.count.get(k, 0), self.attrs.get(k)
+        ang = np.zeros((o, angle_feat_size), np.float32)
+        box = np.zeros((o, 3), np.float32)
+        if o:
+            for j in range(o):
+                ang[j] = angle_feature(a['directions'][j, 0] - base_heading, a['directions'][j, 1] - base_elevation, angle_feat_size)
+                w, h = a['sizes'][j]
+                box[j, :2] = [h / 480, w / 640]
+                box[j, 2] = box[j, 0] * box[j, 1]
+        rows = np.arange(self.start.get(k, 0), self.start.get(k, 0) + o, dtype=np.int64)
+        return rows, ang, box, (a['obj_ids'] if o else []), (a['names'] if o else np.zeros(0, np.int64))
+
+    def gather(self, obj_rows, out_dtype=None):
+        """obj_rows int64 [B, O] (-1 = padding) on the table's device -> [B, O, D]"""
+        return self._fs.gather(obj_rows, out_dtype)
+
+    def host_rows(self, obj_rows):
+        return self._fs.host_rows(obj_rows)
+
+
 class GraphSim:
     """The batch of simulators of EnvBatch + R2RNavBatch._get_obs (M/r2r/env.py:26-96,335-377) on ScanGraphs.
 
     episodes: list of dicts {instr_id, scan (ScanGraph), path [vpids], heading, instr_encoding}.  `features`: an object with
     `row(scan_name, vpid) -> int` (features.FeatureStore): observations carry feature ROW numbers, not feature arrays."""
 
-    def __init__(self, features=None, angle_feat_size=4):
+    def __init__(self, features=None, angle_feat_size=4, objects=None):
         self.features = features
-        self.angle_feat_size = angle_feat_size
+        self.objects = objects              # ObjectStore: REVERIE / SOON observations (M/reverie/env.py:451-486); episodes then carry
+        self.angle_feat_size = angle_feat_size      # 'obj_id' (the target object, may be None) and 'end_vps' (viewpoints that see it)
         self.view_angle_fts = view_angle_feature_table(angle_feat_size)
         self.batch, self.state = [], []
 
@@ -494,6 +570,14 @@ class GraphSim:
                         'view_angle_fts': self.view_angle_fts[view], 'candidate': cands,
                         'instr_encoding': ep['instr_encoding'], 'gt_path': ep['path'],
                         'distance': float(dist[scan.index[vp], scan.index[ep['path'][-1]]])})
+            if self.objects is not None:
+                # (the simulator reports the continuous heading; on this navigator it is the snapped view's, as for the candidates)
+                rows, ang, box, ids, names = self.objects.attributes(scan.name, vp, bh, be, self.angle_feat_size)
+                ob = obs[-1]
+                ob.update({'obj_rows': rows, 'obj_ang_fts': ang, 'obj_box_fts': box, 'obj_ids': ids, 'obj_name': names,
+                           'gt_end_vps': ep.get('end_vps', []), 'gt_obj_id': ep.get('obj_id')})
+                if ep.get('end_vps'):           # several goal viewpoints on REVERIE: distance to the nearest (env.py:493-503)
+                    ob['distance'] = float(min(dist[scan.index[vp], scan.index[e]] for e in ep['end_vps']))
         return obs
 
 
@@ -509,7 +593,7 @@ def language_inputs(obs, pad_id=0):
     return {'txt_ids': torch.from_numpy(ids), 'txt_masks': torch.from_numpy(mask)}
 
 
-def panorama_inputs(obs, angle_feat_size=4, width=None):
+def panorama_inputs(obs, angle_feat_size=4, width=None, obj_width=None):
     """_panorama_feature_variable_do (M/r2r/agent.py:82-148): candidate views first (nav type 1), then the views no candidate
     used (nav type 0), padded to the longest panorama of the batch (or `width`).  The 768-wide image features are NOT assembled
     here: `view_rows[b, j]` = feature_row * 36 + view index of token j (-1: padding) for a device gather."""
@@ -546,8 +630,45 @@ def panorama_inputs(obs, angle_feat_size=4, width=None):
         view_rows[b, :lens[b]] = rows[b]
         loc_fts[b, :lens[b]] = locs[b]
         nav_types[b, :lens[b]] = types[b]
-    return {'view_rows': torch.from_numpy(view_rows), 'loc_fts': torch.from_numpy(loc_fts), 'nav_types': torch.from_numpy(nav_types),
-            'view_lens': torch.tensor(lens, dtype=torch.int64), 'cand_vpids': cand_vpids}
+    out = {'view_rows': torch.from_numpy(view_rows), 'loc_fts': torch.from_numpy(loc_fts), 'nav_types': torch.from_numpy(nav_types),
+           'view_lens': torch.tensor(lens, dtype=torch.int64), 'cand_vpids': cand_vpids}
+    if 'obj_ids' in obs[0]:
+        out.update(panorama_object_inputs(obs, out, angle_feat_size, obj_width))
+    return out
+
+
+def panorama_object_inputs(obs, pano, angle_feat_size=4, obj_width=None):
+    """The object half of `_panorama_feature_variable_do` of the REVERIE agent (M/reverie/agent_obj_goat.py:180-271): object tokens follow
+    the views of their panorama (nav type 2), `loc_fts` / `nav_types` cover views + objects (padded to the longest row of the batch),
+    `reverie_obj_*` are the per-object tensors the image embedding consumes.  obj_rows[b, j] = row of ObjectStore.table (-1: padding)."""
+    B = len(obs)
+    A = angle_feat_size + 3
+    olens = [len(ob['obj_ids']) for ob in obs]
+    vlens = [int(x) for x in pano['view_lens']]
+    O = max(olens) if obj_width is None else obj_width
+    if O < max(olens):
+        raise ValueError('panorama_object_inputs: a viewpoint has %d objects, the bucket holds %d' % (max(olens), O))
+    Wv = pano['view_rows'].shape[1]
+    W = max(v + o for v, o in zip(vlens, olens)) if obj_width is None else Wv + O
+    obj_rows = np.full((B, O), -1, np.int64)
+    obj_locs = np.zeros((B, O, A), np.float32)
+    obj_names = np.zeros((B, O), np.int64)
+    loc_fts = np.zeros((B, W, A), np.float32)
+    nav_types = np.zeros((B, W), np.int64)
+    rnav = np.zeros((B, 36 + O), np.int64)
+    vloc, vty = pano['loc_fts'].numpy(), pano['nav_types'].numpy()
+    for b, ob in enumerate(obs):
+        v, o = vlens[b], olens[b]
+        loc_fts[b, :v], nav_types[b, :v] = vloc[b, :v], vty[b, :v]
+        if o:
+            ol = np.concatenate([ob['obj_ang_fts'], ob['obj_box_fts']], 1)
+            obj_rows[b, :o], obj_locs[b, :o], obj_names[b, :o] = ob['obj_rows'], ol, np.asarray(ob['obj_name'], np.int64)
+            loc_fts[b, v:v + o], nav_types[b, v:v + o] = ol, 2
+            rnav[b, 36:36 + o] = 2
+    return {'loc_fts': torch.from_numpy(loc_fts), 'nav_types': torch.from_numpy(nav_types), 'obj_rows': torch.from_numpy(obj_rows),
+            'reverie_obj_lens': torch.tensor(olens, dtype=torch.int64), 'reverie_obj_locs': torch.from_numpy(obj_locs),
+            'reverie_obj_names': torch.from_numpy(obj_names), 'reverie_obj_nav_types': torch.from_numpy(rnav),
+            'obj_ids': [list(ob['obj_ids']) for ob in obs]}
 
 
 def gmap_order(gmap):
@@ -584,7 +705,7 @@ def gmap_inputs(obs, gmaps, width=None, angle_feat_size=4):
             'gmap_lens': lens, 'no_vp_left': list(no_left)}
 
 
-def vp_inputs(obs, gmaps, cand_vpids, view_lens, nav_types, width, angle_feat_size=4, gmap_pos=None):
+def vp_inputs(obs, gmaps, cand_vpids, view_lens, nav_types, width, angle_feat_size=4, gmap_pos=None, obj_lens=None):
     """_nav_vp_variable_mem (M/r2r/agent.py:271-304) without the embeddings: [stop], [MEM], then the panorama tokens.
     width = panorama width + 2.  gmap_pos = (gmap_vpids, gmap_pos_fts [B, G, angle_feat_size + 3]) of gmap_inputs on the SAME
     observations: the candidates and the start node are nodes of the map and their features are seen from the same viewpoint under
@@ -607,9 +728,29 @@ def vp_inputs(obs, gmaps, cand_vpids, view_lens, nav_types, width, angle_feat_si
     nav_types = torch.as_tensor(nav_types)
     view_lens = torch.as_tensor(view_lens)
     nav = torch.cat([torch.ones(B, 1, dtype=torch.bool), torch.zeros(B, 1, dtype=torch.bool), nav_types == 1], 1)
+    if obj_lens is not None:        # REVERIE (_nav_vp_variable_do, M/reverie/agent_obj_goat.py:345-388): object tokens behind the views
+        obj_lens = torch.as_tensor(obj_lens)
+        masks = torch.arange(width)[None, :] < (view_lens + obj_lens + 2)[:, None]
+        obj = torch.cat([torch.ones(B, 1, dtype=torch.bool), torch.zeros(B, 1, dtype=torch.bool), nav_types == 2], 1)
+        return {'vp_pos_fts': torch.from_numpy(pos), 'vp_masks': masks, 'vp_nav_masks': nav, 'vp_obj_masks': obj,
+                'vp_cand_vpids': [[None, None] + list(x) for x in cand_vpids]}
     masks = torch.arange(width)[None, :] < (view_lens + 2)[:, None]
     return {'vp_pos_fts': torch.from_numpy(pos), 'vp_masks': masks, 'vp_nav_masks': nav,
             'vp_cand_vpids': [[None, None] + list(x) for x in cand_vpids]}
+
+
+def teacher_object(obs, ended, view_lens, ignoreid=-100):
+    """_teacher_object (M/reverie/agent_obj_goat.py:419-436): at a goal viewpoint the index of the target object among the local tokens
+    ([stop], [MEM], views, objects); everywhere else — and when the target is not among the detected objects — the ignore value."""
+    t = np.full(len(obs), ignoreid, np.int64)
+    for i, ob in enumerate(obs):
+        if ended[i] or ob['viewpoint'] not in ob['gt_end_vps']:
+            continue
+        for j, oid in enumerate(ob['obj_ids']):
+            if str(oid) == str(ob['gt_obj_id']):
+                t[i] = j + int(view_lens[i]) + 2
+                break
+    return t
 
 
 def teacher_action(obs, vpids, ended, visited_masks=None, imitation_learning=False, t=None, ignoreid=-100):
@@ -657,8 +798,10 @@ class NavRollout:
     bucket (shape-stable steps: a captured step graph per bucket can be replayed; None = the reference's per-batch maxima)."""
 
     def __init__(self, model, sim, features, max_action_len=15, fusion='dynamic', ignoreid=-100, pano_width=None, gmap_buckets=None,
-                 device='cuda', hoist_text_kv=True):
+                 device='cuda', hoist_text_kv=True, obj_width=None):
         self.model, self.sim, self.features = model, sim, features
+        self.objects = getattr(sim, 'objects', None)      # REVERIE / SOON: object tokens + object grounding (M/reverie/agent_obj_goat.py:560-790)
+        self.obj_width = obj_width
         self.max_action_len, self.fusion, self.ignoreid = max_action_len, fusion, ignoreid
         self.pano_width, self.gmap_buckets = pano_width, gmap_buckets
         self.hoist_text_kv = hoist_text_kv      # K|V projections of the instruction once per episode (nav_model.text_kv) instead of per step
@@ -678,7 +821,7 @@ class NavRollout:
         for i, g in enumerate(gmaps):
             if not ended[i]:
                 g.node_step_ids[obs[i]['viewpoint']] = t + 1
-        pano = panorama_inputs(obs, self.sim.angle_feat_size, self.pano_width)
+        pano = panorama_inputs(obs, self.sim.angle_feat_size, self.pano_width, self.obj_width)
         return pano
 
     def run(self, episodes, feedback='teacher', extras=None, train_ml=1.0, compute_loss=True, sampler=None):
@@ -695,6 +838,9 @@ class NavRollout:
         for g, ob in zip(gmaps, obs):
             g.update_graph(ob)
         traj = [{'instr_id': ob['instr_id'], 'path': [[ob['viewpoint']]]} for ob in obs]
+        if self.objects is not None:
+            for tr in traj:
+                tr['pred_objid'] = None
         lang = language_inputs(obs)
         self.host_s = time.perf_counter() - t_host
         lang_in = mv(lang)
@@ -706,6 +852,8 @@ class NavRollout:
         just_ended = np.zeros(B, bool)
         last_embeds = None
         ml_loss = 0.0
+        og_loss = 0.0
+        has_obj = self.objects is not None
         steps = 0
         self.actions = []           # the action index of every sample at every step taken (TeacherEpisode.plan(actions=) re-walks them)
         for t in range(self.max_action_len):
@@ -715,6 +863,12 @@ class NavRollout:
             pin = {'view_img_fts': self.features.gather(pano['view_rows'].to(dev, non_blocking=True)), 'loc_fts': pano['loc_fts'].to(dev, non_blocking=True),
                    'nav_types': pano['nav_types'].to(dev, non_blocking=True), 'view_lens': pano['view_lens'].to(dev, non_blocking=True),
                    'already_dropout': False}
+            if has_obj:
+                pin.update({'reverie_obj_img_fts': self.objects.gather(pano['obj_rows'].to(dev, non_blocking=True)),
+                            'reverie_obj_lens': pano['reverie_obj_lens'].to(dev, non_blocking=True),
+                            'reverie_obj_names': pano['reverie_obj_names'].to(dev, non_blocking=True),
+                            'reverie_obj_locs': pano['reverie_obj_locs'].to(dev, non_blocking=True),
+                            'reverie_obj_nav_types': pano['reverie_obj_nav_types'].to(dev, non_blocking=True)})
             pin.update(extras.get('panorama', {}))
             pano_embeds, pano_masks, fused = self.model('panorama', dd(pin))
             if fused is None:                                   # not adaptive_pano_fusion: masked mean (M/r2r/agent.py:545-547)
@@ -729,15 +883,15 @@ class NavRollout:
                             store.accumulate(i, cvp, j)
             n_nodes = max(2 + len(g.node_positions) for g in gmaps)
             gin = gmap_inputs(obs, gmaps, self._bucket(n_nodes), self.sim.angle_feat_size)
-            W = pano['view_rows'].shape[1]
+            W = pano['nav_types'].shape[1]              # (REVERIE: views + objects)
             vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], W + 2, self.sim.angle_feat_size,
-                            gmap_pos=(gin['gmap_vpids'], gin['gmap_pos_fts'].numpy()))
+                            gmap_pos=(gin['gmap_vpids'], gin['gmap_pos_fts'].numpy()), obj_lens=pano['reverie_obj_lens'] if has_obj else None)
             G = gin['gmap_step_ids'].shape[1]
             nav_vpids = gin['gmap_vpids'] if self.fusion != 'local' else vin['vp_cand_vpids']
             target = None
             if compute_loss or feedback == 'teacher':
                 target = teacher_action(obs, nav_vpids, ended, visited_masks=gin['gmap_visited_masks'].numpy() if self.fusion != 'local' else None,
-                                        imitation_learning=(feedback == 'teacher'), t=t, ignoreid=self.ignoreid)
+                                        imitation_learning=(feedback == 'teacher' and not has_obj), t=t, ignoreid=self.ignoreid)      # (the REVERIE agent has the shortest-path expert only, M/reverie/agent_obj_goat.py:390-417)
             self.host_s += time.perf_counter() - t_host
             zero = pano_embeds.new_zeros(B, 1, pano_embeds.shape[-1])
             memtok = zero if last_embeds is None else last_embeds.unsqueeze(1).to(pano_embeds.dtype)
@@ -754,6 +908,10 @@ class NavRollout:
             if target is not None and compute_loss:
                 ml_loss = ml_loss + torch.nn.functional.cross_entropy(logits.float(), torch.from_numpy(target).to(dev, non_blocking=True),
                                                                       reduction='sum', ignore_index=self.ignoreid)
+                if has_obj:                 # object grounding at the goal viewpoints (M/reverie/agent_obj_goat.py:705-707)
+                    otgt = teacher_object(obs, ended, pano['view_lens'], self.ignoreid)
+                    og_loss = og_loss + torch.nn.functional.cross_entropy(out['obj_logits'].float(), torch.from_numpy(otgt).to(dev, non_blocking=True),
+                                                                          reduction='sum', ignore_index=self.ignoreid)
             if feedback == 'teacher':
                 a_t = target
                 stop = [ob['viewpoint'] == ob['gt_path'][-1] for ob in obs]
@@ -766,12 +924,21 @@ class NavRollout:
                     act = torch.as_tensor(sampler(t, probs), dtype=torch.int64, device=probs.device)
                 else:
                     act = torch.distributions.Categorical(probs).sample()
-                back = torch.stack([act.to(torch.float32), probs[:, 0].detach()], 0).cpu().numpy()
+                rows = [act.to(torch.float32), probs[:, 0].detach()]
+                if has_obj:                 # the best object of every sample's current viewpoint rides in the same read-back (:680-690)
+                    vl = pano['view_lens'].to(dev)
+                    pos = torch.arange(out['obj_logits'].shape[1], device=dev)[None, :]
+                    ol = torch.where(pos >= (vl + 2)[:, None], out['obj_logits'].detach().float(), torch.full_like(out['obj_logits'], -float('inf'), dtype=torch.float32))
+                    rows.append((ol.argmax(1) - (vl + 2)).to(torch.float32))
+                back = torch.stack(rows, 0).cpu().numpy()
                 a_t = back[0].astype(np.int64)
                 stop = (a_t == 0) if feedback == 'argmax' else [ob['viewpoint'] == ob['gt_path'][-1] for ob in obs]
                 for i, g in enumerate(gmaps):
                     if not ended[i]:
                         g.node_stop_scores[obs[i]['viewpoint']] = {'stop': float(back[1, i])}
+                        if has_obj:
+                            ids = obs[i]['obj_ids']
+                            g.node_stop_scores[obs[i]['viewpoint']]['og'] = ids[int(back[2, i])] if len(ids) > 0 else None
             else:
                 raise ValueError('invalid feedback option %r' % (feedback,))
             t_host = time.perf_counter()
@@ -796,9 +963,11 @@ class NavRollout:
             if True:
                 for i in range(B):
                     if (not ended[i]) and just_ended[i] and gmaps[i].node_stop_scores:
-                        stop_node = max(gmaps[i].node_stop_scores.items(), key=lambda kv: kv[1]['stop'])[0]
+                        stop_node, score = max(gmaps[i].node_stop_scores.items(), key=lambda kv: kv[1]['stop'])
                         if obs[i]['viewpoint'] != stop_node:
                             traj[i]['path'].append(gmaps[i].graph.path(obs[i]['viewpoint'], stop_node))
+                        if has_obj:
+                            traj[i]['pred_objid'] = score.get('og')             # (:761)
             obs = self.sim.step(moves)
             for i, ob in enumerate(obs):
                 if not ended[i]:
@@ -808,6 +977,11 @@ class NavRollout:
             if ended.all():
                 break
         loss = ml_loss * train_ml / B if compute_loss else None
+        self.ml_loss = loss
+        self.og_loss = None
+        if compute_loss and has_obj:            # self.loss += ml_loss; self.loss += og_loss, both * train_ml / batch_size (:781-787)
+            self.og_loss = og_loss * train_ml / B
+            loss = loss + self.og_loss
         self.steps = steps
         return loss, traj
 

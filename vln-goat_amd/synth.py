@@ -481,6 +481,19 @@ def rollout_episodes(scan, rs, B=3, max_steps=5, starts=None):
     return eps
 
 
+def reverie_episodes(scan, objects, rs, B=3, max_steps=5, starts=None):
+    """REVERIE-style episodes (M/reverie/env.py:136-151): rollout_episodes plus a target object — one of the objects the path's last
+    viewpoint sees (None where it sees none) — and `end_vps`, the viewpoints the target can be seen from (here: the last viewpoint and,
+    for every other episode, its first neighbour as well)."""
+    eps = rollout_episodes(scan, rs, B, max_steps, starts)
+    for b, ep in enumerate(eps):
+        last = ep['path'][-1]
+        ids = objects.attrs['%s_%s' % (scan.name, last)]['obj_ids'][:objects.count['%s_%s' % (scan.name, last)]]
+        ep['obj_id'] = ids[int(rs.randint(len(ids)))] if len(ids) else None
+        ep['end_vps'] = [last] + ([scan.vpids[scan.adj[scan.index[last]][0]]] if b % 2 else [])
+    return eps
+
+
 def make_rollout_case(seed=17, n_nodes=24, B=3, max_steps=5, scan_seed=9):
     """scan, float32 features [n_vp, 36, 768], episodes and the BACL / FACL dictionaries (in the reference's on-disk shapes:
     [K, 768] features, [K] probabilities) of the end-to-end rollout golden (tests/golden/rollout_episode.npz).  numpy
