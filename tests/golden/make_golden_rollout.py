@@ -241,7 +241,7 @@ def main_reverie():
         for name in ('view_img_fts', 'loc_fts', 'nav_types', 'view_lens', 'reverie_obj_img_fts', 'reverie_obj_lens', 'reverie_obj_locs',
                      'reverie_obj_nav_types', 'reverie_obj_names'):
             out[k + name] = pano[name].numpy()
-        for name in ('vp_pos_fts', 'vp_masks', 'vp_nav_masks', 'vp_obj_masks', 'gmap_pos_fts', 'gmap_visited_masks'):
+        for name in ('vp_pos_fts', 'vp_masks', 'vp_nav_masks', 'vp_obj_masks', 'gmap_pos_fts', 'gmap_visited_masks', 'gmap_masks'):
             out[k + name] = nav[name].numpy()
         out[k + 'target'], out[k + 'obj_target'] = tgt.numpy(), otgt.numpy()
         ids['steps'].append({'cand_vpids': pano['cand_vpids'], 'obj_ids': [[int(x) for x in o] for o in pano['obj_ids']],
@@ -377,6 +377,131 @@ def episode_case():
     path = os.path.join(HERE, 'rollout_episode.npz')
     np.savez_compressed(path, **store)
     print('wrote', path, os.path.getsize(path) // 1024, 'KiB  loss', float(loss), 'steps', t + 1)
+
+
+def reverie_episode_case():
+    """The REVERIE rollout (M/reverie/agent_obj_goat.py:560-790) end to end on the REFERENCE model (dataset = 'reverie': object tokens,
+    object-grounding head) with the REVERIE agent's builders: teacher feedback with the shortest-path expert, navigation loss + object
+    grounding loss, per-step navigation and object logits, the gradient fingerprint and random projections of every parameter.
+    -> rollout_episode_reverie.npz"""
+    agent, gu = import_agent()
+    import reverie.agent_obj_goat as ragent
+    import reverie.data_utils as rdu
+    import models.vilmodel_GOAT as vg
+    from collections import defaultdict
+    from vln_goat_amd import nav_model, rollout, synth
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import projections
+    dd = lambda d: defaultdict(lambda: None, d)
+    args = SimpleNamespace(**{**EP_ARGS, 'dataset': 'reverie', 'obj_feat_size': 768})
+    cfg = nav_model.nav_config_from_args(args)
+    torch.manual_seed(0)
+    ref = vg.GlocalTextPathNavCMT(cfg)
+    ours = nav_model.GlocalTextPathNavCMT(cfg)
+    ref.load_state_dict(synth.seeded_state_dict(ours, seed=EP_WEIGHT_SEED))
+    ref.eval()
+    scan, feats, eps, dicts, objects = synth.make_reverie_rollout_case()
+
+    class Rows:
+        def row(self, s, vp):
+            return scan.index[vp]
+    sim = rollout.GraphSim(Rows(), objects=objects)
+    db = rdu.ObjectFeatureDB.__new__(rdu.ObjectFeatureDB)
+    db.obj_feat_size, db._feature_store = 768, {}
+    otab = objects.table.numpy()
+    for key, n in objects.count.items():
+        a = objects.attrs[key]
+        db._feature_store[key] = (otab[objects.start[key]:objects.start[key] + n],
+                                  {'directions': a['directions'], 'sizes': a['sizes'], 'obj_ids': a['obj_ids'], 'names': a['names']} if n else {})
+
+    def robs_of(obs):
+        out = ref_obs(obs, feats)
+        for ro, ob, ep in zip(out, obs, eps):
+            f, ang, box, ids, names = db.get_object_feature(ob['scan'], ob['viewpoint'], ob['heading'], ob['elevation'], 4, max_objects=None)
+            ro.update({'obj_img_fts': f, 'obj_ang_fts': ang, 'obj_box_fts': box, 'obj_ids': ids, 'obj_name': names,
+                       'gt_end_vps': ep['end_vps'], 'gt_obj_id': ep['obj_id']})
+        return out
+    obs = sim.reset(eps)
+    Bn = len(obs)
+    me = SimpleNamespace(args=SimpleNamespace(image_feat_size=768, act_visited_nodes=False, enc_full_graph=True, ignoreid=-100, expert_policy='spl'),
+                         env=SimpleNamespace(shortest_distances={scan.name: {a: {b: float(scan.shortest()[0][i, j]) for j, b in enumerate(scan.vpids)}
+                                                                             for i, a in enumerate(scan.vpids)}}))
+    A, R2R = ragent.GMapObjectNavAgent, agent.GMapNavAgent
+    robs = robs_of(obs)
+    gmaps = [gu.GraphMap(ob['viewpoint']) for ob in robs]
+    for g, ob in zip(gmaps, robs):
+        g.update_graph(ob)
+    instr_zdict = {k: dicts[k] for k in ('instr_direction_features', 'instr_direction_pzs', 'instr_landmark_features', 'instr_landmark_pzs')}
+    img_zdict = {'img_features': dicts['img_features'], 'img_pzs': dicts['img_pzs']}
+    front = {k: torch.from_numpy(np.array([dicts[k]] * Bn)) for k in ('txt_feats', 'vp_feats', 'gmap_feats')}
+    # (both instruction dictionaries, through the R2R agent's language builder: the model's type_2 intervention needs the direction
+    #  dictionary, which the REVERIE agent's own `_language_variable` does not pass)
+    lang = R2R._language_variable(me, robs, instr_zdict, front['txt_feats'])
+    txt_embeds = ref('language', dd(lang))
+    ended = np.zeros(Bn, bool)
+    last = None
+    ml_loss = og_loss = 0.0
+    store = {}
+    max_len = 6
+    for t in range(max_len):
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.node_step_ids[robs[i]['viewpoint']] = t + 1
+        pano = A._panorama_feature_variable_do(me, robs, img_zdict, noise=None)
+        pano_embeds, pano_masks, fused = ref('panorama', dd(pano))
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.update_node_embed(robs[i]['viewpoint'], fused[i], rewrite=True)
+                for j, cvp in enumerate(pano['cand_vpids'][i]):
+                    if not g.graph.visited(cvp):
+                        g.update_node_embed(cvp, pano_embeds[i, j])
+        nav = A._nav_gmap_variable(me, robs, gmaps, last)
+        nav.update(A._nav_vp_variable_do(me, robs, gmaps, pano_embeds, pano['cand_vpids'], pano['view_lens'], pano['reverie_obj_lens'],
+                                         pano['nav_types'], last))
+        nav.update({'txt_embeds': txt_embeds, 'txt_masks': lang['txt_masks'], 'front_txt_feats': front['txt_feats'],
+                    'front_vp_feats': front['vp_feats'], 'front_gmap_feats': front['gmap_feats']})
+        out = ref('navigation', dd(nav))
+        last = out['cls_embeds']
+        logits = out['fused_logits']
+        tgt = A._teacher_action(me, robs, nav['gmap_vpids'], ended, visited_masks=nav['gmap_visited_masks'])
+        otgt = A._teacher_object(me, robs, ended, pano['view_lens'])
+        ml_loss = ml_loss + torch.nn.functional.cross_entropy(logits, tgt, reduction='sum', ignore_index=-100)
+        og_loss = og_loss + torch.nn.functional.cross_entropy(out['obj_logits'], otgt, reduction='sum', ignore_index=-100)
+        store['s%d_fused_logits' % t] = logits.detach().numpy()
+        store['s%d_obj_logits' % t] = out['obj_logits'].detach().numpy()
+        store['s%d_cls_embeds' % t] = out['cls_embeds'].detach().numpy()
+        store['s%d_target' % t], store['s%d_obj_target' % t] = tgt.numpy(), otgt.numpy()
+        moves = []
+        for i in range(Bn):
+            stop = obs[i]['viewpoint'] == obs[i]['gt_path'][-1]
+            if stop or ended[i] or nav['no_vp_left'][i] or t == max_len - 1:
+                moves.append(None)
+            else:
+                nxt = nav['gmap_vpids'][i][int(tgt[i])]
+                hop = gmaps[i].graph.path(obs[i]['viewpoint'], nxt)
+                prev = obs[i]['viewpoint'] if len(hop) == 1 else hop[-2]
+                moves.append((nxt, next(c['pointId'] for c in scan.candidates(prev) if c['viewpointId'] == nxt)))
+        obs = sim.step(moves)
+        robs = robs_of(obs)
+        for i, ob in enumerate(robs):
+            if not ended[i]:
+                gmaps[i].update_graph(ob)
+        ended = np.logical_or(ended, np.array([m is None for m in moves]))
+        if ended.all():
+            break
+    loss = ml_loss * 1.0 / Bn + og_loss * 1.0 / Bn
+    loss.backward()
+    store['n_steps'] = np.array([t + 1])
+    store['loss'] = np.array([float(loss)], np.float32)
+    store['ml_loss'] = np.array([float(ml_loss) / Bn], np.float32)
+    store['og_loss'] = np.array([float(og_loss) / Bn], np.float32)
+    store['param_names'] = np.array([n for n, _ in ref.named_parameters()])
+    store['grad_fp'] = np.stack([fingerprint(p.grad) for _, p in ref.named_parameters()])
+    store['grad_proj'] = np.stack([projections(p.grad) for _, p in ref.named_parameters()])
+    path = os.path.join(HERE, 'rollout_episode_reverie.npz')
+    np.savez_compressed(path, **store)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB  loss', float(loss), 'ml', float(ml_loss) / Bn, 'og', float(og_loss) / Bn, 'steps', t + 1,
+          'object targets', [store['s%d_obj_target' % k].tolist() for k in range(t + 1)])
 
 
 def scripted_actions(t, nav, ended, rs):
@@ -528,9 +653,11 @@ if __name__ == '__main__':
         episode_case()
     elif sys.argv[1:] == ['reverie']:
         main_reverie()
+        reverie_episode_case()
     else:
         main()
         if not sys.argv[1:]:
             episode_case()
             sample_episode_case()
             main_reverie()
+            reverie_episode_case()

@@ -372,3 +372,64 @@ def test_sampled_episode_step_graphs_match_the_eager_rollout():
                 assert torch.equal(plan[k], v), k
     for t in range(T):
         assert np.array_equal(plan['s%d_target' % t].numpy(), z['s%d_target' % t]), t
+
+
+def test_reverie_rollout_matches_the_reference_rollout():
+    """VERDICT r4 #9 — BASELINE configs[4]'s dataset in fine-tuning: NavRollout with an ObjectStore (object observations, object tokens in the
+    panorama, the object-grounding loss at goal viewpoints, the [MEM] slot left selectable as in the REVERIE agent) against the rollout of
+    the imported reference — REVERIE agent builders + reference model (tests/golden/make_golden_rollout.py reverie): per-step navigation
+    and object logits, [MEM] states, navigation + grounding loss, gradient fingerprints and random projections of every parameter."""
+    from helpers import check_projections, projections
+    from vln_goat_amd import nav_model, rollout, synth
+    z = np.load(os.path.join(HERE, 'golden', 'rollout_episode_reverie.npz'))
+    scan, feats, eps, dicts, objects = synth.make_reverie_rollout_case()
+    cfg = nav_model.nav_config_from_args(SimpleNamespace(**{**EP_ARGS, 'dataset': 'reverie', 'obj_feat_size': 768}))
+    torch.manual_seed(0)
+    model = nav_model.GlocalTextPathNavCMT(cfg)
+    model.load_state_dict(synth.seeded_state_dict(model, seed=11))
+    model = model.cuda().eval()
+    store = _store(scan, feats, torch.float32)
+    objects.to('cuda')
+    sim = rollout.GraphSim(store, objects=objects)
+    ro = rollout.NavRollout(lambda mode, batch: model(mode, batch), sim, store, max_action_len=6)
+    rec = []
+    inner = ro.model
+
+    def spy(mode, batch):
+        out = inner(mode, batch)
+        if mode == 'navigation':
+            rec.append(out)
+        return out
+    ro.model = spy
+    loss, traj = ro.run(eps, feedback='teacher', extras=synth.rollout_extras(dicts, len(eps), 'cuda'))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert ro.steps == int(z['n_steps'][0]) == len(rec)
+    for t, out in enumerate(rec):
+        for key in ('fused_logits', 'obj_logits'):
+            ref = z['s%d_%s' % (t, key)]
+            got = out[key].detach().float().cpu().numpy()
+            fin = np.isfinite(ref)
+            assert got.shape == ref.shape and np.array_equal(fin, np.isfinite(got)), (t, key)
+            assert np.abs(got[fin] - ref[fin]).max() <= 1e-3 * max(1.0, np.abs(ref[fin]).max()), (t, key)
+        assert np.abs(out['cls_embeds'].detach().float().cpu().numpy() - z['s%d_cls_embeds' % t]).max() <= 1e-3
+    assert abs(float(ro.ml_loss) - float(z['ml_loss'][0])) <= 1e-3 * float(z['ml_loss'][0])
+    assert float(z['og_loss'][0]) > 0 and abs(float(ro.og_loss) - float(z['og_loss'][0])) <= 1e-3 * max(1.0, float(z['og_loss'][0]))
+    assert abs(float(loss) - float(z['loss'][0])) <= 1e-3 * float(z['loss'][0])
+    names = [str(n) for n in z['param_names']]
+    params = dict(model.named_parameters())
+    top = float(z['grad_fp'][:, 0].max())
+    for n, fp, pr in zip(names, z['grad_fp'], z['grad_proj']):
+        g = params[n].grad
+        norm = 0.0 if g is None else float(g.double().norm())
+        assert abs(norm - float(fp[0])) <= 2e-3 * max(float(fp[0]), 1e-3 * top), (n, norm, float(fp[0]))
+        check_projections(projections(g), pr, max(float(fp[0]), 1e-3 * top), 2e-3, n)
+    for ep, tr in zip(eps, traj):
+        assert tr['path'][0] == [ep['path'][0]] and 'pred_objid' in tr
+    # argmax feedback: the episode ends with a predicted object id taken from the viewpoint with the best stop score
+    with torch.no_grad():
+        _, traj2 = ro.run(eps, feedback='argmax', extras=synth.rollout_extras(dicts, len(eps), 'cuda'), compute_loss=False)
+    for tr in traj2:
+        last_vp = tr['path'][-1][-1]
+        ids = objects.attrs['%s_%s' % (scan.name, last_vp)]['obj_ids'][:objects.count['%s_%s' % (scan.name, last_vp)]]
+        assert tr['pred_objid'] is None or tr['pred_objid'] in ids, (tr['pred_objid'], ids)

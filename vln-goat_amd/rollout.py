@@ -679,7 +679,7 @@ def gmap_order(gmap):
     return [None, None] + visited + unvisited, [0, 1] + [1] * len(visited) + [0] * len(unvisited), len(unvisited) == 0
 
 
-def gmap_inputs(obs, gmaps, width=None, angle_feat_size=4):
+def gmap_inputs(obs, gmaps, width=None, angle_feat_size=4, mem_selectable=False):
     """_nav_gmap_variable (M/r2r/agent.py:151-237) without the embeddings (NodeEmbedStore.gather)."""
     B = len(obs)
     vpids, vis, no_left = zip(*[gmap_order(g) for g in gmaps])
@@ -699,7 +699,9 @@ def gmap_inputs(obs, gmaps, width=None, angle_feat_size=4):
         pair[b, :n, :n] = g.pair_dists(vpids[b])
         vmask[b, :n] = np.asarray(vis[b], bool)
         gmask[b, :n] = True
-    gmask[:, 1] = False                 # the [MEM] token cannot be chosen (:209)
+    if not mem_selectable:              # the [MEM] token cannot be chosen (M/r2r/agent.py:209).  The REVERIE agent's copy of this builder lacks
+        gmask[:, 1] = False             # that line (M/reverie/agent_obj_goat.py:273-343): there the slot stays selectable (its viewpoint id is
+                                        # None: choosing it ends the episode like [stop]) — mem_selectable=True reproduces it
     return {'gmap_vpids': [list(v) for v in vpids], 'gmap_step_ids': torch.from_numpy(step_ids), 'gmap_pos_fts': torch.from_numpy(pos),
             'gmap_visited_masks': torch.from_numpy(vmask), 'gmap_pair_dists': torch.from_numpy(pair), 'gmap_masks': torch.from_numpy(gmask),
             'gmap_lens': lens, 'no_vp_left': list(no_left)}
@@ -882,7 +884,7 @@ class NavRollout:
                         if not g.graph.visited(cvp):
                             store.accumulate(i, cvp, j)
             n_nodes = max(2 + len(g.node_positions) for g in gmaps)
-            gin = gmap_inputs(obs, gmaps, self._bucket(n_nodes), self.sim.angle_feat_size)
+            gin = gmap_inputs(obs, gmaps, self._bucket(n_nodes), self.sim.angle_feat_size, mem_selectable=has_obj)
             W = pano['nav_types'].shape[1]              # (REVERIE: views + objects)
             vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], W + 2, self.sim.angle_feat_size,
                             gmap_pos=(gin['gmap_vpids'], gin['gmap_pos_fts'].numpy()), obj_lens=pano['reverie_obj_lens'] if has_obj else None)

@@ -494,6 +494,16 @@ def reverie_episodes(scan, objects, rs, B=3, max_steps=5, starts=None):
     return eps
 
 
+def make_reverie_rollout_case(seed=23, n_nodes=22, B=3, max_steps=5, scan_seed=12, max_objects=5):
+    """make_rollout_case with objects on the viewpoints and a target object per episode (REVERIE): -> scan, features, episodes,
+    dictionaries, rollout.ObjectStore (float32 table on the host; `.to(device)` before use)."""
+    from . import rollout
+    scan, feats, _, dicts = make_rollout_case(seed, n_nodes, B, max_steps, scan_seed)
+    objects = rollout.ObjectStore.synthetic([scan], D=768, max_objects=max_objects, seed=seed + 1, dtype=torch.float32, p_empty=0.2)
+    eps = reverie_episodes(scan, objects, np.random.RandomState(seed + 2), B, max_steps)
+    return scan, feats, eps, dicts, objects
+
+
 def make_rollout_case(seed=17, n_nodes=24, B=3, max_steps=5, scan_seed=9):
     """scan, float32 features [n_vp, 36, 768], episodes and the BACL / FACL dictionaries (in the reference's on-disk shapes:
     [K, 768] features, [K] probabilities) of the end-to-end rollout golden (tests/golden/rollout_episode.npz).  numpy
