@@ -147,11 +147,41 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(AttnArgs p) {
   const bf16_t* Vb = reinterpret_cast<const bf16_t*>(p.V) + b * p.v_bs + h * HD;
   bf16_t* Ob = reinterpret_cast<bf16_t*>(p.Ow) + b * p.o_bs + h * HD;
   GOAT_STAMP(0);
+  // (key mask and dropout counter requested before the operands: behind them they were a second / third dependent round trip)
+  const float km_pre = tid < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + tid] : 0.f) : -INFINITY;
+  const uint64_t rng_bump = p.rng_dev ? *p.rng_dev : 0ull;
   {
-    const StageOp ops[3] = {{Kb, kl, p.k_rs, p.Lk, NKT * 32}, {Vb, vl, p.v_rs, p.Lk, NKT * 32}, {Qb, ql, p.q_rs, p.Lq, nqt * 32}};
-    stage_ops<3, 12>(ops, tid, nth);      // (80 x 80 on three waves: 12 chunks per lane, one round trip)
+    // lane (row group tid / 8, chunk tid % 8) moves its chunk of rows r0, r0 + nth / 8, ...: one 32-bit offset add per load on a
+    // wave-uniform base (see attn2_bwd_shared_kernel: the flat chunk -> (operand, row, chunk) mapping of stage_ops cost ~80 instructions
+    // per 16-byte load); 4 rows per lane and operand in flight (K, V, Q: 12 loads) before the first LDS write
+    constexpr int U = 4;
+    const int r0 = tid >> 3, cc8 = (tid & 7) * NE, rstep = nth >> 3;
+    const int maxrows = (NKT > nqt ? NKT : nqt) * 32;
+    for (int rb = 0; rb < maxrows; rb += U * rstep) {
+      uint4 vk[U], vv[U], vq[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = rb + r0 + u * rstep;
+        vk[u] = uint4{0u, 0u, 0u, 0u}; vv[u] = uint4{0u, 0u, 0u, 0u}; vq[u] = uint4{0u, 0u, 0u, 0u};
+        if (r < p.Lk) {
+          vk[u] = *reinterpret_cast<const uint4*>(Kb + (uint32_t)(r * (int)p.k_rs + cc8));
+          vv[u] = *reinterpret_cast<const uint4*>(Vb + (uint32_t)(r * (int)p.v_rs + cc8));
+        }
+        if (r < p.Lq) vq[u] = *reinterpret_cast<const uint4*>(Qb + (uint32_t)(r * (int)p.q_rs + cc8));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = rb + r0 + u * rstep;
+        if (r < NKT * 32) {
+          *reinterpret_cast<uint4*>(kl + r * LSTR + cc8) = vk[u];
+          *reinterpret_cast<uint4*>(vl + r * LSTR + cc8) = vv[u];
+        }
+        if (r < nqt * 32) *reinterpret_cast<uint4*>(ql + r * LSTR + cc8) = vq[u];
+      }
+    }
   }
-  for (int i = tid; i < NKT * 32; i += nth) kml[i] = i < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + i] : 0.f) : -INFINITY;
+  if (tid < NKT * 32) kml[tid] = km_pre;
+  for (int i = tid + nth; i < NKT * 32; i += nth) kml[i] = i < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + i] : 0.f) : -INFINITY;
   GOAT_STAMP(1);
   __syncthreads();
   GOAT_STAMP(2);
@@ -159,7 +189,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(AttnArgs p) {
   const bool drop = p.p > 0.f;
   const uint32_t thr = goat_thr16(p.p);
   const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
-  const HeadRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull), p.offset, (uint32_t)blockIdx.x);
+  const HeadRng rng(p.seed + rng_bump, p.offset, (uint32_t)blockIdx.x);
   // a wave takes query tiles wave, wave + #waves, ... (one each up to 128 queries; two for the 129..256-row sequences)
   for (int qti = wave; qti < nqt; qti += (nth >> 6)) {
   const int q0 = qti * 32, q = q0 + l31;
@@ -507,6 +537,13 @@ __device__ __forceinline__ bf16x8 bfrag_nrow(const bf16_t* lds, int row_base, in
   return f;
 }
 
+#if GOAT_ATTN_TIMING      // (experiments: the backward kernel's stamps go to `dbias` as uint32[B * nh * 8], wave 0 of every block; bias must be NULL)
+#define GOAT_BSTAMP(i_) do { if (tid == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); reinterpret_cast<uint32_t*>(p.dbias)[blockIdx.x * 8 + (i_)] = (uint32_t)__builtin_amdgcn_s_memtime(); } } while (0)
+#define GOAT_BSTAMP_NW(i_) do { if (tid == 0) reinterpret_cast<uint32_t*>(p.dbias)[blockIdx.x * 8 + (i_)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)      /* no wait: issue time only */
+#else
+#define GOAT_BSTAMP(i_) do { } while (0)
+#define GOAT_BSTAMP_NW(i_) do { } while (0)
+#endif
 __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x;
@@ -528,81 +565,84 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
   const bf16_t* Vb = reinterpret_cast<const bf16_t*>(p.V) + b * p.v_bs + h * HD;
   const bf16_t* Ob = reinterpret_cast<const bf16_t*>(p.O) + b * p.o_bs + h * HD;
   const bf16_t* dOb = reinterpret_cast<const bf16_t*>(p.dO) + b * p.do_bs + h * HD;
-  // Staging: the first DD chunks per lane of dO and of O are requested BEFORE Q / K / V (registers are free here), so that a head's
-  // operands cost about one HBM round trip (80 x 80 on three waves: 4 + 4 + 12 16-byte loads per lane, all in flight together;
-  // the first version — Q / K / V in two rounds of 8, then dO / O — spent three dependent round trips, 6 of a workgroup's ~17 us).
-  constexpr int DD = 4;
-#define GOAT_DO_LOAD(c0_)                                                                          \
-  _Pragma("unroll") for (int d = 0; d < DD; ++d) {                                                 \
-    const int c = (c0_) + d * nth, r = c >> 3, cc = c & 7;                                         \
-    dv[d] = uint4{0u, 0u, 0u, 0u};                                                                 \
-    ov[d] = uint4{0u, 0u, 0u, 0u};                                                                 \
-    if (c < nqt * 32 * 8 && r < p.Lq) {                                                            \
-      dv[d] = *reinterpret_cast<const uint4*>(dOb + (int64_t)r * p.do_rs + cc * NE);               \
-      ov[d] = *reinterpret_cast<const uint4*>(Ob + (int64_t)r * p.o_rs + cc * NE);                 \
-    }                                                                                              \
+  GOAT_BSTAMP(0);
+  // The small per-row vectors (log-sum-exp, key mask) and the device-side dropout counter are requested FIRST, into registers: behind the
+  // operand staging they were a second and third dependent HBM round trip (cycle stamps, profiles/round5_attention_bwd_phases.txt:
+  // staging 14.0k of a block's 36.5k cycles).  One value per lane covers up to 64 x #waves rows; longer sequences loop below.
+  const int lrow = tid;
+  const float lse_pre = (lrow < nqt * 32 && lrow < p.Lq) ? p.lse[((int64_t)b * p.nh + h) * p.Lq + lrow] : -INFINITY;
+  const float km_pre = lrow < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + lrow] : 0.f) : -INFINITY;
+  const uint64_t rng_bump = p.rng_dev ? *p.rng_dev : 0ull;
+  // Staging.  Lane (row group r0 = tid / 8, 16-byte chunk cc = tid % 8) moves chunk cc of rows r0, r0 + nth / 8, ... of every operand: the
+  // chunk is fixed per lane and the row advances by a constant, so a load costs one 32-bit offset add on a wave-uniform base (the
+  // first version mapped a flat chunk index over Q | K | V to (operand, row, chunk) per load: ~80 instructions of selects and 64-bit
+  // multiplies per 16-byte load — cycle stamps, profiles/round5_attention_bwd_phases.txt: 7.4k cycles before the LAST load was even
+  // issued, on an idle chip).  U = 4 rows per lane and operand cover 32 * #waves rows, i.e. K and V always (waves >= key tiles): the
+  // 4 + 4 (dO, O) + 12 (Q, K, V) loads of a lane are all in flight before the first LDS write.  Rows past the sequence read as zero.
+  constexpr int U = 4;
+  const int r0 = tid >> 3, cc8 = (tid & 7) * NE, rstep = nth >> 3;
+#define GOAT_ROWS_LOAD(v_, g_, rs_, n_, rbase_)                                                    \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                  \
+    const int r = (rbase_) + r0 + u * rstep;                                                       \
+    v_[u] = uint4{0u, 0u, 0u, 0u};                                                                 \
+    if (r < (n_)) v_[u] = *reinterpret_cast<const uint4*>((g_) + (uint32_t)(r * (int)(rs_) + cc8)); \
   }
-  // dO -> LDS, with D_q on the way: the 8 lanes that move a row's eight 16-byte chunks reduce their partial dot products
-#define GOAT_DO_PUT(c0_)                                                                           \
-  _Pragma("unroll") for (int d = 0; d < DD; ++d) {                                                 \
-    const int c = (c0_) + d * nth, r = c >> 3, cc = c & 7;                                         \
-    const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(&dv[d]), o8 = *reinterpret_cast<const bf16x8*>(&ov[d]); \
+#define GOAT_ROWS_PUT(v_, l_, pad_, rbase_)                                                        \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                  \
+    const int r = (rbase_) + r0 + u * rstep;                                                       \
+    if (r < (pad_)) *reinterpret_cast<uint4*>((l_) + r * LSTR + cc8) = v_[u];                      \
+  }
+  // dO -> LDS, with D_q = sum_d dO[q, d] O[q, d] on the way: the 8 lanes of a row reduce their partial dot products (DPP, no LDS)
+#define GOAT_DO_PUT(rbase_)                                                                        \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                  \
+    const int r = (rbase_) + r0 + u * rstep;                                                       \
+    const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(&dv[u]), o8 = *reinterpret_cast<const bf16x8*>(&ov[u]); \
     float part = 0.f;                                                                              \
     _Pragma("unroll") for (int e = 0; e < NE; ++e) part += (float)d8[e] * (float)o8[e];            \
-    part += __shfl_xor(part, 1, 64);                                                               \
-    part += __shfl_xor(part, 2, 64);                                                               \
-    part += __shfl_xor(part, 4, 64);                                                               \
-    if (c < nqt * 32 * 8) {                                                                        \
-      *reinterpret_cast<uint4*>(dol + r * LSTR + cc * NE) = dv[d];                                 \
-      if (cc == 0) Dl[r] = part;                                                                   \
+    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0xB1, 0xF, 0xF, false));   /* lane ^ 1 */ \
+    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x4E, 0xF, 0xF, false));   /* lane ^ 2 */ \
+    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x141, 0xF, 0xF, false));  /* row_half_mirror: the other quad of the 8 */ \
+    if (r < nqt * 32) {                                                                            \
+      *reinterpret_cast<uint4*>(dol + r * LSTR + cc8) = dv[u];                                     \
+      if ((tid & 7) == 0) Dl[r] = part;                                                            \
     }                                                                                              \
   }
   {
-    uint4 dv[DD], ov[DD];
-    GOAT_DO_LOAD(tid);
-    {
-      // Q | K | V rows as one index space of 16-byte chunks, SD loads in flight per lane; the LDS destination is recomputed from the
-      // chunk index at the store (stage_ops keeps SD pointers alive beside the data: with SD = 12 it spilled 77 registers here)
-      constexpr int SD = 12;
-      const int nq8 = nqt * 32 * 8, nk8 = nkt * 32 * 8, total = nq8 + 2 * nk8;
-      for (int c0 = tid; c0 < total; c0 += nth * SD) {
-        uint4 v[SD];
-#pragma unroll
-        for (int d = 0; d < SD; ++d) {
-          const int c = c0 + d * nth;
-          const int w = c < nq8 ? 0 : (c < nq8 + nk8 ? 1 : 2);
-          const int cl = c - (w == 0 ? 0 : (w == 1 ? nq8 : nq8 + nk8)), r = cl >> 3, cc = cl & 7;
-          const bf16_t* src = (w == 0 ? Qb + (int64_t)r * p.q_rs : (w == 1 ? Kb + (int64_t)r * p.k_rs : Vb + (int64_t)r * p.v_rs)) + cc * NE;
-          v[d] = uint4{0u, 0u, 0u, 0u};
-          if (c < total && r < (w == 0 ? p.Lq : p.Lk)) v[d] = *reinterpret_cast<const uint4*>(src);
-        }
-#pragma unroll
-        for (int d = 0; d < SD; ++d) {
-          const int c = c0 + d * nth;
-          const int w = c < nq8 ? 0 : (c < nq8 + nk8 ? 1 : 2);
-          const int cl = c - (w == 0 ? 0 : (w == 1 ? nq8 : nq8 + nk8)), r = cl >> 3, cc = cl & 7;
-          bf16_t* dst = (w == 0 ? ql : (w == 1 ? kl : vl)) + r * LSTR + cc * NE;
-          if (c < total) *reinterpret_cast<uint4*>(dst) = v[d];
-        }
-      }
-    }
-    GOAT_DO_PUT(tid);
+    uint4 dv[U], ov[U], vq[U], vk[U], vv[U];
+    GOAT_ROWS_LOAD(dv, dOb, p.do_rs, p.Lq, 0);
+    GOAT_ROWS_LOAD(ov, Ob, p.o_rs, p.Lq, 0);
+    GOAT_ROWS_LOAD(vq, Qb, p.q_rs, p.Lq, 0);
+    GOAT_ROWS_LOAD(vk, Kb, p.k_rs, p.Lk, 0);
+    GOAT_ROWS_LOAD(vv, Vb, p.v_rs, p.Lk, 0);
+    GOAT_BSTAMP_NW(7);
+    GOAT_DO_PUT(0);
+    GOAT_ROWS_PUT(vq, ql, nqt * 32, 0);
+    GOAT_ROWS_PUT(vk, kl, nkt * 32, 0);
+    GOAT_ROWS_PUT(vv, vl, nkt * 32, 0);
   }
-  for (int c0 = tid + nth * DD; c0 < nqt * 32 * 8; c0 += nth * DD) {      // (longer sequences)
-    uint4 dv[DD], ov[DD];      // (arrays of their own: shared with the hoisted first pass they end up in scratch memory)
-    GOAT_DO_LOAD(c0);
-    GOAT_DO_PUT(c0);
+  for (int rb = U * rstep; rb < nqt * 32; rb += U * rstep) {      // (more query tiles than waves: the remaining Q / dO / O rows)
+    uint4 dv[U], ov[U], vq[U];
+    GOAT_ROWS_LOAD(dv, dOb, p.do_rs, p.Lq, rb);
+    GOAT_ROWS_LOAD(ov, Ob, p.o_rs, p.Lq, rb);
+    GOAT_ROWS_LOAD(vq, Qb, p.q_rs, p.Lq, rb);
+    GOAT_DO_PUT(rb);
+    GOAT_ROWS_PUT(vq, ql, nqt * 32, rb);
   }
-#undef GOAT_DO_LOAD
+#undef GOAT_ROWS_LOAD
+#undef GOAT_ROWS_PUT
 #undef GOAT_DO_PUT
-  for (int i = tid; i < nqt * 32; i += nth) lsel[i] = i < p.Lq ? p.lse[((int64_t)b * p.nh + h) * p.Lq + i] : -INFINITY;
-  for (int i = tid; i < nkt * 32; i += nth) kml[i] = i < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + i] : 0.f) : -INFINITY;
+  if (lrow < nqt * 32) lsel[lrow] = lse_pre;
+  if (lrow < nkt * 32) kml[lrow] = km_pre;
+  for (int i = tid + nth; i < nqt * 32; i += nth) lsel[i] = i < p.Lq ? p.lse[((int64_t)b * p.nh + h) * p.Lq + i] : -INFINITY;
+  for (int i = tid + nth; i < nkt * 32; i += nth) kml[i] = i < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + i] : 0.f) : -INFINITY;
+  GOAT_BSTAMP(1);
   __syncthreads();
+  GOAT_BSTAMP(2);
 
   const bool drop = p.p > 0.f;
   const uint32_t thr = goat_thr16(p.p);
   const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
-  const HeadRng rng(p.seed + (p.rng_dev ? *p.rng_dev : 0ull), p.offset, (uint32_t)blockIdx.x);
+  const HeadRng rng(p.seed + rng_bump, p.offset, (uint32_t)blockIdx.x);
   f32x16 ra[2], rb[2];           // phase 1: ra = dK^T, rb = dV^T; phase 2: ra = dQ^T
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -623,7 +663,7 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
     // (bias / its gradient: one 64-bit base per sample + 32-bit element offsets — with 64-bit addresses per register the compiler
     // hoisted sixteen of them out of the query-tile loop and spilled them)
     const float* bias_b = p.bias ? p.bias + (int64_t)b * p.Lq * p.Lk : nullptr;
-    float* dbias_b = p.dbias ? p.dbias + (int64_t)b * p.Lq * p.Lk : nullptr;
+    float* dbias_b = (p.dbias && !GOAT_ATTN_TIMING) ? p.dbias + (int64_t)b * p.Lq * p.Lk : nullptr;
     // dropout bits: the pair hash of (q * Lk + key) >> 1 serves this lane and its neighbour (key ^ 1) when q * Lk is even: with an even
     // Lk every lane hashes half of its 16 queries and takes the other half from lane ^ 1 (one DPP move instead of a second hash)
     const bool lk_even = (p.Lk & 1) == 0;
@@ -640,15 +680,18 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
       float lq[16], dq[16];                 // lse and D of this lane's 16 queries (q0 + 4*hi + 8*g + {0..3})
       load_kmask(lsel, it, hi, lq);
       load_kmask(Dl, it, hi, dq);
+      // P = exp(S scale + mask (+ bias) - lse) as ONE fma + exp2 per element: the exponent's additive part c = (mask - lse) log2(e)
+      // is formed per query row (-inf for padded queries / masked or padded keys: exp2(-inf) = 0, no select), the bias joins it
+      constexpr float LOG2E = 1.4426950408889634f;
+      const float sl2 = p.scale * LOG2E;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lq[r] = (lq[r] != -INFINITY && kv) ? (kmv - lq[r]) * LOG2E : -INFINITY;
       if (p.bias != nullptr) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int q = q0 + c_row(r, lane);
-          s[r] = s[r] * p.scale + ((q < p.Lq && kv) ? bias_b[(uint32_t)(q * p.Lk + key)] : 0.f);
+          lq[r] += ((q < p.Lq && kv) ? bias_b[(uint32_t)(q * p.Lk + key)] : 0.f) * LOG2E;
         }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] *= p.scale;
       }
       bf16x8 apf[TSTEPS], asf[TSTEPS];      // P (dropped) and dS as the MFMA fragments of k-step 0 / 1 (registers r8 / r8 + 8)
 #pragma unroll
@@ -661,7 +704,7 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
             const int odd = lane & 1;
             const uint32_t qh = (uint32_t)(q0 + (odd ? c_row(r8 + 8, lane) : c_row(r8, lane)));
             const uint32_t mine = rng.pair((qh * (uint32_t)p.Lk + (uint32_t)key) >> 1);
-            const uint32_t theirs = (uint32_t)__shfl_xor((int)mine, 1, 64);
+            const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, false);      // lane ^ 1 (quad_perm 1,0,3,2)
             h0 = odd ? theirs : mine;
             h1 = odd ? mine : theirs;
           } else {
@@ -674,7 +717,7 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
           const int r = r8 + 8 * half;
           const int q = q0 + c_row(r, lane);
           // (padded queries: lse = -inf -> exp(+inf) would be inf: guarded; masked keys: kmv = -inf -> 0)
-          const float pr = (lq[r] != -INFINITY && kv) ? __expf(s[r] + kmv - lq[r]) : 0.f;
+          const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, lq[r]));
           float keep = 1.f;
           if (drop) {
             const uint32_t idx = (uint32_t)q * (uint32_t)p.Lk + (uint32_t)key, hh = half ? h1 : h0;
@@ -686,7 +729,7 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
           asf[half][r8] = (bf16_t)(d * p.scale);
         }
       }
-      if (p.dbias != nullptr && kv) {
+      if (dbias_b != nullptr && kv) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int q = q0 + c_row(r, lane);
@@ -706,7 +749,9 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
       }
     }
   }
+  GOAT_BSTAMP(3);
   __syncthreads();      // the dS image is complete; Q, dO and V are dead from here on
+  GOAT_BSTAMP(4);
 #define GOAT_DQB (reinterpret_cast<bf16_t*>(p.dQ) + b * p.dq_bs + h * HD)
 #define GOAT_DKB (reinterpret_cast<bf16_t*>(p.dK) + b * p.dk_bs + h * HD)
 #define GOAT_DVB (reinterpret_cast<bf16_t*>(p.dV) + b * p.dv_bs + h * HD)
@@ -714,6 +759,7 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
     store_tile(vl + wave * TILE, ra, GOAT_DKB, p.dk_rs, wave * 32, p.Lk, lane);
     store_tile(vl + wave * TILE, rb, GOAT_DVB, p.dv_rs, wave * 32, p.Lk, lane);
   }
+  GOAT_BSTAMP(5);
   // ---- phase 2, query tiles wave, wave + #waves, ...: lane = query.  dQ^T += K^T · dS^T over all key tiles
   for (int qt = wave; qt < nqt; qt += (nth >> 6)) {
     const int q0 = qt * 32;
@@ -731,6 +777,7 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
     }
     store_tile(ql + qt * TILE, ra, GOAT_DQB, p.dq_rs, q0, p.Lq, lane);
   }
+  GOAT_BSTAMP(6);
 #undef GOAT_DQB
 #undef GOAT_DKB
 #undef GOAT_DVB

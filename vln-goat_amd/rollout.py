@@ -866,6 +866,10 @@ class NavRollout:
                    'nav_types': pano['nav_types'].to(dev, non_blocking=True), 'view_lens': pano['view_lens'].to(dev, non_blocking=True),
                    'already_dropout': False}
             if has_obj:
+                if pano['obj_rows'].shape[1] == 0:          # no viewpoint of this step sees an object: one padding slot (the kernels take no
+                    pano['obj_rows'] = torch.full((B, 1), -1, dtype=torch.int64)                # zero-width tensors; obj_lens = 0 masks it)
+                    pano['reverie_obj_names'] = torch.zeros((B, 1), dtype=torch.int64)
+                    pano['reverie_obj_locs'] = torch.zeros((B, 1, pano['loc_fts'].shape[2]), dtype=torch.float32)
                 pin.update({'reverie_obj_img_fts': self.objects.gather(pano['obj_rows'].to(dev, non_blocking=True)),
                             'reverie_obj_lens': pano['reverie_obj_lens'].to(dev, non_blocking=True),
                             'reverie_obj_names': pano['reverie_obj_names'].to(dev, non_blocking=True),
