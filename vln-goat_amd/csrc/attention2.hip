@@ -544,13 +544,16 @@ __device__ __forceinline__ bf16x8 bfrag_nrow(const bf16_t* lds, int row_base, in
 #define GOAT_BSTAMP(i_) do { } while (0)
 #define GOAT_BSTAMP_NW(i_) do { } while (0)
 #endif
+// DSS_: dS row stride in elements (compile time: the 16 image stores of a pair take immediate offsets); DROP / LKE: dropout on / even Lk
+// (uniform branches inside the unrolled element loops cost an s_cbranch each: this kernel is bound by the instructions ONE wave issues)
+template <int DSS_, bool DROP, bool LKE>
 __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x;
   const int hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
   const int nqt = (p.Lq + 31) / 32, nkt = (p.Lk + 31) / 32;
-  const int DSS = nkt * 32 + DSP;                               // dS row stride in elements
+  constexpr int DSS = DSS_;                                     // dS row stride in elements (>= 32 nkt + DSP)
   bf16_t* ql = reinterpret_cast<bf16_t*>(smem);
   bf16_t* dol = ql + nqt * TILE;
   bf16_t* kl = dol + nqt * TILE;
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
   // operand staging they were a second and third dependent HBM round trip (cycle stamps, profiles/round5_attention_bwd_phases.txt:
   // staging 14.0k of a block's 36.5k cycles).  One value per lane covers up to 64 x #waves rows; longer sequences loop below.
   const int lrow = tid;
-  const float lse_pre = (lrow < nqt * 32 && lrow < p.Lq) ? p.lse[((int64_t)b * p.nh + h) * p.Lq + lrow] : -INFINITY;
+  const float lse_pre = (lrow < nqt * 32 && lrow < p.Lq) ? p.lse[((int64_t)b * p.nh + h) * p.Lq + lrow] : -INFINITY;      // (stored below as lse log2(e); +inf for padded / fully masked rows)
   const float km_pre = lrow < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + lrow] : 0.f) : -INFINITY;
   const uint64_t rng_bump = p.rng_dev ? *p.rng_dev : 0ull;
   // Staging.  Lane (row group r0 = tid / 8, 16-byte chunk cc = tid % 8) moves chunk cc of rows r0, r0 + nth / 8, ... of every operand: the
@@ -631,15 +634,21 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
 #undef GOAT_ROWS_LOAD
 #undef GOAT_ROWS_PUT
 #undef GOAT_DO_PUT
-  if (lrow < nqt * 32) lsel[lrow] = lse_pre;
-  if (lrow < nkt * 32) kml[lrow] = km_pre;
-  for (int i = tid + nth; i < nqt * 32; i += nth) lsel[i] = i < p.Lq ? p.lse[((int64_t)b * p.nh + h) * p.Lq + i] : -INFINITY;
-  for (int i = tid + nth; i < nkt * 32; i += nth) kml[i] = i < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + i] : 0.f) : -INFINITY;
+  // lsel = lse log2(e), +inf for padded and fully masked queries; kml = mask log2(e), -inf for masked / padded keys:
+  // P = exp2(S scale log2(e) + kml - lsel) is then 0 wherever either says so, without a select
+  constexpr float LOG2E = 1.4426950408889634f;
+  if (lrow < nqt * 32) lsel[lrow] = lse_pre != -INFINITY ? lse_pre * LOG2E : INFINITY;
+  if (lrow < nkt * 32) kml[lrow] = km_pre * LOG2E;
+  for (int i = tid + nth; i < nqt * 32; i += nth) {
+    const float l = i < p.Lq ? p.lse[((int64_t)b * p.nh + h) * p.Lq + i] : -INFINITY;
+    lsel[i] = l != -INFINITY ? l * LOG2E : INFINITY;
+  }
+  for (int i = tid + nth; i < nkt * 32; i += nth) kml[i] = (i < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + i] : 0.f) : -INFINITY) * LOG2E;
   GOAT_BSTAMP(1);
   __syncthreads();
   GOAT_BSTAMP(2);
 
-  const bool drop = p.p > 0.f;
+  constexpr bool drop = DROP;
   const uint32_t thr = goat_thr16(p.p);
   const float keep_scale = drop ? 1.f / (1.f - p.p) : 1.f;
   const HeadRng rng(p.seed + rng_bump, p.offset, (uint32_t)blockIdx.x);
@@ -666,26 +675,27 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
     float* dbias_b = (p.dbias && !GOAT_ATTN_TIMING) ? p.dbias + (int64_t)b * p.Lq * p.Lk : nullptr;
     // dropout bits: the pair hash of (q * Lk + key) >> 1 serves this lane and its neighbour (key ^ 1) when q * Lk is even: with an even
     // Lk every lane hashes half of its 16 queries and takes the other half from lane ^ 1 (one DPP move instead of a second hash)
-    const bool lk_even = (p.Lk & 1) == 0;
+    constexpr bool lk_even = LKE;
+    const float sl2 = p.scale * LOG2E;
+    const uint32_t Lku = (uint32_t)p.Lk;
+    const uint32_t hsh = lk_even ? (uint32_t)(key & 1) * 16u : 0u;      // even Lk: the element's half of the pair hash is the key's parity
     for (int it = 0; it < nqt; ++it) {
       const int q0 = it * 32;
-      f32x16 s, dp;
+      // S and dP of the pair: the first k-step starts from a zero accumulator operand (no 32 v_mov)
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(ql + q0 * LSTR, l31, 0, hi), kf[0], zero16, 0, 0, 0);
+      f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(dol + q0 * LSTR, l31, 0, hi), vf[0], zero16, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
+      for (int ks = 1; ks < KSTEPS; ++ks) {
         mma32(s, lds_frag(ql + q0 * LSTR, l31, ks, hi), kf[ks]);
         mma32(dp, lds_frag(dol + q0 * LSTR, l31, ks, hi), vf[ks]);
       }
-      float lq[16], dq[16];                 // lse and D of this lane's 16 queries (q0 + 4*hi + 8*g + {0..3})
+      float lq[16], dq[16];                 // lse log2(e) and D of this lane's 16 queries (q0 + 4*hi + 8*g + {0..3})
       load_kmask(lsel, it, hi, lq);
       load_kmask(Dl, it, hi, dq);
-      // P = exp(S scale + mask (+ bias) - lse) as ONE fma + exp2 per element: the exponent's additive part c = (mask - lse) log2(e)
-      // is formed per query row (-inf for padded queries / masked or padded keys: exp2(-inf) = 0, no select), the bias joins it
-      constexpr float LOG2E = 1.4426950408889634f;
-      const float sl2 = p.scale * LOG2E;
+      // exponent's additive part per query: c = mask log2(e) - lse log2(e) (+ bias log2(e)); -inf kills the element
 #pragma unroll
-      for (int r = 0; r < 16; ++r) lq[r] = (lq[r] != -INFINITY && kv) ? (kmv - lq[r]) * LOG2E : -INFINITY;
+      for (int r = 0; r < 16; ++r) lq[r] = kmv - lq[r];
       if (p.bias != nullptr) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -693,36 +703,36 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
           lq[r] += ((q < p.Lq && kv) ? bias_b[(uint32_t)(q * p.Lk + key)] : 0.f) * LOG2E;
         }
       }
+      // element index of (first query of this lane, key); register r adds ((r / 4) * 8 + r % 4) * Lk — wave-uniform
+      const uint32_t ibase = (uint32_t)(q0 + 4 * hi) * Lku + (uint32_t)key;
       bf16x8 apf[TSTEPS], asf[TSTEPS];      // P (dropped) and dS as the MFMA fragments of k-step 0 / 1 (registers r8 / r8 + 8)
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const uint32_t o0 = (uint32_t)((r8 >> 2) * 8 + (r8 & 3)) * Lku, o1 = o0 + 16u * Lku;      // (register r8 + 8: queries 16 further)
         // pair hashes of elements (query of register r8, key) and (query of register r8 + 8, key)
         uint32_t h0 = 0, h1 = 0;
         if (drop) {
           if (lk_even) {
             // even lanes hash register r8, odd lanes register r8 + 8 (lane and lane ^ 1 hold the same queries and share the pair index)
             const int odd = lane & 1;
-            const uint32_t qh = (uint32_t)(q0 + (odd ? c_row(r8 + 8, lane) : c_row(r8, lane)));
-            const uint32_t mine = rng.pair((qh * (uint32_t)p.Lk + (uint32_t)key) >> 1);
+            const uint32_t mine = rng.pair((ibase + (odd ? o1 : o0)) >> 1);
             const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, false);      // lane ^ 1 (quad_perm 1,0,3,2)
-            h0 = odd ? theirs : mine;
-            h1 = odd ? mine : theirs;
+            h0 = (odd ? theirs : mine) >> hsh;
+            h1 = (odd ? mine : theirs) >> hsh;
           } else {
-            h0 = rng.pair(((uint32_t)(q0 + c_row(r8, lane)) * (uint32_t)p.Lk + (uint32_t)key) >> 1);
-            h1 = rng.pair(((uint32_t)(q0 + c_row(r8 + 8, lane)) * (uint32_t)p.Lk + (uint32_t)key) >> 1);
+            const uint32_t i0 = ibase + o0, i1 = ibase + o1;
+            h0 = rng.pair(i0 >> 1) >> ((i0 & 1u) * 16u);
+            h1 = rng.pair(i1 >> 1) >> ((i1 & 1u) * 16u);
           }
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           const int r = r8 + 8 * half;
-          const int q = q0 + c_row(r, lane);
-          // (padded queries: lse = -inf -> exp(+inf) would be inf: guarded; masked keys: kmv = -inf -> 0)
           const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, lq[r]));
           float keep = 1.f;
-          if (drop) {
-            const uint32_t idx = (uint32_t)q * (uint32_t)p.Lk + (uint32_t)key, hh = half ? h1 : h0;
-            keep = (((idx & 1u) ? (hh >> 16) : (hh & 0xFFFFu)) >= thr) ? keep_scale : 0.f;
-          }
+          if (drop) keep = ((half ? h1 : h0) & 0xFFFFu) >= thr ? keep_scale : 0.f;
           const float d = pr * (dp[r] * keep - dq[r]);
           s[r] = d;
           apf[half][r8] = (bf16_t)(pr * keep);
@@ -737,8 +747,11 @@ __global__ __launch_bounds__(512) void attn2_bwd_shared_kernel(AttnArgs p) {
         }
       }
       // dS image: element (query, key) as bf16; the 32 lanes of a half write 64 contiguous bytes of one row
+      {
+        bf16_t* dl = dsl + (q0 + 4 * hi) * DSS + key;          // (compile-time stride: immediate offsets)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dsl[(q0 + c_row(r, lane)) * DSS + key] = asf[r >> 3][r & 7];
+        for (int r = 0; r < 16; ++r) dl[((r >> 2) * 8 + (r & 3)) * DSS] = asf[r >> 3][r & 7];
+      }
 #pragma unroll
       for (int st = 0; st < TSTEPS; ++st) {
 #pragma unroll
@@ -838,11 +851,29 @@ int goat_attn2_bwd(hipStream_t st, const AttnArgs& a) {
   // GOAT_ATTN_BWD_DUP=1: the round-2 kernel (both roles recompute S / dP) for every problem (A/B experiments)
   static const bool shared_ds = !(getenv("GOAT_ATTN_BWD_DUP") && getenv("GOAT_ATTN_BWD_DUP")[0] == '1');
   if (shared_ds) {
-    const size_t sms = (size_t)(2 * nqt + 2 * nkt) * TILE * 2 + (size_t)nqt * 32 * (nkt * 32 + DSP) * 2 + (size_t)(2 * nqt + nkt) * 32 * 4;
+    const int dss = nkt == 1 ? 40 : (nkt == 2 ? 72 : (nkt == 3 ? 104 : (nkt <= 5 ? 168 : 264)));      // dS row stride (elements): 32 nkt + 8 (of the class's largest nkt)
+    const size_t sms = (size_t)(2 * nqt + 2 * nkt) * TILE * 2 + (size_t)nqt * 32 * dss * 2 + (size_t)(2 * nqt + nkt) * 32 * 4;
     if (sms <= 160 * 1024) {
-      static size_t cur_s = 0;
-      if (int e = set_smem(attn2_bwd_shared_kernel, sms, cur_s)) return e;
-      hipLaunchKernelGGL(attn2_bwd_shared_kernel, dim3(a.B * a.nh), dim3(64 * (nkt > 2 ? nkt : 2)), sms, st, a);
+      const bool drop = a.p > 0.f, lke = (a.Lk & 1) == 0;
+      const dim3 grid(a.B * a.nh), block(64 * (nkt > 2 ? nkt : 2));
+#define GOAT_BWD_LAUNCH(DSS_, D_, E_)                                                                   \
+  do {                                                                                                  \
+    static size_t cur_s = 0;                                                                            \
+    if (int e = set_smem(attn2_bwd_shared_kernel<DSS_, D_, E_>, sms, cur_s)) return e;                  \
+    hipLaunchKernelGGL((attn2_bwd_shared_kernel<DSS_, D_, E_>), grid, block, sms, st, a);               \
+  } while (0)
+#define GOAT_BWD_DE(DSS_)                                                                               \
+  do {                                                                                                  \
+    if (drop) { if (lke) GOAT_BWD_LAUNCH(DSS_, true, true); else GOAT_BWD_LAUNCH(DSS_, true, false); }  \
+    else GOAT_BWD_LAUNCH(DSS_, false, true);              /* (no dropout: the parity flag is unused) */  \
+  } while (0)
+      if (dss == 40) GOAT_BWD_DE(40);
+      else if (dss == 72) GOAT_BWD_DE(72);
+      else if (dss == 104) GOAT_BWD_DE(104);
+      else if (dss == 168) GOAT_BWD_DE(168);
+      else GOAT_BWD_DE(264);
+#undef GOAT_BWD_DE
+#undef GOAT_BWD_LAUNCH
       GOAT_LAUNCH_CHECK();
       return 0;
     }
