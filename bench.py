@@ -1165,7 +1165,7 @@ def dagger_iteration(model, te, bufs, batches, extras, arena, sim, store, B, T, 
     two = None
     if not os.environ.get('GOAT_BENCH_NO_TWO_PASS'):
         try:
-            two = two_pass_iteration(call, te, bufs, g, batches, extras, arena, sim, store, ro, max_action_len)
+            two = two_pass_iteration(call, te, bufs, g, batches, extras, arena, sim, store, ro, max_action_len, ml_weight)
         except Exception as e:      # noqa: BLE001
             two = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     forms = {'single_pass_eager': round(dt * 1e3, 2)}
@@ -1173,6 +1173,9 @@ def dagger_iteration(model, te, bufs, batches, extras, arena, sim, store, B, T, 
         forms['two_pass'] = two['ms_per_iteration']
         if isinstance(two.get('pass1_captured'), dict) and 'ms_per_iteration' in two['pass1_captured']:
             forms['two_pass_pass1_captured'] = two['pass1_captured']['ms_per_iteration']
+            ov = two['pass1_captured'].get('teacher_overlapped')
+            if isinstance(ov, dict) and 'ms_per_iteration' in ov:
+                forms['two_pass_teacher_overlapped'] = ov['ms_per_iteration']
     best = min(forms, key=forms.get)
     return {'best_form': best, 'best_ms_per_iteration': forms[best], 'forms_ms': forms,
             'ms_per_iteration': round(dt * 1e3, 2), 'sample_rollout_ms': round(sum(t_s) / n * 1e3, 2), 'sample_steps': round(sum(steps) / n, 1),
@@ -1182,7 +1185,7 @@ def dagger_iteration(model, te, bufs, batches, extras, arena, sim, store, B, T, 
                     '+ their backward passes into one gradient arena: the reference iteration of train_alg=dagger' % ml_weight}
 
 
-def two_pass_iteration(call, te, bufs, g_teacher, batches, extras, arena, sim, store, ro, max_action_len):
+def two_pass_iteration(call, te, bufs, g_teacher, batches, extras, arena, sim, store, ro, max_action_len, ml_weight=0.2):
     """The same iteration with the sampled half in TWO passes: (1) the sampled rollout under no_grad, no loss — it only fixes
     the trajectory (rollout.NavRollout.actions; eager, one read-back per step); (2) TeacherEpisode.plan(actions=) re-walks it on the host
     with the DAgger labels and the episode graph captured at T = max_action_len replays forward + backward (dropout masks drawn anew);
@@ -1267,11 +1270,85 @@ def two_pass_iteration(call, te, bufs, g_teacher, batches, extras, arena, sim, s
                           'EpisodeBuffers.load_part, one B x G read-back per step, sampling on the host; the finished plan feeds pass 2' % (max_action_len + 1)}
     except Exception as e:      # noqa: BLE001
         graphs = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    if isinstance(graphs, dict) and 'ms_per_iteration' in graphs and not os.environ.get('GOAT_BENCH_NO_OVERLAP'):
+        try:
+            graphs['teacher_overlapped'] = overlapped_iteration(call, te, te_s, bufs, bufs_s, batches, extras, arena, max_action_len, ml_weight, tune)
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            graphs['teacher_overlapped'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     return {'ms_per_iteration': round(ms(t1) + ms(t2) + ms(t3), 2), 'pass1_no_grad_rollout_ms': ms(t1), 'plan_along_actions_ms': ms(t2),
             'sampled_graph_plus_teacher_part_ms': ms(t3), 'sample_steps': round(sum(steps) / len(steps), 1), 'episode_bucket_T': max_action_len,
             'pass1_captured': graphs,
             'what': 'sampled rollout under no_grad (eager, fixes the trajectory) + host plan along the recorded actions + replay of the episode '
                     'graph captured at T = %d (forward + backward of the sampled half) + the teacher part as above' % max_action_len}
+
+
+def overlapped_iteration(call, te, te_s, bufs, bufs_s, batches, extras, arena, max_action_len, ml_weight, tune):
+    """The two-pass iteration with the TEACHER half moved into the shadow of pass 1.  Pass 1 is host-bound — per step the
+    host builds the step's tables (1.4 ms), copies them, replays a forward graph, reads B x G probabilities back and samples — and leaves
+    the GPU idle ~40 % of its 48 ms; the teacher rollout depends on nothing the policy samples.  So its captured graph (zero-first form:
+    it clears the gradient arena and writes the teacher gradients x ml_weight) is launched on a side stream BEFORE pass 1 and runs in
+    pass 1's gaps; the sampled half then replays in ACCUMULATE form behind it.  Same sum d(L_sample + ml_weight L_teacher) in the arena.
+    Pass 1's step graphs are captured without the dropout-counter bump (rollout.SampledEpisode(bump_masks=False)): the counter must not
+    move between the teacher graph's forward and backward kernels."""
+    import numpy as np
+    from vln_goat_amd import hipops, rollout
+
+    def teacher_zero():
+        arena.zero('nav')
+        hipops.RngState.dev.add_(0x9E3779B1)
+        (te.body(call, bufs, extras) * ml_weight).backward()
+
+    def sampled_acc():
+        hipops.RngState.dev.add_(0x9E3779B1)
+        te_s.body(call, bufs_s, extras).backward()
+    auto, hipops.AUTOTUNE = hipops.AUTOTUNE, hipops.AUTOTUNE and tune
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                teacher_zero()
+                sampled_acc()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        teacher_zero()                                 # (every slice written in this step: the capture below records the accumulate form)
+        g_sa = torch.cuda.CUDAGraph()
+        with _goat_graph(g_sa):
+            sampled_acc()
+        g_t0 = torch.cuda.CUDAGraph()
+        with _goat_graph(g_t0):
+            teacher_zero()
+        se = rollout.SampledEpisode(te_s, call, bufs_s, extras, bump_masks=False)
+        torch.cuda.synchronize()
+    finally:
+        hipops.AUTOTUNE = auto
+    rng = np.random.RandomState(17)
+    tstream = torch.cuda.Stream()
+    n, tt, t_plan, t_p1, usteps = 4, [], [], [], []
+    for it in range(n + 1):
+        batch = batches[it % len(batches)]
+        t0 = time.perf_counter()
+        bufs.load(te.plan(batch))                      # the teacher's host plan + H2D
+        ta = time.perf_counter()
+        tstream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(tstream):
+            g_t0.replay()                              # teacher forward + backward: runs beside pass 1
+        plan, _ = se.run(batch, rng)                   # pass 1 (host-paced)
+        tb = time.perf_counter()
+        bufs_s.load(plan)
+        torch.cuda.current_stream().wait_stream(tstream)
+        g_sa.replay()                                  # sampled half, accumulating behind the teacher's gradients
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        if it:
+            tt.append(tc - t0), t_plan.append(ta - t0), t_p1.append(tb - ta), usteps.append(se.steps)
+    ms = lambda v: round(sum(v) / len(v) * 1e3, 2)
+    return {'ms_per_iteration': ms(tt), 'teacher_plan_ms': ms(t_plan), 'pass1_beside_teacher_graph_ms': ms(t_p1),
+            'sampled_graph_ms': round(ms(tt) - ms(t_plan) - ms(t_p1), 2), 'sample_steps': round(sum(usteps) / len(usteps), 1),
+            'what': 'teacher plan + H2D, teacher graph (zero-first form, loss x %.1f) launched on a side stream, pass 1 as captured step graphs '
+                    'beside it, then the sampled episode graph (T = %d) in accumulate form' % (ml_weight, max_action_len)}
 
 
 def navigator_leg(args, model, ep, arena, B, T, frozen_s):

@@ -1487,7 +1487,10 @@ class SampledEpisode:
         se = SampledEpisode(te, model, bufs, extras)              # captures T + 1 small graphs (bufs holds any valid plan)
         plan, actions = se.run(episodes, rng);  bufs.load(plan);  episode_graph.replay()"""
 
-    def __init__(self, te, model, bufs, extras=None):
+    def __init__(self, te, model, bufs, extras=None, bump_masks=True):
+        """bump_masks=False: the step graphs do not advance the device-side dropout counter (they read whatever it holds): for running
+        this pass BESIDE a training graph on another stream — a bump between that graph's forward and backward kernels would make its
+        backward regenerate other masks than its forward drew; a forward-only pass needs no particular counter value."""
         from collections import defaultdict
         from . import hipops
         self.te, self.bufs = te, bufs
@@ -1497,7 +1500,7 @@ class SampledEpisode:
         dd = lambda d: defaultdict(lambda: None, d)
 
         def fresh_masks():                  # (a replay draws new dropout masks: the in-graph bump of the device-side counter, if one is in use)
-            if hipops.RngState.dev is not None:
+            if bump_masks and hipops.RngState.dev is not None:
                 hipops.RngState.dev.add_(0x9E3779B1)
 
         def language():
