@@ -180,8 +180,10 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(AttnArgs p) {
       }
     }
   }
-  if (tid < NKT * 32) kml[tid] = km_pre;
-  for (int i = tid + nth; i < NKT * 32; i += nth) kml[i] = i < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + i] : 0.f) : -INFINITY;
+  // (the mask is kept times log2(e): the softmax below runs on exp2 with the scale folded into one fma per element)
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  if (tid < NKT * 32) kml[tid] = km_pre * LOG2E;
+  for (int i = tid + nth; i < NKT * 32; i += nth) kml[i] = (i < p.Lk ? (p.kmask ? p.kmask[(int64_t)b * p.Lk + i] : 0.f) : -INFINITY) * LOG2E;
   GOAT_STAMP(1);
   __syncthreads();
   GOAT_STAMP(2);
@@ -209,14 +211,15 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(AttnArgs p) {
     for (int ks = 0; ks < KSTEPS; ++ks) mma32(s[jt], lds_frag(kl + jt * TILE, l31, ks, hi), qf[ks]);
   }
   GOAT_STAMP(3);
-  // scale + additive key mask (registers), optional bias (one uniform branch around independent loads), row max
+  // scale + additive key mask (registers), optional bias (one uniform branch around independent loads), row max — in the log2 domain
   float m = -INFINITY;
+  const float sl2 = p.scale * LOG2E;
 #pragma unroll
   for (int jt = 0; jt < NKT; ++jt) {
     float km[16];
     load_kmask(kml, jt, hi, km);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[jt][r] = s[jt][r] * p.scale + km[r];
+    for (int r = 0; r < 16; ++r) s[jt][r] = fmaf(s[jt][r], sl2, km[r]);
   }
   if (p.bias != nullptr) {
     const float* brow = p.bias + ((int64_t)b * p.Lq + (qv ? q : 0)) * p.Lk;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = jt * 32 + c_row(r, lane);
-        s[jt][r] += (qv && key < p.Lk) ? brow[key] : 0.f;
+        s[jt][r] += ((qv && key < p.Lk) ? brow[key] : 0.f) * LOG2E;
       }
   }
 #pragma unroll
@@ -239,18 +242,31 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(AttnArgs p) {
   for (int jt = 0; jt < NKT; ++jt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = __expf(s[jt][r] - msafe);
+      const float e = __builtin_amdgcn_exp2f(s[jt][r] - msafe);
       s[jt][r] = e;
       l += e;
     }
   l += __shfl_xor(l, 32, 64);
   const float inv = l > 0.f ? 1.f / l : 0.f;
-  if (qv && hi == 0) p.lse[((int64_t)b * p.nh + h) * p.Lq + q] = (l > 0.f) ? (msafe + __logf(l)) : -INFINITY;
+  if (qv && hi == 0) p.lse[((int64_t)b * p.nh + h) * p.Lq + q] = (l > 0.f) ? (msafe * LN2 + __logf(l)) : -INFINITY;
 
   GOAT_STAMP(4);
   // dropout: the keep bits of 4 consecutive keys from 2 pair hashes (3 when q * Lk is odd)
   const uint32_t idx0 = (uint32_t)q * (uint32_t)p.Lk;
-  if (drop) {
+  if (drop && (p.Lk & 1) == 0) {       // even Lk: every group of 4 keys starts on a pair boundary — two hashes, no parity select
+    const float ik = inv * keep_scale;
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const uint32_t pi = (idx0 + jt * 32 + 4 * hi + 8 * g4) >> 1;
+        const uint32_t h0 = rng.pair(pi), h1 = rng.pair(pi + 1);
+        s[jt][4 * g4 + 0] = (h0 & 0xFFFFu) >= thr ? s[jt][4 * g4 + 0] * ik : 0.f;
+        s[jt][4 * g4 + 1] = (h0 >> 16) >= thr ? s[jt][4 * g4 + 1] * ik : 0.f;
+        s[jt][4 * g4 + 2] = (h1 & 0xFFFFu) >= thr ? s[jt][4 * g4 + 2] * ik : 0.f;
+        s[jt][4 * g4 + 3] = (h1 >> 16) >= thr ? s[jt][4 * g4 + 3] * ik : 0.f;
+      }
+  } else if (drop) {
 #pragma unroll
     for (int jt = 0; jt < NKT; ++jt)
 #pragma unroll
