@@ -713,19 +713,19 @@ class WgradQueue:
             p.rows, p.n_out, p.n_in = dy.shape[0], dy.shape[1], x.shape[1]
 
     @classmethod
-    def _tail_split(cls, q):
-        """indices of the problems to run in a second launch on small tiles, or None.  With 256x128 tiles a group is a whole number
-        of rounds over the 256 CUs plus a tail (e.g. sixteen text-layer problems: 864 tiles = 3.375 rounds, the last one 37 % full).
-        Problems whose tiles add up to just over the tail are taken out and run afterwards on 128x128 tiles (two workgroups per CU,
-        half the duration): 3 full rounds + half a round instead of 4."""
+    def _tail_split(cls, q, rows=256, cols=128):
+        """indices of the problems to run in a second launch on half-size tiles, or None.  With rows x cols tiles a group is a whole
+        number of rounds over the 256 CUs plus a tail (e.g. sixteen text-layer problems on 256 x 128: 864 tiles = 3.375 rounds, the last
+        one 37 % full; six text layers on 256 x 256: 648 tiles = 2.53 rounds).  Problems whose tiles add up to just over the tail are
+        taken out and run afterwards on tiles of half the size (half the duration): e.g. 2 full rounds + 1.06 half rounds instead of 3."""
         if len(q) < 2 or len({t[0].shape[0] for t in q}) != 1:        # tiles of equal duration only (same contraction length)
             return None
-        tiles = [((t[0].shape[1] + 255) // 256) * ((t[1].shape[1] + 127) // 128) for t in q]
-        total, ncu = sum(tiles), 256
+        tiles = [((t[0].shape[1] + rows - 1) // rows) * ((t[1].shape[1] + cols - 1) // cols) for t in q]
+        total, ncu = sum(tiles), N_CU
         rem = total % ncu
         if total < ncu or rem == 0 or rem > 208:
             return None
-        best = None                                                   # smallest subset sum >= rem (n <= 16: dynamic programme over sums)
+        best = None                                                   # smallest subset sum >= rem (n <= 24: dynamic programme over sums)
         reach = {0: ()}
         for i, t in enumerate(tiles):
             for sm, idx in list(reach.items()):
@@ -747,6 +747,11 @@ class WgradQueue:
         if tail is not None:
             head = tuple(i for i in range(n) if i not in tail)
             plans.append([(head, (256, 3)), (tail, (128, EIGHT_WAVES | 2))])
+        if USE_PP:          # round 5: the same cut for the ping-pong 256 x 256 tile (tail on 128 x 256: half the rows, same columns)
+            tail = cls._tail_split(q, 256, 256)
+            if tail is not None:
+                head = tuple(i for i in range(n) if i not in tail)
+                plans.append([(head, (tile(256, 256), PINGPONG | 2)), (tail, (tile(128, 256), PINGPONG | 2))])
         return plans
 
     @classmethod
@@ -778,9 +783,13 @@ class WgradQueue:
                 for arr, m, cfg in parts:
                     _lib.check(_lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), m, cfg[0], cfg[1]), 'goat_wgrad_grouped (tuning)')
             try:
-                t = _time_cfg(run)
+                t = _time_cfg(run, reps=int(os.environ.get('GOAT_WGRAD_TUNE_REPS', '9')))      # (a group runs 0.1-0.5 ms: nine repetitions cost nothing and the picks stop flipping between runs)
             except RuntimeError:
                 continue
+            if os.environ.get('GOAT_WGRAD_PLAN_LOG'):
+                import sys
+                print('[wgrad group] %d problems rows %s: %s -> %.1f us' % (n, sorted({t_[0].shape[0] for t_ in q}), ' + '.join(
+                    '%d x %s %s' % (len(i_), tile_name(c_[0]), stage_name(c_[1])) for i_, c_ in cand), t * 1e3), file=sys.stderr)
             if best is None or t < best[0]:
                 best = (t, cand)
         plan = cls.tuned[key] = best[1] if best is not None else default
