@@ -87,5 +87,20 @@ int main() {
                      nthreads, wgpc, per, bps / 1e12, bps / 256 / 1e9, bps / 256 / 2.4e9);
             }
           }
+  // ---- round 5: the weight stream of a FULL-ROW fused kernel (BertSelfOutput = dense 768 -> 768 + dropout + residual +
+  // LayerNorm in one kernel needs whole output rows per workgroup, i.e. every workgroup streams the WHOLE 768 x 768 bf16 weight,
+  // 1.18 MB, through its LDS).  M = 3840 rows as 16- / 32- / 64-row tiles = 240 / 120 / 60 workgroups of 8 waves; each moves 1.18 MB
+  // (19 iterations x 8 waves x 8 KiB) out of a 1.18 MB window that stays L2-resident.  Time per launch = the floor of such a kernel
+  // before its first MFMA, its activation loads, its epilogue and the LayerNorm: compare with goat_gemm_bf16 (9.8 us) +
+  // goat_ln_fwd (6.9 us) + one kernel boundary (1.7 us) = 18.4 us for the pair it would replace.
+  printf("\nfull-row weight stream: 1.18 MB per workgroup from an L2-resident 1.18 MB window, 512 threads, 8 pieces per wave in flight\n");
+  for (int wgs : {60, 120, 240}) {
+    const uint32_t win = 768u * 1536u + 2048u;
+    const int it = 19;
+    double bps = run<8, 0>(d, win, 1536, 1, 512, wgs, it, sink);
+    const double bytes = (double)wgs * it * 8 * 8 * 1024;
+    printf("  %3d workgroups (%2d-row tiles): %6.2f us per launch   (%.1f TB/s over the chip, %.1f B/clk per active CU)\n", wgs, 3840 / wgs,
+           bytes / bps * 1e6, bps / 1e12, bps / wgs / 2.4e9);
+  }
   return 0;
 }
