@@ -795,8 +795,26 @@ class WgradQueue:
         plan = cls.tuned[key] = best[1] if best is not None else default
         return plan
 
+    ORDER = os.environ.get('GOAT_WGRAD_ORDER', 'spread')       # 'queue': the order the backward pass produced the problems in
+
+    @classmethod
+    def _spread(cls, q):
+        """The problems of a group re-ordered so that every contraction length (rows) is spread evenly over the sequence.  The group
+        kernel gives each XCD one contiguous chunk of the tile order (shared operand panels stay in one L2); a tile's duration is
+        proportional to its contraction length, so a queue that holds the 8640-row panorama problems in one run and the 3840-row text
+        problems in another hands some XCDs 2.25 x the work of others.  Problems write distinct slices: any order is valid."""
+        if cls.ORDER != 'spread' or len({t[0].shape[0] for t in q}) < 2:
+            return q
+        by = {}
+        for i, t in enumerate(q):
+            by.setdefault(t[0].shape[0], []).append(i)
+        n = len(q)
+        slots = sorted(((k + 0.5) * n / len(ix), -rows, i) for rows, ix in by.items() for k, i in enumerate(ix))
+        return [q[i] for _, _, i in slots]
+
     @classmethod
     def _launch(cls, q):
+        q = cls._spread(q)
         for idx, cfg in cls._pick_plan(q):
             items = [q[i] for i in idx]
             n = len(items)
