@@ -98,6 +98,29 @@ def main(only=None):
             # NPROJ seeded random projections <grad, r_j> per parameter (helpers.projections): every element is covered, not only the first 8
             pg_ = dict(ref.named_parameters())
             store[task + '_grad_proj'] = np.stack([projections(pg_[str(n)].grad) for n in store['param_names']])
+            if name.endswith('_full'):
+                # What stock bf16 autocast does to THIS task's gradients on the reference itself (the yardstick of the bf16 GPU test's
+                # norm check): per parameter ||g_autocast|| / ||g_fp32|| and the relative L2 error.
+                g32 = {n: p_.grad.detach().clone() for n, p_ in ref.named_parameters() if p_.grad is not None}
+                ref.zero_grad(set_to_none=True)
+                with torch.autocast('cpu', dtype=torch.bfloat16):
+                    if task == 'cfp':
+                        lv = cfp_loss_from_outputs(*ref(batch, task, compute_loss=False), ref_cfg.cfp_temperature)
+                    else:
+                        lv = ref(batch, task, compute_loss=True)
+                lv.float().mean().backward()
+                ratios, errs = [], []
+                for n in store['param_names']:
+                    g_ac, g = pg_[str(n)].grad, g32.get(str(n))
+                    if g is None or g_ac is None or float(g.norm()) == 0.0:
+                        ratios.append(1.0), errs.append(0.0)
+                        continue
+                    ratios.append(float(g_ac.float().norm() / g.norm()))
+                    errs.append(float((g_ac.float() - g).norm() / g.norm()))
+                store[task + '_grad_norm_ratio_autocast'] = np.array(ratios, dtype=np.float32)
+                store[task + '_grad_err_autocast'] = np.array(errs, dtype=np.float32)
+                print(name, task, 'autocast norm deviation: median %.4f max %.4f' % (
+                    float(np.median(np.abs(np.array(ratios) - 1))), float(np.abs(np.array(ratios) - 1).max())), flush=True)
             with torch.no_grad():
                 if task == 'sap':
                     gl, ll, fl, _, _ = ref(batch, task, compute_loss=False)

@@ -327,6 +327,7 @@ def test_full_size_matches_reference_golden(case, task, dtype):
     params = dict(model.named_parameters())
     gmax = float(fp[:, 0].max())
     rtol, tiny = (2e-3, 1e-6) if dtype == torch.float32 else (None, 2e-3)
+    e_ac = gold[task + '_grad_err_autocast'] if (task + '_grad_err_autocast') in gold else None
     bad, cosines = [], []
     for i, n in enumerate(names):
         refp, gotp = fp[i], fingerprint(params[n].grad)
@@ -341,8 +342,13 @@ def test_full_size_matches_reference_golden(case, task, dtype):
         else:
             # bf16: the norm of every gradient tensor (rounding noise moves a norm only to second order; a mis-scaled or
             # partly missing gradient moves it one-for-one).  Cancelling sums (the door gates) are excluded as in the small cases.
-            if not any(k in n for k in ILL_CONDITIONED) and abs(gotp[0] / refp[0] - 1.0) > 0.06:
-                bad.append((n, gotp[0], refp[0]))
+            # Bound: 6 %, or — for the few tensors whose gradient stock bf16 autocast itself gets visibly wrong on the REFERENCE (sums that
+            # cancel: adaptive_pano_attn, a Linear(H, 1) in front of a softmax pooling, has 4.6 % relative error under torch.autocast in
+            # the sap pass) — the yardstick of the navigation tests, 3.5 x the reference-under-autocast's relative L2 error + 0.03
+            # (<task>_grad_err_autocast of the fixture, tests/golden/make_golden_pretrain.py; an error e moves a norm by at most e).
+            nb = 0.06 if e_ac is None else max(0.06, 3.5 * float(e_ac[i]) + 0.03)
+            if not any(k in n for k in ILL_CONDITIONED) and abs(gotp[0] / refp[0] - 1.0) > nb:
+                bad.append((n, gotp[0], refp[0], nb))
             # ... and its DIRECTION: cosine between the leading elements of the bf16 gradient and the fp32 reference's (a norm
             # cannot see a permuted / sign-flipped / half-missing gradient whose magnitude happens to fit).  Only where those
             # leading elements carry signal (well above the tensor's own rounding floor).

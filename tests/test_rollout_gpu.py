@@ -433,3 +433,120 @@ def test_reverie_rollout_matches_the_reference_rollout():
         last_vp = tr['path'][-1][-1]
         ids = objects.attrs['%s_%s' % (scan.name, last_vp)]['obj_ids'][:objects.count['%s_%s' % (scan.name, last_vp)]]
         assert tr['pred_objid'] is None or tr['pred_objid'] in ids, (tr['pred_objid'], ids)
+
+
+def test_teacher_episode_with_objects_matches_the_eager_reverie_rollout():
+    """The shape-stable episode body (TeacherEpisode, the code the captured episode graph replays) on REVERIE observations: object rows
+    gathered from the device-resident ObjectStore, object tokens behind the views, `vp_obj_masks`, the shortest-path expert, navigation +
+    object-grounding loss — loss and every gradient equal NavRollout (pinned to the imported reference by the test above) run at the
+    same panorama / object widths, eagerly and through ONE captured graph replayed on a second batch (float32, dropout off)."""
+    from vln_goat_amd import nav_model, rollout, synth
+    scan, feats, eps, dicts, objects = synth.make_reverie_rollout_case()
+    other = synth.reverie_episodes(scan, objects, np.random.RandomState(77), B=3, max_steps=4, starts=[2, 9, 15])
+    cfg = nav_model.nav_config_from_args(SimpleNamespace(**{**EP_ARGS, 'dataset': 'reverie', 'obj_feat_size': 768}))
+    torch.manual_seed(0)
+    model = nav_model.GlocalTextPathNavCMT(cfg)
+    model.load_state_dict(synth.seeded_state_dict(model, seed=11))
+    model = model.cuda().eval()
+    store = _store(scan, feats, torch.float32)
+    objects.to('cuda')
+    sim = rollout.GraphSim(store, objects=objects)
+    call = lambda mode, batch: model(mode, batch)
+    ex = synth.rollout_extras(dicts, 3, 'cuda')
+    T, W, O = 5, 38, 6
+    te = rollout.TeacherEpisode(sim, store, n_steps=T, text_len=32, pano_width=W, gmap_width=lambda t: 32, obj_width=O)
+    bufs = rollout.EpisodeBuffers(te.plan(eps))
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = {}
+
+    def step():
+        for p in params:
+            p.grad = None
+        out['loss'] = te.body(call, bufs, ex)
+        out['loss'].backward()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    out.clear()
+    g = torch.cuda.CUDAGraph()
+    with _goat_graph(g):
+        step()
+    grads = {id(p): p.grad for p in params if p.grad is not None}
+    names = {id(p): k for k, p in model.named_parameters()}
+    n_og = 0
+    for batch in (other, eps):
+        plan = te.plan(batch)
+        n_og += sum(int((plan['s%d_obj_target' % t] >= 0).sum()) for t in range(T))
+        bufs.load(plan)
+        g.replay()
+        torch.cuda.synchronize()
+        got_loss = float(out['loss'])
+        got = {k: v.detach().float().clone() for k, v in grads.items()}
+        for p in params:
+            p.grad = None
+        ro = rollout.NavRollout(call, sim, store, max_action_len=T, pano_width=W, gmap_buckets=(32,), obj_width=O)
+        ref, traj = ro.run(batch, feedback='teacher', extras=ex)
+        ref.backward()
+        torch.cuda.synchronize()
+        assert abs(got_loss - float(ref)) <= 1e-3 * max(1.0, abs(float(ref))), (got_loss, float(ref))
+        assert [t['path'] for t in traj] == [t['path'] for t in plan['_traj']]
+        top = max(float(p.grad.abs().max()) for p in params if p.grad is not None)
+        n, bad = 0, []
+        for p in params:
+            if p.grad is None:
+                assert id(p) not in got or float(got[id(p)].abs().max()) <= 1e-6 * top, names[id(p)]
+                continue
+            a, b = got[id(p)], p.grad.float()
+            if float((a - b).abs().max()) > 2e-3 * max(float(b.abs().max()), 0.05 * top):
+                bad.append((names[id(p)], tuple(p.shape), float((a - b).abs().max()), float(b.abs().max())))
+            n += 1
+        assert not bad, (len(bad), bad[:8])
+        assert n > 100
+    assert n_og >= 1            # at least one step of the two batches carries an object-grounding target
+
+
+_STALE_GRAPH_PROBE = r'''
+import sys
+sys.path.insert(0, %r)
+import torch
+from vln_goat_amd import hipops
+m = torch.nn.Linear(64, 64).cuda()
+x = torch.randn(8, 64, device='cuda')
+keep = {}
+def step():
+    for p in m.parameters():
+        p.grad = None
+    y = m(x).sum()
+    y.backward()
+    keep['y'] = y            # (the mistake: the warm-up pass's loss, hence its autograd graph, survives into the capture)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    step()
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+try:
+    with hipops.graph(g):
+        step()
+    print('CAPTURED')
+except BaseException as e:
+    print('RAISED', type(e).__name__, str(e)[:300].replace(chr(10), ' '))
+'''
+
+
+def test_capture_with_a_live_warmup_graph_fails_loudly():
+    """hipops.graph turns torch's "AccumulateGrad node's stream does not match" warning into an error: an activation of the warm-up pass
+    kept alive (an attribute, the loss) makes the captured backward accumulate parameter gradients on the warm-up stream, OUTSIDE the
+    capture — replays then return garbage gradients (how the REVERIE episode capture first failed).  Run in a child process: the
+    runtime may not survive an aborted capture."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', _STALE_GRAPH_PROBE % root], capture_output=True, text=True, timeout=300)
+    assert 'CAPTURED' not in r.stdout, r.stdout + r.stderr[-2000:]
+    assert 'AccumulateGrad' in (r.stdout + r.stderr), r.stdout + r.stderr[-2000:]

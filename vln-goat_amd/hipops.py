@@ -504,18 +504,28 @@ class graph:
         self.ctx = torch.cuda.graph(g, **kw)
 
     def __enter__(self):
+        import warnings
         _CAPTURING.append(self.g)
         _FORKED[0] = False
+        # A tensor of an earlier (warm-up) pass still alive keeps that pass's autograd graph alive, and with it AccumulateGrad nodes bound
+        # to the warm-up stream: the captured backward then accumulates parameter gradients OUTSIDE the capture (replays return garbage
+        # gradients or hipStreamEndCapture crashes; found with an attribute that held a warm-up activation).  torch warns about exactly
+        # this; inside a capture of this package the warning is an error.
+        self._warn = warnings.catch_warnings()
+        self._warn.__enter__()
+        warnings.filterwarnings('error', message=".*AccumulateGrad node's stream does not match.*")
         try:
             return self.ctx.__enter__()
         except BaseException:
             _CAPTURING.pop()
+            self._warn.__exit__(None, None, None)
             raise
 
     def __exit__(self, *exc):
         try:
             return self.ctx.__exit__(*exc)
         finally:
+            self._warn.__exit__(None, None, None)
             if _CAPTURING and _CAPTURING[-1] is self.g:
                 _CAPTURING.pop()
             keep = (_FORKED[0] or bool(os.environ.get('GOAT_GRAPH_RETAIN_ALL'))) and not os.environ.get('GOAT_NO_GRAPH_RETAIN')

@@ -188,7 +188,7 @@ class CausalImageEmbeddings(nn.Module):
         return self.do_img_concat_layernorm(x)
 
     def encode(self, view_img_fts, loc_fts, view_lens, z_img_features=None, z_img_pzs=None, loc_before=False,
-               nav_types=None, obj_fts=None, obj_lens=None, obj_names=None):
+               nav_types=None, obj_fts=None, obj_lens=None, obj_names=None, obj_concat=None):
         """-> (embeds [N,W,H], masks [N,W] bool, fused [N,H] | None).  `loc_before` = pre-training order
         (location added before the intervention, M:225-252); per-step navigation adds it after (M:688-691).
         REVERIE/SOON (M:693-720): object tokens follow the views of every row; loc_fts / nav_types are [N,W,...]."""
@@ -203,9 +203,12 @@ class CausalImageEmbeddings(nn.Module):
             o = self.obj_reverie_layer_norm(o)
             N, V, H = x.shape
             W = nav_types.shape[1]
-            ci = graphmap.build_obj_concat_index(view_lens, obj_lens, V, o.shape[1], W)
             src = torch.cat([x.reshape(N * V, H), o.reshape(-1, H)], 0)
-            x = hipops.gather_segmean(src, ci[0].to(x.device), ci[1].to(x.device), None, N * W).view(N, W, H)
+            if obj_concat is not None:      # (idx, start, inv_idx, inv_start) already on the device: shape-stable callers (captured episodes:
+                x = hipops.gather_segmean(src, obj_concat[0], obj_concat[1], None, N * W, tuple(obj_concat[2:4])).view(N, W, H)      # no host read of the lengths)
+            else:
+                ci = graphmap.build_obj_concat_index(view_lens, obj_lens, V, o.shape[1], W)
+                x = hipops.gather_segmean(src, ci[0].to(x.device), ci[1].to(x.device), None, N * W).view(N, W, H)
             x = x + self.loc_layer_norm(self.loc_linear(loc_fts.to(dt))) \
                 + hipops.embedding(nav_types, self.nav_type_embedding.weight, out_dtype=dt)
             x = self.layer_norm(x, p_out=_p(self.dropout))
@@ -334,10 +337,10 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
 
     # ---- panorama -------------------------------------------------------------------------------------
     def forward_panorama_do_per_step(self, view_img_fts, loc_fts, nav_types, view_lens, z_img_features=None, z_img_pzs=None,
-                                     reverie_obj_fts=None, reverie_obj_lens=None, reverie_obj_names=None):
+                                     reverie_obj_fts=None, reverie_obj_lens=None, reverie_obj_names=None, reverie_obj_concat=None):
         return self.img_embeddings.encode(view_img_fts, loc_fts, view_lens, z_img_features, z_img_pzs, loc_before=False,
                                           nav_types=nav_types, obj_fts=reverie_obj_fts, obj_lens=reverie_obj_lens,
-                                          obj_names=reverie_obj_names)
+                                          obj_names=reverie_obj_names, obj_concat=reverie_obj_concat)
 
     # ---- navigation -------------------------------------------------------------------------------------
     def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
@@ -451,7 +454,7 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
             return self.forward_panorama_do_per_step(batch['view_img_fts'], batch['loc_fts'], batch['nav_types'],
                                                      batch['view_lens'], batch['z_img_features'], batch['z_img_pzs'],
                                                      batch['reverie_obj_img_fts'], batch['reverie_obj_lens'],
-                                                     batch['reverie_obj_names'])
+                                                     batch['reverie_obj_names'], batch['reverie_obj_concat'])
         if mode == 'navigation':
             return self.forward_navigation_per_step(
                 batch['txt_embeds'], batch['txt_masks'], batch['gmap_img_embeds'], batch['gmap_step_ids'], batch['gmap_pos_fts'],

@@ -1008,10 +1008,16 @@ class TeacherEpisode:
     those tensors — captured once into a hipGraph, it is replayed for every new batch of episodes.  Episodes shorter than the
     plan's step count carry target -100 (ignored) after their end, as the reference's `ended` bookkeeping does."""
 
-    def __init__(self, sim, features, n_steps, text_len, pano_width=40, gmap_width=default_gmap_width, fusion='dynamic', ignoreid=-100):
+    def __init__(self, sim, features, n_steps, text_len, pano_width=40, gmap_width=default_gmap_width, fusion='dynamic', ignoreid=-100,
+                 obj_width=20):
         self.sim, self.features = sim, features
         self.T, self.L, self.W, self.gw = n_steps, text_len, pano_width, gmap_width
         self.fusion, self.ignoreid = fusion, ignoreid
+        # REVERIE / SOON (sim.objects: an ObjectStore): up to `obj_width` object tokens behind the views of every panorama, the
+        # object-grounding loss at goal viewpoints (M/reverie/agent_obj_goat.py:560-790).  WT = tokens per panorama (views + objects).
+        self.objects = getattr(sim, 'objects', None)
+        self.O = obj_width if self.objects is not None else 0
+        self.WT = self.W + self.O
 
     # ---- host ---------------------------------------------------------------------------------------------------------------
     def plan(self, episodes, actions=None):
@@ -1041,6 +1047,11 @@ class TeacherEpisode:
         fts = hipops.gather_segmean(self.features.dev, t_[k + 'feat_idx'], t_[k + 'feat_start'], None, n * self.W, None)
         pin = {'view_img_fts': fts.view(n, self.W, -1), 'loc_fts': t_[k + 'loc_fts'], 'nav_types': t_[k + 'nav_types'],
                'view_lens': t_[k + 'view_lens'], 'already_dropout': False}
+        if self.objects is not None:
+            ofts = hipops.gather_segmean(self.objects._fs.dev, t_[k + 'obj_idx'], t_[k + 'obj_start'], None, n * self.O, None)
+            pin.update({'reverie_obj_img_fts': ofts.view(n, self.O, -1), 'reverie_obj_lens': t_[k + 'reverie_obj_lens'],
+                        'reverie_obj_names': t_[k + 'reverie_obj_names'],
+                        'reverie_obj_concat': (t_[k + 'ocat_idx'], t_[k + 'ocat_start'], t_[k + 'ocat_inv_idx'], t_[k + 'ocat_inv_start'])})
         for name, z in (extras or {}).get('panorama', {}).items():      # per-sample dictionary copies ([B, K, ...]) follow the joint batch
             pin[name] = z.repeat(n // B, *([1] * (z.dim() - 1))) if (torch.is_tensor(z) and n != B and z.dim() > 1 and z.shape[0] == B) else z
         return model('panorama', defaultdict(lambda: None, pin))
@@ -1055,7 +1066,7 @@ class TeacherEpisode:
 
     def _nav_step(self, model, t_, s, txt, txt_kv, pano, pmask, fused, pool, last, nav_extras):
         """navigation step s over the tables 's<s>_*': node embeddings gathered from `pool` (the panoramas of this and all earlier steps,
-        appended to here) and the previous [MEM] state `last`.  -> (logits of the configured fusion, the new [MEM] state)"""
+        appended to here) and the previous [MEM] state `last`.  -> (logits of the configured fusion, the new [MEM] state, object logits | None)"""
         from collections import defaultdict
         from . import hipops
         k = 's%d_' % s
@@ -1063,7 +1074,7 @@ class TeacherEpisode:
         if fused is None:
             fused = torch.sum(pano * pmask.unsqueeze(2), 1) / torch.sum(pmask, 1, keepdim=True)
         H = pano.shape[-1]
-        pool += [pano.reshape(B * self.W, H), fused.to(pano.dtype)]
+        pool += [pano.reshape(B * self.WT, H), fused.to(pano.dtype)]
         src = torch.cat(pool + ([last.to(pano.dtype)] if last is not None else []), 0)
         G = t_[k + 'gmap_step_ids'].shape[1]
         gimg = hipops.gather_segmean(src, t_[k + 'csr_idx'], t_[k + 'csr_start'], t_[k + 'csr_scale'], B * G,
@@ -1071,15 +1082,17 @@ class TeacherEpisode:
         zero = pano.new_zeros(B, 1, H)
         memtok = zero if last is None else last.unsqueeze(1).to(pano.dtype)
         nin = {'txt_embeds': txt, 'txt_masks': t_['txt_masks'], 'gmap_img_embeds': gimg,
-               'vp_img_embeds': torch.cat([zero, memtok, pano], 1), 'vp_obj_masks': None, 'flops_count': False, 'txt_kv': txt_kv,
-               'nav_fusion': t_[k + 'nav_fusion']}
+               'vp_img_embeds': torch.cat([zero, memtok, pano], 1), 'flops_count': False, 'txt_kv': txt_kv,
+               'vp_obj_masks': t_[k + 'vp_obj_masks'] if self.objects is not None else None, 'nav_fusion': t_[k + 'nav_fusion']}
         for name in ('gmap_step_ids', 'gmap_pos_fts', 'gmap_pair_dists', 'gmap_visited_masks', 'gmap_masks', 'vp_pos_fts', 'vp_masks',
                      'vp_nav_masks'):
             nin[name] = t_[k + name]
         nin.update(nav_extras)
         out = model('navigation', defaultdict(lambda: None, nin))
         logits = {'local': out['local_logits'], 'global': out['global_logits']}.get(self.fusion, out['fused_logits'])
-        return logits, out['cls_embeds']
+        # (the object logits are RETURNED, not kept on self: a tensor of a warm-up pass alive at capture time keeps that pass's autograd
+        #  graph alive, whose AccumulateGrad nodes are bound to the warm-up stream — the captured backward then accumulates off-graph)
+        return logits, out['cls_embeds'], out.get('obj_logits')
 
     def body(self, model, bufs, extras=None, hoist_text_kv=True, hoist_pano=True):
         """forward + imitation loss of the planned episodes from the tensors of `bufs` (EpisodeBuffers.t): no host data, no
@@ -1118,14 +1131,29 @@ class TeacherEpisode:
                 pano, pmask, fused = (None if x is None else x[s] for x in whole_s)
             else:
                 pano, pmask, fused = panoramas(k, B)
-            logits, last = self._nav_step(model, t_, s, txt_h[s], kv_h[s], pano, pmask, fused, pool, last, nav_extras)
+            logits, last, obj_logits = self._nav_step(model, t_, s, txt_h[s], kv_h[s], pano, pmask, fused, pool, last, nav_extras)
             if self.ignoreid < 0:
                 ce_rows.append(hipops.cross_entropy_rows(logits, t_[k + 'target'], self.ignoreid))          # (summed once behind the loop)
+                if self.objects is not None:        # object grounding at the goal viewpoints (M/reverie/agent_obj_goat.py:705-707)
+                    ce_rows.append(hipops.cross_entropy_rows(obj_logits, t_[k + 'obj_target'], self.ignoreid))
             else:
                 loss = loss + torch.nn.functional.cross_entropy(logits.float(), t_[k + 'target'], reduction='sum', ignore_index=self.ignoreid)
+                if self.objects is not None:
+                    loss = loss + torch.nn.functional.cross_entropy(obj_logits.float(), t_[k + 'obj_target'], reduction='sum', ignore_index=self.ignoreid)
         if ce_rows:
             loss = loss + torch.stack(ce_rows, 0).sum()
         return loss / B
+
+
+def _obj_concat_tables(view_lens, obj_lens, V, O, W, prefix):
+    """the [views | objects] row assembly of n panoramas (graphmap.build_obj_concat_index) and its inverse as fixed-size tables"""
+    from . import graphmap
+    n = len(view_lens)
+    ci = graphmap.build_obj_concat_index(view_lens, obj_lens, V, O, W)
+    inv = graphmap.inverse_index(ci[0], ci[1], None, n * V + n * O)
+    n_tok = int(ci[1][-1])
+    return {prefix + 'ocat_idx': _pad1np(ci[0].numpy()[:n_tok], n * W, -1, np.int32), prefix + 'ocat_start': ci[1],
+            prefix + 'ocat_inv_idx': _pad1np(inv[0].numpy()[:n_tok], n * W, -1, np.int32), prefix + 'ocat_inv_start': inv[1]}
 
 
 class EpisodePlanner:
@@ -1167,8 +1195,9 @@ class EpisodePlanner:
             if not ended[i]:
                 g.node_step_ids[obs[i]['viewpoint']] = t + 1
         self.n_traj += int((~ended).sum())
-        pano = panorama_inputs(obs, afs, te.W)
-        store.advance(B, te.W)
+        has_obj = te.objects is not None
+        pano = panorama_inputs(obs, afs, te.W, te.O if has_obj else None)
+        store.advance(B, te.WT)
         for i, g in enumerate(gmaps):
             if not ended[i]:
                 store.rewrite(i, obs[i]['viewpoint'])
@@ -1176,10 +1205,11 @@ class EpisodePlanner:
                     if not g.graph.visited(cvp):
                         store.accumulate(i, cvp, j)
         G = te.gw(t)
-        gin = gmap_inputs(obs, gmaps, G, afs)
-        vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], te.W + 2, afs,
-                        gmap_pos=(gin['gmap_vpids'], gin['gmap_pos_fts'].numpy()))
-        target = teacher_action(obs, gin['gmap_vpids'], ended, gin['gmap_visited_masks'].numpy(), self.imitation, t, te.ignoreid)
+        gin = gmap_inputs(obs, gmaps, G, afs, mem_selectable=has_obj)
+        vin = vp_inputs(obs, gmaps, pano['cand_vpids'], pano['view_lens'], pano['nav_types'], te.WT + 2, afs,
+                        gmap_pos=(gin['gmap_vpids'], gin['gmap_pos_fts'].numpy()), obj_lens=pano['reverie_obj_lens'] if has_obj else None)
+        # (the REVERIE agent has the shortest-path expert only, M/reverie/agent_obj_goat.py:390-417)
+        target = teacher_action(obs, gin['gmap_vpids'], ended, gin['gmap_visited_masks'].numpy(), self.imitation and not has_obj, t, te.ignoreid)
         k = 's%d_' % t
         # feature gather of the panorama tokens: compact CSR (padding slots = empty segments)
         rows = pano['view_rows'].reshape(-1).numpy()
@@ -1194,7 +1224,18 @@ class EpisodePlanner:
             out[k + name] = gin[name]
         for name in ('vp_pos_fts', 'vp_masks', 'vp_nav_masks'):
             out[k + name] = vin[name]
-        out[k + 'nav_fusion'] = nav_model.nav_fusion_matrix(vin['vp_cand_vpids'], gin['gmap_vpids'], gin['gmap_visited_masks'], G, te.W + 2)
+        if has_obj:
+            orow = pano['obj_rows'].reshape(-1).numpy()
+            ov = orow >= 0
+            oidx = np.full(orow.shape[0], -1, np.int32)
+            oidx[:int(ov.sum())] = orow[ov]
+            out[k + 'obj_idx'] = torch.from_numpy(oidx)
+            out[k + 'obj_start'] = torch.from_numpy(np.concatenate([[0], np.cumsum(ov)]).astype(np.int32))
+            out[k + 'reverie_obj_lens'], out[k + 'reverie_obj_names'] = pano['reverie_obj_lens'], pano['reverie_obj_names']
+            out[k + 'vp_obj_masks'] = vin['vp_obj_masks']
+            out[k + 'obj_target'] = torch.from_numpy(teacher_object(obs, ended, pano['view_lens'], te.ignoreid))
+            out.update(_obj_concat_tables(pano['view_lens'], pano['reverie_obj_lens'], te.W, te.O, te.WT, k))
+        out[k + 'nav_fusion'] = nav_model.nav_fusion_matrix(vin['vp_cand_vpids'], gin['gmap_vpids'], gin['gmap_visited_masks'], G, te.WT + 2)
         # host-side label validation, as train_step.collate_indices does for pre-training (goat_ce_fwd cannot raise; an
         # out-of-range target would only show up as a NaN loss): a teacher action is a map slot of this step or the ignore value
         if ((target >= G) | ((target < 0) & (target != te.ignoreid))).any():
@@ -1268,6 +1309,18 @@ class EpisodePlanner:
         out['all_feat_start'] = torch.from_numpy(np.concatenate(starts + [[off]]).astype(np.int32))
         for name in ('loc_fts', 'nav_types', 'view_lens'):
             out['all_' + name] = torch.cat([out['s%d_%s' % (t, name)] for t in range(te.T)], 0)
+        if te.objects is not None:
+            valid_rows, starts, off = [], [], 0
+            for t in range(te.T):
+                st = out['s%d_obj_start' % t].numpy()
+                valid_rows.append(out['s%d_obj_idx' % t].numpy()[:int(st[-1])])
+                starts.append(st[:-1] + off)
+                off += int(st[-1])
+            out['all_obj_idx'] = _pad1np(np.concatenate(valid_rows), te.T * B * te.O, -1, np.int32)
+            out['all_obj_start'] = torch.from_numpy(np.concatenate(starts + [[off]]).astype(np.int32))
+            for name in ('reverie_obj_lens', 'reverie_obj_names'):
+                out['all_' + name] = torch.cat([out['s%d_%s' % (t, name)] for t in range(te.T)], 0)
+            out.update(_obj_concat_tables(out['all_view_lens'], out['all_reverie_obj_lens'], te.W, te.O, te.WT, 'all_'))
         out['_traj'], out['_n_traj'] = self.traj, self.n_traj
         return out
 
@@ -1518,7 +1571,7 @@ class SampledEpisode:
                 fresh_masks()
                 mine = list(pool)
                 pano, pmask, fused = te._panoramas(model, t_, extras, 's%d_' % s, B, B)
-                logits, new_last = te._nav_step(model, t_, s, self.txt, self.txt_kv, pano, pmask, fused, mine, last, nav_extras)
+                logits, new_last, _ = te._nav_step(model, t_, s, self.txt, self.txt_kv, pano, pmask, fused, mine, last, nav_extras)
                 return torch.softmax(logits.float(), 1), mine, new_last
             g, (probs, pool, last) = self._capture(step)
             self.g_step.append(g)
