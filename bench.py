@@ -927,6 +927,17 @@ def large_batch_leg(args):
     return out
 
 
+_T0 = [None]
+
+
+def _progress(msg):
+    """GOAT_BENCH_PROGRESS=1: timestamped stage marks on stderr (where a leg's wall time goes; the JSON line on stdout is untouched)"""
+    if os.environ.get('GOAT_BENCH_PROGRESS'):
+        import time as _t
+        _T0[0] = _T0[0] or _t.perf_counter()
+        print('[bench +%.1fs] %s' % (_t.perf_counter() - _T0[0], msg), file=sys.stderr, flush=True)
+
+
 def config4_leg(args, rank=0, world=1):
     """BASELINE.json configs[3] per rank: the fine-tuning model's calls of one rollout (text once, then panorama + navigation
     per step with the [MEM] token carried: back-propagation through time) with BACL + FACL on, at the shapes of
@@ -1026,6 +1037,7 @@ def config4_leg(args, rank=0, world=1):
                 run, launch = (lambda i: (g.replay(), exchange())), 'hipGraph replay' + (', then the gradient exchange' if world > 1 else '')
             except Exception as e:      # noqa: BLE001
                 reset_capture(e, 'the navigation episode')
+    _progress('config4: episode captured, timing')
     n = max(6, min(args.steps, 20)) if world == 1 and args.leg else args.steps
     dt = timed(run, n, 2 if world == 1 and args.leg else args.warmup, world)
     dp_diag = None
@@ -1052,12 +1064,14 @@ def config4_leg(args, rank=0, world=1):
                                           'bus_GBps': round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1) if nbytes and world > 1 else None}}
         except Exception as e:      # noqa: BLE001
             dp_diag = {'error': '%s: %s' % (type(e).__name__, e)}
+    _progress('config4: timed; roofline leg')
     roof = None
     if not args.no_roofline and world == 1:
         r = gemm_roofline(args, model, None, None, cycle=episode)
         roof = {k: r[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'launches_per_cycle', 'avg_launch_us',
                                   'algorithmic_gflop_per_launch', 'algorithmic_bytes_per_launch', 'gemm_ms_per_cycle', 'method')}
         roof['traffic'], roof['traffic_source'] = committed_traffic('_config4')
+    _progress('config4: navigator leg')
     nav = None
     if not args.no_graph and not os.environ.get('GOAT_BENCH_NO_NAVIGATOR') and world == 1 and not in_graph:
         try:
@@ -1373,10 +1387,12 @@ def navigator_leg(args, model, ep, arena, B, T, frozen_s):
         for b in range(B):
             sc = scans[(k + b) % len(scans)]
             dist, _ = sc.shortest()
-            while True:
-                s0 = int(rs.randint(len(sc.vpids)))
+            path = []
+            for _ in range(64):           # (a ground-truth path of >= T viewpoints where the scan has one: a 60-viewpoint scan's longest shortest
+                s0 = int(rs.randint(len(sc.vpids)))          #  path is ~8 viewpoints, so at GOAT_NAV_T=15 the samples end early, as R2R's do under max_action_len 15)
                 far = int(np.argsort(dist[s0])[-1 - int(rs.randint(6))])
-                path = sc.shortest_path(sc.vpids[s0], sc.vpids[far])
+                cand = sc.shortest_path(sc.vpids[s0], sc.vpids[far])
+                path = cand if len(cand) > len(path) else path
                 if len(path) >= T:
                     break
             n_tok = int(rs.randint(L // 2, L - 1))
@@ -1420,6 +1436,7 @@ def navigator_leg(args, model, ep, arena, B, T, frozen_s):
     # buffer and launches the episode graph (a ~3 000-node hipGraphLaunch holds the calling thread for several ms): with the navigation
     # step's parallel branches the replay takes 19 ms, and plan (13 ms) + copy + launch behind one another no longer fit under it (a
     # worker THREAD was measured too: 21.4-24.3 ms per episode — the table builders hold the GIL)
+    _progress('navigator: teacher episode captured')
     pw = rollout.PlanWorker(te, store.keys, scans)
     state = {'submitted': 0, 'plan_s': [], 'n_traj': []}
 
@@ -1445,6 +1462,7 @@ def navigator_leg(args, model, ep, arena, B, T, frozen_s):
     wait_ms = sum(in_loop) / len(in_loop) * 1e3          # mean time the training process waited for a plan inside the timed loop
     plan_ms = sum(state['worker_s'][-n:]) / n * 1e3      # what one plan costs: measured around TeacherEpisode.plan inside the worker
     n_traj = sum(state['n_traj'][-n:])
+    _progress('navigator: teacher loop timed; DAgger iteration')
     dagger = None
     if arena is not None and not os.environ.get('GOAT_BENCH_NO_DAGGER'):
         try:
