@@ -509,6 +509,84 @@ def test_teacher_episode_with_objects_matches_the_eager_reverie_rollout():
     assert n_og >= 1            # at least one step of the two batches carries an object-grounding target
 
 
+def test_reverie_sampled_rollout_in_two_passes_matches_the_single_pass():
+    """The sampled half of the DAgger iteration on REVERIE observations, in the form bench.py times: pass 1 = rollout.SampledEpisode (captured
+    forward graphs per step, object tokens and `vp_obj_masks` included, one read-back per step, a deterministic policy-dependent sampler),
+    pass 2 = TeacherEpisode.body over the plan pass 1 returns.  Action probabilities, actions and the plan equal the eager
+    NavRollout(feedback='sample') / TeacherEpisode.plan(actions=); loss (navigation + object grounding at the goal viewpoints the walk
+    reaches) and every gradient equal the single-pass eager sampled rollout at the same widths (float32, dropout off).  NavRollout's
+    REVERIE path is pinned to the imported reference by test_reverie_rollout_matches_the_reference_rollout."""
+    from vln_goat_amd import nav_model, rollout, synth
+    scan, feats, eps, dicts, objects = synth.make_reverie_rollout_case()
+    cfg = nav_model.nav_config_from_args(SimpleNamespace(**{**EP_ARGS, 'dataset': 'reverie', 'obj_feat_size': 768}))
+    torch.manual_seed(0)
+    model = nav_model.GlocalTextPathNavCMT(cfg)
+    model.load_state_dict(synth.seeded_state_dict(model, seed=11))
+    model = model.cuda().eval()
+    store = _store(scan, feats, torch.float32)
+    objects.to('cuda')
+    sim = rollout.GraphSim(store, objects=objects)
+    call = lambda mode, batch: model(mode, batch)
+    ex = synth.rollout_extras(dicts, 3, 'cuda')
+    T, W, O = 5, 38, 6
+    as_np = lambda x: x.detach().float().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+    def policy(t, probs):           # the most probable map node that is not [stop] for two steps, then the most probable slot
+        pr = as_np(probs)
+        go = np.where(pr[:, 1:].max(1) > 0, pr[:, 1:].argmax(1) + 1, 0)
+        return go if t < 2 else pr.argmax(1)
+    params = [p for p in model.parameters()]
+    names = {id(p): n for n, p in model.named_parameters()}
+    # single pass: eager autograd through the sampled rollout
+    ro = rollout.NavRollout(call, sim, store, max_action_len=T, pano_width=W, gmap_buckets=(32,), obj_width=O)
+    seen = []
+    ref_loss, ref_traj = ro.run(eps, feedback='sample', extras=ex, sampler=lambda t, pr: (seen.append(as_np(pr).copy()), policy(t, pr))[1])
+    ref_actions = [np.asarray(a).copy() for a in ro.actions]
+    ref_loss.backward()
+    torch.cuda.synchronize()
+    ref = {id(p): (None if p.grad is None else p.grad.detach().clone()) for p in params}
+    ref_value = float(ref_loss.detach())
+    del ref_loss
+    for p in params:
+        p.grad = None
+    # pass 1: captured forward graphs
+    te = rollout.TeacherEpisode(sim, store, n_steps=T, text_len=32, pano_width=W, gmap_width=lambda t: 32, obj_width=O)
+    bufs = rollout.EpisodeBuffers(te.plan(eps))
+    se = rollout.SampledEpisode(te, call, bufs, ex)
+    got = []
+    plan, actions = se.run(eps, sampler=lambda t, pr: (got.append(as_np(pr).copy()), policy(t, pr))[1])
+    assert len(got) == len(seen) == se.steps
+    for t, (a, b) in enumerate(zip(got, seen)):
+        G = b.shape[1]
+        assert np.abs(a[:, :G] - b).max() <= 2e-4, (t, float(np.abs(a[:, :G] - b).max()))
+    assert all(np.array_equal(x, y) for x, y in zip(actions, ref_actions))
+    want = te.plan(eps, actions=actions)
+    for k, v in want.items():
+        if torch.is_tensor(v):
+            assert torch.equal(plan[k], v), k
+    # (the walk itself; the rollout's trajectory may carry one more hop: the evaluation-side move to the node with the best stop score,
+    #  M/reverie/agent_obj_goat.py:756-771, which no loss sees)
+    for tr, rt in zip(plan['_traj'], ref_traj):
+        assert tr['path'] == rt['path'][:len(tr['path'])] and len(rt['path']) - len(tr['path']) <= 1
+    # pass 2: the episode body over that plan
+    bufs.load(plan)
+    loss = te.body(call, bufs, ex)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - ref_value) <= 2e-5 * max(1.0, abs(ref_value)), (float(loss), ref_value)
+    top = max(float(g.abs().max()) for g in ref.values() if g is not None)
+    n = 0
+    for p in params:
+        a, b = p.grad, ref[id(p)]
+        if b is None:
+            assert a is None or float(a.abs().max()) <= 1e-6 * top, names[id(p)]
+            continue
+        scale = max(float(b.abs().max()), 1e-3 * top)
+        assert float((a - b).abs().max()) <= 5e-4 * scale, (names[id(p)], float((a - b).abs().max()), scale)
+        n += 1
+    assert n > 100
+
+
 _STALE_GRAPH_PROBE = r'''
 import sys
 sys.path.insert(0, %r)
