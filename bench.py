@@ -954,7 +954,7 @@ def config4_leg(args, rank=0, world=1):
     vln_goat_amd.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
     # T = 6: the length of an R2R ground-truth path (5-7 viewpoints; the teacher-forced rollout of M/r2r/agent.py stops at its end; the
     # reference caps rollouts at max_action_len 15, scripts/run_r2r_goat.sh:35 — GOAT_NAV_T=15 runs that as a stress case).  Round 3 timed T = 3.
-    B, T = 12, int(os.environ.get('GOAT_NAV_T', '6'))
+    B, T = int(os.environ.get('GOAT_NAV_B', '12')), int(os.environ.get('GOAT_NAV_T', '6'))
     ep = synth.make_nav_episode(B=B, L=200, n_steps=T, seed=21 + rank, vocab_size=50265, extra_nodes=54 - T)      # G = 60 map nodes at the last step; every rank rolls out its own shard
     mv = lambda x: x.cuda() if torch.is_tensor(x) else x
     for st in ep['steps']:            # the agent's collate: logit-fusion matrix of the step from the id strings (host)
@@ -1078,6 +1078,12 @@ def config4_leg(args, rank=0, world=1):
             nav = navigator_leg(args, model, ep, arena[0], B, T, dt / n)
         except Exception as e:      # noqa: BLE001
             nav = {'error': '%s: %s' % (type(e).__name__, e)}
+        if not os.environ.get('GOAT_BENCH_NO_REVERIE_NAV'):
+            _progress('config4: REVERIE navigator leg')
+            try:
+                nav['reverie'] = reverie_navigator_leg(args, ep, B, T)
+            except Exception as e:      # noqa: BLE001
+                nav['reverie'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     return {'value': round(B * T * world * n / dt, 1), 'unit': 'trajectory-steps/s', 'ms_per_episode': round(dt / n * 1e3, 3), 'episodes': n,
             'launch': launch, 'roofline': roof, 'navigator': nav, 'dp': dp_diag, 'per_rank_batch': B, 'steps_per_episode': T,
             'workload': 'map_nav_src fine-tune model calls of one rollout (run_r2r_goat.sh shapes): 6,3,2 layers, batch 12, L=200, %d steps x ' % T +
@@ -1363,6 +1369,114 @@ def overlapped_iteration(call, te, te_s, bufs, bufs_s, batches, extras, arena, m
             'sampled_graph_ms': round(ms(tt) - ms(t_plan) - ms(t_p1), 2), 'sample_steps': round(sum(usteps) / len(usteps), 1),
             'what': 'teacher plan + H2D, teacher graph (zero-first form, loss x %.1f) launched on a side stream, pass 1 as captured step graphs '
                     'beside it, then the sampled episode graph (T = %d) in accumulate form' % (ml_weight, max_action_len)}
+
+
+def reverie_navigator_leg(args, ep, B, T):
+    """The graph-only navigator on REVERIE observations (M/reverie/agent_obj_goat.py; BASELINE.json configs[4]'s dataset in fine-tuning): the
+    fine-tuning model with the object-grounding head, 36 views + up to 20 objects per panorama (object features resident in HBM next to
+    the view features), teacher forcing with the shortest-path expert, navigation + grounding loss, backward — NEW episodes every
+    iteration: host plan in the worker process (object tables included), one pinned H2D, replay of the captured episode graph."""
+    import numpy as np
+    import time
+    import vln_goat_amd
+    from types import SimpleNamespace
+    from vln_goat_amd import features, hipops, nav_model, rollout
+    a = SimpleNamespace(num_l_layers=6, num_x_layers=3, num_pano_layers=2, dropout=0.1, feat_dropout=0.5, vocab_size=50265,
+                        do_back_img=True, do_back_txt=True, do_front_img=True, do_front_his=True, do_front_txt=True,
+                        do_back_txt_type='type_2', do_back_img_type='type_1', do_add_method='door', mode='train', dataset='reverie',
+                        obj_feat_size=768)
+    torch.manual_seed(0)
+    model = nav_model.GlocalTextPathNavCMT(nav_model.nav_config_from_args(a)).cuda().train()
+    dt_ = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    rs = np.random.RandomState(57)
+    scans = [rollout.ScanGraph.synthetic('rscan%d' % k, n=60, seed=70 + k, degree=3) for k in range(4)]
+    keys = ['%s_%s' % (sc.name, vp) for sc in scans for vp in sc.vpids]
+    store = features.FeatureStore.synthetic(keys, D=768, seed=5, dtype=dt_).to('cuda')
+    O = 20
+    objects = rollout.ObjectStore.synthetic(scans, D=768, max_objects=O, seed=9, dtype=dt_, p_empty=0.2).to('cuda')
+    sim = rollout.GraphSim(store, objects=objects)
+    L = ep['txt_ids'].shape[1]
+
+    def batch_of_episodes(k):
+        eps = []
+        for b in range(B):
+            sc = scans[(k + b) % len(scans)]
+            dist, _ = sc.shortest()
+            path = []
+            for _ in range(64):
+                s0 = int(rs.randint(len(sc.vpids)))
+                far = int(np.argsort(dist[s0])[-1 - int(rs.randint(6))])
+                cand = sc.shortest_path(sc.vpids[s0], sc.vpids[far])
+                path = cand if len(cand) > len(path) else path
+                if len(path) >= T:
+                    break
+            path = path[:T]                  # (the goal viewpoint is observed at step T - 1 at the latest: its grounding target is inside the episode)
+            key = '%s_%s' % (sc.name, path[-1])
+            ids = objects.attrs[key]['obj_ids'][:objects.count[key]]
+            n_tok = int(rs.randint(L // 2, L - 1))
+            eps.append({'instr_id': 'r%d_b%d' % (k, b), 'scan': sc, 'path': path, 'heading': float(rs.uniform(0, 2 * np.pi)),
+                        'instr_encoding': [0] + rs.randint(3, 50000, n_tok - 2).tolist() + [2],
+                        'obj_id': ids[int(rs.randint(len(ids)))] if len(ids) else None, 'end_vps': [path[-1]]})
+        return eps
+    batches = [batch_of_episodes(k) for k in range(6)]
+    te = rollout.TeacherEpisode(sim, store, n_steps=T, text_len=L, pano_width=38, gmap_width=lambda t: 64, obj_width=O)
+    extras = {'language': {k: ep[k] for k in ('instr_z_direction_features', 'instr_z_direction_pzs', 'instr_z_landmark_features',
+                                              'instr_z_landmark_pzs', 'front_txt_feats')},
+              'panorama': {'z_img_features': ep['z_img_features'], 'z_img_pzs': ep['z_img_pzs']},
+              'navigation': {'front_txt_feats': ep['front_txt_feats'], 'front_vp_feats': ep['front_vp_feats'],
+                             'front_gmap_feats': ep['front_gmap_feats']}}
+    plan0 = te.plan(batches[0])
+    n_og = sum(int((plan0['s%d_obj_target' % t] >= 0).sum()) for t in range(T))
+    bufs = rollout.EpisodeBuffers(plan0)
+    call = lambda mode, batch: model(mode, batch)
+    params = list(model.parameters())
+
+    def episode():
+        for p in params:
+            p.grad = None
+        hipops.RngState.dev.add_(0x9E3779B1)
+        te.body(call, bufs, extras).backward()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            episode()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with _goat_graph(g):
+        episode()
+    pw = rollout.PlanWorker(te, store.keys, scans)
+    state = {'submitted': 0, 'n_traj': [], 'wait': [], 'worker_s': []}
+
+    def run(i):
+        while pw.pending < 2:
+            pw.submit(batches[state['submitted'] % len(batches)])
+            state['submitted'] += 1
+        t0 = time.perf_counter()
+        plan = pw.result()
+        state['wait'].append(time.perf_counter() - t0)
+        pw.submit(batches[state['submitted'] % len(batches)])
+        state['submitted'] += 1
+        state['n_traj'].append(plan['_n_traj'])
+        state['worker_s'].append(plan.get('_plan_s', 0.0))
+        bufs.load(plan)
+        g.replay()
+    n = 12
+    try:
+        dt = timed(run, n, 3, 1)
+    finally:
+        while pw.pending:
+            pw.result()
+        pw.close()
+    n_traj = sum(state['n_traj'][-n:])
+    return {'ms_per_episode': round(dt / n * 1e3, 3), 'value': round(n_traj / dt, 1), 'unit': 'trajectory-steps/s', 'episodes': n,
+            'host_plan_ms': round(sum(state['worker_s'][-n:]) / n * 1e3, 2), 'host_plan_wait_ms': round(sum(state['wait'][-n:]) / n * 1e3, 2),
+            'grounding_targets_in_first_batch': n_og,
+            'what': 'graph-only navigator on REVERIE observations: 4 synthetic scans (60 viewpoints, up to %d objects each), %d new episodes per '
+                    'iteration, T = %d, 38 views + %d objects per panorama, map width 64, text bucket %d, teacher forcing (shortest-path expert), '
+                    'navigation + object-grounding loss, fwd + bwd; host plan (worker process) + one pinned H2D + replay of the captured '
+                    'episode graph' % (O, B, T, O, L)}
 
 
 def navigator_leg(args, model, ep, arena, B, T, frozen_s):

@@ -492,6 +492,13 @@ class ObjectStore:
         self._fs.to(device)
         return self
 
+    def meta(self):
+        """a copy WITHOUT the feature table (row numbers, directions, sizes, ids, names only): what a host-side planner needs
+        (PlanWorker ships it to its worker process; `attributes` works, `gather` / `table` do not)."""
+        m = ObjectStore.__new__(ObjectStore)
+        m.start, m.count, m.attrs, m.D, m._fs = self.start, self.count, self.attrs, self.D, None
+        return m
+
     @property
     def table(self):
         return self._fs.table
@@ -1342,9 +1349,9 @@ def _plan_worker_main(conn, spec):
     torch.set_num_threads(1)          # small host tensors only: the default intra-op pool (one thread per core: 128-256 on the GPU boxes) costs
                                       # tens of ms in wake-ups per plan (measured: 60 ms per plan with the pool, 13 ms without)
     scans = spec['scans']
-    te = TeacherEpisode(GraphSim(_RowIndex(spec['keys']), spec['angle_feat_size']), None, spec['n_steps'], spec['text_len'],
-                        pano_width=spec['pano_width'], gmap_width=lambda t, w=spec['gmap_widths']: w[min(t, len(w) - 1)],
-                        fusion=spec['fusion'], ignoreid=spec['ignoreid'])
+    te = TeacherEpisode(GraphSim(_RowIndex(spec['keys']), spec['angle_feat_size'], objects=spec.get('objects')), None, spec['n_steps'],
+                        spec['text_len'], pano_width=spec['pano_width'], gmap_width=lambda t, w=spec['gmap_widths']: w[min(t, len(w) - 1)],
+                        fusion=spec['fusion'], ignoreid=spec['ignoreid'], obj_width=spec.get('obj_width', 20))
     while True:
         try:
             episodes = conn.recv()
@@ -1383,7 +1390,8 @@ class PlanWorker:
         self.conn, child = ctx.Pipe()
         scans = {sc.name: sc for sc in (scans.values() if isinstance(scans, dict) else scans)}
         spec = {'keys': list(keys), 'scans': scans, 'angle_feat_size': te.sim.angle_feat_size, 'n_steps': te.T, 'text_len': te.L,
-                'pano_width': te.W, 'gmap_widths': [int(te.gw(t)) for t in range(max(te.T, 1))], 'fusion': te.fusion, 'ignoreid': te.ignoreid}
+                'pano_width': te.W, 'gmap_widths': [int(te.gw(t)) for t in range(max(te.T, 1))], 'fusion': te.fusion, 'ignoreid': te.ignoreid,
+                'objects': te.objects.meta() if te.objects is not None else None, 'obj_width': te.O}      # (REVERIE: object metadata, no features)
         self.proc = ctx.Process(target=_plan_worker_main, args=(child, spec), daemon=True)
         self.proc.start()
         child.close()
