@@ -581,7 +581,7 @@ def gemm_roofline(args, model, gb, arena=None, tasks=None, cycle=None):
             + (M_ * N_ * 2 if epi_ in (3, 4) else 0)
     return {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'traffic': traffic, 'traffic_unit': 'bytes/launch (L2-miss reads x2-corrected + writes; rocprofv3 --pmc)',
-            'traffic_source': tsrc, 'algorithmic_bytes_per_launch': round(algo_bytes / max(n, 1)), 'kernel': 'gemm2_kernel / pp_kernel / gemm2_group_kernel / pp_group_kernel (goat_gemm_bf16, goat_wgrad_grouped) + gemm_nt_kernel', 'launches_per_cycle': n,
+            'traffic_source': tsrc, 'algorithmic_bytes_per_launch': round(algo_bytes / max(n, 1)), 'kernel': 'gemm2_kernel / pp_kernel / gemm2_group_kernel / pp_group_kernel / pp_group_sk_kernel (goat_gemm_bf16, goat_wgrad_grouped[_balanced]) + gemm_nt_kernel', 'launches_per_cycle': n,
             'avg_launch_us': round(tot_ms * 1e3 / max(n, 1), 2),
             'algorithmic_gflop_per_launch': round(tot_fl / max(n, 1) / 1e9, 3),
             'gemm_ms_per_cycle': round(tot_ms, 3),

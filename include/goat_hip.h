@@ -262,6 +262,17 @@ typedef struct goat_wgrad_problem {
   int accumulate;
 } goat_wgrad_problem;
 int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs, int n, int bm, int nstage);
+/* Contraction-balanced form of the same launch (round 5).  goat_wgrad_grouped gives every output tile a workgroup, so a group is
+ * whole rounds of tiles over the CUs plus a tail, and a group that mixes contraction lengths (panorama rows beside text rows) ends
+ * with most CUs idle.  Here ONE workgroup per CU takes an equal, contiguous share of the group's K-tile iterations; a tile cut by a
+ * share boundary is summed through `workspace` in a fixed order (deterministic; differs from goat_wgrad_grouped by float32
+ * summation order only).  Ping-pong tiles only: bm = 256 | 256 << 16, 128 | 256 << 16, 256 | 128 << 16 (as goat_wgrad_grouped's bm).
+ * workspace: goat_wgrad_balanced_ws_bytes(bm) bytes, 256-byte aligned, ZEROED once by the caller before the first launch (the kernel
+ * leaves its flags zero), and not shared by launches that may run concurrently (one per stream).  GOAT_E_SHAPE when the group has
+ * fewer K-tile iterations than the device has CUs (use goat_wgrad_grouped). */
+int goat_wgrad_grouped_balanced(void* stream, const goat_wgrad_problem* probs, int n, int bm, void* workspace,
+                                int64_t workspace_bytes);
+int goat_wgrad_balanced_ws_bytes(int bm);   /* < 0: bm is not one of the tiles above */
 
 /* Embedding tables (float32 masters):  out[r,:] = word[ids[r],:] + type[type_ids ? type_ids[r] : 0,:] + pos[r % L,:]
  * cast to `dtype` — the three nn.Embedding lookups and two adds of BertEmbeddings.forward

@@ -64,6 +64,26 @@ for gname, probs in GROUPS.items():
         rows_, cols_ = bm & 0xFFFF, (bm >> 16) or 128
         tiles = sum(((o + rows_ - 1) // rows_) * ((i_ + cols_ - 1) // cols_) for _, o, i_ in probs)
         res.append((us, hipops.tile_name(bm), ns, tiles))
+    for bm in (T(256, 256), T(128, 256), 256):            # contraction-balanced launch (goat_wgrad_grouped_balanced): one workgroup per CU
+        nb = L.goat_wgrad_balanced_ws_bytes(bm)
+        ws = torch.zeros(nb, dtype=torch.uint8, device='cuda')
+        st = torch.cuda.current_stream().cuda_stream
+        i = [0]
+
+        def run():
+            arr = sets[i[0] % ROT][0]
+            i[0] += 1
+            rc = L.goat_wgrad_grouped_balanced(st, ctypes.addressof(arr), len(probs), bm, ws.data_ptr(), nb)
+            assert rc == 0, rc
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append((e0.elapsed_time(e1) * 1e3 / 10, hipops.tile_name(bm), 0x402, 256))
     print('%s: %.1f GFLOP' % (gname, fl / 1e9))
     for us, name, ns, tiles in sorted(res):
-        print('   %-8s s%d%s  tiles %4d  %7.1f us  %6.0f TF' % (name, ns & 0xFF, ' 8w' if ns & 0x100 else (' pp' if ns & 0x200 else '   '), tiles, us, fl / us / 1e6))
+        print('   %-8s s%d%s  tiles %4d  %7.1f us  %6.0f TF' % (name, ns & 0xFF, ' 8w' if ns & 0x100 else (' pp' if ns & 0x200 else (' bal' if ns & 0x400 else '   ')), tiles, us, fl / us / 1e6))

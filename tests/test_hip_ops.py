@@ -824,6 +824,80 @@ def test_wgrad_grouped(ops):
             _close(dw, 2 * rw, torch.bfloat16, 'grouped dW accumulate')
 
 
+def test_wgrad_grouped_balanced(ops):
+    """goat_wgrad_grouped_balanced (one workgroup per CU, equal shares of the group's K-tile iterations, cut tiles summed through the
+    workspace): mixed contraction lengths so that shares hold tails, whole tiles and heads, and tiles whose contraction spans three
+    workgroups (rows 40000 on few tiles); ragged edges, row-strided dY, bias sums.  Against float32 torch, against the one-workgroup-
+    per-tile launch, bit-identical from launch to launch (flags return to zero), accumulate on top of stale contents."""
+    import ctypes
+    from vln_goat_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(78)
+    cases = [[(3840, 768, 768), (1000, 2304, 768), (8640, 768, 3072), (3840, 3072, 768), (37, 8, 768), (576, 1001, 768), (8640, 2304, 768)],
+             [(40000, 256, 512), (40000, 300, 256), (640, 768, 768)],
+             [(1776, o, i) for (o, i) in ((2304, 768), (768, 768), (3072, 768), (768, 3072))] + [(1056, 768, 768), (1056, 3072, 768)]]
+    st = torch.cuda.current_stream().cuda_stream
+    for shapes in cases:
+        for bm in (256 | 256 << 16, 128 | 256 << 16, 256):
+            nb = L.goat_wgrad_balanced_ws_bytes(bm)
+            assert nb > 0
+            ws = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+            arr = (_lib.WgradProblem * len(shapes))()
+            keep, refs = [], []
+            for i, (rows, n_out, n_in) in enumerate(shapes):
+                ld = (n_out + 7) // 8 * 8 + 8
+                dyb = (torch.randn(rows, ld, generator=g) * 0.5).to(DEV, torch.bfloat16)
+                dy = dyb[:, :n_out]
+                x = torch.randn(rows, n_in, generator=g).to(DEV, torch.bfloat16)
+                dw = torch.full((n_out, n_in), 7.0, device=DEV)
+                db = torch.zeros(n_out, device=DEV)
+                q = arr[i]
+                q.dy, q.ld_dy, q.x, q.ld_x, q.dw, q.ld_dw, q.dbias = dy.data_ptr(), ld, x.data_ptr(), n_in, dw.data_ptr(), n_in, db.data_ptr()
+                q.rows, q.n_out, q.n_in, q.accumulate = rows, n_out, n_in, 0
+                keep.append((dyb, x, dw, db))
+                refs.append((dy.float().T @ x.float(), dy.float().sum(0)))
+            assert L.goat_wgrad_grouped_balanced(st, ctypes.addressof(arr), len(shapes), bm, ws.data_ptr(), nb) == 0
+            first = [(dw.clone(), db.clone()) for (_, _, dw, db) in keep]
+            for (dw, db), (rw, rb) in zip(first, refs):
+                _close(dw, rw, torch.bfloat16, 'balanced dW')
+                _close(db, rb, torch.bfloat16, 'balanced dbias')
+            assert int(ws[-256 * 32:].view(torch.int32).abs().sum()) == 0, 'flags must return to zero'
+            # the per-tile launch on the same operands: same numbers up to float32 summation order
+            for (_, _, dw, db) in keep:
+                dw.fill_(7.0)
+                db.zero_()
+            assert L.goat_wgrad_grouped(st, ctypes.addressof(arr), len(shapes), bm, 0x202) == 0
+            for (dw0, db0), (_, _, dw, db) in zip(first, keep):
+                assert float((dw0 - dw).abs().max()) <= 1e-4 * max(1.0, float(dw.abs().max())), 'balanced vs per-tile'
+                assert float((db0 - db).abs().max()) <= 1e-4 * max(1.0, float(db.abs().max()))
+            # deterministic: five more launches reproduce the first bit for bit
+            for _ in range(5):
+                for (_, _, dw, db) in keep:
+                    dw.fill_(-3.0)
+                    db.zero_()
+                assert L.goat_wgrad_grouped_balanced(st, ctypes.addressof(arr), len(shapes), bm, ws.data_ptr(), nb) == 0
+                for (dw0, db0), (_, _, dw, db) in zip(first, keep):
+                    assert torch.equal(dw0, dw) and torch.equal(db0, db)
+            for i in range(len(shapes)):
+                arr[i].accumulate = 1
+                arr[i].dbias = None
+            assert L.goat_wgrad_grouped_balanced(st, ctypes.addressof(arr), len(shapes), bm, ws.data_ptr(), nb) == 0
+            for (_, _, dw, _), (rw, _) in zip(keep, refs):
+                _close(dw, 2 * rw, torch.bfloat16, 'balanced dW accumulate')
+    # fewer iterations than CUs: refused, the caller uses the per-tile launch
+    arr = (_lib.WgradProblem * 1)()
+    dy, x, dw = torch.zeros(64, 256, device=DEV, dtype=torch.bfloat16), torch.zeros(64, 256, device=DEV, dtype=torch.bfloat16), torch.zeros(256, 256, device=DEV)
+    q = arr[0]
+    q.dy, q.ld_dy, q.x, q.ld_x, q.dw, q.ld_dw, q.dbias = dy.data_ptr(), 256, x.data_ptr(), 256, dw.data_ptr(), 256, None
+    q.rows, q.n_out, q.n_in, q.accumulate = 64, 256, 256, 0
+    bm = 256 | 256 << 16
+    nb = L.goat_wgrad_balanced_ws_bytes(bm)
+    ws = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    assert L.goat_wgrad_grouped_balanced(st, ctypes.addressof(arr), 1, bm, ws.data_ptr(), nb) == -2
+    assert L.goat_wgrad_grouped_balanced(st, ctypes.addressof(arr), 1, bm, ws.data_ptr(), nb - 1) != 0
+    assert L.goat_wgrad_balanced_ws_bytes(64) < 0
+
+
 def test_gemm_bf16_full_size_every_tile_no_corruption(ops):
     """Full-size FFN-up shape (3840 x 3072 x 768, GELU + saved pre-activation) on every tile the autotuner may pick, launched
     several times: no NaN / wrong element anywhere.  (Round 2 found isolated wrong elements on the 4-wave 128x128 tile only at

@@ -61,6 +61,8 @@ SIGNATURES = {
     'goat_dict_wsum_fwd': [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_dict_wsum_bwd': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     'goat_wgrad_grouped': [_vp, _vp, _i32, _i32, _i32],
+    'goat_wgrad_grouped_balanced': [_vp, _vp, _i32, _i32, _vp, _i64],
+    'goat_wgrad_balanced_ws_bytes': [_i32],
     'goat_grad_sqnorm': [_vp, _vp, _vp, _i32, _vp],
     'goat_adamw_step': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _vp],
     'goat_sap_fuse_fwd': [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],

@@ -129,17 +129,8 @@ static int group_stages(hipStream_t st, const GroupArgs& g, int nstage) {
   return GOAT_E_ARG;
 }
 
-extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs, int n, int bm, int nstage) {
-  if (!probs || n < 1 || n > GROUP_MAX) return GOAT_E_ARG;
-  const bool eight = (nstage & GOAT_GEMM_8WAVES) != 0;       // as in goat_gemm_bf16: the 128-row tile on eight waves
-  const bool pp = (nstage & GOAT_GEMM_PP) != 0;
-  nstage &= ~(GOAT_GEMM_8WAVES | GOAT_GEMM_PP);
-  int bn = (bm >> 16) & 0xFFFF;
-  bm &= 0xFFFF;
-  if (bn == 0) bn = 128;
-  if (nstage < 2 || nstage > 4 || (bm & (bm - 1)) || (bn & (bn - 1))) return GOAT_E_ARG;
-  if (pp ? (eight || !pp_tile_ok(bm, bn, nstage) || (bm == 128 && bn == 128)) : !tile_ok(bm, bn, eight)) return GOAT_E_ARG;
-  GroupArgs g;
+// argument block of a grouped launch from the caller's problem list (validation shared by the two entry points)
+static int build_group(const goat_wgrad_problem* probs, int n, int bm, int bn, GroupArgs& g) {
   g.n = n;
   int tiles = 0;
   for (int i = 0; i < n; ++i) {
@@ -165,6 +156,21 @@ extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs,
     tiles += a.tiles_m * a.tiles_n;
   }
   for (int i = n; i <= GROUP_MAX; ++i) g.tile_start[i] = tiles;
+  return 0;
+}
+
+extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs, int n, int bm, int nstage) {
+  if (!probs || n < 1 || n > GROUP_MAX) return GOAT_E_ARG;
+  const bool eight = (nstage & GOAT_GEMM_8WAVES) != 0;       // as in goat_gemm_bf16: the 128-row tile on eight waves
+  const bool pp = (nstage & GOAT_GEMM_PP) != 0;
+  nstage &= ~(GOAT_GEMM_8WAVES | GOAT_GEMM_PP);
+  int bn = (bm >> 16) & 0xFFFF;
+  bm &= 0xFFFF;
+  if (bn == 0) bn = 128;
+  if (nstage < 2 || nstage > 4 || (bm & (bm - 1)) || (bn & (bn - 1))) return GOAT_E_ARG;
+  if (pp ? (eight || !pp_tile_ok(bm, bn, nstage) || (bm == 128 && bn == 128)) : !tile_ok(bm, bn, eight)) return GOAT_E_ARG;
+  GroupArgs g;
+  if (int e = build_group(probs, n, bm, bn, g)) return e;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (pp) return goat_g5_group(st, g, bm, bn, nstage);
   if (bn != 128) return goat_g3_group(st, g, bm, bn, nstage);
@@ -172,4 +178,23 @@ extern "C" int goat_wgrad_grouped(void* stream, const goat_wgrad_problem* probs,
   if (bm == 256) return group_stages<T256>(st, g, nstage);
   if (eight) return group_stages<T128X8>(st, g, nstage);
   return group_stages<T128>(st, g, nstage);
+}
+
+// Contraction-balanced form of the grouped launch (gemm5_tile.hpp: pp_group_sk_kernel): ping-pong tiles 256x256 / 128x256 / 256x128.
+extern "C" int goat_wgrad_grouped_balanced(void* stream, const goat_wgrad_problem* probs, int n, int bm, void* workspace, int64_t workspace_bytes) {
+  if (!probs || n < 1 || n > GROUP_MAX) return GOAT_E_ARG;
+  int bn = (bm >> 16) & 0xFFFF;
+  bm &= 0xFFFF;
+  if (bn == 0) bn = 128;
+  if (goat_g5_group_sk_ws_bytes(bm, bn) < 0) return GOAT_E_ARG;
+  GroupArgs g;
+  if (int e = build_group(probs, n, bm, bn, g)) return e;
+  return goat_g5_group_sk(reinterpret_cast<hipStream_t>(stream), g, bm, bn, 2, workspace, workspace_bytes);
+}
+
+extern "C" int goat_wgrad_balanced_ws_bytes(int bm) {
+  int bn = (bm >> 16) & 0xFFFF;
+  bm &= 0xFFFF;
+  if (bn == 0) bn = 128;
+  return (int)goat_g5_group_sk_ws_bytes(bm, bn);       // 256 slots of <= 264 KiB: fits an int
 }

@@ -28,3 +28,17 @@ int goat_g5_group(hipStream_t st, const goat_g2::GroupArgs& g, int bm, int bn, i
   if (bm == 256 && bn == 128 && nstage == 2) return pp_launch_group<P256x128>(st, g);
   return GOAT_E_ARG;
 }
+
+int goat_g5_group_sk(hipStream_t st, const goat_g2::GroupArgs& g, int bm, int bn, int nstage, void* ws, int64_t ws_bytes) {
+  if (bm == 256 && bn == 256 && nstage == 2) return pp_launch_group_sk<P256x256>(st, g, ws, ws_bytes);
+  if (bm == 128 && bn == 256 && nstage == 2) return pp_launch_group_sk<P128x256>(st, g, ws, ws_bytes);
+  if (bm == 256 && bn == 128 && nstage == 2) return pp_launch_group_sk<P256x128>(st, g, ws, ws_bytes);
+  return GOAT_E_ARG;
+}
+
+int64_t goat_g5_group_sk_ws_bytes(int bm, int bn) {
+  if (bm == 256 && bn == 256) return pp_sk_ws_bytes<P256x256>();
+  if (bm == 128 && bn == 256) return pp_sk_ws_bytes<P128x256>();
+  if (bm == 256 && bn == 128) return pp_sk_ws_bytes<P256x128>();
+  return -1;
+}

@@ -139,10 +139,66 @@ __device__ __forceinline__ bf16x8 pp_frag(const uint32_t (&v)[4], uint32_t off) 
   }
 }
 
-template <class CF, bool TA, bool TB, typename OutT, int EPI, bool SPLITK>
-__device__ __forceinline__ void pp_tile(const G2Args& p, int bid, int split) {
+// ---- contraction-balanced ("stream-K") grouped launches: one SEGMENT = K-tiles [kt_begin, kt_end) of one output tile.
+// A workgroup that does not own the END of the tile's contraction leaves its accumulators (and bias-gradient partial sums) in its
+// workspace slot and raises the slot's per-wave flags; the workgroup that owns the end (the FINISHER) waits for the n_in slots
+// below its own (they are written first thing by lower-numbered workgroups, see pp_group_sk_kernel), adds them in a fixed order
+// (deterministic) and runs the normal epilogue.  Slot layout (floats): [wave 8][(i * NI + j) * 4 + q][lane 64][4], then
+// [wave 8][i][lane 64] bias partial sums.  Data crosses XCDs, whose L2s are not coherent with each other inside a kernel: it is
+// written and read with system-scope (sc0 sc1) 16-byte accesses, 1 KiB contiguous per wave instruction, the flags with
+// agent-scope atomics.
+struct SkSeg {
+  int kt_begin, kt_end;
+  float* part_out;          // non-finisher: this workgroup's slot (else nullptr)
+  uint32_t* flag_out;       // 8 flags (one per wave) of that slot
+  const float* part_in;     // finisher: slot of the nearest contributor (workgroup w - 1); contributor c is at part_in - c * slot_floats
+  uint32_t* flag_in;        //           its flags; contributor c at flag_in - c * 8
+  int n_in;
+  int slot_floats;
+};
+// Sixteen 16-byte pieces of a slot (four accumulator tiles' worth per lane) in ONE asm statement each way, so that the register cost
+// of the exchange is fixed (64 temporaries on the load side, none on the store side) — left to the scheduler, the 128 loads of a
+// 256 x 256 tile were hoisted over each other and the main loop spilled.  `base` is wave-uniform, voff = lane * 16.
+__device__ __forceinline__ void sk_store_batch(const float* base, uint32_t voff, const f32x4 (&v)[16]) {
+  const float *b0 = base, *b1 = base + 1024, *b2 = base + 2048, *b3 = base + 3072;
+  asm volatile(
+      "global_store_dwordx4 %16, %0, %17 sc0 sc1\n\tglobal_store_dwordx4 %16, %1, %17 offset:1024 sc0 sc1\n\t"
+      "global_store_dwordx4 %16, %2, %17 offset:2048 sc0 sc1\n\tglobal_store_dwordx4 %16, %3, %17 offset:3072 sc0 sc1\n\t"
+      "global_store_dwordx4 %16, %4, %18 sc0 sc1\n\tglobal_store_dwordx4 %16, %5, %18 offset:1024 sc0 sc1\n\t"
+      "global_store_dwordx4 %16, %6, %18 offset:2048 sc0 sc1\n\tglobal_store_dwordx4 %16, %7, %18 offset:3072 sc0 sc1\n\t"
+      "global_store_dwordx4 %16, %8, %19 sc0 sc1\n\tglobal_store_dwordx4 %16, %9, %19 offset:1024 sc0 sc1\n\t"
+      "global_store_dwordx4 %16, %10, %19 offset:2048 sc0 sc1\n\tglobal_store_dwordx4 %16, %11, %19 offset:3072 sc0 sc1\n\t"
+      "global_store_dwordx4 %16, %12, %20 sc0 sc1\n\tglobal_store_dwordx4 %16, %13, %20 offset:1024 sc0 sc1\n\t"
+      "global_store_dwordx4 %16, %14, %20 offset:2048 sc0 sc1\n\tglobal_store_dwordx4 %16, %15, %20 offset:3072 sc0 sc1\n\t"
+      "s_nop 1"
+      :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]),
+         "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3)
+      : "memory");
+}
+__device__ __forceinline__ void sk_load_batch(const float* base, uint32_t voff, f32x4 (&v)[16]) {
+  const float *b0 = base, *b1 = base + 1024, *b2 = base + 2048, *b3 = base + 3072;
+  asm volatile(
+      "global_load_dwordx4 %0, %16, %17 sc0 sc1\n\tglobal_load_dwordx4 %1, %16, %17 offset:1024 sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %16, %17 offset:2048 sc0 sc1\n\tglobal_load_dwordx4 %3, %16, %17 offset:3072 sc0 sc1\n\t"
+      "global_load_dwordx4 %4, %16, %18 sc0 sc1\n\tglobal_load_dwordx4 %5, %16, %18 offset:1024 sc0 sc1\n\t"
+      "global_load_dwordx4 %6, %16, %18 offset:2048 sc0 sc1\n\tglobal_load_dwordx4 %7, %16, %18 offset:3072 sc0 sc1\n\t"
+      "global_load_dwordx4 %8, %16, %19 sc0 sc1\n\tglobal_load_dwordx4 %9, %16, %19 offset:1024 sc0 sc1\n\t"
+      "global_load_dwordx4 %10, %16, %19 offset:2048 sc0 sc1\n\tglobal_load_dwordx4 %11, %16, %19 offset:3072 sc0 sc1\n\t"
+      "global_load_dwordx4 %12, %16, %20 sc0 sc1\n\tglobal_load_dwordx4 %13, %16, %20 offset:1024 sc0 sc1\n\t"
+      "global_load_dwordx4 %14, %16, %20 offset:2048 sc0 sc1\n\tglobal_load_dwordx4 %15, %16, %20 offset:3072 sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9]),
+        "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+      : "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3)
+      : "memory");
+}
+
+// SK: 0 = a whole tile (every other launch form); segments of a contraction-balanced group: 1 = publish, 2 = finish, 3 = whole tile
+template <class CF, bool TA, bool TB, typename OutT, int EPI, bool SPLITK, int SK = 0>
+__device__ __forceinline__ void pp_tile(const G2Args& p, int bid, int split, const SkSeg* sk = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int MI = CF::MI, NI = CF::NI, NB = CF::NB, BM = CF::BM, BN = CF::BN, AH = CF::AH, BSZ = CF::BSZ;
+  static_assert(SK == 0 || (!SPLITK && sizeof(OutT) == 4 && TA), "segments: float32 weight-gradient tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Blk<TA, 32 * MI> BA;      // one A half-block
   typedef Blk<TB, 128 * NI> BB;     // the B block
@@ -153,7 +209,9 @@ __device__ __forceinline__ void pp_tile(const G2Args& p, int bid, int split) {
   constexpr bool SWAP = !SPLITK && sizeof(OutT) == 2;
   constexpr uint32_t B_BASE = 4 * AH;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tid_ = threadIdx.x;
+  if constexpr (SK != 0) asm volatile("" : "+v"(tid_));      // (called in a loop: keeps the lane-only address parts from being hoisted out of it and held in registers across the tiles)
+  const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wn = wave & 3;
   const int hi = lane >> 5, l31 = lane & 31;
 
@@ -169,6 +227,7 @@ __device__ __forceinline__ void pp_tile(const G2Args& p, int bid, int split) {
     kt_end = min(kt_end, kt_begin + p.k_tiles_per_split);
     if (kt_begin >= kt_end) return;
   }
+  if constexpr (SK != 0) { kt_begin = sk->kt_begin; kt_end = sk->kt_end; }
   const int nkt = kt_end - kt_begin;
 
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
@@ -375,6 +434,59 @@ __device__ __forceinline__ void pp_tile(const G2Args& p, int bid, int split) {
   // From here on the LDS ring is free: the last fragment reads of both groups completed before the barrier that ended the last
   // MEM phase, and no LDS-DMA is in flight.  Group 0 starts its epilogue while group 1 is in its last MFMA phase.
   const int wrow0 = grp * WROWS, wcol0 = wn * WCOLS;
+  if constexpr (SK == 1 || SK == 2) {
+    constexpr int WAVE_FLOATS = MI * NI * 16 * 64, BS0 = 8 * WAVE_FLOATS;
+    static_assert((MI * NI) % 4 == 0, "the exchange moves four accumulator tiles per batch");
+    const uint32_t voff = (uint32_t)lane * 16u;
+    if constexpr (SK == 1) {
+      const float* o = sk->part_out + wave * WAVE_FLOATS;
+#pragma unroll
+      for (int b = 0; b < MI * NI / 4; ++b) {
+        f32x4 v[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int idx = b * 4 + k;
+            const f32x16& t = acc[idx / NI][idx % NI];
+            v[k * 4 + q] = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+          }
+        sk_store_batch(o + b * 4096, voff, v);
+      }
+      if (do_colsum) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          __hip_atomic_store(sk->part_out + BS0 + (wave * MI + i) * 64 + lane, bsum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(sk->flag_out + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    } else {
+    for (int c = 0; c < sk->n_in; ++c) {
+      uint32_t* fl = sk->flag_in - c * 8 + wave;
+      while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
+      asm volatile("" ::: "memory");
+      const float* o = sk->part_in - (int64_t)c * sk->slot_floats + wave * WAVE_FLOATS;
+      // (plain loads: the publisher wrote through to memory before raising the flag, and this XCD's L2 cannot hold an older copy of the
+      //  slot — it is only ever read here, after the flag, and L2s are invalidated between kernels)
+#pragma unroll
+      for (int idx = 0; idx < MI * NI; ++idx)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(o + (idx * 4 + q) * 256 + lane * 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[idx / NI][idx % NI][4 * q + e] += v[e];
+        }
+      if (do_colsum) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          bsum[i] += __hip_atomic_load(sk->part_in - (int64_t)c * sk->slot_floats + BS0 + (wave * MI + i) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    }
+    }
+  }
   if (TA && do_colsum) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -546,6 +658,93 @@ __global__ __launch_bounds__(512) void pp_group_kernel(GroupArgs g) {
   pp_tile<CF, true, true, float, GOAT_EPI_NONE, false>(p, pos - g.tile_start[pi], 0);
 }
 
+// Contraction-balanced grouped weight gradients.  pp_group_kernel gives every output tile a workgroup: 432 tiles of 256 x 256 on 256
+// CUs are two rounds for 1.69 rounds of work, and a group that mixes contraction lengths (8640-row panorama problems beside 3840-row
+// text problems) ends with most CUs idle.  Here the grid is ONE workgroup per CU and the group's K-tile iterations — tiles in the
+// group's tile order, K-tiles in order inside a tile — are cut into gridDim.x equal contiguous ranges.  A range is at most: the tail
+// of a tile another workgroup started, whole tiles, the head of a tile the next workgroup finishes.  The HEAD segment (the only one
+// whose result has to travel) runs FIRST and goes to the workgroup's slot; the segment that begins mid-tile runs LAST and waits for
+// the slots of the workgroups below it: a workgroup only ever waits for lower positions, which published before doing anything
+// else, so the wait is short and cannot deadlock (positions of one XCD chunk are dispatched in order; across a chunk boundary the
+// producer is one of the at most seven workgroups everyone else does not depend on).  Sums are formed in a fixed order: results are
+// deterministic (they differ from pp_group_kernel's by float32 summation order only).
+struct SkGroupArgs {
+  GroupArgs g;
+  int iter_start[GROUP_MAX + 1];      // first K-tile iteration of problem i in the group's iteration order
+  float* ws;                          // gridDim.x slots of slot_floats floats
+  uint32_t* flags;                    // gridDim.x x 8, zero between launches (finishers clear what they consume)
+  int slot_floats;
+};
+static_assert(sizeof(SkGroupArgs) <= 4000, "SkGroupArgs must fit the kernel-argument segment");
+
+template <class CF>
+__global__ __launch_bounds__(512) void pp_group_sk_kernel(SkGroupArgs s) {
+  const int G = gridDim.x;
+  const int w = xcd_chunk_position(blockIdx.x, G);
+  const int W = s.iter_start[s.g.n];
+  const int b0 = (int)((int64_t)w * W / G), b1 = (int)((int64_t)(w + 1) * W / G);
+  if (b0 >= b1) return;
+  // tile bounds [T0, T0 + kt) of the tile that holds iteration x, and its problem (unrolled search: only run before the loop, so that
+  // the 25 iteration offsets are not kept in scalar registers across the tiles)
+  auto locate = [&](int x, int& pi, int& T0, int& kt) {
+    pi = 0;
+#pragma unroll
+    for (int i = 1; i < GROUP_MAX; ++i)
+      if (i < s.g.n && x >= s.iter_start[i]) pi = i;
+    kt = s.g.prob[pi].k_tiles_per_split;
+    T0 = s.iter_start[pi] + (x - s.iter_start[pi]) / kt * kt;
+  };
+  int piF, T0F, ktF, piL, T0L, ktL;
+  locate(b0, piF, T0F, ktF);
+  locate(b1 - 1, piL, T0L, ktL);
+  const int first_end = min(b1, T0F + ktF);                  // first segment [b0, first_end)
+  const bool head = (T0L + ktL > b1) && T0L > b0;            // a separate last segment [T0L, b1) that does not finish its tile
+  const bool lone = first_end < T0F + ktF;                   // the whole range lies inside one tile and does not finish it
+  const int mid_end = head ? T0L : b1;
+  SkSeg sg;
+  sg.slot_floats = s.slot_floats;
+  sg.part_out = s.ws + (int64_t)w * s.slot_floats;
+  sg.flag_out = s.flags + w * 8;
+  sg.part_in = s.ws + (int64_t)(w - 1) * s.slot_floats;
+  sg.flag_in = s.flags + (w - 1) * 8;
+  sg.n_in = 0;
+  // 1. the segment whose result travels (three inlined copies of the tile — publish / whole / finish — instead of one with both
+  //    exchange paths: with both, the 256 x 256 tile spilled inside its main loop)
+  if (head || lone) {
+    const int pi = __builtin_amdgcn_readfirstlane(head ? piL : piF), T0 = head ? T0L : T0F, kt = head ? ktL : ktF;
+    sg.kt_begin = (head ? T0L : b0) - T0;
+    sg.kt_end = b1 - T0;
+    const G2Args p = s.g.prob[pi];
+    pp_tile<CF, true, true, float, GOAT_EPI_NONE, false, 1>(p, (T0 - s.iter_start[pi]) / kt, 0, &sg);
+    if (lone) return;
+  }
+  // 2. whole tiles [first_end, mid_end)
+  int xm = first_end, pim = piF;
+  if (xm >= s.iter_start[pim + 1]) ++pim;
+  while (xm < mid_end) {
+    pim = __builtin_amdgcn_readfirstlane(pim);
+    const G2Args p = s.g.prob[pim];
+    const int kt = p.k_tiles_per_split;
+    sg.kt_begin = 0;
+    sg.kt_end = kt;
+    pp_tile<CF, true, true, float, GOAT_EPI_NONE, false, 3>(p, (xm - s.iter_start[pim]) / kt, 0, &sg);
+    xm += kt;
+    if (xm >= s.iter_start[pim + 1]) ++pim;
+  }
+  // 3. the first segment [b0, first_end): finishes its tile; contributors are the workgroups below whose range reaches into the tile
+  {
+    int n = 0;
+    if (b0 > T0F)
+      while (w - 1 - n >= 0 && (int)((int64_t)(w - n) * W / G) > T0F) ++n;
+    sg.n_in = n;
+    sg.kt_begin = b0 - T0F;
+    sg.kt_end = first_end - T0F;
+    const int pi = __builtin_amdgcn_readfirstlane(piF);
+    const G2Args p = s.g.prob[pi];
+    pp_tile<CF, true, true, float, GOAT_EPI_NONE, false, 2>(p, (T0F - s.iter_start[pi]) / ktF, 0, &sg);
+  }
+}
+
 template <class CF, bool TA, bool TB, typename OutT, int EPI, bool SPLITK>
 int pp_launch(hipStream_t st, const G2Args& a, int split) {
   static_assert(CF::SMEM <= 160 * 1024, "LDS exceeds the CU's 160 KiB");
@@ -606,6 +805,46 @@ int pp_launch_group(hipStream_t st, const GroupArgs& g) {
   hipLaunchKernelGGL(kern, dim3(g.tile_start[g.n]), dim3(512), CF::SMEM, st, g);
   GOAT_LAUNCH_CHECK();
   return 0;
+}
+
+
+// bytes of workspace a contraction-balanced group launch needs for tile CF on this device (slots + flags)
+template <class CF>
+constexpr int pp_sk_slot_floats() { return 8 * CF::MI * CF::NI * 16 * 64 + 8 * CF::MI * 64; }
+inline int pp_cu_count();
+template <class CF>
+int pp_launch_group_sk(hipStream_t st, const GroupArgs& g, void* ws, int64_t ws_bytes) {
+  auto kern = pp_group_sk_kernel<CF>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  static_assert(CF::SMEM > 80 * 1024, "one workgroup per CU (the wait relies on every workgroup being resident or ahead in dispatch order)");
+  const int G = pp_cu_count();
+  SkGroupArgs s;
+  s.g = g;
+  int it = 0;
+  for (int i = 0; i < g.n; ++i) {
+    s.iter_start[i] = it;
+    it += (g.tile_start[i + 1] - g.tile_start[i]) * g.prob[i].k_tiles_per_split;
+  }
+  for (int i = g.n; i <= GROUP_MAX; ++i) s.iter_start[i] = it;
+  if (it < G) return GOAT_E_SHAPE;                                     // fewer iterations than workgroups: nothing to balance
+  s.slot_floats = pp_sk_slot_floats<CF>();
+  const int64_t flag_off = ((int64_t)G * s.slot_floats * 4 + 255) / 256 * 256;
+  if (ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < flag_off + (int64_t)G * 32) return GOAT_E_ARG;
+  s.ws = reinterpret_cast<float*>(ws);
+  s.flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + flag_off);
+  hipLaunchKernelGGL(kern, dim3(G), dim3(512), CF::SMEM, st, s);
+  GOAT_LAUNCH_CHECK();
+  return 0;
+}
+template <class CF>
+int64_t pp_sk_ws_bytes() {
+  const int G = pp_cu_count();
+  return ((int64_t)G * pp_sk_slot_floats<CF>() * 4 + 255) / 256 * 256 + (int64_t)G * 32;
 }
 
 
@@ -994,3 +1233,5 @@ int pp_dispatch_persist(hipStream_t st, const G2Args& a, int trans_a, int trans_
 int goat_g5_dispatch(hipStream_t st, const goat_g2::G2Args& a, int bm, int bn, int trans_a, int trans_b, int dtype_out, int epi,
                      int split, int nstage, bool persist);
 int goat_g5_group(hipStream_t st, const goat_g2::GroupArgs& g, int bm, int bn, int nstage);
+int goat_g5_group_sk(hipStream_t st, const goat_g2::GroupArgs& g, int bm, int bn, int nstage, void* ws, int64_t ws_bytes);
+int64_t goat_g5_group_sk_ws_bytes(int bm, int bn);

@@ -268,6 +268,7 @@ def save_tuned(path):
 
 EIGHT_WAVES = 0x100     # GOAT_GEMM_8WAVES (include/goat_hip.h): flag in the nstage argument of goat_gemm_bf16
 PINGPONG = 0x200        # GOAT_GEMM_PP: the ping-pong main loop (csrc/gemm5_tile.hpp); tiles 256x256, 192x256, 128x256, 256x128, 128x128
+BALANCED = 0x800        # (grouped weight gradients only) goat_wgrad_grouped_balanced: one workgroup per CU, equal shares of the group's K-tile iterations
 PERSIST = 0x400         # GOAT_GEMM_PERSIST (with PINGPONG): one workgroup per CU walks the tiles, next tile's first K-tile requested before the epilogue
 USE_PP = os.environ.get('GOAT_GEMM_NO_PP', '0') == '0'
 USE_PERSIST = os.environ.get('GOAT_GEMM_NO_PERSIST', '0') == '0'
@@ -284,7 +285,7 @@ def tile_name(t):
 
 
 def stage_name(ns):
-    return ('pp' if ns & PINGPONG else 's%d' % (ns & 0xFF)) + ('8w' if ns & EIGHT_WAVES else '') + ('P' if ns & PERSIST else '')
+    return ('pp' if ns & PINGPONG else 's%d' % (ns & 0xFF)) + ('8w' if ns & EIGHT_WAVES else '') + ('P' if ns & PERSIST else '') + ('B' if ns & BALANCED else '')
 
 
 def _tile_candidates(ta, tb, M, N):
@@ -678,6 +679,7 @@ class WgradQueue:
         """Drop queued problems (GradArena.zero() calls this: anything still queued at the start of a step belongs to a
         backward pass that was aborted by an exception — its tensors must not be written into the new step)."""
         cls.queues, cls.pending_ids, cls._callback_armed = {}, {}, False
+        cls._balanced_i = 0
         LnReduceQueue.items = []
 
     @classmethod
@@ -706,8 +708,39 @@ class WgradQueue:
                 for i in range(0, len(q), cls.MAX):
                     cls._launch(q[i:i + cls.MAX])
 
+    # contraction-balanced launch as a tuner candidate: opt-in.  Same-box A/B of the step with it among the candidates: 5.321 / 5.316 ms
+    # without, 5.322 / 5.315 with (profiles/round5_wgrad_balanced.txt) — it wins only on groups that mix 8640-row and 3840-row problems.
+    USE_BALANCED = os.environ.get('GOAT_WGRAD_BALANCED', '0') == '1'
     CANDIDATES = ((256, 3), (128, EIGHT_WAVES | 2), (tile(256, 256), 2)) + (      # tile configurations a group may run on
-        ((tile(256, 256), PINGPONG | 2), (tile(128, 256), PINGPONG | 2), (256, PINGPONG | 2)) if USE_PP else ())
+        ((tile(256, 256), PINGPONG | 2), (tile(128, 256), PINGPONG | 2), (256, PINGPONG | 2)) if USE_PP else ()) + (
+        ((tile(256, 256), BALANCED | PINGPONG | 2),) if USE_PP and USE_BALANCED else ())
+    _balanced_ws = {}       # (device, tile, i) -> zeroed workspace of the i-th balanced launch of a step (-1: the tuner's).  Launches of one step may
+    _balanced_i = 0         # overlap on different streams, so each has its own; the eager warm-up step allocates them, the captured step finds them
+    _last_ws = None         # (an allocation inside a capture would put its zero fill into the graph)
+
+    @classmethod
+    def _balanced_args(cls, cfg):
+        """(workspace pointer, bytes) of the launch _run just made"""
+        return (cls._last_ws.data_ptr(), cls._last_ws.numel())
+
+    @classmethod
+    def _run(cls, arr, n, cfg, tuning=False):
+        """one grouped launch on the current stream -> status"""
+        if not cfg[1] & BALANCED:
+            return _lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), n, cfg[0], cfg[1])
+        i = -1
+        if not tuning:
+            i, cls._balanced_i = cls._balanced_i, cls._balanced_i + 1
+        key = (torch.cuda.current_device(), cfg[0], i)
+        ws = cls._balanced_ws.get(key)
+        if ws is None:
+            nb = _lib.lib().goat_wgrad_balanced_ws_bytes(cfg[0])
+            if nb <= 0:
+                return -1
+            ws = cls._balanced_ws[key] = torch.zeros(nb, dtype=torch.uint8, device='cuda')
+        cls._last_ws = ws
+        return _lib.lib().goat_wgrad_grouped_balanced(_stream(), ctypes.addressof(arr), n, cfg[0], ws.data_ptr(), ws.numel())
+
     tuned = {}              # group signature (rows, n_out, n_in per problem) -> configuration, timed on first sight (AUTOTUNE)
     TUNE = os.environ.get('GOAT_WGRAD_GROUP_TUNE', '1') != '0'
 
@@ -791,7 +824,7 @@ class WgradQueue:
 
             def run():
                 for arr, m, cfg in parts:
-                    _lib.check(_lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), m, cfg[0], cfg[1]), 'goat_wgrad_grouped (tuning)')
+                    _lib.check(cls._run(arr, m, cfg, tuning=True), 'goat_wgrad_grouped (tuning)')
             try:
                 t = _time_cfg(run, reps=int(os.environ.get('GOAT_WGRAD_TUNE_REPS', '9')))      # (a group runs 0.1-0.5 ms: nine repetitions cost nothing and the picks stop flipping between runs)
             except RuntimeError:
@@ -833,13 +866,14 @@ class WgradQueue:
             if PROFILE is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            st = _lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), n, cfg[0], cfg[1])
+            st = cls._run(arr, n, cfg)
             if PROFILE is not None:
                 e1.record()
                 fl = sum(2.0 * t[0].shape[0] * t[0].shape[1] * t[1].shape[1] for t in items)
                 by = sum((t[0].shape[0] * t[0].shape[1] + t[1].shape[0] * t[1].shape[1]) * 2 + t[0].shape[1] * t[1].shape[1] * 4 for t in items)
                 PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 %s %s' % (tile_name(cfg[0]), stage_name(cfg[1]))),
-                                ('goat_wgrad_grouped', (ctypes.addressof(arr), n, cfg[0], cfg[1]), (arr, items))))
+                                (('goat_wgrad_grouped', (ctypes.addressof(arr), n, cfg[0], cfg[1]), (arr, items)) if not cfg[1] & BALANCED else
+                                 ('goat_wgrad_grouped_balanced', (ctypes.addressof(arr), n, cfg[0]) + cls._balanced_args(cfg), (arr, items)))))
             _lib.check(st, 'goat_wgrad_grouped(n=%d)' % n)
 
 
