@@ -1196,6 +1196,9 @@ def dagger_iteration(model, te, bufs, batches, extras, arena, sim, store, B, T, 
             ov = two['pass1_captured'].get('teacher_overlapped')
             if isinstance(ov, dict) and 'ms_per_iteration' in ov:
                 forms['two_pass_teacher_overlapped'] = ov['ms_per_iteration']
+                pr = ov.get('pass1_on_a_high_priority_stream')
+                if isinstance(pr, dict) and 'ms_per_iteration' in pr:
+                    forms['two_pass_teacher_overlapped_pass1_high_priority'] = pr['ms_per_iteration']
     best = min(forms, key=forms.get)
     return {'best_form': best, 'best_ms_per_iteration': forms[best], 'forms_ms': forms,
             'ms_per_iteration': round(dt * 1e3, 2), 'sample_rollout_ms': round(sum(t_s) / n * 1e3, 2), 'sample_steps': round(sum(steps) / n, 1),
@@ -1346,26 +1349,45 @@ def overlapped_iteration(call, te, te_s, bufs, bufs_s, batches, extras, arena, m
         hipops.AUTOTUNE = auto
     rng = np.random.RandomState(17)
     tstream = torch.cuda.Stream()
-    n, tt, t_plan, t_p1, usteps = 4, [], [], [], []
-    for it in range(n + 1):
-        batch = batches[it % len(batches)]
-        t0 = time.perf_counter()
-        bufs.load(te.plan(batch))                      # the teacher's host plan + H2D
-        ta = time.perf_counter()
-        tstream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(tstream):
-            g_t0.replay()                              # teacher forward + backward: runs beside pass 1
-        plan, _ = se.run(batch, rng)                   # pass 1 (host-paced)
-        tb = time.perf_counter()
-        bufs_s.load(plan)
-        torch.cuda.current_stream().wait_stream(tstream)
-        g_sa.replay()                                  # sampled half, accumulating behind the teacher's gradients
-        torch.cuda.synchronize()
-        tc = time.perf_counter()
-        if it:
-            tt.append(tc - t0), t_plan.append(ta - t0), t_p1.append(tb - ta), usteps.append(se.steps)
+    hp = torch.cuda.Stream(priority=-1)                # pass 1 on a high-priority stream (second measurement below)
     ms = lambda v: round(sum(v) / len(v) * 1e3, 2)
+
+    def measure(prio):
+        n, tt, t_plan, t_p1, usteps = 4, [], [], [], []
+        for it in range(n + 1):
+            batch = batches[it % len(batches)]
+            t0 = time.perf_counter()
+            bufs.load(te.plan(batch))                      # the teacher's host plan + H2D
+            ta = time.perf_counter()
+            tstream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(tstream):
+                g_t0.replay()                              # teacher forward + backward: runs beside pass 1
+            if prio:                                       # the step graphs of pass 1 go ahead of the teacher graph's kernels wherever both are ready
+                hp.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(hp):
+                    plan, _ = se.run(batch, rng)
+                torch.cuda.current_stream().wait_stream(hp)
+            else:
+                plan, _ = se.run(batch, rng)               # pass 1 (host-paced)
+            tb = time.perf_counter()
+            bufs_s.load(plan)
+            torch.cuda.current_stream().wait_stream(tstream)
+            g_sa.replay()                                  # sampled half, accumulating behind the teacher's gradients
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            if it:
+                tt.append(tc - t0), t_plan.append(ta - t0), t_p1.append(tb - ta), usteps.append(se.steps)
+        return tt, t_plan, t_p1, usteps
+    pr = None
+    if not os.environ.get('GOAT_BENCH_NO_PRIO'):
+        try:
+            ptt, _, pp1, _ = measure(True)
+            pr = {'ms_per_iteration': ms(ptt), 'pass1_beside_teacher_graph_ms': ms(pp1)}
+        except Exception as e:      # noqa: BLE001
+            pr = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+    tt, t_plan, t_p1, usteps = measure(False)
     return {'ms_per_iteration': ms(tt), 'teacher_plan_ms': ms(t_plan), 'pass1_beside_teacher_graph_ms': ms(t_p1),
+            'pass1_on_a_high_priority_stream': pr,
             'sampled_graph_ms': round(ms(tt) - ms(t_plan) - ms(t_p1), 2), 'sample_steps': round(sum(usteps) / len(usteps), 1),
             'what': 'teacher plan + H2D, teacher graph (zero-first form, loss x %.1f) launched on a side stream, pass 1 as captured step graphs '
                     'beside it, then the sampled episode graph (T = %d) in accumulate form' % (ml_weight, max_action_len)}
