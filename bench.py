@@ -18,6 +18,7 @@ kernel: algorithmic FLOPs / HIP-event time per launch, measured live) and `cpu_b
 = a port of the reference path, timed on the host cores of this box on a bounded sample).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -315,8 +316,9 @@ def make_steps(args, model, gb, world, wrapper, tasks=None):
                                                 mixed_tasks=['mlm'] if phased and 'mlm' in TASKS else ())    # (no-ops at N = 1)
         phased = phased and arena[0] is not None
         try:
-            for task in TASKS:
-                eager_phased(task) if phased else step_body(task)
+            with (hipops.Branch.like_capture() if not os.environ.get('GOAT_BENCH_NO_LIKE_CAPTURE') else contextlib.nullcontext()):   # parallel branches as in the capture: the grouped weight gradients the tuner times are the capture's groups
+                for task in TASKS:
+                    eager_phased(task) if phased else step_body(task)
         except Exception as e:      # never lose an N > 1 run to the overlap machinery: fall back to backward, then one all-reduce
             if not phased:
                 raise
@@ -523,14 +525,15 @@ def gemm_roofline(args, model, gb, arena=None, tasks=None, cycle=None):
     hipops.PROFILE = []
     if cycle is not None:                    # (config 4: one eager rollout instead of a pre-training task cycle)
         cycle()
-    for task in (tasks if tasks is not None else (TASKS if cycle is None else ())):
-        if arena is not None:
-            arena.zero(task)                 # same launch set as the timed steps (grouped weight gradients included)
-        else:
-            for p in model.parameters():
-                p.grad = None
-        loss = model(gb, task, compute_loss=True)
-        loss.mean().backward()
+    with hipops.Branch.like_capture():       # parallel branches as in the captured steps: the same grouped weight-gradient launches, on their tuned plans
+        for task in (tasks if tasks is not None else (TASKS if cycle is None else ())):
+            if arena is not None:
+                arena.zero(task)                 # same launch set as the timed steps (grouped weight gradients included)
+            else:
+                for p in model.parameters():
+                    p.grad = None
+            loss = model(gb, task, compute_loss=True)
+            loss.mean().backward()
     torch.cuda.synchronize()
     recs = hipops.PROFILE
     hipops.PROFILE = None
@@ -768,7 +771,7 @@ def ragged_bucket_leg(args, m, B):
             hipops.RngState.dev.add_(0x9E3779B1)
             model(gb, task, compute_loss=True).mean().backward()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), hipops.Branch.like_capture():
             for _ in range(2):
                 for t in tasks:
                     body(t)
@@ -998,9 +1001,10 @@ def config4_leg(args, rank=0, world=1):
             for p in params:
                 p.grad = None
             arena[0] = wrapper.build_arena()
-        for _ in range(2):
-            episode()
-            dp.reduce_finetune_gradients((wrapper, wcritic))
+        with hipops.Branch.like_capture():
+            for _ in range(2):
+                episode()
+                dp.reduce_finetune_gradients((wrapper, wcritic))
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     exchange = lambda: dp.reduce_finetune_gradients((wrapper, wcritic))      # no-op at N = 1 (unless --in-graph-comm forces the one-rank group)
@@ -1161,7 +1165,8 @@ def dagger_iteration(model, te, bufs, batches, extras, arena, sim, store, B, T, 
     with torch.cuda.stream(side):
         for i in range(2):                         # warm-up: tunes the GEMM shapes of the longer sampled rollouts, then the accumulate path
             sample_part(i)
-            teacher_part()
+            with hipops.Branch.like_capture():
+                teacher_part()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     sample_part(0)                                 # the capture below must see every slice already written in this step
@@ -1234,7 +1239,7 @@ def two_pass_iteration(call, te, bufs, g_teacher, batches, extras, arena, sim, s
     try:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), hipops.Branch.like_capture():
             for _ in range(2):
                 sampled_body()
         torch.cuda.current_stream().wait_stream(side)
@@ -1330,7 +1335,7 @@ def overlapped_iteration(call, te, te_s, bufs, bufs_s, batches, extras, arena, m
     try:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), hipops.Branch.like_capture():
             for _ in range(2):
                 teacher_zero()
                 sampled_acc()
@@ -1460,7 +1465,7 @@ def reverie_navigator_leg(args, ep, B, T):
         te.body(call, bufs, extras).backward()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
+    with torch.cuda.stream(side), hipops.Branch.like_capture():
         for _ in range(2):
             episode()
     torch.cuda.current_stream().wait_stream(side)
@@ -1560,7 +1565,7 @@ def navigator_leg(args, model, ep, arena, B, T, frozen_s):
         te.body(call, bufs, extras).backward()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
+    with torch.cuda.stream(side), hipops.Branch.like_capture():
         for _ in range(2):
             episode()
     torch.cuda.current_stream().wait_stream(side)

@@ -550,6 +550,25 @@ class Branch:
 
     off = set(filter(None, os.environ.get('GOAT_BRANCH_OFF', '').split(',')))     # (diagnostics: sites that run on the caller's stream)
 
+    @classmethod
+    def like_capture(cls):
+        """`with Branch.like_capture(): warm_up()` — an EAGER pass that forks the parallel branches exactly as a capture of the same code will
+        (mode 'capture' forks only while capturing).  What depends on which stream an op is issued on then sees the capture's picture:
+        WgradQueue keeps one queue per stream, so the grouped weight-gradient launches of the warm-up — the ones the tuner times — are the
+        groups the captured step will launch."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev = cls.mode
+            if prev == 'capture':
+                cls.mode = 'always'
+            try:
+                yield
+            finally:
+                cls.mode = prev
+        return ctx()
+
     def __init__(self, name, site=None):
         self.name = name
         self.site = site
@@ -635,7 +654,14 @@ class WgradQueue:
     The first write of a slice in a step overwrites it; a later write (shared weights, BPTT) is queued as an accumulation —
     never in the same group as an earlier write of that slice (hipops._sink flushes first)."""
     enabled = os.environ.get('GOAT_WGRAD_GROUP', '1') != '0'
-    cfg = tuple(int(v) for v in os.environ.get('GOAT_WGRAD_GROUP_CFG', '256,3').split(','))   # (tile = rows | cols << 16, ring stages | 0x100 = eight waves on 128x128): scripts/wgrad_group_bench.py, profiles/round2_wgrad_grouped.txt
+    # (tile = rows | cols << 16, ring stages | 0x100 = eight waves on 128x128 | 0x200 = ping-pong): scripts/wgrad_group_bench.py.  The configuration of a
+    # group the tuner has not timed — above all the groups of a CAPTURED step when its eager warm-up ran on one stream: a capture forks parallel
+    # branches, each stream has its own queue, so the groups differ from the warm-up's and miss the tuned plans (found in round 5: 10 of the 12
+    # groups of the headline cycle ran this default, then 256 x 128 on three ring slots; the 256 x 256 ping-pong tile wins nearly every group the
+    # tuner times: step 5.30 -> 5.18 ms same box, profiles/round5_wgrad_default_cfg_ab.txt).  Branch.like_capture() makes a warm-up form the capture's groups.
+    cfg = tuple(int(v) for v in os.environ['GOAT_WGRAD_GROUP_CFG'].split(',')) if 'GOAT_WGRAD_GROUP_CFG' in os.environ else (
+        tuple(int(v) for v in os.environ['GOAT_WGRAD_DEFAULT_CFG'].split(',')) if 'GOAT_WGRAD_DEFAULT_CFG' in os.environ else (   # (A/B: default without switching the tuner off)
+            (256 | 256 << 16, 0x200 | 2) if USE_PP else (256, 3)))
     MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '24'))      # problems per launch = the kernel's GROUP_MAX (round 1: 8 / 12 / 16 -> 7.12 / 7.09 /
                                                                  # 7.06 ms per step; round 4, same box, three alternations: 16 -> 5.80 / 5.81 / 5.80, 24 -> 5.75 / 5.76 / 5.76)
     # (round 2 also had a mode that ran the grouped launches on a stream of their own, off the dgrad chain: 6.52 vs 6.28 ms per step — the
@@ -809,9 +835,18 @@ class WgradQueue:
             return default
         key = tuple((t[0].shape[0], t[0].shape[1], t[1].shape[1]) for t in q)
         plan = cls.tuned.get(key)
+        log = os.environ.get('GOAT_WGRAD_PLAN_LOG')
         if plan is not None:
+            if log == '2':
+                import sys
+                print('[wgrad group] hit  %d problems rows %s capturing=%s -> %s' % (n, sorted({t_[0].shape[0] for t_ in q}), torch.cuda.is_current_stream_capturing(),
+                      ' + '.join('%d x %s %s' % (len(i_), tile_name(c_[0]), stage_name(c_[1])) for i_, c_ in plan)), file=sys.stderr)
             return plan
         if not AUTOTUNE or PROFILE is not None or torch.cuda.is_current_stream_capturing():
+            if log == '2':
+                import sys
+                print('[wgrad group] MISS %d problems rows %s autotune=%s profile=%s capturing=%s -> default' % (
+                    n, sorted({t_[0].shape[0] for t_ in q}), AUTOTUNE, PROFILE is not None, torch.cuda.is_current_stream_capturing()), file=sys.stderr)
             return default
         scratch = [torch.empty((t[0].shape[1], t[1].shape[1]), dtype=torch.float32, device=t[0].device) for t in q]
         best = None
