@@ -268,6 +268,7 @@ def make_steps(args, model, gb, world, wrapper, tasks=None):
     TASKS = tuple(tasks) if tasks is not None else globals()['TASKS']
     hipops.manual_seed(1234)
     hipops.AUTOTUNE = not args.no_autotune     # first sight of a GEMM shape times (tile, LDS stages, split-K) candidates
+    hipops.WgradQueue.FORCE_TUNE = not args.no_autotune      # (grouped weight gradients are timed even where GEMM-shape tuning is switched off below)
     hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')
     params = list(model.parameters())
     arena = [None]
@@ -969,6 +970,7 @@ def config4_leg(args, rank=0, world=1):
     params = list(model.parameters())
     hipops.manual_seed(4321)
     hipops.AUTOTUNE = not args.no_autotune     # first sight of a GEMM shape times (tile, LDS stages, split-K) candidates
+    hipops.WgradQueue.FORCE_TUNE = not args.no_autotune      # (grouped weight gradients are timed even where GEMM-shape tuning is switched off below)
     hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')       # per-replay dropout counter
 
     arena = [None]

@@ -440,6 +440,9 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
             cfg = _tune_gemm(key, a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_opts or (split_k,), colsum_out)
         else:
             cfg = _heuristic_cfg(ta, tb, M, N, Kc, split_k) + (split_k,)
+            if os.environ.get('GOAT_GEMM_CFG_LOG'):      # (diagnostics: shapes that run on the heuristic, e.g. first seen inside a capture)
+                import sys
+                print('[gemm cfg] heuristic %s capturing=%s autotune=%s' % (key, torch.cuda.is_current_stream_capturing(), AUTOTUNE), file=sys.stderr)
     bm, nstage, split_cfg = cfg
     # a split launch accumulates with atomics: only allowed when the caller zero-filled `out` (split requested / split_opts
     # given), asked for the clear (zero_first) or accumulates anyway.  A tuned entry with split > 1 must never be applied to a
@@ -769,6 +772,7 @@ class WgradQueue:
 
     tuned = {}              # group signature (rows, n_out, n_in per problem) -> configuration, timed on first sight (AUTOTUNE)
     TUNE = os.environ.get('GOAT_WGRAD_GROUP_TUNE', '1') != '0'
+    FORCE_TUNE = False      # time unseen groups even while AUTOTUNE is off (bench.py keeps GEMM-shape tuning off around its T = 15 rollout graphs: ~100 shapes; a group costs milliseconds)
 
     @staticmethod
     def _fill(arr, items, scratch=None):
@@ -842,7 +846,7 @@ class WgradQueue:
                 print('[wgrad group] hit  %d problems rows %s capturing=%s -> %s' % (n, sorted({t_[0].shape[0] for t_ in q}), torch.cuda.is_current_stream_capturing(),
                       ' + '.join('%d x %s %s' % (len(i_), tile_name(c_[0]), stage_name(c_[1])) for i_, c_ in plan)), file=sys.stderr)
             return plan
-        if not AUTOTUNE or PROFILE is not None or torch.cuda.is_current_stream_capturing():
+        if not (AUTOTUNE or cls.FORCE_TUNE) or PROFILE is not None or torch.cuda.is_current_stream_capturing():
             if log == '2':
                 import sys
                 print('[wgrad group] MISS %d problems rows %s autotune=%s profile=%s capturing=%s -> default' % (
