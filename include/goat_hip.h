@@ -246,7 +246,7 @@ int goat_gather_segmean_bwd(void* stream, int dtype, const void* dout,
                             const int32_t* idx, const int32_t* start, const float* scale,
                             float* dsrc32, int n_out, int H);
 
-/* Grouped weight gradients: n <= 24 independent problems dW_i[n_out,n_in] (float32) = dY_i[rows,n_out]^T · X_i[rows,n_in]
+/* Grouped weight gradients: n <= 48 independent problems dW_i[n_out,n_in] (float32) = dY_i[rows,n_out]^T · X_i[rows,n_in]
  * (bf16 operands, any row count — the contraction tail is zero-filled) in ONE launch of the goat_gemm_bf16 tile
  * kernel, unsplit.  The autograd of the several nn.Linear of a transformer block (P/model/Bert_backbone.py:170-172,302,
  * 348,362) produces weight gradients of 36-144 tiles each; together they fill the 256 CUs without the split-K atomics

@@ -824,6 +824,52 @@ def test_wgrad_grouped(ops):
             _close(dw, 2 * rw, torch.bfloat16, 'grouped dW accumulate')
 
 
+def test_wgrad_grouped_forty_eight_problems(ops):
+    """The argument block of a grouped launch holds 48 problems (64-byte records expanded on the device): 48 problems of mixed shapes in
+    one launch, per-tile and balanced forms; a 49th is refused."""
+    import ctypes
+    from vln_goat_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(79)
+    shapes = [((200 + 37 * i) % 900 + 64, (96 * (i % 5) + 40), (128 * (i % 4) + 72)) for i in range(48)]
+    arr = (_lib.WgradProblem * 49)()
+    keep, refs = [], []
+    for i, (rows, n_out, n_in) in enumerate(shapes + [shapes[0]]):
+        ld = (n_out + 7) // 8 * 8
+        dyb = (torch.randn(rows, ld, generator=g) * 0.5).to(DEV, torch.bfloat16)
+        dy = dyb[:, :n_out]
+        ldx = (n_in + 7) // 8 * 8
+        xb = torch.randn(rows, ldx, generator=g).to(DEV, torch.bfloat16)
+        x = xb[:, :n_in]
+        dw = torch.full((n_out, n_in), 7.0, device=DEV)
+        db = torch.zeros(n_out, device=DEV)
+        q = arr[i]
+        q.dy, q.ld_dy, q.x, q.ld_x, q.dw, q.ld_dw, q.dbias = dy.data_ptr(), ld, x.data_ptr(), ldx, dw.data_ptr(), n_in, db.data_ptr()
+        q.rows, q.n_out, q.n_in, q.accumulate = rows, n_out, n_in, 0
+        keep.append((dyb, xb, dw, db))
+        refs.append((dy.float().T @ x.float(), dy.float().sum(0)))
+    st = torch.cuda.current_stream().cuda_stream
+    for bm, ns in ((256 | 256 << 16, 0x202), (256, 3), (128, 0x102)):
+        for (_, _, dw, db) in keep:
+            dw.fill_(7.0)
+            db.zero_()
+        assert L.goat_wgrad_grouped(st, ctypes.addressof(arr), 48, bm, ns) == 0
+        for (_, _, dw, db), (rw, rb) in list(zip(keep, refs))[:48]:
+            _close(dw, rw, torch.bfloat16, '48 problems dW')
+            _close(db, rb, torch.bfloat16, '48 problems dbias')
+    bm = 256 | 256 << 16
+    nb = L.goat_wgrad_balanced_ws_bytes(bm)
+    ws = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    for (_, _, dw, db) in keep:
+        dw.fill_(7.0)
+        db.zero_()
+    assert L.goat_wgrad_grouped_balanced(st, ctypes.addressof(arr), 48, bm, ws.data_ptr(), nb) == 0
+    for (_, _, dw, db), (rw, rb) in list(zip(keep, refs))[:48]:
+        _close(dw, rw, torch.bfloat16, '48 problems dW (balanced)')
+        _close(db, rb, torch.bfloat16, '48 problems dbias (balanced)')
+    assert L.goat_wgrad_grouped(st, ctypes.addressof(arr), 49, bm, 0x202) != 0
+
+
 def test_wgrad_grouped_balanced(ops):
     """goat_wgrad_grouped_balanced (one workgroup per CU, equal shares of the group's K-tile iterations, cut tiles summed through the
     workspace): mixed contraction lengths so that shares hold tails, whole tiles and heads, and tiles whose contraction spans three

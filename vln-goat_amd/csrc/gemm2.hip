@@ -141,19 +141,17 @@ static int build_group(const goat_wgrad_problem* probs, int n, int bm, int bn, G
     if ((reinterpret_cast<uintptr_t>(q.dy) & 15) || (reinterpret_cast<uintptr_t>(q.x) & 15)) return GOAT_E_SHAPE;
     const int64_t a_bytes = (int64_t)q.rows * q.ld_dy * 2, b_bytes = (int64_t)q.rows * q.ld_x * 2;
     if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) return GOAT_E_SHAPE;
-    G2Args& a = g.prob[i];
-    a.A = q.dy; a.B = q.x; a.C = q.dw; a.bias = nullptr; a.aux = nullptr;
-    a.lda = q.ld_dy; a.ldb = q.ld_x; a.ldc = q.ld_dw; a.ldaux = 0;
+    if (q.ld_dy >= (1ll << 31) || q.ld_x >= (1ll << 31) || q.ld_dw >= (1ll << 31)) return GOAT_E_SHAPE;
+    GroupProb& a = g.prob[i];
+    a.A = q.dy; a.B = q.x; a.C = q.dw; a.colsum = q.dbias;
+    a.lda = (int)q.ld_dy; a.ldb = (int)q.ld_x; a.ldc = (int)q.ld_dw;
     a.M = q.n_out; a.N = q.n_in; a.Kc = q.rows;
-    a.tiles_m = (q.n_out + bm - 1) / bm;
-    a.tiles_n = (q.n_in + bn - 1) / bn;
-    a.k_tiles_per_split = (q.rows + BK - 1) / BK;
-    a.a_bytes = (uint32_t)a_bytes; a.b_bytes = (uint32_t)b_bytes;
-    a.colsum = q.dbias;
     a.accum = q.accumulate ? 1 : 0;
-    a.group_m = pick_group_m(a.tiles_m, a.tiles_n, bm, bn);
+    const int tiles_m = (q.n_out + bm - 1) / bm, tiles_n = (q.n_in + bn - 1) / bn;
+    a.group_m = (short)pick_group_m(tiles_m, tiles_n, bm, bn);
+    a.pad_ = 0;
     g.tile_start[i] = tiles;
-    tiles += a.tiles_m * a.tiles_n;
+    tiles += tiles_m * tiles_n;
   }
   for (int i = n; i <= GROUP_MAX; ++i) g.tile_start[i] = tiles;
   return 0;

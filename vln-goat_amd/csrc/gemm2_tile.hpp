@@ -693,10 +693,37 @@ __global__ __launch_bounds__(CF::NTH) void gemm2_kernel(G2Args p) {
 // Grouped weight-gradient launch: up to GROUP_MAX (24) independent TN problems (dW_i = dY_i^T · X_i, float32 out, unsplit)
 // share one grid, so the many small weight gradients of a layer fill the chip together instead of each being split
 // along the contraction (atomics + a zero fill) to do so.  Problem i owns tiles [tile_start[i], tile_start[i+1]).
-constexpr int GROUP_MAX = 24;   // (the argument block stays under the 4 KiB kernel-argument limit)
-static_assert(sizeof(G2Args) * GROUP_MAX + 4 * (GROUP_MAX + 2) <= 4000, "GroupArgs must fit the kernel-argument segment");
+constexpr int GROUP_MAX = 48;   // (the argument block stays under the 4 KiB kernel-argument limit)
+// One problem of a grouped launch, 64 bytes: what cannot be recomputed on the device.  (Round 1-5 passed a whole G2Args — 120 bytes —
+// per problem: 24 problems per launch; the text encoder's 47 weight gradients then took two launches, each with its own ramp and
+// tail: 16 -> 24 problems per launch was worth 1 % of the step, profiles/round5_wgrad_group_max.txt.)
+struct GroupProb {
+  const void* A; const void* B; void* C; float* colsum;
+  int lda, ldb, ldc;
+  int M, N, Kc;
+  short accum, group_m;
+  int pad_;
+  template <int BM, int BN>
+  __host__ __device__ __forceinline__ G2Args expand() const {
+    G2Args a;
+    a.A = A; a.B = B; a.C = C; a.bias = nullptr; a.aux = nullptr;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = 0;
+    a.M = M; a.N = N; a.Kc = Kc;
+    a.tiles_m = (M + BM - 1) / BM;
+    a.tiles_n = (N + BN - 1) / BN;
+    a.k_tiles_per_split = (Kc + BK - 1) / BK;
+    a.a_bytes = (uint32_t)Kc * (uint32_t)lda * 2u;      // transposed operands: Kc rows of lda / ldb elements (checked < 2 GiB on the host)
+    a.b_bytes = (uint32_t)Kc * (uint32_t)ldb * 2u;
+    a.colsum = colsum;
+    a.accum = accum;
+    a.group_m = group_m;
+    return a;
+  }
+};
+static_assert(sizeof(GroupProb) == 64, "GroupProb is 64 bytes");
+static_assert(sizeof(GroupProb) * GROUP_MAX + 4 * (2 * GROUP_MAX + 8) + 32 <= 4000, "GroupArgs (and the balanced launch's iteration table) must fit the kernel-argument segment");
 struct GroupArgs {
-  G2Args prob[GROUP_MAX];
+  GroupProb prob[GROUP_MAX];
   int tile_start[GROUP_MAX + 1];
   int n;
 };
@@ -707,7 +734,7 @@ __global__ __launch_bounds__(CF::NTH) void gemm2_group_kernel(GroupArgs g) {
 #pragma unroll
   for (int i = 1; i < GROUP_MAX; ++i)
     if (i < g.n && pos >= g.tile_start[i]) pi = i;
-  const G2Args p = g.prob[pi];
+  const G2Args p = g.prob[pi].template expand<CF::BM, CF::BN>();
   gemm2_tile<CF, true, true, float, GOAT_EPI_NONE, false, NSTAGE>(p, pos - g.tile_start[pi], 0);
 }
 

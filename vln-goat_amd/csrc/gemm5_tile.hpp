@@ -654,7 +654,7 @@ __global__ __launch_bounds__(512) void pp_group_kernel(GroupArgs g) {
 #pragma unroll
   for (int i = 1; i < GROUP_MAX; ++i)
     if (i < g.n && pos >= g.tile_start[i]) pi = i;
-  const G2Args p = g.prob[pi];
+  const G2Args p = g.prob[pi].template expand<CF::BM, CF::BN>();
   pp_tile<CF, true, true, float, GOAT_EPI_NONE, false>(p, pos - g.tile_start[pi], 0);
 }
 
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(512) void pp_group_sk_kernel(SkGroupArgs s) {
 #pragma unroll
     for (int i = 1; i < GROUP_MAX; ++i)
       if (i < s.g.n && x >= s.iter_start[i]) pi = i;
-    kt = s.g.prob[pi].k_tiles_per_split;
+    kt = (s.g.prob[pi].Kc + BK - 1) / BK;
     T0 = s.iter_start[pi] + (x - s.iter_start[pi]) / kt * kt;
   };
   int piF, T0F, ktF, piL, T0L, ktL;
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(512) void pp_group_sk_kernel(SkGroupArgs s) {
     const int pi = __builtin_amdgcn_readfirstlane(head ? piL : piF), T0 = head ? T0L : T0F, kt = head ? ktL : ktF;
     sg.kt_begin = (head ? T0L : b0) - T0;
     sg.kt_end = b1 - T0;
-    const G2Args p = s.g.prob[pi];
+    const G2Args p = s.g.prob[pi].template expand<CF::BM, CF::BN>();
     pp_tile<CF, true, true, float, GOAT_EPI_NONE, false, 1>(p, (T0 - s.iter_start[pi]) / kt, 0, &sg);
     if (lone) return;
   }
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(512) void pp_group_sk_kernel(SkGroupArgs s) {
   if (xm >= s.iter_start[pim + 1]) ++pim;
   while (xm < mid_end) {
     pim = __builtin_amdgcn_readfirstlane(pim);
-    const G2Args p = s.g.prob[pim];
+    const G2Args p = s.g.prob[pim].template expand<CF::BM, CF::BN>();
     const int kt = p.k_tiles_per_split;
     sg.kt_begin = 0;
     sg.kt_end = kt;
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(512) void pp_group_sk_kernel(SkGroupArgs s) {
     sg.kt_begin = b0 - T0F;
     sg.kt_end = first_end - T0F;
     const int pi = __builtin_amdgcn_readfirstlane(piF);
-    const G2Args p = s.g.prob[pi];
+    const G2Args p = s.g.prob[pi].template expand<CF::BM, CF::BN>();
     pp_tile<CF, true, true, float, GOAT_EPI_NONE, false, 2>(p, (T0F - s.iter_start[pi]) / ktF, 0, &sg);
   }
 }
@@ -828,7 +828,7 @@ int pp_launch_group_sk(hipStream_t st, const GroupArgs& g, void* ws, int64_t ws_
   int it = 0;
   for (int i = 0; i < g.n; ++i) {
     s.iter_start[i] = it;
-    it += (g.tile_start[i + 1] - g.tile_start[i]) * g.prob[i].k_tiles_per_split;
+    it += (g.tile_start[i + 1] - g.tile_start[i]) * ((g.prob[i].Kc + BK - 1) / BK);
   }
   for (int i = g.n; i <= GROUP_MAX; ++i) s.iter_start[i] = it;
   if (it < G) return GOAT_E_SHAPE;                                     // fewer iterations than workgroups: nothing to balance

@@ -665,7 +665,7 @@ class WgradQueue:
     cfg = tuple(int(v) for v in os.environ['GOAT_WGRAD_GROUP_CFG'].split(',')) if 'GOAT_WGRAD_GROUP_CFG' in os.environ else (
         tuple(int(v) for v in os.environ['GOAT_WGRAD_DEFAULT_CFG'].split(',')) if 'GOAT_WGRAD_DEFAULT_CFG' in os.environ else (   # (A/B: default without switching the tuner off)
             (256 | 256 << 16, 0x200 | 2) if USE_PP else (256, 3)))
-    MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '24'))      # problems per launch = the kernel's GROUP_MAX (round 1: 8 / 12 / 16 -> 7.12 / 7.09 /
+    MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '48'))      # problems per launch = the kernel's GROUP_MAX (48 since the last session of round 5: 24 / 32 / 48 -> 5.03 / 5.02 / 4.99 ms per step; round 1: 8 / 12 / 16 -> 7.12 / 7.09 /
                                                                  # 7.06 ms per step; round 4, same box, three alternations: 16 -> 5.80 / 5.81 / 5.80, 24 -> 5.75 / 5.76 / 5.76)
     # (round 2 also had a mode that ran the grouped launches on a stream of their own, off the dgrad chain: 6.52 vs 6.28 ms per step — the
     #  kernels contend, they do not fill idle CUs: removed in round 3)
