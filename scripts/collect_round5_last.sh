@@ -2,7 +2,7 @@
 # Last collection of round 5 (final tree): rocprofv3 kernel stats of the default bench command with / without the roofline leg, the step
 # breakdown, the default bench line, smoke().  Run on the GPU box through gpurun; summaries are copied to profiles/round5_last_*.
 set -u
-OUT=/root/repo/gpurun_out/r5last
+OUT=/root/repo/gpurun_out/r5final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export GOAT_BENCH_NO_PER_TASK=1
