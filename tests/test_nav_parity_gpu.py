@@ -282,6 +282,69 @@ def test_extract_cfp_features_and_zdict_update_match_reference_golden(dtype):
     assert np.abs(got - ref).max() / max(1.0, np.abs(ref).max()) < tol
 
 
+def test_weight_gradients_of_one_slice_are_merged():
+    """BPTT under the gradient arena, bf16: a recurrent block (two Linears of width 256 / 512) applied five times to 64-row inputs queues five
+    weight-gradient problems per weight.  With hipops.WgradQueue.MERGE they become ONE problem per weight over the concatenated rows and one
+    grouped launch; without, the second use of a weight flushes the queue (one launch per step).  Same gradients (float32 summation order
+    only), equal to plain autograd."""
+    import vln_goat_amd
+    from vln_goat_amd import dp, hipops, layers
+
+    class Cell(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = layers.Linear(256, 512)
+            self.b = layers.Linear(512, 256)
+
+        def forward(self, x, task=None):
+            h = x
+            for _ in range(5):
+                h = h + self.b(torch.relu(self.a(h)))
+            return h.float().pow(2).mean()
+
+    torch.manual_seed(3)
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    keep_merge, keep_run = hipops.WgradQueue.MERGE, hipops.WgradQueue._run
+    try:
+        model = Cell().cuda()
+        x = (torch.randn(64, 256, device='cuda') * 0.5).to(torch.bfloat16).requires_grad_(True)
+        model(x).backward()
+        ref = {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
+        wrapper = dp.GoatDataParallel(model)
+        wrapper.record_usage('nav')
+        for p in model.parameters():
+            p.grad = None
+        arena = wrapper.build_arena()
+        counts = []
+
+        def counting_run(arr, n, cfg, tuning=False):
+            if not tuning:
+                counts[-1][0] += 1
+                counts[-1][1] += n
+            return keep_run.__func__(hipops.WgradQueue, arr, n, cfg, tuning)
+        hipops.WgradQueue._run = counting_run
+        grads = []
+        for merge in (True, False):
+            hipops.WgradQueue.MERGE = merge
+            counts.append([0, 0])
+            arena.flat.fill_(5.0)
+            arena.zero('nav')
+            model(x).backward()
+            torch.cuda.synchronize()
+            grads.append({n: p.grad.detach().float().clone() for n, p in model.named_parameters()})
+            for n, p in model.named_parameters():
+                assert p.grad is arena.views[id(p)], n
+        (l_on, p_on), (l_off, p_off) = counts
+        assert (l_on, p_on) == (1, 2) and l_off == 5 and p_off == 10, counts
+        for n in ref:
+            sc = float(ref[n].abs().max())
+            assert float((grads[0][n] - grads[1][n]).abs().max()) <= 2e-5 * sc, n
+            assert float((grads[0][n] - ref[n]).abs().max()) <= 2e-5 * sc + 3e-7, n
+    finally:
+        hipops.WgradQueue.MERGE, hipops.WgradQueue._run = keep_merge, keep_run
+        vln_goat_amd.set_compute_dtype(torch.float32)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_nav_episode_gradient_arena_equals_autograd(dtype):
     """The fine-tuning model under dp.GradArena: a 3-step rollout with BPTT writes every shared weight several times per

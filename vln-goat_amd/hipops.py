@@ -677,17 +677,57 @@ class WgradQueue:
     queues = {}             # HIP stream handle -> (torch stream, [(dy, x, w_sink, b_sink, accumulate)]): tensors are kept alive until
     pending_ids = {}        # the launch, which happens on the stream the problems were produced on;  id(param) -> stream handle
     _callback_armed = False
+    # Merging (last session of round 5).  A weight used several times in one backward pass — every weight of the navigation model in a
+    # T-step episode (BPTT), shared cross-modal layers — used to force a flush at its second use (two problems writing one slice cannot share
+    # a launch), so an episode's backward ran one grouped launch PER STEP, each reading and re-writing the float32 gradient of every weight:
+    # 16 launches of ~180 us per 6-step episode, bound by that traffic, not by MFMA (contraction lengths of 12 ... 768 rows).  Now small
+    # problems of the same slice stay queued together and become ONE problem at launch time: dW = [dY_1; dY_2; ...]^T [X_1; X_2; ...] (the
+    # row blocks copied into one buffer each — cheap while rows < 2 n_out n_in / (n_out + n_in), the copy against a read-modify-write of dW).
+    MERGE = os.environ.get('GOAT_WGRAD_MERGE', '1') != '0'
+    distinct = {}           # HIP stream handle -> set of queued slices (data pointers): the flush threshold counts problems AFTER merging
+    MAX_ITEMS, MAX_SLICES = 8192, 1024        # (bounds on queued tensors / distinct slices)
+
+    @classmethod
+    def mergeable(cls, rows, n_out, n_in):
+        return cls.MERGE and cls.enabled and rows * (n_out + n_in) < 2 * n_out * n_in and n_out % 8 == 0 and n_in % 8 == 0      # (the concatenated operands are contiguous: row length = leading dimension, a multiple of 8)
 
     @classmethod
     def push(cls, dy, x, w_sink, b_sink, param_ids, accumulate):
         st = torch.cuda.current_stream()
         q = cls.queues.setdefault(st.cuda_stream, (st, []))[1]
         q.append((dy, x, w_sink, b_sink, int(bool(accumulate))))
+        d = cls.distinct.setdefault(st.cuda_stream, [set(), set()])      # [every queued slice, slices with a problem too large to merge]
+        d[0].add(w_sink.data_ptr())
+        if not cls.mergeable(dy.shape[0], dy.shape[1], x.shape[1]):
+            d[1].add(w_sink.data_ptr())
         for i in param_ids:
             cls.pending_ids[i] = st.cuda_stream
         cls.arm()
-        if len(q) >= cls.MAX and not cls.DEFER_ALL:
+        # full = MAX slices that will not be merged with later problems; the small (mergeable) ones wait for the other steps' problems of
+        # their weight — an episode's backward is then a handful of launches at its end instead of one per step
+        if (len(d[1]) >= cls.MAX and not cls.DEFER_ALL) or len(d[0]) >= cls.MAX_SLICES or len(q) >= cls.MAX_ITEMS:
             cls.flush(st.cuda_stream)
+
+    @staticmethod
+    def _merge(q):
+        """problems of one slice -> one problem over the concatenated rows (queue order kept by first occurrence; the merged problem overwrites /
+        accumulates as its first member did, later members were accumulations by construction)"""
+        seen = {}
+        for i, t in enumerate(q):
+            seen.setdefault((t[2].data_ptr(), t[3].data_ptr() if t[3] is not None else 0, t[0].dtype), []).append(i)
+        if len(seen) == len(q):
+            return q
+        out = []
+        for key, idx in seen.items():
+            t0 = q[idx[0]]
+            if len(idx) == 1:
+                out.append((idx[0], t0))
+                continue
+            dy = torch.cat([q[i][0] for i in idx], 0)
+            x = torch.cat([q[i][1] for i in idx], 0)
+            out.append((idx[0], (dy, x, t0[2], t0[3], t0[4])))
+        out.sort(key=lambda e: e[0])
+        return [t for _, t in out]
 
     @classmethod
     def arm(cls):
@@ -708,6 +748,7 @@ class WgradQueue:
         """Drop queued problems (GradArena.zero() calls this: anything still queued at the start of a step belongs to a
         backward pass that was aborted by an exception — its tensors must not be written into the new step)."""
         cls.queues, cls.pending_ids, cls._callback_armed = {}, {}, False
+        cls.distinct = {}
         cls._balanced_i = 0
         LnReduceQueue.items = []
 
@@ -731,9 +772,11 @@ class WgradQueue:
                 continue
             st, q = ent
             cls.queues[h] = (st, [])
+            cls.distinct.pop(h, None)
             for pid in [k for k, v in cls.pending_ids.items() if v == h]:
                 del cls.pending_ids[pid]
             with torch.cuda.stream(st):
+                q = cls._merge(q)
                 for i in range(0, len(q), cls.MAX):
                     cls._launch(q[i:i + cls.MAX])
 
@@ -944,23 +987,26 @@ class LnReduceQueue:
             _lib.check(_lib.lib().goat_ln_reduce_batched(_stream(), ctypes.addressof(arr), len(group), H), 'goat_ln_reduce_batched')
 
 
-def _sink(param):
+def _sink(param, keep_queued=False):
     """Gradient-arena slice bound to `param` (dp.GradArena.attach), or None.  When it is bound — i.e. still the
     object behind param.grad — backward passes accumulate the parameter's gradient straight into it and return
     None to autograd (no temporary, no zero-fill, no `grad += dW` kernel).  Setting param.grad = None (or to any
-    other tensor) silently restores the ordinary autograd path."""
+    other tensor) silently restores the ordinary autograd path.
+    keep_queued: the caller is about to queue ANOTHER weight-gradient problem for this slice on this stream and the two may be merged
+    (WgradQueue.mergeable): a queued write of the same stream then stays queued."""
     if param is None:
         return None
     if WgradQueue.pending_ids and id(param) in WgradQueue.pending_ids:
-        WgradQueue.flush_param(id(param))      # a queued write of this slice must land before anything else touches it
+        if not (keep_queued and WgradQueue.pending_ids[id(param)] == torch.cuda.current_stream().cuda_stream):
+            WgradQueue.flush_param(id(param))      # a queued write of this slice must land before anything else touches it
     s = param.__dict__.get('_goat_sink')
     return s if (s is not None and param.grad is s) else None
 
 
-def _sink_cat(params):
+def _sink_cat(params, keep_queued=False):
     """One [sum(rows), ...] view over the arena slices of several parameters if they are adjacent in the arena
     (query/key/value weights of a block), else None."""
-    sinks = [_sink(p) for p in params]
+    sinks = [_sink(p, keep_queued) for p in params]
     if any(t is None for t in sinks):
         return None
     for a, b in zip(sinks, sinks[1:]):
@@ -1025,6 +1071,8 @@ def _wgrad_impl(dy, x, want_bias, w_sink=None, b_sink=None, first=False, b_first
                 and not torch.is_grad_enabled()):
             WgradQueue.push(dy, x, w_sink, db if want_bias else None, defer_ids, accumulate=not first)
             return None, None
+        for i in (defer_ids or ()):
+            WgradQueue.flush_param(i)           # (a write left queued for merging must land before this direct one)
         gemm(dy, x, w_sink, ta=True, tb=True, split_k=split, colsum_out=db if want_bias else None,
              split_opts=(1, 2, 3, 4, 6, 8) if tunable else None, accumulate=not first, zero_first=first)
         return None, (db if (want_bias and b_sink is None) else None)
@@ -1138,8 +1186,9 @@ class _LinearFn(torch.autograd.Function):
             if dwt is not w_sink:
                 dw, db = dwt, dbt
         elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            w_sink = None if ctx.pad else _sink(weight)
-            b_sink = _sink(ctx.bias) if w_sink is not None else None
+            keep = WgradQueue.mergeable(dy2.shape[0], dy2.shape[1], x2.shape[1])      # small (BPTT-step) problems of one weight are merged into one
+            w_sink = None if ctx.pad else _sink(weight, keep)
+            b_sink = _sink(ctx.bias, keep) if w_sink is not None else None
             first = w_sink is not None and _first_touch(weight)
             b_first = b_sink is not None and _first_touch(ctx.bias)
             _prep_fallback(*(([] if w_sink is not None else [weight]) + ([] if b_sink is not None else [ctx.bias])))
@@ -1265,8 +1314,9 @@ class _FfnFn(torch.autograd.Function):
             du = act_bwd(du, u, ctx.act, ctx.p, ctx.rng)
         else:
             gemm(dy2, W2, du, tb=True, epi=_ACT_DEPI[ctx.act], aux=u)
-        s2 = _sink(ctx.w2)
-        sb2 = _sink(ctx.b2) if s2 is not None else None
+        k2 = WgradQueue.mergeable(dy2.shape[0], dy2.shape[1], h.shape[1])
+        s2 = _sink(ctx.w2, k2)
+        sb2 = _sink(ctx.b2, k2) if s2 is not None else None
         f2 = s2 is not None and _first_touch(ctx.w2)
         bf2 = sb2 is not None and _first_touch(ctx.b2)
         _prep_fallback(*(([] if s2 is not None else [ctx.w2]) + ([] if sb2 is not None else [ctx.b2])))
@@ -1274,8 +1324,9 @@ class _FfnFn(torch.autograd.Function):
         W1 = _shadow(ctx.w1, x2.dtype)  # [F, H]
         dx = torch.empty_like(x2)
         gemm(du, W1, dx, tb=True)
-        s1 = _sink(ctx.w1)
-        sb1 = _sink(ctx.b1) if s1 is not None else None
+        k1 = WgradQueue.mergeable(du.shape[0], du.shape[1], x2.shape[1])
+        s1 = _sink(ctx.w1, k1)
+        sb1 = _sink(ctx.b1, k1) if s1 is not None else None
         f1 = s1 is not None and _first_touch(ctx.w1)
         bf1 = sb1 is not None and _first_touch(ctx.b1)
         _prep_fallback(*(([] if s1 is not None else [ctx.w1]) + ([] if sb1 is not None else [ctx.b1])))
@@ -1415,8 +1466,9 @@ class _MultiLinearFn(torch.autograd.Function):
             dx = torch.empty_like(x2)
             gemm(dy2, W, dx, tb=True)
             dx = dx.view(ctx.xshape)
-        w_sink = _sink_cat(ws)
-        b_sink = _sink_cat(ctx.bs) if w_sink is not None else None
+        keep = WgradQueue.mergeable(dy2.shape[0], dy2.shape[1], x2.shape[1])
+        w_sink = _sink_cat(ws, keep)
+        b_sink = _sink_cat(ctx.bs, keep) if w_sink is not None else None
         first = w_sink is not None and _first_touch(*ws)
         b_first = b_sink is not None and _first_touch(*ctx.bs)
         _prep_fallback(*(([] if w_sink is not None else list(ws)) + ([] if b_sink is not None else list(ctx.bs))))
