@@ -1460,16 +1460,31 @@ def reverie_navigator_leg(args, ep, B, T):
     call = lambda mode, batch: model(mode, batch)
     params = list(model.parameters())
 
+    arena = [None]
+
     def episode():
-        for p in params:
-            p.grad = None
+        if arena[0] is not None:
+            arena[0].zero('nav')             # gradient arena: the weight gradients of the episode's Linears are deferred, merged per weight over the steps, grouped
+        else:
+            for p in params:
+                p.grad = None
         hipops.RngState.dev.add_(0x9E3779B1)
         te.body(call, bufs, extras).backward()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side), hipops.Branch.like_capture():
+    with torch.cuda.stream(side):
         for _ in range(2):
             episode()
+        if not args.no_arena:
+            from vln_goat_amd import dp
+            wrapper = dp.GoatDataParallel(model)
+            wrapper.record_usage('nav')
+            for p in params:
+                p.grad = None
+            arena[0] = wrapper.build_arena()
+        with hipops.Branch.like_capture():
+            for _ in range(2):
+                episode()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
