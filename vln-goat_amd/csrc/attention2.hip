@@ -894,9 +894,18 @@ int goat_attn2_bwd(hipStream_t st, const AttnArgs& a) {
       return 0;
     }
   }
-  const int nwv = nqt + nkt <= 8 ? nqt + nkt : 8;
-  const size_t sm = (size_t)(2 * nqt + 2 * nkt) * TILE * 2 + (size_t)(2 * nqt + nkt) * 32 * 4 + (nqt + nkt > 8 ? (size_t)nwv * TILE * 2 : 0);
-  if (sm > 160 * 1024) return GOAT_E_SHAPE;          // (e.g. 200 x 200: the caller falls back to the streaming kernels of attention.hip)
+  int nwv = nqt + nkt <= 8 ? nqt + nkt : 8;
+  const size_t sm0 = (size_t)(2 * nqt + 2 * nkt) * TILE * 2 + (size_t)(2 * nqt + nkt) * 32 * 4;
+  size_t sm = sm0 + (nqt + nkt > 8 ? (size_t)nwv * TILE * 2 : 0);
+  // more roles than waves: every wave owns a staging tile, so fewer waves need less LDS.  200 x 200 (the 200-token instructions of the
+  // fine-tuning episodes: 7 x 7 tiles) is 164.6 KiB on eight waves and 155.6 KiB on six — three rounds of roles instead of two, against
+  // the streaming kernels of attention.hip it used to fall back to (48 + 39 us per call; profiles/round5_attention_L200_bwd.txt)
+  static const int min_waves = getenv("GOAT_ATTN_BWD_MIN_WAVES") ? atoi(getenv("GOAT_ATTN_BWD_MIN_WAVES")) : 6;      // (8: the behaviour before, for A/B)
+  while (sm > 160 * 1024 && nqt + nkt > 8 && nwv > min_waves) {
+    --nwv;
+    sm = sm0 + (size_t)nwv * TILE * 2;
+  }
+  if (sm > 160 * 1024) return GOAT_E_SHAPE;          // (e.g. 256 x 256: the caller falls back to the streaming kernels of attention.hip)
   static size_t cur = 0, cur_m = 0;
   if (nqt + nkt > 8) {
     if (int e = set_smem(attn2_bwd_kernel<true>, sm, cur_m)) return e;
