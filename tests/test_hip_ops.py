@@ -1352,3 +1352,124 @@ def test_cross_entropy_rows_with_masked_actions_and_ignored_rows(ops, N):
     _close(got, ref, torch.float32, 'loss')
     assert torch.equal(torch.isfinite(g_got), torch.isfinite(lg.grad))
     _close(torch.nan_to_num(g_got), torch.nan_to_num(lg.grad), torch.float32, 'dlogits')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,Lq,Lk,n', [(6, 23, 80, 6), (3, 80, 37, 3)])
+def test_linear_bank_matches_one_projection_per_layer(ops, dtype, B, Lq, Lk, n):
+    """All layers' cross-attention K|V projections of one attended sequence as ONE GEMM (hipops.linear_bank; reference loop
+    P/model/Bert_backbone.py:765-781) against one multi_linear per layer + fan-out: forward results identical bit for bit; the
+    gradients agree within the dtype's tolerance with a float64 reference (the bank rounds the gradient of the attended sequence
+    ONCE, the per-layer path n + 1 times) — and attention writes its key|value gradient straight into the bank's buffer."""
+    H, nh = 768, 12
+    g = torch.Generator().manual_seed(3)
+    x0 = (torch.randn(B, Lk, H, generator=g) * 0.5)
+    q0 = [(torch.randn(B, Lq, H, generator=g) * 0.5) for _ in range(n)]
+    Ws = [[torch.randn(H, H, generator=g) * 0.03 for _ in range(2)] for _ in range(n)]
+    bs = [[torch.randn(H, generator=g) * 0.1 for _ in range(2)] for _ in range(n)]
+    do = [torch.randn(B, Lq, H, generator=g) for _ in range(n)]
+    kmask = torch.zeros(B, Lk)
+    kmask[0, Lk - 5:] = -10000.0
+
+    def run(bank):
+        x = x0.to(DEV, dtype).requires_grad_()
+        qs = [t.to(DEV, dtype).requires_grad_() for t in q0]
+        params = [[(torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))) for w, b in zip(Wl, bl)] for Wl, bl in zip(Ws, bs)]
+        if bank:
+            kvs = ops.linear_bank(x, params)
+            assert all(kv.stride(1) == n * 2 * H for kv in kvs)
+        else:
+            kvs = [ops.multi_linear(h, [p[0] for p in grp], [p[1] for p in grp]) for h, grp in zip(ops.fanout(x, n), params)]
+        outs = [ops.attention(qs[i], kvs[i], kmask.to(DEV), None, nh, 0.0) for i in range(n)]
+        loss = sum((o.float() * d.to(DEV)).sum() for o, d in zip(outs, do))
+        loss.backward()
+        torch.cuda.synchronize()
+        return ([kv.detach().float().cpu() for kv in kvs], [o.detach().float().cpu() for o in outs], x.grad.float().cpu(),
+                [t.grad.float().cpu() for t in qs], [[(w.grad.cpu(), b.grad.cpu()) for w, b in grp] for grp in params])
+
+    kv_b, o_b, dx_b, dq_b, dp_b = run(True)
+    kv_l, o_l, dx_l, dq_l, dp_l = run(False)
+    for a, b in zip(kv_b + o_b, kv_l + o_l):
+        assert torch.equal(a, b), 'the bank changes a forward result'
+    for a, b in zip(dq_b, dq_l):
+        assert torch.equal(a, b)
+    # float64 reference of the same graph
+    x = x0.double().requires_grad_()
+    qs = [t.double().requires_grad_() for t in q0]
+    if dtype == torch.bfloat16:
+        x = x0.bfloat16().double().requires_grad_()
+        qs = [t.bfloat16().double().requires_grad_() for t in q0]
+    pr = [[(w.double().requires_grad_() if dtype == torch.float32 else w.bfloat16().double().requires_grad_(), b.double().requires_grad_())
+           for w, b in zip(Wl, bl)] for Wl, bl in zip(Ws, bs)]
+    loss = 0
+    for i in range(n):
+        k = (x @ pr[i][0][0].t() + pr[i][0][1]).view(B, Lk, nh, 64).transpose(1, 2)
+        v = (x @ pr[i][1][0].t() + pr[i][1][1]).view(B, Lk, nh, 64).transpose(1, 2)
+        qh = qs[i].view(B, Lq, nh, 64).transpose(1, 2)
+        s = qh @ k.transpose(-1, -2) / 8.0 + kmask.double()[:, None, None, :]
+        o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, Lq, H)
+        loss = loss + (o * do[i].double()).sum()
+    loss.backward()
+    _close(dx_b, x.grad, dtype, 'bank dx')
+    _close(dx_l, x.grad, dtype, 'per-layer dx')
+    e_b = (dx_b.double() - x.grad).abs().max()
+    e_l = (dx_l.double() - x.grad).abs().max()
+    if dtype == torch.bfloat16:
+        assert e_b <= 1.5 * e_l + 1e-6, (float(e_b), float(e_l))    # one rounding instead of n + 1
+    for i in range(n):
+        for j in range(2):
+            _close(dp_b[i][j][0], pr[i][j][0].grad, dtype, 'bank dW %d %d' % (i, j))
+            _close(dp_b[i][j][1], pr[i][j][1].grad, dtype, 'bank db %d %d' % (i, j))
+            _close(dp_b[i][j][0], dp_l[i][j][0], dtype, 'dW vs per-layer')
+
+
+@pytest.mark.parametrize('M', [515, 3840, 8641])
+@pytest.mark.parametrize('form', ['plain', 'res_drop_fork', 'z_out', 'fork_in', 'out_drop_post'])
+def test_layer_norm_backward_768_kernel_matches_the_generic_kernel(ops, M, form):
+    """ln_bwd768_kernel (bf16 rows of 768: 8-byte chunks, packed rows in flight, <= 128 VGPRs) against the generic ln_bwd_kernel on the same
+    inputs and dropout counters: same column partials, row statistics summed in another lane order — equal to float rounding."""
+    H = 768
+    g = torch.Generator().manual_seed(M)
+    x0 = torch.randn(M, H, generator=g)
+    r0 = torch.randn(M, H, generator=g)
+    dy0, dy1 = torch.randn(M, H, generator=g), torch.randn(M, H, generator=g)
+    gamma0, beta0 = 1 + 0.1 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
+
+    def run(generic):
+        if generic:
+            os.environ['GOAT_LN_BWD_GENERIC'] = '1'
+        else:
+            os.environ.pop('GOAT_LN_BWD_GENERIC', None)
+        try:
+            ops.manual_seed(11)
+            x = x0.to(DEV, torch.bfloat16).requires_grad_()
+            r = r0.to(DEV, torch.bfloat16).requires_grad_()
+            gamma, beta = gamma0.to(DEV).requires_grad_(), beta0.to(DEV).requires_grad_()
+            a, b = dy0.to(DEV, torch.bfloat16), dy1.to(DEV, torch.bfloat16)
+            if form == 'plain':
+                y = ops.layer_norm(x, gamma, beta, 1e-12)
+                y.backward(a)
+            elif form == 'res_drop_fork':
+                y1, y2 = ops.layer_norm(x, gamma, beta, 1e-12, r, 0.1, fork=True)
+                torch.autograd.backward([y1, y2], [a, b])
+            elif form == 'z_out':
+                y, zz = ops.layer_norm(x, gamma, beta, 1e-5, r, 0.1, z_out=True)
+                torch.autograd.backward([y, zz], [a, b])
+            elif form == 'fork_in':
+                y, xs = ops.layer_norm(x, gamma, beta, 1e-5, fork_in=True)
+                torch.autograd.backward([y, xs], [a, b])
+            else:
+                post = r
+                y = ops.layer_norm(x, gamma, beta, 1e-12, p_out=0.1, post_add=post)
+                y.backward(a)
+            torch.cuda.synchronize()
+            return [t.grad.float().cpu() for t in (x, r, gamma, beta) if t.grad is not None]
+        finally:
+            os.environ.pop('GOAT_LN_BWD_GENERIC', None)
+
+    new, old = run(False), run(True)
+    assert len(new) == len(old) and len(new) >= 3
+    for i, (a, b) in enumerate(zip(new, old)):
+        scale = b.abs().max().clamp_min(1e-6)
+        assert (a - b).abs().max() / scale < 1e-2, (form, i, float((a - b).abs().max() / scale))       # (a bf16 ulp where a rounding flips)
+        assert (a - b).abs().mean() / scale < 2e-5, (form, i, float((a - b).abs().mean() / scale))

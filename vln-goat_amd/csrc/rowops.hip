@@ -258,6 +258,196 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd_kernel(const T* __restrict__ 
   }                                                                        // (pre-zeroed) gradient; no second launch
 }
 
+// ---- bf16, H = 768 (every LayerNorm of the model at its hidden size): the backward on a register diet.
+// The generic kernel above keeps two rows in flight as float (16-byte chunks: the second chunk of a 768-wide row occupies half the
+// lanes) and needs 192 VGPRs — two waves per SIMD, and ONE slot beside a 240-VGPR GEMM workgroup of the other graph branch (measured
+// in the step: 18.9 us against 10.7 alone).  Here a lane owns 12 elements of a row as THREE 8-BYTE chunks (all 64 lanes busy), the
+// row being reduced lives in float, the NEXT row of the wave is in flight in its packed bf16 form (12 registers for dy | z, converted
+// on use): <= 96 VGPRs -> five waves per SIMD alone, two beside a GEMM wave.  Same arithmetic, order and results as ln_bwd_kernel.
+__device__ __forceinline__ void goat_store_stream8(bf16_t* p, const bf16x4& v) {
+#if GOAT_ROW_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(p));
+#else
+  *reinterpret_cast<bf16x4*>(p) = v;
+#endif
+}
+
+template <int NWV, int RIF, bool DROP, bool DY2, bool EXTRA>
+__device__ __forceinline__ void ln_bwd768_body(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dy2,
+                                                             const bf16_t* __restrict__ z, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd, float p,
+                                                             uint64_t seed, uint64_t offset, const uint64_t* __restrict__ rng_dev,
+                                                             bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, float* __restrict__ ws,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             const bf16_t* __restrict__ dx_add, int pre_add, int M, float p_out,
+                                                             uint64_t offset_out, bf16_t* __restrict__ d_post) {
+  constexpr int H = 768, NC = 3, E = 4;
+  extern __shared__ float lsum[];  // [NWV][2][H] column partials, then gamma [H] (read per row: 12 registers less than holding it)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* __restrict__ lgam = lsum + NWV * 2 * H;
+  float dg[NC][E], db[NC][E];
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+      *reinterpret_cast<f32x4*>(lgam + (lane + 64 * i) * E) = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * E);
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+#pragma unroll
+    for (int e = 0; e < E; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+  __syncthreads();
+  if (rng_dev) seed += *rng_dev;
+  const int rstride = gridDim.x * NWV;
+  for (int row0 = blockIdx.x * NWV + wave; row0 < M; row0 += RIF * rstride) {
+    // RIF rows of the wave in flight in their packed form (the loads of all of them are issued before the first reduction)
+    bf16x4 pdy[RIF][NC], pz[RIF][NC], pdy2[RIF][NC];
+    float mus[RIF], rss[RIF];
+#pragma unroll
+    for (int u = 0; u < RIF; ++u) {
+      const int row = row0 + u * rstride;
+      if (row < M) {
+        const uint32_t rb = (uint32_t)row * H + lane * E;      // (the launcher sends rows beyond 2^31 bytes to the generic kernel)
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          pdy[u][i] = *reinterpret_cast<const bf16x4*>(dy + rb + 64 * E * i);
+          pz[u][i] = *reinterpret_cast<const bf16x4*>(z + rb + 64 * E * i);
+          if (DY2) pdy2[u][i] = *reinterpret_cast<const bf16x4*>(dy2 + rb + 64 * E * i);
+        }
+        mus[u] = mean[row];
+        rss[u] = rstd[row];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RIF; ++u) {
+      __builtin_amdgcn_sched_barrier(0);      // one row in float at a time: the conversions of row u + 1 stay behind row u's stores
+      const int row = row0 + u * rstride;
+      if (row >= M) break;
+      float d[NC][E], xh[NC][E];
+      const float mu = mus[u], rs = rss[u];
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          d[i][e] = (float)pdy[u][i][e];
+          if (DY2) d[i][e] += (float)pdy2[u][i][e];      // the second upstream gradient of the same tensor (its other consumer)
+          xh[i][e] = ((float)pz[u][i][e] - mu) * rs;
+        }
+      const uint32_t rbase = (uint32_t)row * H + lane * E;
+      if (EXTRA) {
+        if (p_out > 0.f) {       // forward dropped its OUTPUT with this mask
+          const GoatRng rng(seed);
+          const float ko = 1.f / (1.f - p_out);
+#pragma unroll
+          for (int i = 0; i < NC; ++i) {
+            const uint32_t km = rng.keep_bits<E>(offset_out + rbase + 64 * E * i, goat_thr16(p_out));
+#pragma unroll
+            for (int e = 0; e < E; ++e) d[i][e] = ((km >> e) & 1u) ? d[i][e] * ko : 0.f;
+          }
+        }
+        if (d_post) {
+#pragma unroll
+          for (int i = 0; i < NC; ++i) {
+            bf16x4 t;
+#pragma unroll
+            for (int e = 0; e < E; ++e) t[e] = (bf16_t)d[i][e];
+            goat_store_stream8(d_post + rbase + 64 * E * i, t);
+          }
+        }
+      }
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(lgam + (lane + 64 * i) * E);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float dd = d[i][e];
+          dg[i][e] += dd * xh[i][e];
+          db[i][e] += dd;
+          const float dxh = dd * g[e];
+          c1 += dxh;
+          c2 += dxh * xh[i][e];
+          d[i][e] = dxh;
+        }
+      }
+      c1 = wave_sum(c1) / H;
+      c2 = wave_sum(c2) / H;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const uint32_t base = rbase + 64 * E * i;
+        float o[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = (d[i][e] - c1 - xh[i][e] * c2) * rs;
+        if (EXTRA && dx_add && pre_add) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(dx_add + base);
+#pragma unroll
+          for (int e = 0; e < E; ++e) o[e] += (float)t[e];
+        }
+        if (dres) {
+          bf16x4 t;
+#pragma unroll
+          for (int e = 0; e < E; ++e) t[e] = (bf16_t)o[e];
+          goat_store_stream8(dres + base, t);
+        }
+        if (DROP) {
+          const GoatRng rng(seed);
+          const float ks = 1.f / (1.f - p);
+          const uint32_t km = rng.keep_bits<E>(offset + base, goat_thr16(p));
+#pragma unroll
+          for (int e = 0; e < E; ++e) o[e] = ((km >> e) & 1u) ? o[e] * ks : 0.f;
+        }
+        if (EXTRA && dx_add && !pre_add) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(dx_add + base);
+#pragma unroll
+          for (int e = 0; e < E; ++e) o[e] += (float)t[e];
+        }
+        if (dx) {
+          bf16x4 t;
+#pragma unroll
+          for (int e = 0; e < E; ++e) t[e] = (bf16_t)o[e];
+          goat_store_stream8(dx + base, t);
+        }
+      }
+    }
+  }
+  // block reduction of the column partials (as ln_bwd_kernel)
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int col = (lane + 64 * i) * E;
+    f32x4 a, b;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { a[e] = dg[i][e]; b[e] = db[i][e]; }
+    *reinterpret_cast<f32x4*>(&lsum[(wave * 2 + 0) * H + col]) = a;
+    *reinterpret_cast<f32x4*>(&lsum[(wave * 2 + 1) * H + col]) = b;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * H; i += 64 * NWV) {
+    const int which = i / H, col = i % H;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) s += lsum[(w * 2 + which) * H + col];
+    if (ws != nullptr) ws[(int64_t)blockIdx.x * 2 * H + i] = s;
+    else atomicAdd((which == 0 ? dgamma : dbeta) + col, s);
+  }
+}
+
+#define GOAT_LN768_PARAMS                                                                                                         \
+  const bf16_t *__restrict__ dy, const bf16_t *__restrict__ dy2, const bf16_t *__restrict__ z, const float *__restrict__ gamma,    \
+      const float *__restrict__ mean, const float *__restrict__ rstd, float p, uint64_t seed, uint64_t offset,                      \
+      const uint64_t *__restrict__ rng_dev, bf16_t *__restrict__ dx, bf16_t *__restrict__ dres, float *__restrict__ ws,              \
+      float *__restrict__ dgamma, float *__restrict__ dbeta, const bf16_t *__restrict__ dx_add, int pre_add, int M, float p_out,     \
+      uint64_t offset_out, bf16_t *__restrict__ d_post
+#define GOAT_LN768_ARGS dy, dy2, z, gamma, mean, rstd, p, seed, offset, rng_dev, dx, dres, ws, dgamma, dbeta, dx_add, pre_add, M, p_out, offset_out, d_post
+// the common forms (post-LN blocks: dropout, forked output) are held to 128 VGPRs = four waves per SIMD; the forms with a joining
+// skip gradient / output dropout / post-add gradient (pre-LN panorama blocks, embeddings) would spill there: three waves per SIMD
+template <int NWV, int RIF, bool DROP, bool DY2>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(4, 8))) void ln_bwd768_kernel(GOAT_LN768_PARAMS) {
+  ln_bwd768_body<NWV, RIF, DROP, DY2, false>(GOAT_LN768_ARGS);
+}
+template <int NWV, int RIF, bool DROP, bool DY2>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(3, 8))) void ln_bwd768x_kernel(GOAT_LN768_PARAMS) {
+  ln_bwd768_body<NWV, RIF, DROP, DY2, true>(GOAT_LN768_ARGS);
+}
+
 // 256 threads = 16 columns x 16 part-groups; every thread sums nparts/16 partials with 4 independent chains
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int nparts, int H, int accumulate) {
@@ -1108,6 +1298,9 @@ extern "C" int goat_ln_fwd(void* stream, int dtype, const void* x, const void* r
 // 8 waves 5.647 / 5.672 / 5.662 ms, 4 waves 5.579 / 5.598 / 5.614 ms; 2 waves (12 KiB, twice the partial rows) is slower again (+0.06 ms).
 #define GOAT_LN_BWD_WAVES 4
 #endif
+#ifndef GOAT_LN_BWD768
+#define GOAT_LN_BWD768 1     // bf16 rows of 768: ln_bwd768_kernel (0: the generic kernel; also GOAT_LN_BWD_GENERIC=1 in the environment)
+#endif
 #ifndef GOAT_LN_RIF
 #define GOAT_LN_RIF 2      // rows in flight per wave (bf16); measured: 4 rows / fewer partial blocks are slower (8.52-8.80 vs 8.45 ms/step)
 #endif
@@ -1194,7 +1387,29 @@ extern "C" int goat_ln_bwd_do(void* stream, int dtype, const void* dy, const voi
                        rstd, p, seed, offset, rng_dev, (T_*)dx, (T_*)d_res, ws, dgamma, dbeta, (const T_*)dx_add, pre_add, M, H, \
                        p_out, offset_out, (T_*)d_post);                                                                       \
   } while (0)
-  if (dtype == GOAT_BF16) {
+  if (dtype == GOAT_BF16 && H == 768 && GOAT_LN_BWD768 && (int64_t)M * H * 2 < (1ll << 31) && !getenv("GOAT_LN_BWD_GENERIC")) {
+    // the 96-VGPR form (ln_bwd768_kernel): same grid, same partial rows, same results
+    const bool drop = p > 0.f, two = dy2 != nullptr, extra = dx_add != nullptr || p_out > 0.f || d_post != nullptr;
+#define GOAT_LN768_LAUNCH(NWV_, DROP_, DY2_, EXTRA_)                                                                          \
+    hipLaunchKernelGGL((EXTRA_ ? ln_bwd768x_kernel<NWV_, GOAT_LN_RIF, DROP_, DY2_> : ln_bwd768_kernel<NWV_, GOAT_LN_RIF, DROP_, DY2_>), dim3(nparts), dim3(64 * NWV_), sm + 768 * sizeof(float), ST(stream),          \
+                       (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)z, gamma, mean, rstd, p, seed, offset, rng_dev,  \
+                       (bf16_t*)dx, (bf16_t*)d_res, ws, dgamma, dbeta, (const bf16_t*)dx_add, pre_add, M, p_out, offset_out,  \
+                       (bf16_t*)d_post)
+#define GOAT_LN768_FLAGS(NWV_)                                                       \
+    do {                                                                             \
+      if (extra) {                                                                   \
+        if (drop) { if (two) GOAT_LN768_LAUNCH(NWV_, true, true, true); else GOAT_LN768_LAUNCH(NWV_, true, false, true); }      \
+        else { if (two) GOAT_LN768_LAUNCH(NWV_, false, true, true); else GOAT_LN768_LAUNCH(NWV_, false, false, true); }         \
+      } else {                                                                       \
+        if (drop) { if (two) GOAT_LN768_LAUNCH(NWV_, true, true, false); else GOAT_LN768_LAUNCH(NWV_, true, false, false); }    \
+        else { if (two) GOAT_LN768_LAUNCH(NWV_, false, true, false); else GOAT_LN768_LAUNCH(NWV_, false, false, false); }       \
+      }                                                                              \
+    } while (0)
+    if (det) GOAT_LN768_FLAGS(4);
+    else GOAT_LN768_FLAGS(GOAT_LN_BWD_WAVES);
+#undef GOAT_LN768_FLAGS
+#undef GOAT_LN768_LAUNCH
+  } else if (dtype == GOAT_BF16) {
     if (int e = ln_check<bf16_t>(H)) return e;
     if (det) { GOAT_LN_DISPATCH(bf16_t, H, GOAT_LN_BWD_LAUNCH(bf16_t, GOAT_LN_RIF, 4)); }
     else { GOAT_LN_DISPATCH(bf16_t, H, GOAT_LN_BWD_LAUNCH(bf16_t, GOAT_LN_RIF, GOAT_LN_BWD_WAVES)); }

@@ -1484,6 +1484,103 @@ def multi_linear(x, weights, biases):
     return _MultiLinearFn.apply(x, *weights, *biases)
 
 
+class _GradSlots:
+    """One [rows, n * width] gradient buffer shared by the n output views of a projection bank: the consumer of view i (an attention
+    backward) writes its gradient straight into columns [i * width, (i + 1) * width) and hands that view back to autograd."""
+
+    def __init__(self, out, n, lead):
+        self.buf = torch.empty_like(out)
+        self.n, self.width, self.lead = n, out.shape[1] // n, lead
+
+    def view(self, i):
+        return self.buf.view(*self.lead, self.buf.shape[1])[..., i * self.width:(i + 1) * self.width]
+
+
+class _LinearBankFn(torch.autograd.Function):
+    """y = x @ cat(W_j)^T + cat(b_j) for the projections of SEVERAL modules that read one activation — the key | value projections of
+    every cross-attention layer of the cross-modal encoders on the sequence they all attend to (P/model/Bert_backbone.py:765-781: the same
+    `kv_embeds` goes to every layer; P/model/vilmodel_goat.py:501-504,631-647) — as ONE GEMM [rows, n * width] instead of one per layer,
+    and in backward ONE dgrad over the concatenated contraction (K = n * width) instead of n dgrads and an n-way add.
+    Returns n views [..., width] of the one result (row stride n * width); hipops.attention reads them through strides and writes the
+    gradient of view i into its columns of one shared buffer (_GradSlots) — no copies on either side."""
+
+    @staticmethod
+    def forward(ctx, x, n, *wb):
+        m = len(wb) // 2
+        ws, bs = wb[:m], wb[m:]
+        _need_gpu(x)
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        W = _shadow_cat(ws, x2.dtype)
+        b = _cat_bias(bs)
+        out = torch.empty((x2.shape[0], W.shape[0]), dtype=x2.dtype, device=x2.device)
+        gemm(x2, W, out, bias=b)
+        ctx.save_for_backward(x2)
+        ctx.ws, ctx.bs, ctx.xshape, ctx.n = ws, bs, x.shape, n
+        need = any(ctx.needs_input_grad)          # (grad mode is off inside forward: the flags say whether a backward pass can come)
+        ctx.slots = _GradSlots(out, n, x.shape[:-1]) if need else None
+        width = W.shape[0] // n
+        full = out.view(*x.shape[:-1], W.shape[0])
+        return tuple(full[..., i * width:(i + 1) * width] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (x2,) = ctx.saved_tensors
+        ws, n, slots = ctx.ws, ctx.n, ctx.slots
+        width = slots.width
+        for i, g in enumerate(grads):          # a gradient that is not already in its slot (another producer than attention, a fan-out sum)
+            dst = slots.view(i)
+            if g is None:
+                dst.zero_()
+            elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
+                dst.copy_(g)
+        dy2 = slots.buf
+        dx = None
+        if ctx.needs_input_grad[0]:
+            W = _shadow_cat(ws, x2.dtype)
+            dx = torch.empty_like(x2)
+            gemm(dy2, W, dx, tb=True)
+            dx = dx.view(ctx.xshape)
+        # weight gradients: one problem per run of parameters that are adjacent in the gradient arena (the key | value pair of a layer),
+        # reading its columns of the shared gradient buffer through the leading dimension
+        per = len(ws) // n
+        dws, dbs = [], []
+        for i in range(n):
+            wi, bi = ws[i * per:(i + 1) * per], ctx.bs[i * per:(i + 1) * per]
+            dyi = dy2[:, i * width:(i + 1) * width]
+            keep = WgradQueue.mergeable(dyi.shape[0], dyi.shape[1], x2.shape[1])
+            w_sink = _sink_cat(wi, keep)
+            b_sink = _sink_cat(bi, keep) if w_sink is not None else None
+            first = w_sink is not None and _first_touch(*wi)
+            b_first = b_sink is not None and _first_touch(*bi)
+            _prep_fallback(*(([] if w_sink is not None else list(wi)) + ([] if b_sink is not None else list(bi))))
+            ids = [id(t) for t in wi] + [id(t) for t in bi]
+            dw, db = wgrad(dyi, x2, True, w_sink, b_sink, first, b_first, ids if w_sink is not None else None)
+            sizes = [w.shape[0] for w in wi]
+            dws += list(torch.split(dw, sizes, 0)) if dw is not None else [None] * per
+            dbs += list(torch.split(db, sizes, 0)) if db is not None else [None] * per
+        return (dx, None) + tuple(dws) + tuple(dbs)
+
+
+LINEAR_BANK = os.environ.get('GOAT_NO_KV_BANK', '0') != '1'       # (diagnostics: A/B against one projection per layer)
+
+
+def linear_bank(x, groups):
+    """groups: n lists of (weight, bias) pairs — the projections of n modules that read x (e.g. [(key, value)] per cross-attention layer).
+    -> n views [..., sum of the group's rows] of ONE GEMM result, each carrying `_goat_grad_slot` for its consumer's backward."""
+    n = len(groups)
+    ws = [w for g in groups for (w, _) in g]
+    bs = [b for g in groups for (_, b) in g]
+    outs = _LinearBankFn.apply(x, n, *ws, *bs)
+    fn = outs[0].grad_fn
+    slots = getattr(fn, 'slots', None) if fn is not None else None
+    if slots is not None:
+        for i, o in enumerate(outs):
+            o._goat_grad_slot = (slots, i)
+    return list(outs)
+
+
 # ----------------------------------------------------------------------------- LayerNorm / dropout
 LN_DETERMINISTIC = os.environ.get('GOAT_LN_DETERMINISTIC', '0') == '1'
 LN_ATOMIC_MAX_ROWS = int(os.environ.get('GOAT_LN_ATOMIC_MAX_ROWS', '4096'))
@@ -1799,8 +1896,16 @@ class _AttnFn(torch.autograd.Function):
     def forward(ctx, a, b, kmask, bias, nh, p):
         _need_gpu(a)
         a = a if a.is_contiguous() else a.contiguous()
+        slot = None
         if b is not None:
-            b = b if b.is_contiguous() else b.contiguous()
+            # a view of a projection bank (linear_bank): rows at the bank's leading dimension; its gradient goes into the bank's buffer
+            # (read through its strides; the FIRST consumer of the view claims the slot — a second reader of the same view, e.g. the steps of
+            # an eager episode that share one projection of the instruction, gets a buffer of its own and autograd adds the two)
+            if b.dim() == 3 and b.stride(2) == 1 and b.stride(0) == b.shape[1] * b.stride(1) and b.stride(1) % 8 == 0 and b.data_ptr() % 16 == 0:
+                slot = b.__dict__.pop('_goat_grad_slot', None)
+            else:
+                b = b.contiguous()
+        ctx.slot = slot
         if b is None:
             B, Lq, H3 = a.shape
             H = H3 // 3
@@ -1811,9 +1916,10 @@ class _AttnFn(torch.autograd.Function):
         else:
             B, Lq, H = a.shape
             Lk = b.shape[1]
+            ldb = b.stride(1)
             q = (a, 0, H, Lq * H)
-            k = (b, 0, 2 * H, Lk * 2 * H)
-            v = (b, H, 2 * H, Lk * 2 * H)
+            k = (b, 0, ldb, Lk * ldb)
+            v = (b, H, ldb, Lk * ldb)
         assert H == nh * 64, 'head_dim must be 64'
         o = torch.empty((B, Lq, H), dtype=a.dtype, device=a.device)
         lse = torch.empty((B, nh, Lq), dtype=torch.float32, device=a.device)
@@ -1840,7 +1946,9 @@ class _AttnFn(torch.autograd.Function):
         nh, p, seed, off, dev, scale = ctx.cfg
         do = do if do.is_contiguous() else do.contiguous()
         da = torch.empty_like(a)
-        db = torch.empty_like(b) if b is not None else None
+        db = None
+        if b is not None:
+            db = ctx.slot[0].view(ctx.slot[1]) if ctx.slot is not None else torch.empty(b.shape, dtype=b.dtype, device=b.device)
         if b is None:
             B, Lq, H3 = a.shape
             H = H3 // 3
@@ -1850,8 +1958,9 @@ class _AttnFn(torch.autograd.Function):
         else:
             B, Lq, H = a.shape
             Lk = b.shape[1]
-            q, k, v = (a, 0, H, Lq * H), (b, 0, 2 * H, Lk * 2 * H), (b, H, 2 * H, Lk * 2 * H)
-            dq, dk, dv = (da, 0, H, Lq * H), (db, 0, 2 * H, Lk * 2 * H), (db, H, 2 * H, Lk * 2 * H)
+            ldb, ldg = b.stride(1), db.stride(1)
+            q, k, v = (a, 0, H, Lq * H), (b, 0, ldb, Lk * ldb), (b, H, ldb, Lk * ldb)
+            dq, dk, dv = (da, 0, H, Lq * H), (db, 0, ldg, Lk * ldg), (db, H, ldg, Lk * ldg)
         dbias = None
         if bias is not None and ctx.needs_input_grad[3]:
             dbias = torch.zeros_like(bias)

@@ -313,16 +313,27 @@ class CrossmodalEncoder(nn.Module):
         self.crossattention = nn.ModuleList([BertCrossLayer(config, with_lang_branch) for _ in range(self.num_top_layer)])
         self.crossattention.apply(init_weights)
 
+    def kv_groups(self):
+        """[(key weight, bias), (value weight, bias)] of every layer's cross-attention: the operands of hipops.linear_bank."""
+        out = []
+        for layer in self.crossattention:
+            sa = layer.crossattention.self
+            out.append([(sa.key.weight, sa.key.bias), (sa.value.weight, sa.value.bias)])
+        return out
+
     def project_kv(self, kv_embeds):
-        """the K|V projections of every layer's cross-attention for one attended sequence (see BertSelfAttention.project_kv)."""
-        kvs = hipops.fanout(kv_embeds, len(self.crossattention))
-        return [layer.crossattention.self.project_kv(kv) for layer, kv in zip(self.crossattention, kvs)]
+        """the K|V projections of every layer's cross-attention for one attended sequence (see BertSelfAttention.project_kv): every layer
+        attends to the SAME `kv_embeds` (P/model/Bert_backbone.py:765-781), so the projections are ONE GEMM [rows, n_layers * 2H]
+        (hipops.linear_bank) and, in backward, one dgrad over the concatenated contraction instead of a dgrad per layer and an add."""
+        return project_kv_bank(kv_embeds, [self])[0]
 
     def forward(self, q_embeds, q_kmask, kv_embeds, kv_kmask, bias=None, kv_cache=None):
         """q_kmask / kv_kmask: additive float32 [B,L] key masks (already -10000-style).  kv_cache: project_kv(kv_embeds)."""
         n = len(self.crossattention)
         # the attended sequence (and the graph-distance bias) is read by every layer: one autograd handle per layer, their gradients
         # meet in ONE launch (hipops.fanout) instead of n - 1 pairwise adds of the autograd engine
+        if kv_cache is None and hipops.LINEAR_BANK:
+            kv_cache = self.project_kv(kv_embeds)
         kvs = hipops.fanout(kv_embeds, n) if kv_cache is None else [kv_embeds] * n
         biases = hipops.fanout(bias, n) if torch.is_tensor(bias) else [bias] * n
         if not isinstance(q_embeds, tuple):
@@ -330,6 +341,22 @@ class CrossmodalEncoder(nn.Module):
         for i, layer in enumerate(self.crossattention):
             q_embeds = layer(q_embeds, kvs[i], q_kmask, kv_kmask, biases[i], fork=i + 1 < n, enc_kv=None if kv_cache is None else kv_cache[i])
         return q_embeds
+
+
+def project_kv_bank(kv_embeds, encoders):
+    """K|V projections of every cross-attention layer of SEVERAL CrossmodalEncoders that attend to one sequence (the instruction, read
+    by the global-map and the local encoder: P/model/vilmodel_goat.py:399,501-504): -> one kv_cache list per encoder."""
+    n = [len(e.crossattention) for e in encoders]
+    if hipops.LINEAR_BANK and kv_embeds.is_cuda:
+        kvs = hipops.linear_bank(kv_embeds, [g for e in encoders for g in e.kv_groups()])
+    else:       # (diagnostics: one projection per layer)
+        hs = hipops.fanout(kv_embeds, sum(n))
+        kvs = [layer.crossattention.self.project_kv(h) for layer, h in zip([l for e in encoders for l in e.crossattention], hs)]
+    out, at = [], 0
+    for k in n:
+        out.append(kvs[at:at + k])
+        at += k
+    return out
 
 
 class BertPooler(nn.Module):

@@ -16,7 +16,7 @@ from torch import nn
 
 from . import graphmap, hipops
 from .layers import (BertAttention, BertLayerNorm, BertPooler, BertPredictionHeadTransform, ClsPrediction,
-                     CrossmodalEncoder, Linear, RobertaAttention, RobertaEmbeddings, RobertaLayer, _p, compute_dtype,
+                     CrossmodalEncoder, Linear, RobertaAttention, RobertaEmbeddings, RobertaLayer, _p, compute_dtype, project_kv_bank,
                      create_transformer_encoder, gen_seq_masks, neg_mask)
 from .pretrain_model import GoatPreTrainedModel, attn_pool
 
@@ -411,8 +411,8 @@ class GlocalTextPathNavCMT(GoatPreTrainedModel):
     def text_kv(self, txt_embeds):
         """per-episode K|V projections of the instruction for the cross-modal layers of the global and the local branch."""
         t = txt_embeds.to(compute_dtype())
-        tg, tl = hipops.fanout(t, 2)
-        return {'global': self.global_encoder.encoder.project_kv(tg), 'local': self.local_encoder.encoder.project_kv(tl)}
+        kg, kl = project_kv_bank(t, [self.global_encoder.encoder, self.local_encoder.encoder])      # one GEMM for the twelve projections
+        return {'global': kg, 'local': kl}
 
     # ---- CFP feature extraction (builds the FACL dictionaries) -------------------------------------------------
     def extract_cfp_features(self, batch):

@@ -15,7 +15,7 @@ from torch import nn
 
 from . import graphmap, hipops
 from .layers import (BertAttention, BertLayerNorm, BertOnlyMLMHead, BertPredictionHeadTransform, ClsPrediction,
-                     CrossmodalEncoder, LayerNorm, Linear, RegionClassification, RobertaEmbeddings, RobertaLayer, _p, compute_dtype,
+                     CrossmodalEncoder, LayerNorm, Linear, RegionClassification, RobertaEmbeddings, RobertaLayer, _p, compute_dtype, project_kv_bank,
                      create_transformer_encoder, gen_seq_masks, neg_mask)
 
 
@@ -375,14 +375,22 @@ class GlocalTextPathCMT(GoatPreTrainedModel):
         txt, txt_kmask = self._text(batch)
         br.join(x, src)
         gmap = None
-        t_g, t_v, t_out = hipops.fanout(txt, 3)           # the text states feed both cross-modal encoders (and the caller)
+        kv_g = kv_v = None
+        if return_gmap_embeds and hipops.LINEAR_BANK:
+            # the text states are the attended sequence of all six cross-attention layers (three global, three local): their key | value
+            # projections are one GEMM in front of the fork (layers.project_kv_bank); one handle for that bank, one for the caller
+            t_kv, t_out = hipops.fanout(txt, 2)
+            kv_g, kv_v = project_kv_bank(t_kv, [self.global_encoder.encoder, self.local_encoder.encoder])
+            t_g = t_v = t_kv
+        else:
+            t_g, t_v, t_out = hipops.fanout(txt, 3)           # the text states feed both cross-modal encoders (and the caller)
         if return_gmap_embeds:
             with hipops.Branch('global') as bg:
                 g, gm = self._gmap_in(batch, src, cache)
                 bias = self.global_encoder.sprels(batch['gmap_pair_dists']) if self.global_encoder.sprel_linear is not None else None
-                gmap = self.global_encoder.encoder(g, neg_mask(gm), t_g, txt_kmask, bias)
+                gmap = self.global_encoder.encoder(g, neg_mask(gm), t_g, txt_kmask, bias, kv_cache=kv_g)
         v, vm = self._vp_in(batch, x, cache)
-        vp = self.local_encoder.encoder(v, neg_mask(vm), t_v, txt_kmask)
+        vp = self.local_encoder.encoder(v, neg_mask(vm), t_v, txt_kmask, kv_cache=kv_v)
         if return_gmap_embeds:
             bg.join(gmap)
         return gmap, vp, t_out
