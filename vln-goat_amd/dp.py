@@ -70,6 +70,7 @@ class _AllGatherCat(torch.autograd.Function):
             dist.all_reduce(out)
             return out
         out = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        _note_collective(x)
         dist.all_gather_into_tensor(out, x.contiguous())       # concatenated along dim 0
         return out.view((W,) + tuple(x.shape))
 
@@ -82,6 +83,7 @@ class _AllGatherCat(torch.autograd.Function):
             dist.all_reduce(dy)
             dx.copy_(dy[_rank()])
         else:
+            _note_collective(dy)
             dist.reduce_scatter_tensor(dx, dy.view((W * ctx.shape[0],) + tuple(ctx.shape[1:])))
         return dx
 
@@ -454,6 +456,7 @@ class GoatDataParallel(torch.nn.Module):
             hipops.RngState.counter = counter
             # DDP constructor semantics: rank-0 parameters/buffers broadcast to all (P/utils/misc.py:58)
             for t in list(model.parameters()) + list(model.buffers()):
+                _note_collective(t.data)
                 dist.broadcast(t.data, 0)
 
     def forward(self, *a, **k):
@@ -561,6 +564,7 @@ class GoatDataParallel(torch.nn.Module):
             # sparse_uniform_rows = True (fixed-shape synthetic batches, bench.py) skips the exchange and its host sync.
             if not getattr(self, 'sparse_uniform_rows', False):
                 cnt = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+                _note_collective(cnt)
                 dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
                 nmax = int(cnt.item())
                 if rows.shape[0] < nmax:
@@ -578,6 +582,7 @@ class GoatDataParallel(torch.nn.Module):
             else:
                 all_rows = torch.empty((W * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)
                 all_ids = torch.empty(W * ids.shape[0], dtype=ids.dtype, device=ids.device)
+                _note_collective(rows)
                 dist.all_gather_into_tensor(all_rows, rows.contiguous())
                 dist.all_gather_into_tensor(all_ids, ids)
             all_rows = all_rows.reshape(-1, rows.shape[1])
@@ -637,6 +642,14 @@ def _note_collective(t):
         _EAGER_SINCE_QUIESCE[0] += 1
 
 
+def quiesce_if_needed():
+    """called by hipops.graph right BEFORE a capture begins (a device synchronise is still legal there): retire the eager RCCL collectives
+    issued since the last quiesce, if any — so a capture that contains collectives never meets a watchdog that still polls earlier ones, and
+    a capture long after the last eager collective costs nothing (the guard used to raise on a stale count)."""
+    if _EAGER_SINCE_QUIESCE[0] > 0:
+        quiesce_collectives()
+
+
 def quiesce_collectives(seconds=0.3):
     """Call right before a hipGraph capture that will contain collectives.  ProcessGroupNCCL's watchdog thread polls the end events of the
     eager collectives issued so far (every 100 ms); on this HIP runtime `hipEventQuery` fails with hipErrorCapturedEvent once the STREAM an
@@ -681,5 +694,6 @@ def broadcast_task(task_names, chosen_index, device):
     """rank 0 picks the task, everyone follows (P/data/loader.py:56-59)."""
     t = torch.tensor([chosen_index], dtype=torch.int64, device=device)
     if _world() > 1:
+        _note_collective(t)
         dist.broadcast(t, 0)
     return task_names[int(t.item())]

@@ -272,7 +272,19 @@ BALANCED = 0x800        # (grouped weight gradients only) goat_wgrad_grouped_bal
 PERSIST = 0x400         # GOAT_GEMM_PERSIST (with PINGPONG): one workgroup per CU walks the tiles, next tile's first K-tile requested before the epilogue
 USE_PP = os.environ.get('GOAT_GEMM_NO_PP', '0') == '0'
 USE_PERSIST = os.environ.get('GOAT_GEMM_NO_PERSIST', '0') == '0'
-N_CU = 256              # (MI355X; only decides which shapes get the persistent candidates timed)
+N_CU = 256              # MI355X; `n_cu()` reads the device (decides which shapes get the persistent candidates timed, and the tail split of a group)
+
+
+def n_cu():
+    """compute units of the current device (the kernels read the same attribute: pp_cu_count())"""
+    global N_CU
+    if not _N_CU_READ[0] and torch.cuda.is_available():
+        N_CU = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count) or N_CU
+        _N_CU_READ[0] = True
+    return N_CU
+
+
+_N_CU_READ = [False]
 
 
 def tile(bm, bn=128):
@@ -313,7 +325,7 @@ def _tile_candidates(ta, tb, M, N):
         if USE_PERSIST and not ta:                # the persistent form of the same tiles where a problem has more tiles than workgroup slots
             for t, ns in [x for x in c if x[1] & PINGPONG]:
                 rows, cols = t & 0xFFFF, (t >> 16) or 128
-                slots = N_CU * (2 if rows * cols <= 128 * 128 else 1)
+                slots = n_cu() * (2 if rows * cols <= 128 * 128 else 1)
                 if ((M + rows - 1) // rows) * ((N + cols - 1) // cols) > slots:
                     c.append((t, ns | PERSIST))
     return c
@@ -519,6 +531,8 @@ class graph:
         self._warn.__enter__()
         warnings.filterwarnings('error', message=".*AccumulateGrad node's stream does not match.*")
         try:
+            from . import dp
+            dp.quiesce_if_needed()      # eager RCCL collectives issued so far are retired before the stream enters capture mode (dp.quiesce_collectives)
             return self.ctx.__enter__()
         except BaseException:
             _CAPTURING.pop()
@@ -714,7 +728,13 @@ class WgradQueue:
         accumulates as its first member did, later members were accumulations by construction)"""
         seen = {}
         for i, t in enumerate(q):
-            seen.setdefault((t[2].data_ptr(), t[3].data_ptr() if t[3] is not None else 0, t[0].dtype), []).append(i)
+            seen.setdefault((t[2].data_ptr(), t[3].data_ptr() if t[3] is not None else 0, t[0].dtype, t[0].shape[1], t[1].shape[1]), []).append(i)
+        # one merged problem per SLICE: two keys on one weight slice (same arena pointer, another shape / bias slice / dtype: e.g. a
+        # concatenated q|k|v sink and q alone on a shared module) would put an overwriting and an accumulating writer of the same words
+        # into one launch (ADVICE r5) — not reachable with today's models; refuse loudly rather than race
+        ptrs = [k[0] for k in seen]
+        if len(set(ptrs)) != len(ptrs):
+            raise RuntimeError('WgradQueue: two queued weight-gradient problems write one arena slice with different shapes / bias slices')
         if len(seen) == len(q):
             return q
         out = []
@@ -837,9 +857,9 @@ class WgradQueue:
         if len(q) < 2 or len({t[0].shape[0] for t in q}) != 1:        # tiles of equal duration only (same contraction length)
             return None
         tiles = [((t[0].shape[1] + rows - 1) // rows) * ((t[1].shape[1] + cols - 1) // cols) for t in q]
-        total, ncu = sum(tiles), N_CU
+        total, ncu = sum(tiles), n_cu()
         rem = total % ncu
-        if total < ncu or rem == 0 or rem > 208:
+        if total < ncu or rem == 0 or rem > ncu * 13 // 16:
             return None
         best = None                                                   # smallest subset sum >= rem (n <= 24: dynamic programme over sums)
         reach = {0: ()}

@@ -532,12 +532,21 @@ class GraphSim:
     episodes: list of dicts {instr_id, scan (ScanGraph), path [vpids], heading, instr_encoding}.  `features`: an object with
     `row(scan_name, vpid) -> int` (features.FeatureStore): observations carry feature ROW numbers, not feature arrays."""
 
-    def __init__(self, features=None, angle_feat_size=4, objects=None):
+    def __init__(self, features=None, angle_feat_size=4, objects=None, seed=0):
         self.features = features
+        self.obj_rng = np.random.RandomState(seed)      # draws the stand-in target object of episodes without one (see _gt_obj_id)
         self.objects = objects              # ObjectStore: REVERIE / SOON observations (M/reverie/env.py:451-486); episodes then carry
         self.angle_feat_size = angle_feat_size      # 'obj_id' (the target object, may be None) and 'end_vps' (viewpoints that see it)
         self.view_angle_fts = view_angle_feature_table(angle_feat_size)
         self.batch, self.state = [], []
+
+    def _gt_obj_id(self, ep, obj_ids):
+        """target object of an observation (M/reverie/env.py:481-484): the episode's `objId`; an episode WITHOUT one (the augmented
+        data) gets a random object of the current viewpoint — np.random.choice(obj_ids) there, this simulator's seeded generator here —
+        so that such episodes contribute to the object-grounding loss as in the reference; None only when the viewpoint has no objects."""
+        if ep.get('obj_id') is not None or len(obj_ids) == 0:
+            return ep.get('obj_id')
+        return obj_ids[int(self.obj_rng.randint(len(obj_ids)))]
 
     @staticmethod
     def _snap(heading, elevation):
@@ -582,7 +591,7 @@ class GraphSim:
                 rows, ang, box, ids, names = self.objects.attributes(scan.name, vp, bh, be, self.angle_feat_size)
                 ob = obs[-1]
                 ob.update({'obj_rows': rows, 'obj_ang_fts': ang, 'obj_box_fts': box, 'obj_ids': ids, 'obj_name': names,
-                           'gt_end_vps': ep.get('end_vps', []), 'gt_obj_id': ep.get('obj_id')})
+                           'gt_end_vps': ep.get('end_vps', []), 'gt_obj_id': self._gt_obj_id(ep, ids)})
                 if ep.get('end_vps'):           # several goal viewpoints on REVERIE: distance to the nearest (env.py:493-503)
                     ob['distance'] = float(min(dist[scan.index[vp], scan.index[e]] for e in ep['end_vps']))
         return obs
@@ -807,8 +816,9 @@ class NavRollout:
     bucket (shape-stable steps: a captured step graph per bucket can be replayed; None = the reference's per-batch maxima)."""
 
     def __init__(self, model, sim, features, max_action_len=15, fusion='dynamic', ignoreid=-100, pano_width=None, gmap_buckets=None,
-                 device='cuda', hoist_text_kv=True, obj_width=None):
+                 device='cuda', hoist_text_kv=True, obj_width=None, teacher_scores=True):
         self.model, self.sim, self.features = model, sim, features
+        self.teacher_scores = teacher_scores    # teacher forcing records stop scores / best objects too, as the reference (one read-back per step)
         self.objects = getattr(sim, 'objects', None)      # REVERIE / SOON: object tokens + object grounding (M/reverie/agent_obj_goat.py:560-790)
         self.obj_width = obj_width
         self.max_action_len, self.fusion, self.ignoreid = max_action_len, fusion, ignoreid
@@ -925,13 +935,20 @@ class NavRollout:
                     otgt = teacher_object(obs, ended, pano['view_lens'], self.ignoreid)
                     og_loss = og_loss + torch.nn.functional.cross_entropy(out['obj_logits'].float(), torch.from_numpy(otgt).to(dev, non_blocking=True),
                                                                           reduction='sum', ignore_index=self.ignoreid)
-            if feedback == 'teacher':
+            if feedback not in ('teacher', 'argmax', 'sample'):
+                raise ValueError('invalid feedback option %r' % (feedback,))
+            if feedback == 'teacher' and not self.teacher_scores:
                 a_t = target
                 stop = [ob['viewpoint'] == ob['gt_path'][-1] for ob in obs]
-            elif feedback in ('argmax', 'sample'):
-                # ONE device -> host copy per step: the chosen actions and the stop probabilities (M/r2r/agent.py:575-580,601-607)
+            else:
+                # ONE device -> host copy per step: the chosen actions and the stop probabilities (M/r2r/agent.py:575-580,601-607).  The
+                # reference records the stop score (and the best object) of the current node in EVERY feedback mode
+                # (M/reverie/agent_obj_goat.py:679-689,754-761): teacher forcing too, so that its trajectories end with the same stop-node
+                # backtrack and predicted object (`teacher_scores=False` skips the read-back where only the loss is used)
                 probs = torch.softmax(logits.detach().float(), 1)
-                if feedback == 'argmax':
+                if feedback == 'teacher':
+                    act = torch.from_numpy(np.asarray(target, np.int64)).to(probs.device)
+                elif feedback == 'argmax':
                     act = probs.argmax(1)
                 elif sampler is not None:           # (a fixed action sequence in place of Categorical.sample(): the sampled-rollout golden)
                     act = torch.as_tensor(sampler(t, probs), dtype=torch.int64, device=probs.device)
@@ -944,7 +961,7 @@ class NavRollout:
                     ol = torch.where(pos >= (vl + 2)[:, None], out['obj_logits'].detach().float(), torch.full_like(out['obj_logits'], -float('inf'), dtype=torch.float32))
                     rows.append((ol.argmax(1) - (vl + 2)).to(torch.float32))
                 back = torch.stack(rows, 0).cpu().numpy()
-                a_t = back[0].astype(np.int64)
+                a_t = target if feedback == 'teacher' else back[0].astype(np.int64)
                 stop = (a_t == 0) if feedback == 'argmax' else [ob['viewpoint'] == ob['gt_path'][-1] for ob in obs]
                 for i, g in enumerate(gmaps):
                     if not ended[i]:
@@ -952,8 +969,6 @@ class NavRollout:
                         if has_obj:
                             ids = obs[i]['obj_ids']
                             g.node_stop_scores[obs[i]['viewpoint']]['og'] = ids[int(back[2, i])] if len(ids) > 0 else None
-            else:
-                raise ValueError('invalid feedback option %r' % (feedback,))
             t_host = time.perf_counter()
             self.actions.append(np.where(ended, 0, np.asarray(a_t, np.int64)))
             moves = []
@@ -970,9 +985,8 @@ class NavRollout:
                     prev = traj[i]['path'][-2][-1] if len(hop) == 1 else hop[-2]
                     view = next(c['pointId'] for c in obs[i]['scan_graph'].candidates(prev) if c['viewpointId'] == nxt)
                     moves.append((nxt, view))
-            # go back to the node with the best stop score (M/r2r/agent.py:665-672).  The reference does this in every feedback mode; teacher
-            # forcing records no stop scores here (they would cost a device -> host read-back per step, and the trainer never reads the
-            # trajectories of its teacher rollouts: M/r2r/agent.py:414-445 uses only the loss), so its dictionary is empty and nothing moves
+            # go back to the node with the best stop score (M/r2r/agent.py:665-672), in every feedback mode as the reference (with
+            # teacher_scores=False a teacher rollout records no scores: its dictionary is empty and nothing moves)
             if True:
                 for i in range(B):
                     if (not ended[i]) and just_ended[i] and gmaps[i].node_stop_scores:

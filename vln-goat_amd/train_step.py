@@ -36,6 +36,8 @@ class TaskSampler:
         if self.step % self.accum_steps == 0:
             tid = torch.multinomial(self.ratios, 1, generator=self.generator).to(self.device)
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                from . import dp
+                dp._note_collective(tid)
                 dist.broadcast(tid, 0)                      # every rank follows rank 0's draw
             self._task_id = int(tid.cpu().item())
         self.step += 1
