@@ -81,8 +81,19 @@ def test_nav_rollout_matches_the_reference_rollout():
             assert np.abs(lead - fp[1:1 + lead.size]).max() <= 2e-3 * max(float(np.abs(fp[1:]).max()), 1e-2 * float(fp[0])), n
             checked += 1
     assert checked > 100
-    # trajectories: the ground-truth paths, hop by hop
+    # trajectories: the ground-truth paths, hop by hop — then, as the reference does in EVERY feedback mode (M/r2r/agent.py:665-672), the
+    # walk back to the visited node with the best stop score when that is not the last one (teacher forcing records the scores too)
     for ep, tr in zip(eps, traj):
+        ends = [h[-1] for h in tr['path']]
+        assert ends[:len(ep['path'])] == ep['path'] and len(ends) <= len(ep['path']) + 1
+        if len(ends) > len(ep['path']):
+            assert tr['path'][-1][0] != ep['path'][-1] or len(tr['path'][-1]) > 1
+            assert ends[-1] in ep['path']                 # a node the episode stood on
+    # with the read-back switched off the teacher rollout records nothing and ends on the ground-truth path
+    ro_plain = rollout.NavRollout(lambda mode, batch: model(mode, batch), sim, store, max_action_len=6, teacher_scores=False)
+    with torch.no_grad():
+        _, traj_plain = ro_plain.run(eps, feedback='teacher', extras=synth.rollout_extras(dicts, len(eps), 'cuda'), compute_loss=False)
+    for ep, tr in zip(eps, traj_plain):
         assert [h[-1] for h in tr['path']] == ep['path']
 
 
@@ -235,7 +246,7 @@ def test_teacher_episode_graph_replays_new_episodes():
             got = {k: v.detach().float().clone() for k, v in grads.items()}
             for p in params:
                 p.grad = None
-            ro = rollout.NavRollout(call, sim, store, max_action_len=T, pano_width=40, gmap_buckets=(16, 32, 48, 64))
+            ro = rollout.NavRollout(call, sim, store, max_action_len=T, pano_width=40, gmap_buckets=(16, 32, 48, 64), teacher_scores=False)      # (the host plan knows no stop scores: like for like)
             ref, traj = ro.run(batch, feedback='teacher', extras=ex)
             ref.backward()
             torch.cuda.synchronize()
@@ -488,7 +499,7 @@ def test_teacher_episode_with_objects_matches_the_eager_reverie_rollout():
         got = {k: v.detach().float().clone() for k, v in grads.items()}
         for p in params:
             p.grad = None
-        ro = rollout.NavRollout(call, sim, store, max_action_len=T, pano_width=W, gmap_buckets=(32,), obj_width=O)
+        ro = rollout.NavRollout(call, sim, store, max_action_len=T, pano_width=W, gmap_buckets=(32,), obj_width=O, teacher_scores=False)      # (the host plan knows no stop scores: like for like)
         ref, traj = ro.run(batch, feedback='teacher', extras=ex)
         ref.backward()
         torch.cuda.synchronize()

@@ -529,3 +529,72 @@ def test_shape_bucketed_static_batch_replays_ragged_batches():
                 assert n > 10
     finally:
         vln_goat_amd.set_compute_dtype(torch.float32)
+
+
+def test_captured_steps_launch_only_measured_configurations():
+    """round 5's largest gain was a silent plan miss (the captured steps ran untuned weight-gradient groups because the eager
+    warm-up formed other groups than the capture).  Procedure of bench.py / a trainer: warm up each task with the tuner on and the parallel
+    branches forked as a capture forks them (Branch.like_capture), then capture.  The capture must not contain ONE GEMM on the static
+    heuristic or ONE weight-gradient group on the default tile (tuning.STATS counts them; STATS_LOG names them).  The same capture after
+    a warm-up WITHOUT like_capture is the negative control: it must show the misses (otherwise the counters count nothing)."""
+    import vln_goat_amd
+    from vln_goat_amd import config as gcfg, hipops, pretrain_model, synth, tuning
+    cfg = gcfg.make_config(num_l_layers=2, num_top_layer=1, num_pano_layers=1, vocab_size=1000)
+    torch.manual_seed(0)
+    model = pretrain_model.GlocalTextPathCMTPreTraining(cfg).cuda().train()
+    gb = synth.batch_to(synth.make_pretrain_batch(B=6, T=[2, 3, 1, 2, 4, 3], L=[30, 22, 16, 25, 40, 33], seed=5, vocab_size=1000, style='rich'), 'cuda')
+    vln_goat_amd.set_compute_dtype(torch.bfloat16)
+    saved = (dict(tuning._TUNED), dict(hipops.WgradQueue.tuned), tuning.AUTOTUNE, hipops.WgradQueue.FORCE_TUNE)
+    try:
+        wrapper, arena = _arena_for(model, gb)
+        hipops.RngState.dev = torch.zeros(1, dtype=torch.int64, device='cuda')
+
+        def body(task):
+            arena.zero(task)
+            hipops.RngState.dev.add_(1)
+            model(gb, task, compute_loss=True).mean().backward()
+
+        def warm(like_capture):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ctx = hipops.Branch.like_capture() if like_capture else __import__('contextlib').nullcontext()
+                with ctx:
+                    for t in ('mlm', 'sap', 'cfp'):
+                        body(t)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+
+        def capture_all():
+            tuning.reset_stats()
+            graphs = []
+            for t in ('mlm', 'sap', 'cfp'):
+                g = torch.cuda.CUDAGraph()
+                with _goat_graph(g):
+                    body(t)
+                graphs.append(g)
+            torch.cuda.synchronize()
+            return graphs, dict(tuning.STATS), list(tuning.STATS_LOG)
+
+        # negative control first (tables empty, tuner on, warm-up on ONE stream): the capture's weight-gradient groups were never timed
+        tuning._TUNED.clear()
+        hipops.WgradQueue.tuned.clear()
+        tuning.AUTOTUNE, hipops.WgradQueue.FORCE_TUNE = True, True
+        warm(like_capture=False)
+        _, st0, log0 = capture_all()
+        assert st0['gemm_heuristic'] == 0, log0[:5]                       # GEMM shapes do not depend on the stream they are issued on
+        assert st0['wgrad_default'] > 0, st0                              # the groups do: this is the round-5 bug, visible to the counter
+        # the procedure: warm up as the capture will run
+        warm(like_capture=True)
+        graphs, st1, log1 = capture_all()
+        assert st1['gemm_heuristic'] == 0 and st1['wgrad_default'] == 0, (st1, log1[:8])
+        assert st1['gemm_tuned'] > 30 and st1['wgrad_tuned'] >= 3, st1
+        for g in graphs:        # and the captured steps replay
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.isfinite(arena.flat).all()
+    finally:
+        tuning._TUNED.clear(); tuning._TUNED.update(saved[0])
+        hipops.WgradQueue.tuned.clear(); hipops.WgradQueue.tuned.update(saved[1])
+        tuning.AUTOTUNE, hipops.WgradQueue.FORCE_TUNE = saved[2], saved[3]
+        vln_goat_amd.set_compute_dtype(torch.float32)

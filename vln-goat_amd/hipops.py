@@ -24,29 +24,7 @@ _ACT_DEPI = {'gelu': EPI_MUL_DGELU, 'relu': EPI_MUL_DRELU}
 
 
 # ----------------------------------------------------------------------------- plumbing
-def _dt(t):
-    if t.dtype == torch.float32:
-        return GOAT_F32
-    if t.dtype == torch.bfloat16:
-        return GOAT_BF16
-    raise RuntimeError('libgoat_hip supports float32 / bfloat16, got %s' % t.dtype)
-
-
-def _epc(t):
-    return 4 if t.dtype == torch.float32 else 8
-
-
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
-
-
-def _need_gpu(t):
-    if not t.is_cuda:
-        raise RuntimeError('GOAT HIP ops need tensors on the GPU (no CPU fallback in the product path)')
-
-
-def _ptr(t, off=0):
-    return t.data_ptr() + off * t.element_size()
+from ._plumbing import _dt, _epc, _need_gpu, _ptr, _stream          # noqa: E402,F401
 
 
 class RngState:
@@ -185,7 +163,7 @@ def refresh_shadows(param, by_id, done=()):
 
 
 # ----------------------------------------------------------------------------- raw kernels
-PROFILE = None   # bench.py sets this to a list to time every goat_gemm_nt launch with HIP events
+# (PROFILE — bench.py's per-launch HIP-event timing — lives in tuning.py beside the autotuner state; `hipops.PROFILE` is an alias)
 
 
 def gemm_nt(a, b, out, bias=None, epi=EPI_NONE, aux=None, split_k=1):
@@ -193,7 +171,7 @@ def gemm_nt(a, b, out, bias=None, epi=EPI_NONE, aux=None, split_k=1):
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K and out.shape[0] == M and out.shape[1] == N
-    if PROFILE is not None:
+    if tuning.PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     st = _lib.lib().goat_gemm_nt(_stream(), _dt(a), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0),
@@ -202,9 +180,9 @@ def gemm_nt(a, b, out, bias=None, epi=EPI_NONE, aux=None, split_k=1):
                                  _ptr(aux) if aux is not None else None,
                                  aux.stride(0) if aux is not None else 0, split_k)
     _lib.check(st, 'goat_gemm_nt(M=%d,N=%d,K=%d)' % (M, N, K))
-    if PROFILE is not None:
+    if tuning.PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, epi, split_k, str(a.dtype)),
+        tuning.PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, epi, split_k, str(a.dtype)),
                         ('goat_gemm_nt', (_dt(a), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0),
                                           M, N, K, _ptr(bias) if bias is not None else None, epi,
                                           _ptr(aux) if aux is not None else None, aux.stride(0) if aux is not None else 0,
@@ -238,166 +216,10 @@ def colsum(x, out=None):
     return out
 
 
-# ----------------------------------------------------------------------------- GEMM configuration / autotuner
-AUTOTUNE = False        # bench.py / trainers may switch this on: first sight of a shape times the candidate configs
-_TUNED = {}             # (ta, tb, M, N, Kc, epi, f32out, split_req) -> (bm, nstage, split)
-_FLUSH = [None]
-TUNED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_gfx950.json')
-
-
-def load_tuned(path=None):
-    """Merge a saved table of autotuned GEMM configurations (measured on an MI355X by bench.py) into _TUNED."""
-    path = path or os.environ.get('GOAT_TUNED_FILE') or TUNED_FILE
-    if os.environ.get('GOAT_NO_TUNED') or not os.path.exists(path):      # GOAT_NO_TUNED=1: re-tune from scratch (bench.py GOAT_SAVE_TUNED=...)
-        return 0
-    with open(path) as f:
-        tab = json.load(f)
-    for k, v in tab.items():
-        kk = json.loads(k)
-        _TUNED.setdefault(tuple(bool(x) if i in (0, 1, 6, 8) else int(x) for i, x in enumerate(kk)), tuple(int(x) for x in v))
-    return len(tab)
-
-
-def save_tuned(path):
-    tab = {json.dumps([int(x) for x in k]): list(v) for k, v in sorted(_TUNED.items())}
-    with open(path, 'w') as f:
-        json.dump(tab, f, indent=0, sort_keys=True)
-    return len(tab)
-
-
-
-EIGHT_WAVES = 0x100     # GOAT_GEMM_8WAVES (include/goat_hip.h): flag in the nstage argument of goat_gemm_bf16
-PINGPONG = 0x200        # GOAT_GEMM_PP: the ping-pong main loop (csrc/gemm5_tile.hpp); tiles 256x256, 192x256, 128x256, 256x128, 128x128
-BALANCED = 0x800        # (grouped weight gradients only) goat_wgrad_grouped_balanced: one workgroup per CU, equal shares of the group's K-tile iterations
-PERSIST = 0x400         # GOAT_GEMM_PERSIST (with PINGPONG): one workgroup per CU walks the tiles, next tile's first K-tile requested before the epilogue
-USE_PP = os.environ.get('GOAT_GEMM_NO_PP', '0') == '0'
-USE_PERSIST = os.environ.get('GOAT_GEMM_NO_PERSIST', '0') == '0'
-N_CU = 256              # MI355X; `n_cu()` reads the device (decides which shapes get the persistent candidates timed, and the tail split of a group)
-
-
-def n_cu():
-    """compute units of the current device (the kernels read the same attribute: pp_cu_count())"""
-    global N_CU
-    if not _N_CU_READ[0] and torch.cuda.is_available():
-        N_CU = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count) or N_CU
-        _N_CU_READ[0] = True
-    return N_CU
-
-
-_N_CU_READ = [False]
-
-
-def tile(bm, bn=128):
-    """tile argument of goat_gemm_bf16 / goat_wgrad_grouped: rows | columns << 16 (128 columns: just the row count)."""
-    return bm if bn == 128 else (bm | (bn << 16))
-
-
-def tile_name(t):
-    return '%dx%d' % (t & 0xFFFF, (t >> 16) or 128)
-
-
-def stage_name(ns):
-    return ('pp' if ns & PINGPONG else 's%d' % (ns & 0xFF)) + ('8w' if ns & EIGHT_WAVES else '') + ('P' if ns & PERSIST else '') + ('B' if ns & BALANCED else '')
-
-
-def _tile_candidates(ta, tb, M, N):
-    """(tile, ring stages) pairs the autotuner times for one GEMM shape.  The 8-wave 192/256-wide tiles (csrc/gemm3.hip) need a
-    power-of-two width on a transposed operand's side; they only pay when the problem has enough rows / columns."""
-    c = [(64, 2), (64, 3), (64, 4), (128, 2), (128, 3), (128, 4), (128, EIGHT_WAVES | 2), (128, EIGHT_WAVES | 3), (128, EIGHT_WAVES | 4)]
-    if M >= 2048:
-        c += [(256, 2), (256, 3)]
-    if not ta and M >= 960:              # 96-row tiles: 3840 / 96 = 40 tile rows -> 240 tiles at N = 768 (one round on 256 CUs)
-        c += [(96, 2), (96, 3), (96, 4)]
-    if N >= 256 and M >= 512:
-        c += [(tile(128, 256), 2), (tile(128, 256), 3)]
-        if M >= 1024:
-            c += [(tile(256, 256), 2)]
-            if not ta:
-                c += [(tile(192, 256), 2)]
-    if N >= 384 and M >= 1024 and not ta and not tb:
-        c += [(tile(256, 192), 2), (tile(192, 192), 2), (tile(192, 192), 3)]
-    if USE_PP and M >= 512 and N >= 256:          # ping-pong main loop (eight waves, >= 128 x 128 tiles)
-        c += [(128, PINGPONG | 2), (tile(128, 256), PINGPONG | 2), (256, PINGPONG | 2)]
-        if M >= 1024:
-            c += [(tile(256, 256), PINGPONG | 2)]
-            if not ta:
-                c += [(tile(192, 256), PINGPONG | 2)]
-        if USE_PERSIST and not ta:                # the persistent form of the same tiles where a problem has more tiles than workgroup slots
-            for t, ns in [x for x in c if x[1] & PINGPONG]:
-                rows, cols = t & 0xFFFF, (t >> 16) or 128
-                slots = n_cu() * (2 if rows * cols <= 128 * 128 else 1)
-                if ((M + rows - 1) // rows) * ((N + cols - 1) // cols) > slots:
-                    c.append((t, ns | PERSIST))
-    return c
-
-
-def _heuristic_cfg(ta, tb, M, N, Kc, split_k):
-    """(bm, nstage) measured with scripts/gemm_bench.py (hot and cold operands)."""
-    tiles128 = ((M + 127) // 128) * ((N + 127) // 128) * max(1, split_k)
-    kper = Kc // max(1, split_k)
-    if ta:
-        return 64, 2
-    if kper >= 2048 and tiles128 >= 150:
-        return 128, 3
-    if tiles128 >= 1024:
-        return 128, 2
-    return 64, 2
-
-
-def _launch_gemm_bf16(a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_k, bm, nstage, colsum_out):
-    args = (_stream(), int(ta), int(tb), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0),
-            _ptr(out), out.stride(0), M, N, Kc,
-            _ptr(bias) if bias is not None else None, epi,
-            _ptr(aux) if aux is not None else None,
-            aux.stride(0) if aux is not None else 0, split_k, bm, nstage,
-            _ptr(colsum_out) if colsum_out is not None else None)
-    st = _lib.lib().goat_gemm_bf16(*args)
-    _lib.check(st, 'goat_gemm_bf16(ta=%d,tb=%d,M=%d,N=%d,Kc=%d,bm=%d,ns=%d,split=%d)' % (ta, tb, M, N, Kc, bm, nstage, split_k))
-
-
-def _time_cfg(fn, reps=4):
-    """median HIP-event time of fn() with the L2 / Infinity Cache flushed before every repetition (inside a
-    training step the operands of a GEMM are cold: they were just produced by another kernel)."""
-    if _FLUSH[0] is None:
-        _FLUSH[0] = torch.empty(320 << 20, dtype=torch.uint8, device='cuda')
-    ts = []
-    for _ in range(reps):
-        _FLUSH[0].zero_()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        fn()
-        e1.record()
-        e1.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    ts.sort()
-    return ts[len(ts) // 2]
-
-
-TUNE_EVENTS = [0]        # shapes timed by the autotuner in this process (0 when tuned_gfx950.json covers the run: bench.py reports it)
-
-
-def _tune_gemm(key, a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_opts, colsum_out):
-    TUNE_EVENTS[0] += 1
-    kt = (Kc + 63) // 64
-    best = None
-    scratch = torch.empty_like(out) if out.dtype == torch.float32 else out
-    cs = torch.zeros_like(colsum_out) if colsum_out is not None else None
-    for split in split_opts:
-        if split > kt:
-            continue
-        for bm, ns in _tile_candidates(ta, tb, M, N):
-            if bm == 128 and (ns & 0xFF) == 4 and out.dtype == torch.bfloat16 and epi != EPI_NONE:
-                continue
-            try:
-                t = _time_cfg(lambda: _launch_gemm_bf16(a, b, scratch, ta, tb, M, N, Kc, bias, epi, aux, split, bm, ns, cs))
-            except RuntimeError:
-                continue
-            if split > 1:       # a split launch needs its float32 output cleared first: count that fill (ms)
-                t += 1.5e-3 + out.numel() * 4 / 4.0e9
-            if best is None or t < best[0]:
-                best = (t, bm, ns, split)
-    _TUNED[key] = best[1:]
-    return best[1:]
+# ----------------------------------------------------------------------------- GEMM configuration / autotuner: tuning.py
+from . import tuning                                                   # noqa: E402
+from .tuning import (BALANCED, EIGHT_WAVES, PERSIST, PINGPONG, TUNED_FILE, TUNE_EVENTS, USE_PERSIST, USE_PP, _FLUSH, _TUNED,      # noqa: E402,F401
+                     _heuristic_cfg, _launch_gemm_bf16, _tile_candidates, _time_cfg, _tune_gemm, load_tuned, n_cu, save_tuned, stage_name, tile, tile_name)
 
 
 # (Dropout inside the FFN GEMM epilogues — round 2's goat_gemm_bf16_dropout — measured 6.25 vs 6.22 ms per step: removed in round 3.)
@@ -448,13 +270,18 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
     key = (ta, tb, M, N, Kc, epi, out.dtype == torch.float32, split_k, bias is not None)
     cfg = _TUNED.get(key)
     if cfg is None:
-        if AUTOTUNE and not torch.cuda.is_current_stream_capturing() and PROFILE is None:
+        if tuning.AUTOTUNE and not torch.cuda.is_current_stream_capturing() and tuning.PROFILE is None:
             cfg = _tune_gemm(key, a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_opts or (split_k,), colsum_out)
         else:
             cfg = _heuristic_cfg(ta, tb, M, N, Kc, split_k) + (split_k,)
+            tuning.STATS['gemm_heuristic'] += 1          # a launch on a configuration nobody measured (tests assert a captured step has none)
+            if len(tuning.STATS_LOG) < 256:
+                tuning.STATS_LOG.append(('gemm', key, bool(torch.cuda.is_current_stream_capturing())))
             if os.environ.get('GOAT_GEMM_CFG_LOG'):      # (diagnostics: shapes that run on the heuristic, e.g. first seen inside a capture)
                 import sys
-                print('[gemm cfg] heuristic %s capturing=%s autotune=%s' % (key, torch.cuda.is_current_stream_capturing(), AUTOTUNE), file=sys.stderr)
+                print('[gemm cfg] heuristic %s capturing=%s autotune=%s' % (key, torch.cuda.is_current_stream_capturing(), tuning.AUTOTUNE), file=sys.stderr)
+    else:
+        tuning.STATS['gemm_tuned'] += 1
     bm, nstage, split_cfg = cfg
     # a split launch accumulates with atomics: only allowed when the caller zero-filled `out` (split requested / split_opts
     # given), asked for the clear (zero_first) or accumulates anyway.  A tuned entry with split > 1 must never be applied to a
@@ -466,545 +293,25 @@ def gemm(a, b, out, ta=False, tb=False, bias=None, epi=EPI_NONE, aux=None, split
     if accumulate and split_k == 1:
         assert epi == EPI_NONE and out.dtype == torch.float32 and bias is None
         epi = EPI_ACCUM
-    if PROFILE is not None:
+    if tuning.PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _launch_gemm_bf16(a, b, out, ta, tb, M, N, Kc, bias, epi, aux, split_k, bm, nstage, colsum_out)
-    if PROFILE is not None:
+    if tuning.PROFILE is not None:
         e1.record()
         cargs = (int(ta), int(tb), _dt(out), _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out),
                  out.stride(0), M, N, Kc, _ptr(bias) if bias is not None else None, epi,
                  _ptr(aux) if aux is not None else None, aux.stride(0) if aux is not None else 0,
                  split_k, bm, nstage, _ptr(colsum_out) if colsum_out is not None else None)
-        PROFILE.append((e0, e1, 2.0 * M * N * Kc, (M, N, Kc, epi, split_k, 'v2 t%d%d %s %s' % (ta, tb, tile_name(bm), stage_name(nstage))),
+        tuning.PROFILE.append((e0, e1, 2.0 * M * N * Kc, (M, N, Kc, epi, split_k, 'v2 t%d%d %s %s' % (ta, tb, tile_name(bm), stage_name(nstage))),
                         ('goat_gemm_bf16', cargs, (a, b, out, bias, aux, colsum_out))))
     return out
 
 
-# ----------------------------------------------------------------------------- hipGraph lifetime (runtime workaround)
-# ROCm 7.2 (libamdhip64 of this torch build): destroying a hipGraphExec whose graph had parallel branches (the side streams of
-# `Branch` below, the communication stream of dp.GradArena) leaves dangling entries in the runtime's pool of parallel launch streams;
-# after two such graphs have been destroyed, the launch of a LATER graph crashes on the host in hip::Graph::UpdateStreams (found by the
-# test suite: capture A, destroy; capture B, destroy; capture C -> segfault in hipGraphLaunch; scripts/dbg_graph_lifetime.py
-# reproduces it).  The graphs that forked a side stream of THIS package during their capture are therefore kept alive for the life of
-# the process — what a trainer does anyway (its step graphs live as long as it does).  Graphs of other code in the process, and graphs of
-# this package without parallel branches, are created and destroyed as torch would.  Round 5: the rule lives in the context manager
-# `hipops.graph` used at this repository's capture sites — torch.cuda.CUDAGraph itself is no longer patched.
-_RETAINED_GRAPHS = []
-_CAPTURING = []             # graphs being captured through hipops.graph (innermost last)
-_FORKED = [False]           # a side stream of this package joined the capture in progress
-_WARNED = [False]
-
-
-def note_parallel_branch():
-    """called where this package forks a side stream (Branch, the arena's communication stream): marks the graph being captured."""
-    if _CAPTURING:
-        _FORKED[0] = True
-    elif not _WARNED[0] and torch.cuda.is_current_stream_capturing() and not os.environ.get('GOAT_NO_GRAPH_RETAIN'):
-        _WARNED[0] = True
-        import warnings
-        warnings.warn('a hipGraph with parallel branches of vln_goat_amd is being captured outside vln_goat_amd.hipops.graph(): keep that '
-                      'torch.cuda.CUDAGraph alive for the life of the process (ROCm 7.2: destroying two such graphs crashes a later graph '
-                      'launch in hip::Graph::UpdateStreams), or capture with hipops.graph(g) which does so')
-
-
-class graph:
-    """`with hipops.graph(g): ...` = `with torch.cuda.graph(g): ...` for captures that run this package's ops.  If a parallel branch of
-    the package (Branch side streams, the arena's communication stream) joined the capture, `g` is kept alive for the life of the process:
-    the runtime workaround described above, applied AT THE CAPTURE SITE (VERDICT r4 #10 — rounds 3-4 patched torch.cuda.CUDAGraph for the
-    whole process at import).  Nothing of torch is modified; graphs captured elsewhere are not touched (note_parallel_branch warns once if
-    one of them forks a branch).  GOAT_NO_GRAPH_RETAIN=1: plain torch.cuda.graph; GOAT_GRAPH_RETAIN_ALL=1: keep every graph captured here."""
-
-    def __init__(self, g, **kw):
-        self.g = g
-        self.ctx = torch.cuda.graph(g, **kw)
-
-    def __enter__(self):
-        import warnings
-        _CAPTURING.append(self.g)
-        _FORKED[0] = False
-        # A tensor of an earlier (warm-up) pass still alive keeps that pass's autograd graph alive, and with it AccumulateGrad nodes bound
-        # to the warm-up stream: the captured backward then accumulates parameter gradients OUTSIDE the capture (replays return garbage
-        # gradients or hipStreamEndCapture crashes; found with an attribute that held a warm-up activation).  torch warns about exactly
-        # this; inside a capture of this package the warning is an error.
-        self._warn = warnings.catch_warnings()
-        self._warn.__enter__()
-        warnings.filterwarnings('error', message=".*AccumulateGrad node's stream does not match.*")
-        try:
-            from . import dp
-            dp.quiesce_if_needed()      # eager RCCL collectives issued so far are retired before the stream enters capture mode (dp.quiesce_collectives)
-            return self.ctx.__enter__()
-        except BaseException:
-            _CAPTURING.pop()
-            self._warn.__exit__(None, None, None)
-            raise
-
-    def __exit__(self, *exc):
-        try:
-            return self.ctx.__exit__(*exc)
-        finally:
-            self._warn.__exit__(None, None, None)
-            if _CAPTURING and _CAPTURING[-1] is self.g:
-                _CAPTURING.pop()
-            keep = (_FORKED[0] or bool(os.environ.get('GOAT_GRAPH_RETAIN_ALL'))) and not os.environ.get('GOAT_NO_GRAPH_RETAIN')
-            if keep and exc[0] is None and not any(x is self.g for x in _RETAINED_GRAPHS):
-                _RETAINED_GRAPHS.append(self.g)
-            _FORKED[0] = False
-
-
-class Branch:
-    """Run a block of ops as a parallel branch: `with Branch('pano') as br: ...; br.join(t1, t2)`.
-
-    GOAT's step has independent sub-graphs (text encoder vs panorama encoder; global-map vs local cross-modal encoder)
-    whose kernels are too small to fill 256 CUs on their own (66-720 workgroups).  Issued on a side HIP stream they
-    become a parallel branch of the captured hipGraph (or run concurrently in eager mode); autograd replays each
-    backward op on the stream of its forward op, so the backward passes of the branches overlap as well.
-    Fork: the side stream first waits for everything issued so far on the caller's stream.  join(): the caller's stream
-    waits for the branch; tensors handed over are registered with the caching allocator (record_stream)."""
-    mode = os.environ.get('GOAT_BRANCH_STREAMS', 'capture')      # 'capture' (default): only while a hipGraph is being captured
-    _streams = {}                                                 # (eager launches are host-bound: no gain, more syncs); 'always'; '0'
-    used = set()            # side streams with work since the last join_all()
-
-    off = set(filter(None, os.environ.get('GOAT_BRANCH_OFF', '').split(',')))     # (diagnostics: sites that run on the caller's stream)
-
-    @classmethod
-    def like_capture(cls):
-        """`with Branch.like_capture(): warm_up()` — an EAGER pass that forks the parallel branches exactly as a capture of the same code will
-        (mode 'capture' forks only while capturing).  What depends on which stream an op is issued on then sees the capture's picture:
-        WgradQueue keeps one queue per stream, so the grouped weight-gradient launches of the warm-up — the ones the tuner times — are the
-        groups the captured step will launch."""
-        import contextlib
-
-        @contextlib.contextmanager
-        def ctx():
-            prev = cls.mode
-            if prev == 'capture':
-                cls.mode = 'always'
-            try:
-                yield
-            finally:
-                cls.mode = prev
-        return ctx()
-
-    def __init__(self, name, site=None):
-        self.name = name
-        self.site = site
-        self.side = None
-
-    def __enter__(self):
-        if Branch.mode == '0' or not torch.cuda.is_available() or self.site in Branch.off:
-            return self
-        if Branch.mode != 'always' and not torch.cuda.is_current_stream_capturing():
-            return self
-        if not torch.is_grad_enabled():
-            # forward-only capture (rollout.SampledEpisode): nothing is saved for a backward pass, so a tensor made on the caller's stream
-            # and read by the branch is released as soon as Python drops it and its block is handed to the caller's next allocation while
-            # the branch may still read it (the allocator orders reuse per allocating stream) — measured: action probabilities that
-            # change from replay to replay.  The inference graphs are small and host-paced; they run on one stream.
-            return self
-        dev = torch.cuda.current_device()
-        self.side = Branch._streams.get((dev, self.name))
-        if self.side is None:
-            self.side = Branch._streams[(dev, self.name)] = torch.cuda.Stream(device=dev)
-        self.main = torch.cuda.current_stream()
-        self.side.wait_stream(self.main)
-        if Branch._stale:               # first fork of a new step: forget the streams of the previous one
-            Branch.used, Branch._stale = set(), False
-        Branch.used.add(self.side)
-        note_parallel_branch()
-        self._ctx = torch.cuda.stream(self.side)
-        self._ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.side is not None:
-            self._ctx.__exit__(*exc)
-        return False
-
-    def join(self, *tensors):
-        if self.side is None:
-            return
-        cur = torch.cuda.current_stream()
-        cur.wait_stream(self.side)
-        hooked = False
-        for t in tensors:
-            if torch.is_tensor(t):
-                t.record_stream(cur)
-                if not hooked and t.requires_grad and torch.is_grad_enabled():
-                    t.register_hook(Branch._arm)      # backward will run part of its ops on the side stream again
-                    hooked = True
-
-    _armed = False
-
-    @staticmethod
-    def _arm(grad):
-        note_parallel_branch()        # (a graph that captures only this backward pass has the side streams as parallel branches too)
-        if not Branch._armed:
-            Branch._armed = True
-            torch.autograd.Variable._execution_engine.queue_callback(Branch._end_of_backward)
-        return None
-
-    @staticmethod
-    def _end_of_backward():
-        Branch._armed = False
-        WgradQueue.flush()
-        Branch.join_all()
-
-    _stale = False
-
-    @classmethod
-    def join_all(cls):
-        """current stream waits for every side stream forked in this step (called at the end of every backward phase: autograd
-        replays backward ops on the stream of their forward op)."""
-        cur = torch.cuda.current_stream()
-        for s in cls.used:
-            cur.wait_stream(s)
-        cls._stale = True
-
-
-class WgradQueue:
-    """Deferred weight gradients.  With a gradient arena attached the weight gradient of a Linear is not needed until the
-    backward pass ends, so instead of launching each small dW = dY^T·X on its own (36-144 tiles: split along the
-    contraction, atomics and a zero fill to occupy 256 CUs) the problems are queued and executed up to sixteen at a time by
-    goat_wgrad_grouped: one unsplit launch that fills the chip.  Flushed when full, when a queued parameter is about
-    to be written again (ordering), and by an autograd-engine callback at the end of the backward pass.
-    The first write of a slice in a step overwrites it; a later write (shared weights, BPTT) is queued as an accumulation —
-    never in the same group as an earlier write of that slice (hipops._sink flushes first)."""
-    enabled = os.environ.get('GOAT_WGRAD_GROUP', '1') != '0'
-    # (tile = rows | cols << 16, ring stages | 0x100 = eight waves on 128x128 | 0x200 = ping-pong): scripts/wgrad_group_bench.py.  The configuration of a
-    # group the tuner has not timed — above all the groups of a CAPTURED step when its eager warm-up ran on one stream: a capture forks parallel
-    # branches, each stream has its own queue, so the groups differ from the warm-up's and miss the tuned plans (found in round 5: 10 of the 12
-    # groups of the headline cycle ran this default, then 256 x 128 on three ring slots; the 256 x 256 ping-pong tile wins nearly every group the
-    # tuner times: step 5.30 -> 5.18 ms same box, profiles/round5_wgrad_default_cfg_ab.txt).  Branch.like_capture() makes a warm-up form the capture's groups.
-    cfg = tuple(int(v) for v in os.environ['GOAT_WGRAD_GROUP_CFG'].split(',')) if 'GOAT_WGRAD_GROUP_CFG' in os.environ else (
-        tuple(int(v) for v in os.environ['GOAT_WGRAD_DEFAULT_CFG'].split(',')) if 'GOAT_WGRAD_DEFAULT_CFG' in os.environ else (   # (A/B: default without switching the tuner off)
-            (256 | 256 << 16, 0x200 | 2) if USE_PP else (256, 3)))
-    MAX = int(os.environ.get('GOAT_WGRAD_GROUP_MAX', '48'))      # problems per launch = the kernel's GROUP_MAX (48 since the last session of round 5: 24 / 32 / 48 -> 5.03 / 5.02 / 4.99 ms per step; round 1: 8 / 12 / 16 -> 7.12 / 7.09 /
-                                                                 # 7.06 ms per step; round 4, same box, three alternations: 16 -> 5.80 / 5.81 / 5.80, 24 -> 5.75 / 5.76 / 5.76)
-    # (round 2 also had a mode that ran the grouped launches on a stream of their own, off the dgrad chain: 6.52 vs 6.28 ms per step — the
-    #  kernels contend, they do not fill idle CUs: removed in round 3)
-    # (diagnostics; measured and NOT adopted) every queued problem waits for the end of the backward pass (or for a re-write of its slice)
-    # and the launches then run back to back, MAX problems each — instead of interleaving with the dgrad chains, whose short kernels on
-    # the OTHER graph branch starve behind a chip-filling grouped launch (profiles/round4_step_ln_attention_by_shape.txt: 10 us kernels
-    # stretched to 200 us).  Same step time (5.80 / 5.80 / 5.82 vs 5.80 / 5.81 / 5.80 ms): what the chains gain, the lost overlap costs.
-    DEFER_ALL = os.environ.get('GOAT_WGRAD_DEFER_ALL', '0') == '1'
-    queues = {}             # HIP stream handle -> (torch stream, [(dy, x, w_sink, b_sink, accumulate)]): tensors are kept alive until
-    pending_ids = {}        # the launch, which happens on the stream the problems were produced on;  id(param) -> stream handle
-    _callback_armed = False
-    # Merging (last session of round 5).  A weight used several times in one backward pass — every weight of the navigation model in a
-    # T-step episode (BPTT), shared cross-modal layers — used to force a flush at its second use (two problems writing one slice cannot share
-    # a launch), so an episode's backward ran one grouped launch PER STEP, each reading and re-writing the float32 gradient of every weight:
-    # 16 launches of ~180 us per 6-step episode, bound by that traffic, not by MFMA (contraction lengths of 12 ... 768 rows).  Now small
-    # problems of the same slice stay queued together and become ONE problem at launch time: dW = [dY_1; dY_2; ...]^T [X_1; X_2; ...] (the
-    # row blocks copied into one buffer each — cheap while rows < 2 n_out n_in / (n_out + n_in), the copy against a read-modify-write of dW).
-    MERGE = os.environ.get('GOAT_WGRAD_MERGE', '1') != '0'
-    distinct = {}           # HIP stream handle -> set of queued slices (data pointers): the flush threshold counts problems AFTER merging
-    MAX_ITEMS, MAX_SLICES = 8192, 1024        # (bounds on queued tensors / distinct slices)
-
-    @classmethod
-    def mergeable(cls, rows, n_out, n_in):
-        return cls.MERGE and cls.enabled and rows * (n_out + n_in) < 2 * n_out * n_in and n_out % 8 == 0 and n_in % 8 == 0      # (the concatenated operands are contiguous: row length = leading dimension, a multiple of 8)
-
-    @classmethod
-    def push(cls, dy, x, w_sink, b_sink, param_ids, accumulate):
-        st = torch.cuda.current_stream()
-        q = cls.queues.setdefault(st.cuda_stream, (st, []))[1]
-        q.append((dy, x, w_sink, b_sink, int(bool(accumulate))))
-        d = cls.distinct.setdefault(st.cuda_stream, [set(), set()])      # [every queued slice, slices with a problem too large to merge]
-        d[0].add(w_sink.data_ptr())
-        if not cls.mergeable(dy.shape[0], dy.shape[1], x.shape[1]):
-            d[1].add(w_sink.data_ptr())
-        for i in param_ids:
-            cls.pending_ids[i] = st.cuda_stream
-        cls.arm()
-        # full = MAX slices that will not be merged with later problems; the small (mergeable) ones wait for the other steps' problems of
-        # their weight — an episode's backward is then a handful of launches at its end instead of one per step
-        if (len(d[1]) >= cls.MAX and not cls.DEFER_ALL) or len(d[0]) >= cls.MAX_SLICES or len(q) >= cls.MAX_ITEMS:
-            cls.flush(st.cuda_stream)
-
-    @staticmethod
-    def _merge(q):
-        """problems of one slice -> one problem over the concatenated rows (queue order kept by first occurrence; the merged problem overwrites /
-        accumulates as its first member did, later members were accumulations by construction)"""
-        seen = {}
-        for i, t in enumerate(q):
-            seen.setdefault((t[2].data_ptr(), t[3].data_ptr() if t[3] is not None else 0, t[0].dtype, t[0].shape[1], t[1].shape[1]), []).append(i)
-        # one merged problem per SLICE: two keys on one weight slice (same arena pointer, another shape / bias slice / dtype: e.g. a
-        # concatenated q|k|v sink and q alone on a shared module) would put an overwriting and an accumulating writer of the same words
-        # into one launch (ADVICE r5) — not reachable with today's models; refuse loudly rather than race
-        ptrs = [k[0] for k in seen]
-        if len(set(ptrs)) != len(ptrs):
-            raise RuntimeError('WgradQueue: two queued weight-gradient problems write one arena slice with different shapes / bias slices')
-        if len(seen) == len(q):
-            return q
-        out = []
-        for key, idx in seen.items():
-            t0 = q[idx[0]]
-            if len(idx) == 1:
-                out.append((idx[0], t0))
-                continue
-            dy = torch.cat([q[i][0] for i in idx], 0)
-            x = torch.cat([q[i][1] for i in idx], 0)
-            out.append((idx[0], (dy, x, t0[2], t0[3], t0[4])))
-        out.sort(key=lambda e: e[0])
-        return [t for _, t in out]
-
-    @classmethod
-    def arm(cls):
-        """(inside a backward pass) have the autograd engine call _end_of_backward when this pass ends."""
-        if not cls._callback_armed:
-            cls._callback_armed = True
-            torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_backward)
-
-    @classmethod
-    def _end_of_backward(cls):
-        cls._callback_armed = False
-        cls.flush()
-        Branch.join_all()           # grouped launches on side streams must land before the caller's stream goes on
-        LnReduceQueue.flush()       # (after the join: the partials may have been produced on side streams)
-
-    @classmethod
-    def reset(cls):
-        """Drop queued problems (GradArena.zero() calls this: anything still queued at the start of a step belongs to a
-        backward pass that was aborted by an exception — its tensors must not be written into the new step)."""
-        cls.queues, cls.pending_ids, cls._callback_armed = {}, {}, False
-        cls.distinct = {}
-        cls._balanced_i = 0
-        LnReduceQueue.items = []
-
-    @classmethod
-    def flush_param(cls, param_id):
-        """A queued write of this parameter's slice must land before the caller touches the slice on ITS stream."""
-        h = cls.pending_ids.get(param_id)
-        if h is not None:
-            st = cls.queues[h][0]
-            cls.flush(h)
-            cur = torch.cuda.current_stream()
-            if cur.cuda_stream != h:
-                cur.wait_stream(st)
-
-    @classmethod
-    def flush(cls, handle=None):
-        """Launch the queued problems of one stream (or of every stream), each group on its own stream."""
-        for h in ([handle] if handle is not None else list(cls.queues)):
-            ent = cls.queues.get(h)
-            if not ent or not ent[1]:
-                continue
-            st, q = ent
-            cls.queues[h] = (st, [])
-            cls.distinct.pop(h, None)
-            for pid in [k for k, v in cls.pending_ids.items() if v == h]:
-                del cls.pending_ids[pid]
-            with torch.cuda.stream(st):
-                q = cls._merge(q)
-                for i in range(0, len(q), cls.MAX):
-                    cls._launch(q[i:i + cls.MAX])
-
-    # contraction-balanced launch as a tuner candidate: opt-in.  Same-box A/B of the step with it among the candidates: 5.321 / 5.316 ms
-    # without, 5.322 / 5.315 with (profiles/round5_wgrad_balanced.txt) — it wins only on groups that mix 8640-row and 3840-row problems.
-    USE_BALANCED = os.environ.get('GOAT_WGRAD_BALANCED', '0') == '1'
-    CANDIDATES = ((256, 3), (128, EIGHT_WAVES | 2), (tile(256, 256), 2)) + (      # tile configurations a group may run on
-        ((tile(256, 256), PINGPONG | 2), (tile(128, 256), PINGPONG | 2), (256, PINGPONG | 2)) if USE_PP else ()) + (
-        ((tile(256, 256), BALANCED | PINGPONG | 2),) if USE_PP and USE_BALANCED else ())
-    _balanced_ws = {}       # (device, tile, i) -> zeroed workspace of the i-th balanced launch of a step (-1: the tuner's).  Launches of one step may
-    _balanced_i = 0         # overlap on different streams, so each has its own; the eager warm-up step allocates them, the captured step finds them
-    _last_ws = None         # (an allocation inside a capture would put its zero fill into the graph)
-
-    @classmethod
-    def _balanced_args(cls, cfg):
-        """(workspace pointer, bytes) of the launch _run just made"""
-        return (cls._last_ws.data_ptr(), cls._last_ws.numel())
-
-    @classmethod
-    def _run(cls, arr, n, cfg, tuning=False):
-        """one grouped launch on the current stream -> status"""
-        if not cfg[1] & BALANCED:
-            return _lib.lib().goat_wgrad_grouped(_stream(), ctypes.addressof(arr), n, cfg[0], cfg[1])
-        i = -1
-        if not tuning:
-            i, cls._balanced_i = cls._balanced_i, cls._balanced_i + 1
-        key = (torch.cuda.current_device(), cfg[0], i)
-        ws = cls._balanced_ws.get(key)
-        if ws is None:
-            nb = _lib.lib().goat_wgrad_balanced_ws_bytes(cfg[0])
-            if nb <= 0:
-                return -1
-            ws = cls._balanced_ws[key] = torch.zeros(nb, dtype=torch.uint8, device='cuda')
-        cls._last_ws = ws
-        return _lib.lib().goat_wgrad_grouped_balanced(_stream(), ctypes.addressof(arr), n, cfg[0], ws.data_ptr(), ws.numel())
-
-    tuned = {}              # group signature (rows, n_out, n_in per problem) -> configuration, timed on first sight (AUTOTUNE)
-    TUNE = os.environ.get('GOAT_WGRAD_GROUP_TUNE', '1') != '0'
-    FORCE_TUNE = False      # time unseen groups even while AUTOTUNE is off (bench.py keeps GEMM-shape tuning off around its T = 15 rollout graphs: ~100 shapes; a group costs milliseconds)
-
-    @staticmethod
-    def _fill(arr, items, scratch=None):
-        for i, (dy, x, w, b, acc) in enumerate(items):
-            p = arr[i]
-            p.dy, p.ld_dy, p.x, p.ld_x = _ptr(dy), dy.stride(0), _ptr(x), x.stride(0)
-            if scratch is None:
-                p.dw, p.ld_dw, p.dbias, p.accumulate = _ptr(w), w.stride(0), (_ptr(b) if b is not None else None), acc
-            else:
-                p.dw, p.ld_dw, p.dbias, p.accumulate = _ptr(scratch[i]), scratch[i].stride(0), None, 0
-            p.rows, p.n_out, p.n_in = dy.shape[0], dy.shape[1], x.shape[1]
-
-    @classmethod
-    def _tail_split(cls, q, rows=256, cols=128):
-        """indices of the problems to run in a second launch on half-size tiles, or None.  With rows x cols tiles a group is a whole
-        number of rounds over the 256 CUs plus a tail (e.g. sixteen text-layer problems on 256 x 128: 864 tiles = 3.375 rounds, the last
-        one 37 % full; six text layers on 256 x 256: 648 tiles = 2.53 rounds).  Problems whose tiles add up to just over the tail are
-        taken out and run afterwards on tiles of half the size (half the duration): e.g. 2 full rounds + 1.06 half rounds instead of 3."""
-        if len(q) < 2 or len({t[0].shape[0] for t in q}) != 1:        # tiles of equal duration only (same contraction length)
-            return None
-        tiles = [((t[0].shape[1] + rows - 1) // rows) * ((t[1].shape[1] + cols - 1) // cols) for t in q]
-        total, ncu = sum(tiles), n_cu()
-        rem = total % ncu
-        if total < ncu or rem == 0 or rem > ncu * 13 // 16:
-            return None
-        best = None                                                   # smallest subset sum >= rem (n <= 24: dynamic programme over sums)
-        reach = {0: ()}
-        for i, t in enumerate(tiles):
-            for sm, idx in list(reach.items()):
-                if sm + t not in reach:
-                    reach[sm + t] = idx + (i,)
-        for sm in sorted(reach):
-            if sm >= rem:
-                best = reach[sm]
-                break
-        if not best or len(best) == len(q):
-            return None
-        return best
-
-    @classmethod
-    def _plans(cls, q):
-        n = len(q)
-        plans = [[(tuple(range(n)), c)] for c in cls.CANDIDATES]
-        tail = cls._tail_split(q)
-        if tail is not None:
-            head = tuple(i for i in range(n) if i not in tail)
-            plans.append([(head, (256, 3)), (tail, (128, EIGHT_WAVES | 2))])
-        if USE_PP:          # round 5: the same cut for the ping-pong 256 x 256 tile (tail on 128 x 256: half the rows, same columns)
-            tail = cls._tail_split(q, 256, 256)
-            if tail is not None:
-                head = tuple(i for i in range(n) if i not in tail)
-                plans.append([(head, (tile(256, 256), PINGPONG | 2)), (tail, (tile(128, 256), PINGPONG | 2))])
-        return plans
-
-    @classmethod
-    def _pick_plan(cls, q):
-        """[(problem indices, tile configuration)]: the launches this group runs as.  Which plan is fastest depends on the mix of
-        problem sizes (whole rounds of tiles over the 256 CUs; e.g. eight text-layer problems: 787 TFLOP/s on 128x128 / 8 waves against
-        720 on 256x128), so each distinct group is timed once on scratch outputs, cold caches, when autotuning is on and no graph is
-        being captured."""
-        n = len(q)
-        default = [(tuple(range(n)), cls.cfg)]
-        if 'GOAT_WGRAD_GROUP_CFG' in os.environ or not cls.TUNE:
-            return default
-        key = tuple((t[0].shape[0], t[0].shape[1], t[1].shape[1]) for t in q)
-        plan = cls.tuned.get(key)
-        log = os.environ.get('GOAT_WGRAD_PLAN_LOG')
-        if plan is not None:
-            if log == '2':
-                import sys
-                print('[wgrad group] hit  %d problems rows %s capturing=%s -> %s' % (n, sorted({t_[0].shape[0] for t_ in q}), torch.cuda.is_current_stream_capturing(),
-                      ' + '.join('%d x %s %s' % (len(i_), tile_name(c_[0]), stage_name(c_[1])) for i_, c_ in plan)), file=sys.stderr)
-            return plan
-        if not (AUTOTUNE or cls.FORCE_TUNE) or PROFILE is not None or torch.cuda.is_current_stream_capturing():
-            if log == '2':
-                import sys
-                print('[wgrad group] MISS %d problems rows %s autotune=%s profile=%s capturing=%s -> default' % (
-                    n, sorted({t_[0].shape[0] for t_ in q}), AUTOTUNE, PROFILE is not None, torch.cuda.is_current_stream_capturing()), file=sys.stderr)
-            return default
-        scratch = [torch.empty((t[0].shape[1], t[1].shape[1]), dtype=torch.float32, device=t[0].device) for t in q]
-        best = None
-        for cand in cls._plans(q):
-            parts = []
-            for idx, cfg in cand:
-                arr = (_lib.WgradProblem * len(idx))()
-                cls._fill(arr, [q[i] for i in idx], [scratch[i] for i in idx])
-                parts.append((arr, len(idx), cfg))
-
-            def run():
-                for arr, m, cfg in parts:
-                    _lib.check(cls._run(arr, m, cfg, tuning=True), 'goat_wgrad_grouped (tuning)')
-            try:
-                t = _time_cfg(run, reps=int(os.environ.get('GOAT_WGRAD_TUNE_REPS', '9')))      # (a group runs 0.1-0.5 ms: nine repetitions cost nothing and the picks stop flipping between runs)
-            except RuntimeError:
-                continue
-            if os.environ.get('GOAT_WGRAD_PLAN_LOG'):
-                import sys
-                print('[wgrad group] %d problems rows %s: %s -> %.1f us' % (n, sorted({t_[0].shape[0] for t_ in q}), ' + '.join(
-                    '%d x %s %s' % (len(i_), tile_name(c_[0]), stage_name(c_[1])) for i_, c_ in cand), t * 1e3), file=sys.stderr)
-            if best is None or t < best[0]:
-                best = (t, cand)
-        plan = cls.tuned[key] = best[1] if best is not None else default
-        return plan
-
-    ORDER = os.environ.get('GOAT_WGRAD_ORDER', 'spread')       # 'queue': the order the backward pass produced the problems in
-
-    @classmethod
-    def _spread(cls, q):
-        """The problems of a group re-ordered so that every contraction length (rows) is spread evenly over the sequence.  The group
-        kernel gives each XCD one contiguous chunk of the tile order (shared operand panels stay in one L2); a tile's duration is
-        proportional to its contraction length, so a queue that holds the 8640-row panorama problems in one run and the 3840-row text
-        problems in another hands some XCDs 2.25 x the work of others.  Problems write distinct slices: any order is valid."""
-        if cls.ORDER != 'spread' or len({t[0].shape[0] for t in q}) < 2:
-            return q
-        by = {}
-        for i, t in enumerate(q):
-            by.setdefault(t[0].shape[0], []).append(i)
-        n = len(q)
-        slots = sorted(((k + 0.5) * n / len(ix), -rows, i) for rows, ix in by.items() for k, i in enumerate(ix))
-        return [q[i] for _, _, i in slots]
-
-    @classmethod
-    def _launch(cls, q):
-        q = cls._spread(q)
-        for idx, cfg in cls._pick_plan(q):
-            items = [q[i] for i in idx]
-            n = len(items)
-            arr = (_lib.WgradProblem * n)()
-            cls._fill(arr, items)
-            if PROFILE is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            st = cls._run(arr, n, cfg)
-            if PROFILE is not None:
-                e1.record()
-                fl = sum(2.0 * t[0].shape[0] * t[0].shape[1] * t[1].shape[1] for t in items)
-                by = sum((t[0].shape[0] * t[0].shape[1] + t[1].shape[0] * t[1].shape[1]) * 2 + t[0].shape[1] * t[1].shape[1] * 4 for t in items)
-                PROFILE.append((e0, e1, fl, ('grouped wgrad', n, by, 0, 1, 'v2 t11 %s %s' % (tile_name(cfg[0]), stage_name(cfg[1]))),
-                                (('goat_wgrad_grouped', (ctypes.addressof(arr), n, cfg[0], cfg[1]), (arr, items)) if not cfg[1] & BALANCED else
-                                 ('goat_wgrad_grouped_balanced', (ctypes.addressof(arr), n, cfg[0]) + cls._balanced_args(cfg), (arr, items)))))
-            _lib.check(st, 'goat_wgrad_grouped(n=%d)' % n)
-
-
-class LnReduceQueue:
-    """Deferred dgamma / dbeta of LayerNorm backward.  With a gradient arena attached the two vectors are not needed until
-    the backward pass ends; goat_ln_bwd then only leaves its per-block column partials behind (accumulate = 2) and ONE
-    goat_ln_reduce_batched launch per backward pass adds the partials of every LayerNorm call to the arena slices — instead
-    of ~1500 contended float atomics per block, or a reduction launch per call (scripts/ln_bench.py: 15.8 -> 9-10 us per call at
-    3840 rows).  Deterministic.  Flushed by WgradQueue's end-of-backward callback."""
-    enabled = os.environ.get('GOAT_LN_DEFER', '1') != '0'
-    MIN_ROWS = 64
-    items = []              # (ws, dgamma sink, dbeta sink, nparts, H): tensors kept alive until the launch
-
-    @classmethod
-    def push(cls, ws, dg, db, nparts, H):
-        cls.items.append((ws, dg, db, nparts, H))
-        WgradQueue.arm()
-
-    @classmethod
-    def flush(cls):
-        items, cls.items = cls.items, []
-        by_h = {}
-        for it in items:
-            by_h.setdefault(it[4], []).append(it)
-        for H, group in by_h.items():
-            arr = (_lib.LnPartial * len(group))()
-            for e, (ws, dg, db, nparts, _) in zip(arr, group):
-                e.ws, e.dgamma, e.dbeta, e.nparts = _ptr(ws), _ptr(dg), _ptr(db), nparts
-            _lib.check(_lib.lib().goat_ln_reduce_batched(_stream(), ctypes.addressof(arr), len(group), H), 'goat_ln_reduce_batched')
+# ----------------------------------------------------------------------------- hipGraph capture / parallel branches: streams.py;
+# deferred weight gradients and LayerNorm column reductions: wgrad_queue.py
+from .streams import Branch, graph, note_parallel_branch, _RETAINED_GRAPHS          # noqa: E402,F401
+from .wgrad_queue import LnReduceQueue, WgradQueue                                   # noqa: E402,F401
 
 
 def _sink(param, keep_queued=False):
@@ -1076,7 +383,7 @@ def _wgrad_impl(dy, x, want_bias, w_sink=None, b_sink=None, first=False, b_first
     else:
         split = max(1, min(int(round(500.0 / tiles)), kt // 24))
     nb = N if want_bias else 0
-    tunable = AUTOTUNE and dy.dtype == torch.bfloat16
+    tunable = tuning.AUTOTUNE and dy.dtype == torch.bfloat16
     if w_sink is not None:
         # gradient-arena slice.  First use in this step: clear it right here (the fill leaves the lines in the
         # Infinity Cache for the split-K atomics) or, unsplit, simply overwrite it; later uses accumulate.
@@ -2569,3 +1876,25 @@ def cfp_tail(go, vo, fwl, to, temperature):
 
 def infonce(g_loc, v_loc, f_loc, t_loc, g_all, v_all, f_all, t_all, target0, temperature):
     return _InfoNceFn.apply(g_loc, v_loc, f_loc, t_loc, g_all, v_all, f_all, t_all, target0, temperature)
+
+
+# ----------------------------------------------------------------------------- aliases of the state that moved to tuning.py
+class _HipopsModule(type(os)):
+    """`hipops.AUTOTUNE` / `hipops.PROFILE` read and write tuning.AUTOTUNE / tuning.PROFILE (bench.py, scripts and trainers written against
+    the round-5 layout switch them through this module)."""
+    _FORWARD = ('AUTOTUNE', 'PROFILE')
+
+    def __getattr__(self, name):
+        if name in _HipopsModule._FORWARD:
+            return getattr(tuning, name)
+        raise AttributeError('module %r has no attribute %r' % (self.__name__, name))
+
+    def __setattr__(self, name, value):
+        if name in _HipopsModule._FORWARD:
+            setattr(tuning, name, value)
+        else:
+            super().__setattr__(name, value)
+
+
+import sys as _sys            # noqa: E402
+_sys.modules[__name__].__class__ = _HipopsModule
