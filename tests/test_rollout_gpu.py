@@ -401,7 +401,7 @@ def test_reverie_rollout_matches_the_reference_rollout():
     model = model.cuda().eval()
     store = _store(scan, feats, torch.float32)
     objects.to('cuda')
-    sim = rollout.GraphSim(store, objects=objects)
+    sim = rollout.GraphSim(store, objects=objects, obj_fallback=False)      # (the fixtures' observations carry the episode's own objId, no random stand-in)
     ro = rollout.NavRollout(lambda mode, batch: model(mode, batch), sim, store, max_action_len=6)
     rec = []
     inner = ro.model
@@ -461,7 +461,7 @@ def test_teacher_episode_with_objects_matches_the_eager_reverie_rollout():
     model = model.cuda().eval()
     store = _store(scan, feats, torch.float32)
     objects.to('cuda')
-    sim = rollout.GraphSim(store, objects=objects)
+    sim = rollout.GraphSim(store, objects=objects, obj_fallback=False)      # (the fixtures' observations carry the episode's own objId, no random stand-in)
     call = lambda mode, batch: model(mode, batch)
     ex = synth.rollout_extras(dicts, 3, 'cuda')
     T, W, O = 5, 38, 6
@@ -536,7 +536,7 @@ def test_reverie_sampled_rollout_in_two_passes_matches_the_single_pass():
     model = model.cuda().eval()
     store = _store(scan, feats, torch.float32)
     objects.to('cuda')
-    sim = rollout.GraphSim(store, objects=objects)
+    sim = rollout.GraphSim(store, objects=objects, obj_fallback=False)      # (the fixtures' observations carry the episode's own objId, no random stand-in)
     call = lambda mode, batch: model(mode, batch)
     ex = synth.rollout_extras(dicts, 3, 'cuda')
     T, W, O = 5, 38, 6

@@ -532,9 +532,10 @@ class GraphSim:
     episodes: list of dicts {instr_id, scan (ScanGraph), path [vpids], heading, instr_encoding}.  `features`: an object with
     `row(scan_name, vpid) -> int` (features.FeatureStore): observations carry feature ROW numbers, not feature arrays."""
 
-    def __init__(self, features=None, angle_feat_size=4, objects=None, seed=0):
+    def __init__(self, features=None, angle_feat_size=4, objects=None, seed=0, obj_fallback=True):
         self.features = features
         self.obj_rng = np.random.RandomState(seed)      # draws the stand-in target object of episodes without one (see _gt_obj_id)
+        self.obj_fallback = obj_fallback                # False: such episodes keep gt_obj_id None (fixtures generated without the random draw)
         self.objects = objects              # ObjectStore: REVERIE / SOON observations (M/reverie/env.py:451-486); episodes then carry
         self.angle_feat_size = angle_feat_size      # 'obj_id' (the target object, may be None) and 'end_vps' (viewpoints that see it)
         self.view_angle_fts = view_angle_feature_table(angle_feat_size)
@@ -544,7 +545,7 @@ class GraphSim:
         """target object of an observation (M/reverie/env.py:481-484): the episode's `objId`; an episode WITHOUT one (the augmented
         data) gets a random object of the current viewpoint — np.random.choice(obj_ids) there, this simulator's seeded generator here —
         so that such episodes contribute to the object-grounding loss as in the reference; None only when the viewpoint has no objects."""
-        if ep.get('obj_id') is not None or len(obj_ids) == 0:
+        if ep.get('obj_id') is not None or len(obj_ids) == 0 or not self.obj_fallback:
             return ep.get('obj_id')
         return obj_ids[int(self.obj_rng.randint(len(obj_ids)))]
 
