@@ -129,7 +129,10 @@ int goat_ln_fwd(void* stream, int dtype, const void* x, const void* residual,
  *   accumulate | GOAT_LN_ADD_BEFORE: dx_add is instead the gradient that reaches the PRE-NORM SUM z = residual + dropout(x) through
  *   its other consumer and joins before the residual / dropout split: d_res <- dz + dx_add, dx <- (dz + dx_add) * mask / (1 - p).
  *   With it one goat_ln_fwd / goat_ln_bwd pair serves "src = skip + dropout(a); n = LayerNorm(src)" of a pre-LN block, where src
- *   itself continues as the next skip connection (hipops.layer_norm(z_out=True)). */
+ *   itself continues as the next skip connection (hipops.layer_norm(z_out=True)).
+ * Kernels: bf16 rows of H = 768 (every LayerNorm of the model at its hidden size) run ln_bwd768_kernel (round 6: 8-byte chunks, rows in
+ *   flight packed as bf16, <= 128 VGPRs); other widths and float32 run the generic ln_bwd_kernel.  Same grid, same partial rows
+ *   (goat_ln_bwd_nparts), same semantics; GOAT_LN_BWD_GENERIC=1 in the environment selects the generic kernel everywhere (A/B, tests). */
 #define GOAT_LN_ADD_BEFORE 4
 typedef struct goat_ln_partial {
   const float* ws;         /* partials written by goat_ln_bwd(..., accumulate = 2): [nparts][2][H] float32 */
@@ -180,7 +183,8 @@ int goat_act_bwd(void* stream, int dtype, const void* dy, const void* u, void* d
  * Replaces BertSelfAttention.forward (P/model/Bert_backbone.py:246-290; additive -10000 masks P/model/ops.py:25-34,
  * graph_sprels bias :690-691) and F.multi_head_attention_forward with key_padding_mask (-inf)
  * (P/model/transformer.py:172-176).  Q/K/V/O are [B, L, nh*64] views with explicit row and batch strides
- * (so q,k,v may be slices of one fused QKV projection).  kmask: float32 [B,Lk] additive or NULL;
+ * (so q,k,v may be slices of one fused QKV projection, or — round 6 — K|V columns of a projection BANK that holds every layer's
+ * cross-attention K|V of one attended sequence: row stride n_layers * 2 * nh * 64; hipops.linear_bank).  kmask: float32 [B,Lk] additive or NULL;
  * bias: float32 [B,Lq,Lk] additive or NULL.  lse: float32 [B,nh,Lq] saved for backward.
  * Lk <= 256.  Rows whose keys are all -inf produce zeros.
  * Dropout bits are a function of (seed + *rng_dev, offset, b, h, q, key) and of the dtype only — never of which kernel family

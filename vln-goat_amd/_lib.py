@@ -99,12 +99,18 @@ class WgradProblem(ctypes.Structure):
                 ('rows', ctypes.c_int), ('n_out', ctypes.c_int), ('n_in', ctypes.c_int), ('accumulate', ctypes.c_int)]
 
 
+LAST_BUILD = [None]        # what the last build() call did: 'reused ...' or 'compiled ...' (__graft_entry__.build prints it)
+
+
 def build(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into csrc/libgoat_hip.so (in-tree, travels with the repo snapshot)."""
+    force = force or os.environ.get('GOAT_FORCE_BUILD', '0') == '1'
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'gemm2_tile.hpp'), os.path.join(CSRC, 'gemm5_tile.hpp'), os.path.join(CSRC, 'attn_args.hpp'), os.path.join(_HERE, '..', 'include', 'goat_hip.h')]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        LAST_BUILD[0] = 'reused (library newer than every source; GOAT_FORCE_BUILD=1 or build(force=True) recompiles)'
         return LIB_PATH
+    LAST_BUILD[0] = 'compiled %d sources with hipcc --offload-arch=gfx950' % len(srcs)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     procs = []
