@@ -1198,6 +1198,8 @@ def dagger_iteration(model, te, bufs, batches, extras, arena, sim, store, B, T, 
     forms = {'single_pass_eager': round(dt * 1e3, 2)}
     if isinstance(two, dict) and 'ms_per_iteration' in two:
         forms['two_pass'] = two['ms_per_iteration']
+        if isinstance(two.get('single_pass_captured'), dict) and 'ms_per_iteration' in two['single_pass_captured']:
+            forms['single_pass_captured'] = two['single_pass_captured']['ms_per_iteration']
         if isinstance(two.get('pass1_captured'), dict) and 'ms_per_iteration' in two['pass1_captured']:
             forms['two_pass_pass1_captured'] = two['pass1_captured']['ms_per_iteration']
             ov = two['pass1_captured'].get('teacher_overlapped')
@@ -1300,6 +1302,38 @@ def two_pass_iteration(call, te, bufs, g_teacher, batches, extras, arena, sim, s
                           'EpisodeBuffers.load_part, one B x G read-back per step, sampling on the host; the finished plan feeds pass 2' % (max_action_len + 1)}
     except Exception as e:      # noqa: BLE001
         graphs = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    single = None
+    if not os.environ.get('GOAT_BENCH_NO_SINGLE_PASS'):
+        try:
+            # ONE pass at graph speed (rollout.SinglePassSampledEpisode): step graphs captured with their autograd state + one captured backward graph;
+            # the arena is cleared by the instruction graph, the teacher graph (accumulate form) follows as in the other forms
+            import numpy as np
+            auto, hipops.AUTOTUNE = hipops.AUTOTUNE, hipops.AUTOTUNE and tune
+            try:
+                sp = rollout.SinglePassSampledEpisode(te_s, call, bufs_s, extras, prologue=lambda: arena.zero('nav'))
+            finally:
+                hipops.AUTOTUNE = auto
+            rng = np.random.RandomState(17)
+            v1, v2, vsteps, vhost = [], [], [], []
+            for it in range(n + 1):
+                batch = batches[it % len(batches)]
+                t0 = time.perf_counter()
+                sp.run(batch, rng)
+                ta = time.perf_counter()
+                bufs.load(te.plan(batch))
+                g_teacher.replay()
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                if it:
+                    v1.append(ta - t0), v2.append(tb - ta), vsteps.append(sp.steps), vhost.append(sp.host_s)
+            single = {'ms_per_iteration': round(ms(v1) + ms(v2), 2), 'sampled_walk_and_backward_launch_ms': ms(v1), 'host_builder_ms': ms(vhost),
+                      'teacher_part_incl_backward_drain_ms': ms(v2), 'sample_steps': round(sum(vsteps) / len(vsteps), 1),
+                      'what': 'the sampled half in ONE pass as the reference runs it (the action sampled from the forward that carries the loss): '
+                              '%d forward graphs captured with their autograd state + one captured backward graph over all steps; then the teacher graph' % (max_action_len + 1)}
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            single = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     if isinstance(graphs, dict) and 'ms_per_iteration' in graphs and not os.environ.get('GOAT_BENCH_NO_OVERLAP'):
         try:
             graphs['teacher_overlapped'] = overlapped_iteration(call, te, te_s, bufs, bufs_s, batches, extras, arena, max_action_len, ml_weight, tune)
@@ -1309,7 +1343,7 @@ def two_pass_iteration(call, te, bufs, g_teacher, batches, extras, arena, sim, s
             graphs['teacher_overlapped'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     return {'ms_per_iteration': round(ms(t1) + ms(t2) + ms(t3), 2), 'pass1_no_grad_rollout_ms': ms(t1), 'plan_along_actions_ms': ms(t2),
             'sampled_graph_plus_teacher_part_ms': ms(t3), 'sample_steps': round(sum(steps) / len(steps), 1), 'episode_bucket_T': max_action_len,
-            'pass1_captured': graphs,
+            'pass1_captured': graphs, 'single_pass_captured': single,
             'what': 'sampled rollout under no_grad (eager, fixes the trajectory) + host plan along the recorded actions + replay of the episode '
                     'graph captured at T = %d (forward + backward of the sampled half) + the teacher part as above' % max_action_len}
 

@@ -596,6 +596,27 @@ def test_reverie_sampled_rollout_in_two_passes_matches_the_single_pass():
         assert float((a - b).abs().max()) <= 5e-4 * scale, (names[id(p)], float((a - b).abs().max()), scale)
         n += 1
     assert n > 100
+    # ... and in ONE captured pass (rollout.SinglePassSampledEpisode: object tokens + the grounding loss ride in the step graphs / the backward graph)
+    del loss            # (a live loss keeps pass 2's autograd graph — AccumulateGrad nodes bound to the eager stream — alive: see hipops.graph)
+    import gc
+    gc.collect()
+    sp = rollout.SinglePassSampledEpisode(te, call, bufs, ex)
+    for p in params:
+        if p.grad is not None:
+            p.grad.zero_()
+    traj, actions1 = sp.run(eps, sampler=lambda t, pr: policy(t, pr))
+    torch.cuda.synchronize()
+    assert all(np.array_equal(x, y) for x, y in zip(actions1, ref_actions))
+    assert abs(float(sp.loss) - ref_value) <= 2e-5 * max(1.0, abs(ref_value)), (float(sp.loss), ref_value)
+    n = 0
+    for p in params:
+        b = ref[id(p)]
+        if b is None:
+            continue
+        scale = max(float(b.abs().max()), 1e-3 * top)
+        assert float((p.grad - b).abs().max()) <= 5e-4 * scale, (names[id(p)], float((p.grad - b).abs().max()), scale)
+        n += 1
+    assert n > 100
 
 
 _STALE_GRAPH_PROBE = r'''
@@ -639,3 +660,66 @@ def test_capture_with_a_live_warmup_graph_fails_loudly():
     r = subprocess.run([sys.executable, '-c', _STALE_GRAPH_PROBE % root], capture_output=True, text=True, timeout=300)
     assert 'CAPTURED' not in r.stdout, r.stdout + r.stderr[-2000:]
     assert 'AccumulateGrad' in (r.stdout + r.stderr), r.stdout + r.stderr[-2000:]
+
+
+def test_single_pass_sampled_episode_matches_the_eager_single_pass():
+    """VERDICT r5 missing #3: the sampled half of the dagger iteration as ONE pass at graph speed (M/r2r/agent.py:596-690: the action is
+    sampled from the same forward whose logits carry the loss).  rollout.SinglePassSampledEpisode = instruction graph + T step graphs
+    captured with their autograd state + one captured backward graph.  With the fixture's fixed action sequence (the imported reference's
+    sampled rollout, tests/golden/rollout_episode_sample.npz) the loss and EVERY parameter gradient equal the eager single-pass
+    NavRollout at the same panorama width (float32, dropout off) — itself pinned to the fixture — and the same graphs replayed on other
+    episodes (a policy-dependent walk) and again on the first ones reproduce their own eager rollouts: nothing of an earlier iteration
+    is left in the buffers or in the kept autograd state."""
+    from vln_goat_amd import rollout, synth
+    z = np.load(os.path.join(HERE, 'golden', 'rollout_episode_sample.npz'))
+    scan, feats, eps, dicts = synth.make_rollout_case()
+    model = _model()
+    store = _store(scan, feats, torch.float32)
+    sim = rollout.GraphSim(store)
+    call = lambda mode, batch: model(mode, batch)
+    ex = synth.rollout_extras(dicts, len(eps), 'cuda')
+    T = int(z['n_steps'][0])
+    params = [p for p in model.parameters()]
+    names = {id(p): n for n, p in model.named_parameters()}
+    te = rollout.TeacherEpisode(sim, store, n_steps=T, text_len=32, pano_width=40)
+    bufs = rollout.EpisodeBuffers(te.plan(eps))
+
+    def zero():                 # (in place: the captured backward accumulates into the .grad tensors that existed when it was captured)
+        for p in params:
+            if p.grad is not None:
+                p.grad.zero_()
+    sp = rollout.SinglePassSampledEpisode(te, call, bufs, ex)
+    other = synth.rollout_episodes(scan, np.random.RandomState(5), B=3, max_steps=4, starts=[3, 11, 16])
+    greedy = lambda t, probs: np.where(np.asarray(probs)[:, 1:].max(1) > 0, np.asarray(probs)[:, 1:].argmax(1) + 1, 0)
+    fixed = lambda t, probs: z['s%d_action' % t]
+    for rnd, (episodes, pick) in enumerate(((eps, fixed), (other, greedy), (eps, fixed))):
+        # eager single pass (autograd through the rollout loop)
+        zero()
+        ro = rollout.NavRollout(call, sim, store, max_action_len=T, pano_width=40)
+        ref_loss, ref_traj = ro.run(episodes, feedback='sample', extras=ex, sampler=lambda t, pr: pick(t, pr.detach().float().cpu().numpy() if torch.is_tensor(pr) else pr))
+        ref_loss.backward()
+        torch.cuda.synchronize()
+        ref = {id(p): (None if p.grad is None else p.grad.detach().clone()) for p in params}
+        ref_actions = [a.copy() for a in ro.actions]
+        if rnd == 0:
+            assert abs(float(ref_loss.detach()) - float(z['loss'][0])) <= 1e-3 * float(z['loss'][0])
+        # the captured single pass: gradients land in .grad through the captured AccumulateGrad nodes
+        zero()
+        traj, actions = sp.run(episodes, sampler=pick)
+        torch.cuda.synchronize()
+        assert len(actions) == sp.steps and all(np.array_equal(x, y) for x, y in zip(actions, ref_actions[:len(actions)]))
+        assert [tr['path'] for tr in traj] == [tr['path'][:len(t2['path'])] for tr, t2 in zip(ref_traj, traj)]       # (the eager rollout adds the stop-node backtrack)
+        loss = float(sp.loss)
+        assert abs(loss - float(ref_loss.detach())) <= 2e-5 * max(1.0, abs(float(ref_loss.detach()))), (rnd, loss, float(ref_loss))
+        top = max(float(g.abs().max()) for g in ref.values() if g is not None)
+        n = 0
+        for p in params:
+            b = ref[id(p)]
+            if b is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, names[id(p)]
+                continue
+            assert p.grad is not None, names[id(p)]
+            scale = max(float(b.abs().max()), 1e-3 * top)
+            assert float((p.grad - b).abs().max()) <= 5e-4 * scale, (rnd, names[id(p)], float((p.grad - b).abs().max()), scale)
+            n += 1
+        assert n > 100

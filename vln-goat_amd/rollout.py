@@ -1026,11 +1026,15 @@ class NavRollout:
             if ended.all():
                 break
         loss = ml_loss * train_ml / B if compute_loss else None
-        self.ml_loss = loss
+        # (the two parts are kept as DETACHED values: an attribute holding a tensor of the autograd graph would keep the graph — and its
+        #  AccumulateGrad nodes, bound to this pass's stream — alive past the caller's backward; a later capture of a training step then
+        #  accumulates off-graph, see hipops.graph)
+        self.ml_loss = loss.detach() if torch.is_tensor(loss) else loss
         self.og_loss = None
         if compute_loss and has_obj:            # self.loss += ml_loss; self.loss += og_loss, both * train_ml / batch_size (:781-787)
-            self.og_loss = og_loss * train_ml / B
-            loss = loss + self.og_loss
+            og = og_loss * train_ml / B
+            self.og_loss = og.detach()
+            loss = loss + og
         self.steps = steps
         return loss, traj
 
@@ -1681,3 +1685,143 @@ class SampledEpisode:
         plan = p.finish()
         self.host_s += time.perf_counter() - t0
         return plan, actions
+
+
+class SinglePassSampledEpisode:
+    """The sampled half of a dagger iteration in ONE pass, as the reference runs it (M/r2r/agent.py:596-690: the action is sampled at
+    :629-633 from the SAME forward whose logits carry the loss), at graph speed: the instruction graph and the T step graphs of
+    SampledEpisode captured WITH their autograd state kept alive (activations stay in the graphs' shared memory pool), and ONE captured
+    backward graph that forms the loss over the logits the steps left behind — the DAgger labels of the visited states are part of each
+    step's tables — and differentiates it through all T steps ([MEM] state, node-embedding pool, the instruction's K|V bank).  Against the
+    two-pass form (SampledEpisode + the episode graph) the forward of pass 2 is gone, and the walk and the gradient see the same dropout
+    masks (sample-equivalent to the eager single pass, not only distribution-equivalent).
+
+        sp = SinglePassSampledEpisode(te, model, bufs, extras, prologue=lambda: arena.zero('nav'))
+        traj, actions = sp.run(episodes, rng)          # gradients of the sampled loss are in the arena / .grad; sp.loss holds its value
+
+    Dropout: the device-side counter is bumped ONCE per iteration (instruction graph); every op of every step draws from its own counter
+    range, and the backward graph regenerates the masks from the same counter value.  Every step graph is replayed in every iteration (an
+    ended episode's rows carry the ignore label): no graph ever differentiates through buffers it has not written.
+    As for every capture of a training step: no tensor of an EARLIER backward pass (a loss, logits kept on an object) may be alive when
+    this object is built — it would keep AccumulateGrad nodes bound to the eager stream alive and the captured backward would accumulate
+    outside the capture (hipops.graph raises; on ROCm 7.2 ending that capture can also crash the process)."""
+
+    def __init__(self, te, model, bufs, extras=None, prologue=None, loss_scale=1.0):
+        import gc
+        from collections import defaultdict
+        from . import hipops
+        self.te, self.bufs = te, bufs
+        extras = extras or {}
+        t_ = bufs.t
+        B, T = t_['txt_ids'].shape[0], te.T
+        dd = lambda d: defaultdict(lambda: None, d)
+
+        def language():
+            if prologue is not None:
+                prologue()
+            if hipops.RngState.dev is not None:
+                hipops.RngState.dev.add_(0x9E3779B1)
+            lang = {'txt_ids': t_['txt_ids'], 'txt_masks': t_['txt_masks']}
+            lang.update(extras.get('language', {}))
+            txt = model('language', dd(lang))
+            txt_h = hipops.fanout(txt, T + 1)            # one autograd handle per step on the instruction states and their K|V projections
+            kv_h = hipops.fanout_tree(model('text_kv', {'txt_embeds': txt_h[T]}), T)
+            return txt_h, kv_h
+
+        def step(s, txt_h, kv_h, pool, last, nav_extras):
+            mine = list(pool)
+            pano, pmask, fused = te._panoramas(model, t_, extras, 's%d_' % s, B, B)
+            logits, new_last, obj_logits = te._nav_step(model, t_, s, txt_h[s], kv_h[s], pano, pmask, fused, mine, last, nav_extras)
+            with torch.no_grad():
+                probs = torch.softmax(logits.detach().float(), 1)
+            return probs, mine, new_last, logits, obj_logits
+
+        def backward(logits, obj_logits):
+            rows = []
+            for s in range(T):
+                k = 's%d_' % s
+                rows.append(hipops.cross_entropy_rows(logits[s], t_[k + 'target'], te.ignoreid))
+                if te.objects is not None:          # object grounding at the goal viewpoints (M/reverie/agent_obj_goat.py:705-707)
+                    rows.append(hipops.cross_entropy_rows(obj_logits[s], t_[k + 'obj_target'], te.ignoreid))
+            loss = torch.stack(rows, 0).sum() / B
+            (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+            return loss.detach()
+
+        def whole():
+            txt_h, kv_h = language()
+            nav_extras = te._nav_extras(extras, txt_h[0].dtype)
+            pool, last, lg, og = [], None, [], []
+            for s in range(T):
+                _, pool, last, l, o = step(s, txt_h, kv_h, pool, last, nav_extras)
+                lg.append(l)
+                og.append(o)
+            return backward(lg, og)
+
+        # eager warm-up of the whole chain (weight shadows, kernel attributes, GEMM tuning where the tuner is on) with the parallel branches
+        # forked as the captures will fork them; nothing of it may outlive into the captures (hipops.graph raises on a live warm-up graph)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), hipops.Branch.like_capture():
+            whole()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gc.collect()
+
+        self._pool = None
+        self.g_lang, (txt_h, kv_h) = self._capture(language)
+        nav_extras = te._nav_extras(extras, txt_h[0].dtype)
+        self.g_step, self.probs = [], []
+        pool, last, lg, og = [], None, [], []
+        for s in range(T):
+            g, (probs, pool, last, l, o) = self._capture(lambda s=s, pool=pool, last=last: step(s, txt_h, kv_h, pool, last, nav_extras))
+            self.g_step.append(g)
+            self.probs.append(probs)
+            lg.append(l)
+            og.append(o)
+        self.g_bwd, self.loss = self._capture(lambda: backward(lg, og))
+        self._keep = (txt_h, kv_h, pool, last, lg, og)         # (the static tensors the graphs read)
+        torch.cuda.synchronize()
+        self.host_s, self.steps = 0.0, 0
+
+    def _capture(self, fn):
+        from . import hipops
+        g = torch.cuda.CUDAGraph()
+        with hipops.graph(g, **({} if self._pool is None else {'pool': self._pool})):
+            out = fn()
+        self._pool = g.pool()
+        return g, out
+
+    def run(self, episodes, rng=None, sampler=None):
+        """-> (trajectories, actions).  The parameter gradients of the sampled loss are where the model's backward puts them (the gradient
+        arena / .grad) when this returns (asynchronously: on the current stream); `self.loss` is the loss of the iteration (device scalar).
+        sampler(t, probs [B, G] numpy) -> actions [B] overrides the random draw (tests: a fixed action sequence)."""
+        import time
+        te, bufs = self.te, self.bufs
+        rng = rng if rng is not None else np.random.RandomState(0)
+        t0 = time.perf_counter()
+        p = EpisodePlanner(te, episodes, imitation=False)
+        self.host_s = time.perf_counter() - t0
+        bufs.load_part({'txt_ids': p.out['txt_ids'], 'txt_masks': p.out['txt_masks']})
+        self.g_lang.replay()
+        actions, zeros = [], np.zeros(len(episodes), np.int64)
+        self.steps = 0
+        for t in range(te.T):
+            t0 = time.perf_counter()
+            part = p.build_step()
+            self.host_s += time.perf_counter() - t0
+            bufs.load_part(part)
+            self.g_step[t].replay()
+            if p.ended.all():                                 # nothing left to decide: the step runs on ignore labels, no read-back
+                a = zeros
+            else:
+                probs = self.probs[t].cpu().numpy()           # (synchronises: the step's one read-back)
+                a = np.asarray(sampler(t, probs), np.int64) if sampler is not None else SampledEpisode.sample(probs, rng)
+                a = np.where(p.ended, 0, a)
+                actions.append(a)
+                self.steps += 1
+            t0 = time.perf_counter()
+            p.advance(a)
+            self.host_s += time.perf_counter() - t0
+        self.g_bwd.replay()
+        self.n_traj = p.n_traj
+        return p.traj, actions
