@@ -723,3 +723,32 @@ def test_single_pass_sampled_episode_matches_the_eager_single_pass():
             assert float((p.grad - b).abs().max()) <= 5e-4 * scale, (rnd, names[id(p)], float((p.grad - b).abs().max()), scale)
             n += 1
         assert n > 100
+
+
+def test_single_pass_sampled_episode_refuses_a_live_earlier_graph():
+    """A loss of an earlier (eager) backward pass kept alive keeps that pass's AccumulateGrad nodes alive; a captured backward would then
+    accumulate outside the capture (garbage gradients; on ROCm 7.2 a crash when the capture ends).  SinglePassSampledEpisode finds the
+    condition in its eager warm-up and raises BEFORE capturing anything; with the tensor released it builds and runs."""
+    import gc
+    from vln_goat_amd import rollout, synth
+    z = np.load(os.path.join(HERE, 'golden', 'rollout_episode_sample.npz'))
+    scan, feats, eps, dicts = synth.make_rollout_case()
+    model = _model()
+    store = _store(scan, feats, torch.float32)
+    sim = rollout.GraphSim(store)
+    call = lambda mode, batch: model(mode, batch)
+    ex = synth.rollout_extras(dicts, len(eps), 'cuda')
+    T = int(z['n_steps'][0])
+    te = rollout.TeacherEpisode(sim, store, n_steps=T, text_len=32, pano_width=40)
+    bufs = rollout.EpisodeBuffers(te.plan(eps))
+    stale = te.body(call, bufs, ex)           # an eager pass on the default stream ...
+    stale.backward()                          # ... whose loss stays referenced
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='earlier pass is still alive'):
+        rollout.SinglePassSampledEpisode(te, call, bufs, ex)
+    del stale
+    gc.collect()
+    sp = rollout.SinglePassSampledEpisode(te, call, bufs, ex)
+    traj, actions = sp.run(eps, sampler=lambda t, probs: z['s%d_action' % t])
+    torch.cuda.synchronize()
+    assert np.isfinite(float(sp.loss)) and len(traj) == len(eps)

@@ -1759,10 +1759,28 @@ class SinglePassSampledEpisode:
 
         # eager warm-up of the whole chain (weight shadows, kernel attributes, GEMM tuning where the tuner is on) with the parallel branches
         # forked as the captures will fork them; nothing of it may outlive into the captures (hipops.graph raises on a live warm-up graph)
+        # A tensor of an EARLIER backward pass that is still alive shows up right here, as torch's AccumulateGrad stream-mismatch warning (the
+        # warm-up runs on a stream of its own): raised as an error BEFORE anything is captured — inside the capture the same condition ends in
+        # a crash of hipStreamEndCapture on ROCm 7.2, not in an exception.
+        import warnings
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), hipops.Branch.like_capture():
-            whole()
+        always = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)                 # (torch emits this warning ONCE per process otherwise: an earlier, harmless occurrence would hide this one)
+        with warnings.catch_warnings():
+            warnings.filterwarnings('error', message=".*AccumulateGrad node's stream does not match.*")
+            try:
+                with torch.cuda.stream(side), hipops.Branch.like_capture():
+                    whole()
+            except UserWarning as e:
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                hipops.WgradQueue.reset()
+                raise RuntimeError('SinglePassSampledEpisode: an autograd graph of an earlier pass is still alive (a loss / logits tensor kept '
+                                   'somewhere): its AccumulateGrad nodes are bound to that pass\'s stream and a captured backward would accumulate '
+                                   'outside the capture.  Release those tensors (del, gc.collect()) before building this object.') from e
+            finally:
+                torch.set_warn_always(always)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         gc.collect()
