@@ -53,10 +53,10 @@ class graph:
         self._warn = warnings.catch_warnings()
         self._warn.__enter__()
         warnings.filterwarnings('error', message=".*AccumulateGrad node's stream does not match.*")
-        # (torch emits that warning once per process unless told otherwise: an earlier harmless occurrence — an eager pass next to kept graphs —
-        #  would hide the one that matters here; round 6)
-        self._always = torch.is_warn_always_enabled()
-        torch.set_warn_always(True)
+        # (torch emits that warning ONCE per process: after a first, possibly harmless occurrence this net no longer catches anything.  Making it
+        #  fire every time was tried in round 6 and is too strict: a parameter whose AccumulateGrad node was created on one CAPTURING stream and
+        #  receives its gradient from another capturing stream (graphs of several tasks kept alive side by side) warns too, and that case is
+        #  correct.  rollout.SinglePassSampledEpisode checks for live earlier graphs in its eager warm-up instead.)
         try:
             from . import dp
             dp.quiesce_if_needed()      # eager RCCL collectives issued so far are retired before the stream enters capture mode (dp.quiesce_collectives)
@@ -64,7 +64,6 @@ class graph:
         except BaseException:
             _CAPTURING.pop()
             self._warn.__exit__(None, None, None)
-            torch.set_warn_always(self._always)
             raise
 
     def __exit__(self, *exc):
@@ -72,7 +71,6 @@ class graph:
             return self.ctx.__exit__(*exc)
         finally:
             self._warn.__exit__(None, None, None)
-            torch.set_warn_always(self._always)
             if _CAPTURING and _CAPTURING[-1] is self.g:
                 _CAPTURING.pop()
             keep = (_FORKED[0] or bool(os.environ.get('GOAT_GRAPH_RETAIN_ALL'))) and not os.environ.get('GOAT_NO_GRAPH_RETAIN')
