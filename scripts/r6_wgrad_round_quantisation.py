@@ -9,8 +9,9 @@ torch.cuda.set_device(0)
 L = _lib.lib()
 cfg = (hipops.tile(256, 256), hipops.PINGPONG | 2)
 ROT = 3
+BIAS = os.environ.get('WG_NO_BIAS', '0') != '1'
 for rows in (3840, 20480):
-    for n in (7, 8, 10, 12, 14, 17, 21):
+    for n in ([int(v) for v in os.environ['WG_N'].split(',')] if 'WG_N' in os.environ else (7, 8, 10, 12, 14, 17, 21)):
         probs = [(rows, 3072, 768)] * n
         fl = sum(2.0 * r * o * i for r, o, i in probs)
         sets = []
@@ -23,7 +24,7 @@ for rows in (3840, 20480):
                 dw = torch.empty(n_out, n_in, device='cuda')
                 db = torch.zeros(n_out, device='cuda')
                 q = arr[k]
-                q.dy, q.ld_dy, q.x, q.ld_x, q.dw, q.ld_dw, q.dbias = dy.data_ptr(), n_out, x.data_ptr(), n_in, dw.data_ptr(), n_in, db.data_ptr()
+                q.dy, q.ld_dy, q.x, q.ld_x, q.dw, q.ld_dw, q.dbias = dy.data_ptr(), n_out, x.data_ptr(), n_in, dw.data_ptr(), n_in, (db.data_ptr() if BIAS else None)
                 q.rows, q.n_out, q.n_in, q.accumulate = r, n_out, n_in, 0
                 keep.append((dy, x, dw, db))
             sets.append((arr, keep))

@@ -341,9 +341,12 @@ __device__ __forceinline__ void gemm2_tile(const G2Args& p, int bid, int split) 
   } while (0)
 #define GOAT_MMA(ks_)                                                                                              \
   do {                                                                                                              \
-    if (TA && do_colsum) {                                                                                          \
+    if (TA && do_colsum) {       /* bias gradient: v_dot2c_f32_bf16 (pair . (1, 1) + acc), four per fragment instead of eight conversions + eight adds (round 6) */ \
       _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[ks_][i][e];                              \
+        _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                                          \
+          const bf16x2 pr_ = {fa[ks_][i][2 * e2], fa[ks_][i][2 * e2 + 1]};                                          \
+          bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr_, bf16x2{(bf16_t)1.0f, (bf16_t)1.0f}, bsum[i], false);       \
+        }                                                                                                           \
     }                                                                                                               \
     if (GOAT_G2_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                             \
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                  \

@@ -251,7 +251,11 @@ __device__ __forceinline__ void pp_tile(const G2Args& p, int bid, int split, con
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   bf16x8 fa[4][MI], fb[4][NI];
 
-  const bool do_colsum = TA && p.colsum != nullptr && tn == 0 && wn == 0;
+  // bias gradient (column tile 0 only).  Whole tiles (SK == 0): the four waves of a group hold the same A fragments, so wave wn sums fragment row block
+  // i == wn — a quarter of the work each, every output row still has ONE writer (deterministic).  Segments of a contraction-balanced launch keep the
+  // one-wave form (their partial sums travel through the workspace in that layout).
+  constexpr bool BS_SPLIT = (SK == 0);
+  const bool do_colsum = TA && p.colsum != nullptr && tn == 0 && (BS_SPLIT ? wn < MI : wn == 0);
   float bsum[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
@@ -271,13 +275,30 @@ __device__ __forceinline__ void pp_tile(const G2Args& p, int bid, int split, con
     fb[KS][0] = pp_frag<TB, BB::W, KS, 0>(vb, bo_);                                                \
     if constexpr (NI > 1) fb[KS][1 < NI ? 1 : 0] = pp_frag<TB, BB::W, KS, 1>(vb, bo_);             \
   } while (0)
+  // Bias gradient of a weight-gradient tile (column tile 0 only): the sum of the A fragments over the contraction.  Rounds 1-5: ONE wave (wave column 0)
+  // converted and added every fragment in FRONT of its MFMA phase — 128 cvt + add per K-tile, ~1000 cycles against the phase's 1024 — and the tiles that
+  // carry it (one column tile in three for a 768-wide input) held their whole round back: grouped launches ran 882 TFLOP/s with it and 1039 without at
+  // 3840 rows, 950 / 1236 at 20 480 (profiles/round6_wgrad_bias_ab.txt).  Round 6: four v_dot2c_f32_bf16 (pair . (1, 1) + acc) per fragment, issued
+  // BEHIND the tile's MFMAs (while the matrix pipe drains), and the four waves of a group — they hold the same A fragments — take one 32-row block each
+  // (BS_SPLIT): 16 instructions per K-tile and wave, one writer per output row as before.  With it 1032 against 1033 without at 3840 rows.
+  // (Interleaving the sums with the MFMAs in a second copy of the loop made the 256 x 256 kernel spill 836 registers.)
+#ifndef GOAT_BSUM_DOT2
+#define GOAT_BSUM_DOT2 1        // (0: the conversions + adds of rounds 1-5, for same-box A/B builds)
+#endif
+#if GOAT_BSUM_DOT2
+#define PP_BSUM(frag_, acc_)                                                                       \
+  do {                                                                                             \
+    _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                             \
+      const bf16x2 pr_ = {frag_[2 * e2], frag_[2 * e2 + 1]};                                       \
+      acc_ = __builtin_amdgcn_fdot2_f32_bf16(pr_, bf16x2{(bf16_t)1.0f, (bf16_t)1.0f}, acc_, false); \
+    }                                                                                              \
+  } while (0)
+#else
+#define PP_BSUM(frag_, acc_)                                                                       \
+  do { _Pragma("unroll") for (int e = 0; e < 8; ++e) acc_ += (float)frag_[e]; } while (0)
+#endif
 #define PP_MMA_ALL()                                                                               \
   do {                                                                                             \
-    if (TA && do_colsum) {                                                                         \
-      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                             \
-        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                             \
-          _Pragma("unroll") for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[ks][i][e];            \
-    }                                                                                              \
     if (GOAT_G5_SETPRIO) __builtin_amdgcn_s_setprio(1);                                            \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                               \
       _Pragma("unroll") for (int i = 0; i < MI; ++i)                                               \
@@ -286,6 +307,15 @@ __device__ __forceinline__ void pp_tile(const G2Args& p, int bid, int split, con
           else mma32(acc[i][j], fa[ks][i], fb[ks][j]);                                             \
         }                                                                                          \
     if (GOAT_G5_SETPRIO) __builtin_amdgcn_s_setprio(0);                                            \
+    if (TA && do_colsum) {                                                                         \
+      if constexpr (BS_SPLIT) {                                                                    \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                             \
+          if (wn == i) { _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) PP_BSUM(fa[ks][i], bsum[i]); } \
+      } else {                                                                                     \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                           \
+          _Pragma("unroll") for (int i = 0; i < MI; ++i) PP_BSUM(fa[ks][i], bsum[i]);              \
+      }                                                                                            \
+    }                                                                                              \
   } while (0)
 
   static_assert(NI <= 2 && MI <= 4, "fragment macros are written for MI <= 4, NI <= 2");
@@ -430,6 +460,7 @@ __device__ __forceinline__ void pp_tile(const G2Args& p, int bid, int split, con
 #undef PP_STAMP
 #undef PP_FRAGS_KS
 #undef PP_MMA_ALL
+#undef PP_BSUM
 
   // From here on the LDS ring is free: the last fragment reads of both groups completed before the barrier that ended the last
   // MEM phase, and no LDS-DMA is in flight.  Group 0 starts its epilogue while group 1 is in its last MFMA phase.
@@ -490,6 +521,7 @@ __device__ __forceinline__ void pp_tile(const G2Args& p, int bid, int split, con
   if (TA && do_colsum) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+      if (BS_SPLIT && i != wn) continue;          // (this wave summed row block wn only)
       float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
       const int row = m0 + wrow0 + i * 32 + l31;
       if (hi == 0 && row < p.M) atomicAdd(p.colsum + row, v);
