@@ -281,7 +281,8 @@ __device__ __forceinline__ void pp_tile(const G2Args& p, int bid, int split, con
   // 3840 rows, 950 / 1236 at 20 480 (profiles/round6_wgrad_bias_ab.txt).  Round 6: four v_dot2c_f32_bf16 (pair . (1, 1) + acc) per fragment, issued
   // BEHIND the tile's MFMAs (while the matrix pipe drains), and the four waves of a group — they hold the same A fragments — take one 32-row block each
   // (BS_SPLIT): 16 instructions per K-tile and wave, one writer per output row as before.  With it 1032 against 1033 without at 3840 rows.
-  // (Interleaving the sums with the MFMAs in a second copy of the loop made the 256 x 256 kernel spill 836 registers.)
+  // (Interleaving the sums with the MFMAs: a second copy of the loop made the 256 x 256 kernel spill 836 registers; one loop with the sums behind a
+  //  wave-uniform branch per (k-step, row block) ran 694 TFLOP/s WITH OR WITHOUT a bias — the branches break the MFMA stream: profiles/round6_wgrad_bias_ab.txt.)
 #ifndef GOAT_BSUM_DOT2
 #define GOAT_BSUM_DOT2 1        // (0: the conversions + adds of rounds 1-5, for same-box A/B builds)
 #endif
